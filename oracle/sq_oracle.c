@@ -1,0 +1,1096 @@
+/*
+ * sq_oracle.c -- CPU restatement of sequali's per-read QC accumulators.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP
+ * path in sequali_amd/csrc.  Nothing under sequali_amd/ may include, link,
+ * import or execute it; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and there only as the checker / reported baseline.
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference/src/sequali/).  The restatement is written for clarity,
+ * not speed: plain u64 tables, no staging tables, no SIMD.  Where the
+ * reference's observable result depends on an evaluation order (the f64
+ * error-rate sum, the first-come caps of the hash tables, the rebuild quirk
+ * of the duplication estimator) that order is reproduced exactly.
+ *
+ * Pinning: tests/test_oracle_golden.py checks this file against fixtures in
+ * tests/golden/ captured from the compiled reference (oracle/_ref), and
+ * tests/test_oracle_vs_ref.py checks it live against oracle/_ref when that
+ * build is present.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oq_error_table.h" /* OQ_ERROR_RATE_BITS[94], generated, see gen_error_table.py */
+
+#define OQ_PHRED_MAX 93
+#define OQ_NUCS 5
+#define OQ_PHREDS 12
+
+/* Same 40-byte layout as struct FastqMeta (_qcmodule.c:337-355) with the
+ * record_start pointer replaced by a byte offset into the batch buffer. */
+typedef struct {
+    uint64_t record_start;
+    uint32_t name_length;
+    uint32_t sequence_offset;
+    uint32_t sequence_length;
+    uint32_t qualities_offset;
+    uint32_t tags_offset;
+    uint32_t tags_length;
+    double accumulated_error_rate;
+} oq_meta;
+
+static double
+oq_error_rate(unsigned q)
+{
+    double d;
+    uint64_t bits = OQ_ERROR_RATE_BITS[q];
+    memcpy(&d, &bits, 8);
+    return d;
+}
+
+double
+oq_score_to_error_rate(unsigned q)
+{
+    return q <= OQ_PHRED_MAX ? oq_error_rate(q) : NAN;
+}
+
+/* _qcmodule.c:1748-1763 -- A/a 0, C/c 1, G/g 2, T/t 3, everything else 4. */
+static inline unsigned
+oq_base_class(uint8_t c)
+{
+    switch (c | 0x20) {
+        case 'a': return 0;
+        case 'c': return 1;
+        case 'g': return 2;
+        case 't': return 3;
+        default: return 4;
+    }
+}
+
+/* _qcmodule.c:1777-1784 */
+static inline unsigned
+oq_phred_bin(unsigned q)
+{
+    return (q > 47 ? 47 : q) >> 2;
+}
+
+/* ------------------------------------------------------------------------
+ * QCMetrics            (_qcmodule.c:1786-2139)
+ * --------------------------------------------------------------------- */
+typedef struct {
+    size_t end_anchor;
+    size_t max_length;
+    uint64_t number_of_reads;
+    uint64_t *base;     /* [max_length][5]  */
+    uint64_t *phred;    /* [max_length][12] */
+    uint64_t *ea_base;  /* [end_anchor][5]  */
+    uint64_t *ea_phred; /* [end_anchor][12] */
+    uint64_t gc[101];
+    uint64_t phred_scores[OQ_PHRED_MAX + 1];
+    int bad_char; /* offending byte of the last failed add, or -1 */
+} oq_qcm;
+
+oq_qcm *
+oq_qcm_new(size_t end_anchor)
+{
+    oq_qcm *m = calloc(1, sizeof(oq_qcm));
+    m->end_anchor = end_anchor;
+    m->ea_base = calloc(end_anchor ? end_anchor : 1, OQ_NUCS * 8);
+    m->ea_phred = calloc(end_anchor ? end_anchor : 1, OQ_PHREDS * 8);
+    m->bad_char = -1;
+    return m;
+}
+
+void
+oq_qcm_free(oq_qcm *m)
+{
+    if (!m) return;
+    free(m->base); free(m->phred); free(m->ea_base); free(m->ea_phred);
+    free(m);
+}
+
+/* QCMetrics_resize, _qcmodule.c:1870-1906 */
+static void
+oq_qcm_grow(oq_qcm *m, size_t n)
+{
+    m->base = realloc(m->base, n * OQ_NUCS * 8);
+    m->phred = realloc(m->phred, n * OQ_PHREDS * 8);
+    memset(m->base + m->max_length * OQ_NUCS, 0, (n - m->max_length) * OQ_NUCS * 8);
+    memset(m->phred + m->max_length * OQ_PHREDS, 0, (n - m->max_length) * OQ_PHREDS * 8);
+    m->max_length = n;
+}
+
+/* QCMetrics_add_meta, _qcmodule.c:1966-2139.  Returns 0, or -1 on an invalid
+ * phred byte with the same partial state the reference leaves behind. */
+static int
+oq_qcm_add_one(oq_qcm *m, const uint8_t *seq, const uint8_t *qual, size_t L,
+               double *err_out)
+{
+    size_t ea = m->end_anchor < L ? m->end_anchor : L; /* :1971 */
+    size_t ea_store = m->end_anchor - ea;              /* :1972 */
+    if (L > m->max_length) oq_qcm_grow(m, L);          /* :1977 */
+    m->number_of_reads += 1;                           /* :1983 */
+
+    /* :2004-2031 per-position base counts and AT/GC totals */
+    uint64_t at = 0, gc = 0;
+    for (size_t i = 0; i < L; i++) {
+        unsigned c = oq_base_class(seq[i]);
+        m->base[i * OQ_NUCS + c] += 1;
+        if (c == 0 || c == 3) at++;
+        else if (c == 1 || c == 2) gc++;
+    }
+    /* :2034-2043 the last `ea` bases again, right-aligned */
+    for (size_t i = 0; i < ea; i++) {
+        unsigned c = oq_base_class(seq[L - ea + i]);
+        m->ea_base[(ea_store + i) * OQ_NUCS + c] += 1;
+    }
+    /* :2045-2058 */
+    if (at + gc > 0) {
+        double pct = (double)gc * (double)100.0 / (double)(at + gc);
+        m->gc[(uint64_t)round(pct)] += 1;
+    }
+    /* :2059-2097 four interleaved accumulators while more than four
+     * qualities remain (loop bound is end-4, not end-3) */
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    size_t i = 0;
+    while (i + 4 < L) {
+        unsigned q0 = (uint8_t)(qual[i] - 33), q1 = (uint8_t)(qual[i + 1] - 33);
+        unsigned q2 = (uint8_t)(qual[i + 2] - 33), q3 = (uint8_t)(qual[i + 3] - 33);
+        if (q0 > OQ_PHRED_MAX || q1 > OQ_PHRED_MAX || q2 > OQ_PHRED_MAX ||
+            q3 > OQ_PHRED_MAX)
+            break; /* :2073-2075 the scalar loop reports it */
+        m->phred[(i + 0) * OQ_PHREDS + oq_phred_bin(q0)] += 1;
+        m->phred[(i + 1) * OQ_PHREDS + oq_phred_bin(q1)] += 1;
+        m->phred[(i + 2) * OQ_PHREDS + oq_phred_bin(q2)] += 1;
+        m->phred[(i + 3) * OQ_PHREDS + oq_phred_bin(q3)] += 1;
+        acc[0] += oq_error_rate(q0);
+        acc[1] += oq_error_rate(q1);
+        acc[2] += oq_error_rate(q2);
+        acc[3] += oq_error_rate(q3);
+        i += 4;
+    }
+    /* :2098-2112 */
+    double total = acc[0] + acc[1] + acc[2] + acc[3];
+    for (; i < L; i++) {
+        unsigned q = (uint8_t)(qual[i] - 33);
+        if (q > OQ_PHRED_MAX) {
+            m->bad_char = qual[i];
+            return -1;
+        }
+        m->phred[i * OQ_PHREDS + oq_phred_bin(q)] += 1;
+        total += oq_error_rate(q);
+    }
+    /* :2114-2124 */
+    for (size_t j = 0; j < ea; j++) {
+        unsigned q = (uint8_t)(qual[L - ea + j] - 33);
+        m->ea_phred[(ea_store + j) * OQ_PHREDS + oq_phred_bin(q)] += 1;
+    }
+    *err_out = total; /* :2126 */
+    /* :2127-2137 */
+    if (L > 0) {
+        double avg = total / (double)L;
+        double avg_phred = -10.0 * log10(avg);
+        m->phred_scores[(uint64_t)floor(avg_phred)] += 1;
+    }
+    return 0;
+}
+
+/* QCMetrics_add_record_array, _qcmodule.c:2183-2204.  Returns 0, or
+ * -(index+1) of the failing record. */
+int64_t
+oq_qcm_add(oq_qcm *m, const uint8_t *buf, oq_meta *metas, size_t n)
+{
+    for (size_t r = 0; r < n; r++) {
+        const uint8_t *rec = buf + metas[r].record_start;
+        if (oq_qcm_add_one(m, rec + metas[r].sequence_offset,
+                           rec + metas[r].qualities_offset,
+                           metas[r].sequence_length,
+                           &metas[r].accumulated_error_rate) != 0)
+            return -(int64_t)(r + 1);
+    }
+    return 0;
+}
+
+size_t oq_qcm_max_length(oq_qcm *m) { return m->max_length; }
+uint64_t oq_qcm_number_of_reads(oq_qcm *m) { return m->number_of_reads; }
+int oq_qcm_bad_char(oq_qcm *m) { return m->bad_char; }
+void oq_qcm_get_base(oq_qcm *m, uint64_t *o) { memcpy(o, m->base, m->max_length * OQ_NUCS * 8); }
+void oq_qcm_get_phred(oq_qcm *m, uint64_t *o) { memcpy(o, m->phred, m->max_length * OQ_PHREDS * 8); }
+void oq_qcm_get_ea_base(oq_qcm *m, uint64_t *o) { memcpy(o, m->ea_base, m->end_anchor * OQ_NUCS * 8); }
+void oq_qcm_get_ea_phred(oq_qcm *m, uint64_t *o) { memcpy(o, m->ea_phred, m->end_anchor * OQ_PHREDS * 8); }
+void oq_qcm_get_gc(oq_qcm *m, uint64_t *o) { memcpy(o, m->gc, sizeof(m->gc)); }
+void oq_qcm_get_phred_scores(oq_qcm *m, uint64_t *o) { memcpy(o, m->phred_scores, sizeof(m->phred_scores)); }
+
+/* ------------------------------------------------------------------------
+ * AdapterCounter       (_qcmodule.c:2391-2823)
+ * bit-parallel shift-AND, adapters packed greedily into 64-bit words.
+ * --------------------------------------------------------------------- */
+typedef struct {
+    size_t first_adapter, n_adapters; /* adapters living in this word */
+    uint64_t init_mask, found_mask;
+    uint64_t class_mask[OQ_NUCS];
+} oq_word;
+
+typedef struct {
+    size_t n_adapters, n_words, max_length;
+    uint64_t number_of_sequences;
+    size_t *len;         /* per adapter */
+    uint64_t *end_bit;   /* per adapter: bit of its last character */
+    oq_word *words;
+    uint64_t **fwd, **rev; /* per adapter [max_length] */
+} oq_adapt;
+
+/* AdapterCounter__new__, _qcmodule.c:2464-2609; populate_bitmask :2450-2462.
+ * `adapters` are n NUL-free byte strings of length lens[i] (<= 64). */
+oq_adapt *
+oq_adapt_new(const uint8_t *const *adapters, const size_t *lens, size_t n)
+{
+    oq_adapt *a = calloc(1, sizeof(oq_adapt));
+    a->n_adapters = n;
+    a->len = calloc(n, sizeof(size_t));
+    a->end_bit = calloc(n, 8);
+    a->fwd = calloc(n, sizeof(uint64_t *));
+    a->rev = calloc(n, sizeof(uint64_t *));
+    a->words = calloc(n ? n : 1, sizeof(oq_word));
+    size_t i = 0;
+    while (i < n) {
+        oq_word *w = &a->words[a->n_words++];
+        size_t used = 0;
+        w->first_adapter = i;
+        while (i < n && used + lens[i] <= 64) { /* :2559 */
+            a->len[i] = lens[i];
+            w->init_mask |= 1ULL << used; /* :2563 */
+            for (size_t j = 0; j < lens[i]; j++) {
+                uint8_t c = adapters[i][j];
+                if (c == 0) continue; /* :2455 */
+                w->class_mask[oq_base_class(c)] |= 1ULL << (used + j);
+            }
+            used += lens[i];
+            a->end_bit[i] = 1ULL << (used - 1); /* :2568 */
+            w->found_mask |= a->end_bit[i];
+            w->n_adapters++;
+            i++;
+        }
+    }
+    return a;
+}
+
+void
+oq_adapt_free(oq_adapt *a)
+{
+    if (!a) return;
+    for (size_t i = 0; i < a->n_adapters; i++) { free(a->fwd[i]); free(a->rev[i]); }
+    free(a->fwd); free(a->rev); free(a->len); free(a->end_bit); free(a->words);
+    free(a);
+}
+
+/* AdapterCounter_add_meta :2786-2823, find_single_matcher :2675-2699,
+ * update_adapter_count_array :2643-2672 */
+static void
+oq_adapt_add_one(oq_adapt *a, const uint8_t *seq, size_t L)
+{
+    a->number_of_sequences += 1;
+    if (L > a->max_length) { /* AdapterCounter_resize :2611-2641 */
+        for (size_t i = 0; i < a->n_adapters; i++) {
+            a->fwd[i] = realloc(a->fwd[i], L * 8);
+            a->rev[i] = realloc(a->rev[i], L * 8);
+            memset(a->fwd[i] + a->max_length, 0, (L - a->max_length) * 8);
+            memset(a->rev[i] + a->max_length, 0, (L - a->max_length) * 8);
+        }
+        a->max_length = L;
+    }
+    for (size_t wi = 0; wi < a->n_words; wi++) {
+        const oq_word *w = &a->words[wi];
+        uint64_t R = 0, seen = 0;
+        for (size_t pos = 0; pos < L; pos++) {
+            R = ((R << 1) | w->init_mask) & w->class_mask[oq_base_class(seq[pos])];
+            if (!(R & w->found_mask)) continue;
+            for (size_t k = w->first_adapter; k < w->first_adapter + w->n_adapters; k++) {
+                if (a->len[k] == 0) break;         /* :2653 zero length ends the list */
+                if (a->end_bit[k] & seen) continue; /* :2657 first hit only */
+                if (R & a->end_bit[k]) {
+                    size_t start = pos - a->len[k] + 1;
+                    a->fwd[k][start] += 1;
+                    a->rev[k][(L - 1) - start] += 1;
+                    seen |= a->end_bit[k];
+                }
+            }
+        }
+    }
+}
+
+void
+oq_adapt_add(oq_adapt *a, const uint8_t *buf, const oq_meta *metas, size_t n)
+{
+    for (size_t r = 0; r < n; r++)
+        oq_adapt_add_one(a, buf + metas[r].record_start + metas[r].sequence_offset,
+                         metas[r].sequence_length);
+}
+
+size_t oq_adapt_max_length(oq_adapt *a) { return a->max_length; }
+size_t oq_adapt_n_words(oq_adapt *a) { return a->n_words; }
+uint64_t oq_adapt_number_of_sequences(oq_adapt *a) { return a->number_of_sequences; }
+void oq_adapt_get(oq_adapt *a, size_t i, uint64_t *fwd, uint64_t *rev)
+{
+    memcpy(fwd, a->fwd[i], a->max_length * 8);
+    memcpy(rev, a->rev[i], a->max_length * 8);
+}
+
+/* ------------------------------------------------------------------------
+ * PerTileQuality       (_qcmodule.c:2975-3222)
+ * --------------------------------------------------------------------- */
+/* unsigned_decimal_integer_from_string, _qcmodule.c:159-180 */
+static int64_t
+oq_parse_decimal(const uint8_t *s, size_t n)
+{
+    if (n < 1 || n > 18) return -1;
+    uint64_t v = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t d = (uint8_t)(s[i] - '0');
+        if (d > 9) return -1;
+        v = v * 10 + d;
+    }
+    return (int64_t)v;
+}
+
+/* illumina_header_to_tile_id, _qcmodule.c:3088-3121: the digits between the
+ * 4th and the 5th ':' */
+int64_t
+oq_tile_id(const uint8_t *name, size_t n)
+{
+    size_t i = 0, colons = 0;
+    for (; i < n; i++) {
+        if (name[i] == ':' && ++colons == 4) break;
+    }
+    size_t start = i + 1;
+    for (size_t j = start; j < n; j++) {
+        if (name[j] == ':') return oq_parse_decimal(name + start, j - start);
+    }
+    return -1;
+}
+
+typedef struct {
+    uint64_t *length_counts;
+    double *total_errors;
+} oq_tile;
+
+typedef struct {
+    int skipped;
+    int64_t skipped_record; /* index, counted over every record ever added */
+    uint64_t records_seen;
+    oq_tile *tiles;
+    size_t n_tiles, max_length;
+    uint64_t number_of_reads;
+    int bad_char;
+} oq_ptq;
+
+oq_ptq *
+oq_ptq_new(void)
+{
+    oq_ptq *p = calloc(1, sizeof(oq_ptq));
+    p->skipped_record = -1;
+    p->bad_char = -1;
+    return p;
+}
+
+void
+oq_ptq_free(oq_ptq *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < p->n_tiles; i++) { free(p->tiles[i].length_counts); free(p->tiles[i].total_errors); }
+    free(p->tiles);
+    free(p);
+}
+
+/* PerTileQuality_add_meta, _qcmodule.c:3123-3222 */
+static int
+oq_ptq_add_one(oq_ptq *p, const uint8_t *name, size_t name_len,
+               const uint8_t *qual, size_t L)
+{
+    if (p->skipped) return 0;
+    int64_t tile = oq_tile_id(name, name_len);
+    if (tile < 0) { /* :3137-3148 module disables itself for good */
+        p->skipped = 1;
+        p->skipped_record = (int64_t)p->records_seen;
+        return 0;
+    }
+    if (L > p->max_length) { /* resize_tiles :3046-3079 */
+        for (size_t i = 0; i < p->n_tiles; i++) {
+            oq_tile *t = &p->tiles[i];
+            if (!t->length_counts) continue;
+            t->length_counts = realloc(t->length_counts, L * 8);
+            t->total_errors = realloc(t->total_errors, L * 8);
+            memset(t->length_counts + p->max_length, 0, (L - p->max_length) * 8);
+            memset(t->total_errors + p->max_length, 0, (L - p->max_length) * 8);
+        }
+        p->max_length = L;
+    }
+    if ((size_t)tile + 1 > p->n_tiles) { /* resize_tile_array :3026-3044 */
+        p->tiles = realloc(p->tiles, ((size_t)tile + 1) * sizeof(oq_tile));
+        memset(p->tiles + p->n_tiles, 0, ((size_t)tile + 1 - p->n_tiles) * sizeof(oq_tile));
+        p->n_tiles = (size_t)tile + 1;
+    }
+    oq_tile *t = &p->tiles[tile];
+    if (!t->length_counts) { /* :3165-3177 */
+        t->length_counts = calloc(p->max_length ? p->max_length : 1, 8);
+        t->total_errors = calloc(p->max_length ? p->max_length : 1, 8);
+    }
+    p->number_of_reads += 1;
+    if (L == 0) return 0;
+    t->length_counts[L - 1] += 1;
+    /* :3189-3220.  The 4-wide loop bails out to the scalar loop on a bad
+     * byte, so every position before the offending one has been added. */
+    for (size_t i = 0; i < L; i++) {
+        unsigned q = (uint8_t)(qual[i] - 33);
+        if (q > OQ_PHRED_MAX) {
+            /* positions of the same 4-group before i were not added by the
+             * unrolled loop but are added by the scalar loop: same result */
+            p->bad_char = qual[i];
+            return -1;
+        }
+        t->total_errors[i] += oq_error_rate(q);
+    }
+    return 0;
+}
+
+int64_t
+oq_ptq_add(oq_ptq *p, const uint8_t *buf, const oq_meta *metas, size_t n)
+{
+    for (size_t r = 0; r < n; r++) {
+        const uint8_t *rec = buf + metas[r].record_start;
+        int ret = oq_ptq_add_one(p, rec, metas[r].name_length,
+                                 rec + metas[r].qualities_offset,
+                                 metas[r].sequence_length);
+        p->records_seen += 1;
+        if (ret != 0) return -(int64_t)(r + 1);
+    }
+    return 0;
+}
+
+int oq_ptq_skipped(oq_ptq *p) { return p->skipped; }
+int64_t oq_ptq_skipped_record(oq_ptq *p) { return p->skipped_record; }
+size_t oq_ptq_max_length(oq_ptq *p) { return p->max_length; }
+uint64_t oq_ptq_number_of_reads(oq_ptq *p) { return p->number_of_reads; }
+size_t oq_ptq_n_tiles_seen(oq_ptq *p)
+{
+    size_t c = 0;
+    for (size_t i = 0; i < p->n_tiles; i++) c += p->tiles[i].length_counts != NULL;
+    return c;
+}
+/* get_tile_counts, _qcmodule.c:3307-3359: ascending tile ids, raw sums and
+ * the reverse-cumulative read counts per position. */
+void
+oq_ptq_get(oq_ptq *p, int64_t *tile_ids, double *errors, uint64_t *counts)
+{
+    size_t k = 0;
+    for (size_t i = 0; i < p->n_tiles; i++) {
+        oq_tile *t = &p->tiles[i];
+        if (!t->length_counts) continue;
+        tile_ids[k] = (int64_t)i;
+        uint64_t running = 0;
+        for (size_t j = p->max_length; j-- > 0;) {
+            running += t->length_counts[j];
+            errors[k * p->max_length + j] = t->total_errors[j];
+            counts[k * p->max_length + j] = running;
+        }
+        k++;
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * Hashes               (wanghash.h:14-63, murmur3.h:47-158)
+ * --------------------------------------------------------------------- */
+uint64_t
+oq_wanghash64(uint64_t k)
+{
+    k = (~k) + (k << 21);
+    k ^= k >> 24;
+    k = k + (k << 3) + (k << 8);
+    k ^= k >> 14;
+    k = k + (k << 2) + (k << 4);
+    k ^= k >> 28;
+    k += k << 31;
+    return k;
+}
+
+uint64_t
+oq_wanghash64_inverse(uint64_t k)
+{
+    uint64_t t;
+    t = k - (k << 31);           k = k - (t << 31);
+    t = k ^ (k >> 28);           k = k ^ (t >> 28);
+    k *= 14933078535860113213ULL; /* 21^-1 mod 2^64 */
+    t = k ^ (k >> 14); t = k ^ (t >> 14); t = k ^ (t >> 14); k = k ^ (t >> 14);
+    k *= 15244667743933553977ULL; /* 265^-1 mod 2^64 */
+    t = k ^ (k >> 24);           k = k ^ (t >> 24);
+    t = ~k; t = ~(k - (t << 21)); t = ~(k - (t << 21)); k = ~(k - (t << 21));
+    return k;
+}
+
+static inline uint64_t oq_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t
+oq_fmix(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+/* MurmurHash3 x64-128, second half of the digest (murmur3.h:47-158) */
+uint64_t
+oq_murmur3_x64_64(const uint8_t *data, size_t len, uint64_t seed)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    size_t nblocks = len / 16;
+    for (size_t i = 0; i < nblocks; i++) {
+        uint64_t k1, k2;
+        memcpy(&k1, data + i * 16, 8);
+        memcpy(&k2, data + i * 16 + 8, 8);
+        k1 *= c1; k1 = oq_rotl(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = oq_rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = oq_rotl(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = oq_rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint8_t *tail = data + nblocks * 16;
+    size_t rem = len & 15;
+    uint64_t k1 = 0, k2 = 0;
+    for (size_t j = rem; j > 8; j--) k2 ^= (uint64_t)tail[j - 1] << (8 * (j - 9));
+    if (rem > 8) { k2 *= c2; k2 = oq_rotl(k2, 33); k2 *= c1; h2 ^= k2; }
+    for (size_t j = rem < 8 ? rem : 8; j > 0; j--) k1 ^= (uint64_t)tail[j - 1] << (8 * (j - 1));
+    if (rem > 0) { k1 *= c1; k1 = oq_rotl(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = oq_fmix(h1); h2 = oq_fmix(h2);
+    h1 += h2; h2 += h1;
+    return h2;
+}
+
+/* ------------------------------------------------------------------------
+ * OverrepresentedSequences  (_qcmodule.c:3435-3942)
+ * --------------------------------------------------------------------- */
+/* reverse_complement_kmer :3634-3655 : complement = bitwise not, then reverse
+ * the 2-bit groups and drop the unused low groups. */
+static uint64_t
+oq_revcomp_kmer(uint64_t kmer, unsigned k)
+{
+    uint64_t x = ~kmer, r = 0;
+    for (unsigned i = 0; i < 32; i++) {
+        r = (r << 2) | (x & 3);
+        x >>= 2;
+    }
+    return r >> (64 - 2 * k);
+}
+
+/* sequence_to_canonical_kmer :3657-3694 (NUCLEOTIDE_TO_TWOBIT :3612-3627).
+ * -1: some char is not ACGTN; -2: ACGTN only but with an N. */
+int64_t
+oq_canonical_kmer(const uint8_t *s, unsigned k)
+{
+    uint64_t kmer = 0;
+    int has_n = 0, has_other = 0;
+    for (unsigned i = 0; i < k; i++) {
+        unsigned c = oq_base_class(s[i]);
+        if (c == 4) {
+            if ((s[i] | 0x20) == 'n') has_n = 1;
+            else has_other = 1;
+            c = 0;
+        }
+        kmer = (kmer << 2) | c;
+    }
+    if (has_other) return -1;
+    if (has_n) return -2;
+    uint64_t rc = oq_revcomp_kmer(kmer, k);
+    return (int64_t)(rc > kmer ? kmer : rc);
+}
+
+typedef struct {
+    unsigned k;
+    uint64_t number_of_sequences, sampled_sequences, total_fragments;
+    uint64_t n_unique, max_unique, sample_every;
+    int64_t frags_start, frags_end;
+    uint64_t table_size;
+    uint64_t *hashes;
+    uint32_t *counts;
+    uint64_t *staging;
+    uint64_t staging_cap;
+    uint64_t warned; /* number of sampled reads that had a non-ACGTN char */
+    int64_t last_warned_record;
+    uint64_t records_seen;
+} oq_ovr;
+
+/* OverrepresentedSequences__new__ :3464-3540 */
+oq_ovr *
+oq_ovr_new(int64_t max_unique, int64_t k, int64_t sample_every,
+           int64_t bases_from_start, int64_t bases_from_end)
+{
+    oq_ovr *o = calloc(1, sizeof(oq_ovr));
+    if (bases_from_start < 0) bases_from_start = UINT32_MAX;
+    if (bases_from_end < 0) bases_from_end = UINT32_MAX;
+    uint64_t bits = (uint64_t)(log2(max_unique * 1.5) + 1);
+    o->k = (unsigned)k;
+    o->max_unique = max_unique;
+    o->sample_every = sample_every;
+    o->table_size = 1ULL << bits;
+    o->hashes = calloc(o->table_size, 8);
+    o->counts = calloc(o->table_size, 4);
+    o->frags_start = (bases_from_start + k - 1) / k;
+    o->frags_end = (bases_from_end + k - 1) / k;
+    o->last_warned_record = -1;
+    return o;
+}
+
+void
+oq_ovr_free(oq_ovr *o)
+{
+    if (!o) return;
+    free(o->hashes); free(o->counts); free(o->staging);
+    free(o);
+}
+
+/* Sequence_duplication_insert_hash :3542-3568 */
+static void
+oq_ovr_insert(oq_ovr *o, uint64_t h)
+{
+    uint64_t mask = o->table_size - 1, i = h & mask;
+    for (;;) {
+        if (o->hashes[i] == 0) {
+            if (o->n_unique < o->max_unique) {
+                o->hashes[i] = h;
+                o->counts[i] = 1;
+                o->n_unique++;
+            }
+            return;
+        }
+        if (o->hashes[i] == h) { o->counts[i]++; return; }
+        i = (i + 1) & mask;
+    }
+}
+
+/* add_to_staging :3588-3608 */
+static void
+oq_stage(uint64_t *t, uint64_t size, uint64_t h)
+{
+    uint64_t mask = size - 1, i = h & mask;
+    for (;;) {
+        if (t[i] == 0) { t[i] = h; return; }
+        if (t[i] == h) return;
+        i = (i + 1) & mask;
+    }
+}
+
+/* OverrepresentedSequences_add_meta :3829-3942 */
+static void
+oq_ovr_add_one(oq_ovr *o, const uint8_t *seq, int64_t L)
+{
+    if (o->number_of_sequences % o->sample_every != 0) {
+        o->number_of_sequences++;
+        return;
+    }
+    o->sampled_sequences++;
+    o->number_of_sequences++;
+    int64_t k = o->k;
+    if (L < k) return;
+    int64_t max_frag = (L + k - 1) / k;
+    int64_t from_mid = max_frag / 2;
+    int64_t n_start = max_frag - from_mid, n_end = from_mid;
+    if (o->frags_start < n_start) n_start = o->frags_start;
+    if (o->frags_end < n_end) n_end = o->frags_end;
+    int64_t total = n_start + n_end;
+    if (total == 0) return; /* log2(0) in the reference; no fragments either way */
+    uint64_t bits = (uint64_t)ceil(log2((double)total * 1.5)); /* :3884 */
+    uint64_t size = 1ULL << bits;
+    if (size > o->staging_cap) {
+        o->staging = realloc(o->staging, size * 8);
+        o->staging_cap = size;
+    }
+    memset(o->staging, 0, size * 8);
+    uint64_t valid = 0;
+    int warn = 0;
+    for (int64_t f = 0; f < total; f++) {
+        int64_t at = f < n_start ? f * k : L - n_end * k + (f - n_start) * k;
+        int64_t km = oq_canonical_kmer(seq + at, (unsigned)k);
+        if (km < 0) {
+            if (km == -1) warn = 1;
+            continue;
+        }
+        valid++;
+        oq_stage(o->staging, size, oq_wanghash64((uint64_t)km));
+    }
+    for (uint64_t i = 0; i < size; i++) /* :3925-3930 flushed in slot order */
+        if (o->staging[i]) oq_ovr_insert(o, o->staging[i]);
+    if (warn) { o->warned++; o->last_warned_record = (int64_t)o->records_seen; }
+    o->total_fragments += valid;
+}
+
+void
+oq_ovr_add(oq_ovr *o, const uint8_t *buf, const oq_meta *metas, size_t n)
+{
+    for (size_t r = 0; r < n; r++) {
+        oq_ovr_add_one(o, buf + metas[r].record_start + metas[r].sequence_offset,
+                       metas[r].sequence_length);
+        o->records_seen++;
+    }
+}
+
+uint64_t oq_ovr_number_of_sequences(oq_ovr *o) { return o->number_of_sequences; }
+uint64_t oq_ovr_sampled_sequences(oq_ovr *o) { return o->sampled_sequences; }
+uint64_t oq_ovr_total_fragments(oq_ovr *o) { return o->total_fragments; }
+uint64_t oq_ovr_unique(oq_ovr *o) { return o->n_unique; }
+uint64_t oq_ovr_table_size(oq_ovr *o) { return o->table_size; }
+uint64_t oq_ovr_warned(oq_ovr *o) { return o->warned; }
+int64_t oq_ovr_last_warned_record(oq_ovr *o) { return o->last_warned_record; }
+/* non-empty slots in slot order: the k-mer (hash inverted) and its count */
+uint64_t
+oq_ovr_get(oq_ovr *o, uint64_t *kmers, uint64_t *counts)
+{
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < o->table_size; i++) {
+        if (!o->hashes[i]) continue;
+        kmers[n] = oq_wanghash64_inverse(o->hashes[i]);
+        counts[n] = o->counts[i];
+        n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * DedupEstimator       (_qcmodule.c:4270-4517)
+ * --------------------------------------------------------------------- */
+typedef struct {
+    uint64_t modulo_bits, table_size, max_stored, stored;
+    uint64_t front_len, front_off, back_len, back_off;
+    uint8_t *fingerprint; /* reused between calls, like the reference's store */
+    uint64_t *hash;
+    uint32_t *count;
+} oq_dedup;
+
+oq_dedup *
+oq_dedup_new(int64_t max_stored, int64_t front_len, int64_t back_len,
+             int64_t front_off, int64_t back_off)
+{
+    oq_dedup *d = calloc(1, sizeof(oq_dedup));
+    uint64_t bits = (uint64_t)(log2(max_stored * 1.5) + 1); /* :4327 */
+    d->table_size = 1ULL << bits;
+    d->max_stored = max_stored;
+    d->front_len = front_len; d->back_len = back_len;
+    d->front_off = front_off; d->back_off = back_off;
+    /* the reference mallocs this (:4352); zero-filled here so that the
+     * stale-byte case of the paired path is at least deterministic */
+    d->fingerprint = calloc(front_len + back_len + 1, 1);
+    d->hash = calloc(d->table_size, 8);
+    d->count = calloc(d->table_size, 4);
+    return d;
+}
+
+void
+oq_dedup_free(oq_dedup *d)
+{
+    if (!d) return;
+    free(d->fingerprint); free(d->hash); free(d->count);
+    free(d);
+}
+
+/* DedupEstimator_increment_modulo :4382-4423 */
+static void
+oq_dedup_rebuild(oq_dedup *d)
+{
+    uint64_t bits = d->modulo_bits + 1, ignore = (1ULL << bits) - 1;
+    uint64_t mask = d->table_size - 1, kept = 0;
+    uint64_t *nh = calloc(d->table_size, 8);
+    uint32_t *nc = calloc(d->table_size, 4);
+    for (uint64_t i = 0; i < d->table_size; i++) {
+        if (d->count[i] == 0 || (d->hash[i] & ignore)) continue;
+        uint64_t j = (d->hash[i] >> bits) & mask;
+        while (nc[j] != 0) j = (j + 1) & mask;
+        nh[j] = d->hash[i];
+        nc[j] = d->count[i];
+        kept++;
+    }
+    free(d->hash); free(d->count);
+    d->hash = nh; d->count = nc;
+    d->modulo_bits = bits;
+    d->stored = kept;
+}
+
+/* Insert a ready-made hash: everything of DedupEstimator_add_fingerprint
+ * (:4425-4460) after the MurmurHash call.  Note: the
+ * pre-rebuild modulo_bits keeps being used for the slot index and the hash
+ * is not re-tested against the new mask. */
+void
+oq_dedup_add_hash(oq_dedup *d, uint64_t h)
+{
+    uint64_t bits = d->modulo_bits;
+    if (h & ((1ULL << bits) - 1)) return;
+    if (d->stored >= d->max_stored) oq_dedup_rebuild(d);
+    uint64_t mask = d->table_size - 1, i = (h >> bits) & mask;
+    for (;;) {
+        if (d->count[i] == 0) {
+            d->hash[i] = h;
+            d->count[i] = 1;
+            d->stored++;
+            return;
+        }
+        if (d->hash[i] == h) { d->count[i]++; return; }
+        i = (i + 1) & mask;
+    }
+}
+
+/* DedupEstimator_add_sequence_ptr :4462-4485 */
+void
+oq_dedup_add_sequence(oq_dedup *d, const uint8_t *seq, size_t L)
+{
+    size_t fp_len = d->front_len + d->back_len;
+    if (L <= fp_len) {
+        oq_dedup_add_hash(d, oq_murmur3_x64_64(seq, L, 0));
+        return;
+    }
+    uint64_t seed = L >> 6;
+    size_t rem = L - fp_len;
+    size_t fo = rem / 2 < d->front_off ? rem / 2 : d->front_off;
+    size_t bo = rem / 2 < d->back_off ? rem / 2 : d->back_off;
+    memcpy(d->fingerprint, seq + fo, d->front_len);
+    memcpy(d->fingerprint + d->front_len, seq + L - (bo + d->back_len), d->back_len);
+    oq_dedup_add_hash(d, oq_murmur3_x64_64(d->fingerprint, fp_len, seed));
+}
+
+/* DedupEstimator_add_sequence_pair_ptr :4487-4517 */
+void
+oq_dedup_add_pair(oq_dedup *d, const uint8_t *s1, int64_t L1,
+                  const uint8_t *s2, int64_t L2)
+{
+    int64_t fp_len = d->front_len + d->back_len;
+    uint64_t seed = (uint64_t)(L1 + L2) >> 6;
+    int64_t fl = (int64_t)d->front_len < L1 ? (int64_t)d->front_len : L1;
+    int64_t fo = (int64_t)d->front_off < L1 - fl ? (int64_t)d->front_off : L1 - fl;
+    int64_t bl = (int64_t)d->back_len < L2 ? (int64_t)d->back_len : L2;
+    int64_t bo = (int64_t)d->back_off < L2 - bl ? (int64_t)d->back_off : L2 - bl;
+    memcpy(d->fingerprint, s1 + fo, fl);
+    memcpy(d->fingerprint + fl, s2 + bo, bl);
+    /* hashed at full length whatever fl + bl is (:4515): stale bytes of the
+     * previous fingerprint fill the gap */
+    oq_dedup_add_hash(d, oq_murmur3_x64_64(d->fingerprint, fp_len, seed));
+}
+
+void
+oq_dedup_add(oq_dedup *d, const uint8_t *buf, const oq_meta *metas, size_t n)
+{
+    for (size_t r = 0; r < n; r++)
+        oq_dedup_add_sequence(d, buf + metas[r].record_start + metas[r].sequence_offset,
+                              metas[r].sequence_length);
+}
+
+void
+oq_dedup_add_pairs(oq_dedup *d, const uint8_t *buf1, const oq_meta *m1,
+                   const uint8_t *buf2, const oq_meta *m2, size_t n)
+{
+    for (size_t r = 0; r < n; r++)
+        oq_dedup_add_pair(d, buf1 + m1[r].record_start + m1[r].sequence_offset,
+                          m1[r].sequence_length,
+                          buf2 + m2[r].record_start + m2[r].sequence_offset,
+                          m2[r].sequence_length);
+}
+
+uint64_t oq_dedup_modulo_bits(oq_dedup *d) { return d->modulo_bits; }
+uint64_t oq_dedup_table_size(oq_dedup *d) { return d->table_size; }
+uint64_t oq_dedup_stored(oq_dedup *d) { return d->stored; }
+/* duplication_counts :4720-4750, non-zero counts in slot order */
+uint64_t
+oq_dedup_get(oq_dedup *d, uint64_t *counts)
+{
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < d->table_size; i++)
+        if (d->count[i]) counts[n++] = d->count[i];
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * InsertSizeMetrics    (_qcmodule.c:5456-5744)
+ * --------------------------------------------------------------------- */
+#define OQ_ADAPTER_STORE 31
+
+typedef struct {
+    uint64_t hash, count;
+    uint8_t len;
+    uint8_t bytes[OQ_ADAPTER_STORE];
+} oq_adapter_entry;
+
+typedef struct {
+    uint64_t *insert_sizes;
+    size_t max_insert;
+    uint64_t total_reads, n_adapters[2];
+    size_t max_adapters, table_size, entries[2];
+    oq_adapter_entry *table[2];
+} oq_isz;
+
+oq_isz *
+oq_isz_new(int64_t max_adapters)
+{
+    oq_isz *z = calloc(1, sizeof(oq_isz));
+    uint64_t bits = (uint64_t)(log2(max_adapters * 1.5) + 1); /* :5525 */
+    z->max_adapters = max_adapters;
+    z->table_size = 1ULL << bits;
+    z->table[0] = calloc(z->table_size, sizeof(oq_adapter_entry));
+    z->table[1] = calloc(z->table_size, sizeof(oq_adapter_entry));
+    z->insert_sizes = calloc(1, 8);
+    return z;
+}
+
+void
+oq_isz_free(oq_isz *z)
+{
+    if (!z) return;
+    free(z->insert_sizes); free(z->table[0]); free(z->table[1]);
+    free(z);
+}
+
+/* NUCLEOTIDE_COMPLEMENT :5613-5631: non-ACGT complements to byte 0 */
+static uint8_t
+oq_complement(uint8_t c)
+{
+    switch (c | 0x20) {
+        case 'a': return 'T';
+        case 'c': return 'G';
+        case 'g': return 'C';
+        case 't': return 'A';
+        default: return 0;
+    }
+}
+
+/* calculate_insert_size :5667-5707 */
+size_t
+oq_insert_size(const uint8_t *s1, size_t L1, const uint8_t *s2, size_t L2)
+{
+    if (L1 < 16 || L2 < 16) return 0;
+    uint8_t head[16], tail[16];
+    for (int i = 0; i < 16; i++) {
+        head[15 - i] = oq_complement(s2[i]);
+        tail[15 - i] = oq_complement(s2[L2 - 16 + i]);
+    }
+    for (size_t i = 0; i + 16 <= L1; i++) {
+        /* pre-filter on upper-cased R1 halves (:5693-5695), then the
+         * Hamming check on the raw R1 bytes (:5696) */
+        int lo_h = 1, hi_h = 1, lo_t = 1, hi_t = 1;
+        for (int j = 0; j < 8; j++) {
+            uint8_t a = s1[i + j] & 0xDF, b = s1[i + 8 + j] & 0xDF;
+            lo_h &= a == head[j]; hi_h &= b == head[8 + j];
+            lo_t &= a == tail[j]; hi_t &= b == tail[8 + j];
+        }
+        if (lo_h || hi_h) {
+            int d = 0;
+            for (int j = 0; j < 16; j++) d += s1[i + j] != head[j];
+            if (d <= 1) return i + 16;
+        }
+        if (lo_t || hi_t) {
+            int d = 0;
+            for (int j = 0; j < 16; j++) d += s1[i + j] != tail[j];
+            if (d <= 1) return i + L2;
+        }
+    }
+    return 0;
+}
+
+/* InsertSizeMetrics_add_adapter :5570-5611 */
+static void
+oq_isz_add_adapter(oq_isz *z, const uint8_t *a, size_t len, int which)
+{
+    uint64_t h = oq_murmur3_x64_64(a, len, 0);
+    oq_adapter_entry *t = z->table[which];
+    int full = z->entries[which] == z->max_adapters;
+    size_t mask = z->table_size - 1, i = h & mask;
+    for (;;) {
+        oq_adapter_entry *e = &t[i];
+        if (e->hash == h) {
+            if (len == e->len && memcmp(a, e->bytes, len) == 0) { e->count++; return; }
+        }
+        else if (e->count == 0) {
+            if (!full) {
+                e->hash = h; e->len = (uint8_t)len; e->count = 1;
+                memcpy(e->bytes, a, len);
+                z->entries[which]++;
+            }
+            return;
+        }
+        i = (i + 1) & mask;
+    }
+}
+
+/* InsertSizeMetrics_add_sequence_pair_ptr :5709-5744 */
+void
+oq_isz_add_pair(oq_isz *z, const uint8_t *s1, size_t L1, const uint8_t *s2, size_t L2)
+{
+    size_t sz = oq_insert_size(s1, L1, s2, L2);
+    if (sz > z->max_insert) {
+        z->insert_sizes = realloc(z->insert_sizes, (sz + 1) * 8);
+        memset(z->insert_sizes + z->max_insert + 1, 0, (sz - z->max_insert) * 8);
+        z->max_insert = sz;
+    }
+    z->total_reads++;
+    z->insert_sizes[sz]++;
+    if (sz == 0) return;
+    if (L1 > sz) {
+        size_t r = L1 - sz;
+        z->n_adapters[0]++;
+        oq_isz_add_adapter(z, s1 + sz, r < OQ_ADAPTER_STORE ? r : OQ_ADAPTER_STORE, 0);
+    }
+    if (L2 > sz) {
+        size_t r = L2 - sz;
+        z->n_adapters[1]++;
+        oq_isz_add_adapter(z, s2 + sz, r < OQ_ADAPTER_STORE ? r : OQ_ADAPTER_STORE, 1);
+    }
+}
+
+void
+oq_isz_add_pairs(oq_isz *z, const uint8_t *buf1, const oq_meta *m1,
+                 const uint8_t *buf2, const oq_meta *m2, size_t n)
+{
+    for (size_t r = 0; r < n; r++)
+        oq_isz_add_pair(z, buf1 + m1[r].record_start + m1[r].sequence_offset,
+                        m1[r].sequence_length,
+                        buf2 + m2[r].record_start + m2[r].sequence_offset,
+                        m2[r].sequence_length);
+}
+
+size_t oq_isz_max_insert(oq_isz *z) { return z->max_insert; }
+uint64_t oq_isz_total_reads(oq_isz *z) { return z->total_reads; }
+uint64_t oq_isz_n_adapters(oq_isz *z, int which) { return z->n_adapters[which]; }
+size_t oq_isz_n_entries(oq_isz *z, int which) { return z->entries[which]; }
+void oq_isz_get_sizes(oq_isz *z, uint64_t *o) { memcpy(o, z->insert_sizes, (z->max_insert + 1) * 8); }
+/* adapter_hash_table_to_python_list :5888-5912, slot order; bytes is
+ * [n][31], zero padded */
+size_t
+oq_isz_get_adapters(oq_isz *z, int which, uint8_t *bytes, uint8_t *lens, uint64_t *counts)
+{
+    size_t n = 0;
+    for (size_t i = 0; i < z->table_size; i++) {
+        oq_adapter_entry *e = &z->table[which][i];
+        if (!e->count) continue;
+        memset(bytes + n * OQ_ADAPTER_STORE, 0, OQ_ADAPTER_STORE);
+        memcpy(bytes + n * OQ_ADAPTER_STORE, e->bytes, e->len);
+        lens[n] = e->len;
+        counts[n] = e->count;
+        n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * Record boundary helpers
+ * --------------------------------------------------------------------- */
+/* fastq_names_are_mates, _qcmodule.c:777-800 (find_space :736-764) */
+int
+oq_names_are_mates(const uint8_t *n1, size_t l1, const uint8_t *n2, size_t l2)
+{
+    size_t id = 0;
+    while (id < l1 && n1[id] != ' ' && n1[id] != '\t') id++;
+    if (l2 < id) return 0;
+    if (l2 > id && !(n2[id] == ' ' || n2[id] == '\t')) return 0;
+    if (id > 0 && (n1[id - 1] == '1' || n1[id - 1] == '2') &&
+        (n2[id - 1] == '1' || n2[id - 1] == '2'))
+        id -= 1;
+    return memcmp(n1, n2, id) == 0;
+}

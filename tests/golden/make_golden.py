@@ -1,0 +1,427 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the compiled reference (oracle/_ref/_qc.abi3.so).
+
+Run in the build container only (needs oracle/_ref, built by `make -C oracle`
+from /root/reference, and the reference's tests/data for the file cases):
+
+    python tests/golden/make_golden.py
+
+Output: tests/golden/*.npz -- for every case the FASTQ text that was fed
+(input, as data) and every getter output of the reference's modules
+(expected).  The reference itself never travels; these files do.
+"""
+from __future__ import annotations
+
+import ctypes
+import gzip
+import io
+import itertools
+import json
+import os
+import string
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+sys.path.insert(0, ROOT)
+import _qc  # noqa: E402  (the reference build)
+
+REFDATA = "/root/reference/tests/data"
+
+ILLUMINA_PROBES = ["AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA",
+                   "GGGGGGGGGGGG", "AAAAAAAAAAAA"]  # adapter_list.tsv:8-15
+NANOPORE_PROBES = ["TTACGTATTGCT", "GCAATACGTAAC", "CTTGCGGGCGGC", "GGTAGTAGGTTC",
+                   "GAGGCGAGCGGT", "CAAGATACGCAC", "GTGACTTGCCTG", "ATCGCCTACCGT",
+                   "TCTATCTTCTTT", "TCTTCAGAGGAG", "GATATTGCTGGG", "TGATATTGCTTT",
+                   "GTACGTATTGCT", "ACGTAACTGAAC"]  # adapter_list.tsv:35-57
+
+
+def read_file(name: str) -> bytes:
+    path = os.path.join(REFDATA, name)
+    opener = gzip.open if name.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        return f.read()
+
+
+def fastq_text(records) -> bytes:
+    return b"".join(b"@%s\n%s\n+\n%s\n" % (n.encode(), s.encode(), q.encode())
+                    for n, s, q in records)
+
+
+def arrays_of(text: bytes, buffersize: int = 128 * 1024):
+    """The reference's own parser, its own chunking."""
+    return list(_qc.FastqParser(io.BytesIO(text), buffersize))
+
+
+def error_rates_of(arr) -> np.ndarray:
+    """accumulated_error_rate of every FastqMeta in a reference array object
+    (object layout: SURVEY 8b interop note; ob_size@16, records@32, 40 B each)."""
+    n = len(arr)
+    raw = (ctypes.c_char * (n * 40)).from_address(id(arr) + 32)
+    return np.frombuffer(bytes(raw), dtype=np.dtype([("pad", "V32"), ("err", "<f8")]))["err"].copy()
+
+
+def qc_outputs(arrays, end_anchor=100, prefix="qc_"):
+    m = _qc.QCMetrics(end_anchor)
+    errs = []
+    for a in arrays:
+        m.add_record_array(a)
+        errs.append(error_rates_of(a))
+    return {
+        prefix + "base": np.array(m.base_count_table(), np.uint64),
+        prefix + "phred": np.array(m.phred_count_table(), np.uint64),
+        prefix + "ea_base": np.array(m.end_anchored_base_count_table(), np.uint64),
+        prefix + "ea_phred": np.array(m.end_anchored_phred_count_table(), np.uint64),
+        prefix + "gc": np.array(m.gc_content(), np.uint64),
+        prefix + "phred_scores": np.array(m.phred_scores(), np.uint64),
+        prefix + "number_of_reads": np.uint64(m.number_of_reads),
+        prefix + "max_length": np.uint64(m.max_length),
+        prefix + "end_anchor": np.uint64(end_anchor),
+        prefix + "error_rates": np.concatenate(errs) if errs else np.zeros(0),
+    }
+
+
+def adapter_outputs(arrays, probes, prefix="ad_"):
+    c = _qc.AdapterCounter(probes)
+    for a in arrays:
+        c.add_record_array(a)
+    counts = c.get_counts()
+    return {
+        prefix + "probes": np.array(probes),
+        prefix + "fwd": np.array([np.array(f, np.uint64) for _, f, _ in counts], np.uint64).reshape(len(probes), -1),
+        prefix + "rev": np.array([np.array(r, np.uint64) for _, _, r in counts], np.uint64).reshape(len(probes), -1),
+        prefix + "max_length": np.uint64(c.max_length),
+        prefix + "number_of_sequences": np.uint64(c.number_of_sequences),
+    }
+
+
+def pertile_outputs(arrays, prefix="pt_"):
+    p = _qc.PerTileQuality()
+    for a in arrays:
+        p.add_record_array(a)
+    tc = p.get_tile_counts()
+    ml = p.max_length
+    return {
+        prefix + "tiles": np.array([t for t, _, _ in tc], np.int64),
+        prefix + "errors": np.array([e for _, e, _ in tc], np.float64).reshape(len(tc), ml),
+        prefix + "counts": np.array([c for _, _, c in tc], np.uint64).reshape(len(tc), ml),
+        prefix + "max_length": np.uint64(ml),
+        prefix + "number_of_reads": np.uint64(p.number_of_reads),
+        prefix + "skipped_reason": np.array(p.skipped_reason or ""),
+    }
+
+
+def overrep_outputs(arrays, prefix="ov_", **kw):
+    import warnings
+    o = _qc.OverrepresentedSequences(**kw)
+    nwarn = 0
+    for a in arrays:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            o.add_record_array(a)
+            nwarn += len(w)
+    sc = o.sequence_counts()
+    keys = sorted(sc)
+    ovr = o.overrepresented_sequences()
+    return {
+        prefix + "kwargs": np.array(json.dumps(kw)),
+        prefix + "seqs": np.array(keys),
+        prefix + "counts": np.array([sc[k] for k in keys], np.uint64),
+        prefix + "number_of_sequences": np.uint64(o.number_of_sequences),
+        prefix + "sampled_sequences": np.uint64(o.sampled_sequences),
+        prefix + "total_fragments": np.uint64(o.total_fragments),
+        prefix + "collected_unique_fragments": np.uint64(o.collected_unique_fragments),
+        prefix + "ovr_counts": np.array([c for c, _, _ in ovr], np.uint64),
+        prefix + "ovr_fracs": np.array([f for _, f, _ in ovr], np.float64),
+        prefix + "ovr_seqs": np.array([s for _, _, s in ovr]),
+    }
+
+
+def dedup_outputs(arrays, arrays2=None, prefix="dd_", **kw):
+    d = _qc.DedupEstimator(**kw)
+    if arrays2 is None:
+        for a in arrays:
+            d.add_record_array(a)
+    else:
+        for a, b in zip(arrays, arrays2):
+            d.add_record_array_pair(a, b)
+    return {
+        prefix + "kwargs": np.array(json.dumps(kw)),
+        prefix + "counts_slot_order": np.array(d.duplication_counts(), np.uint64),
+        prefix + "modulo_bits": np.uint64(d._modulo_bits),
+        prefix + "tracked_sequences": np.uint64(d.tracked_sequences),
+        prefix + "hash_table_size": np.uint64(d._hash_table_size),
+    }
+
+
+def insert_outputs(arrays1, arrays2, prefix="is_", **kw):
+    z = _qc.InsertSizeMetrics(**kw)
+    for a, b in zip(arrays1, arrays2):
+        z.add_record_array_pair(a, b)
+    a1, a2 = z.adapters_read1(), z.adapters_read2()
+    return {
+        prefix + "kwargs": np.array(json.dumps(kw)),
+        prefix + "insert_sizes": np.array(z.insert_sizes(), np.uint64),
+        prefix + "total_reads": np.uint64(z.total_reads),
+        prefix + "n_adapters_read1": np.uint64(z.number_of_adapters_read1),
+        prefix + "n_adapters_read2": np.uint64(z.number_of_adapters_read2),
+        prefix + "ad1_seqs": np.array([s for s, _ in a1]), prefix + "ad1_counts": np.array([c for _, c in a1], np.uint64),
+        prefix + "ad2_seqs": np.array([s for s, _ in a2]), prefix + "ad2_counts": np.array([c for _, c in a2], np.uint64),
+    }
+
+
+def paired_arrays(text1: bytes, text2: bytes):
+    """Lock-step reading like __main__.py:279-285."""
+    p1 = _qc.FastqParser(io.BytesIO(text1))
+    p2 = _qc.FastqParser(io.BytesIO(text2))
+    a1, a2 = [], []
+    for arr in p1:
+        a1.append(arr)
+        a2.append(p2.read(len(arr)))
+    return a1, a2
+
+
+def save(name: str, **arrays):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in list(arrays.items())[:4]}, "...")
+
+
+def single_end_case(name: str, text: bytes, probes, **extra):
+    arrays = arrays_of(text)
+    out = {"fastq": np.frombuffer(text, np.uint8)}
+    out.update(qc_outputs(arrays))
+    out.update(adapter_outputs(arrays, probes))
+    out.update(pertile_outputs(arrays))
+    out.update(overrep_outputs(arrays))
+    out.update(overrep_outputs(arrays, prefix="ov1_", sample_every=1))
+    out.update(overrep_outputs(arrays, prefix="ovcap_", sample_every=1, max_unique_fragments=50,
+                               fragment_length=11, bases_from_start=-1, bases_from_end=-1))
+    out.update(dedup_outputs(arrays))
+    out.update(dedup_outputs(arrays, prefix="dd0_", front_sequence_offset=64, back_sequence_offset=0))
+    out.update(dedup_outputs(arrays, prefix="ddcap_", max_stored_fingerprints=100,
+                             front_sequence_length=5, back_sequence_length=4,
+                             front_sequence_offset=3, back_sequence_offset=2))
+    out.update(extra)
+    save(name, **out)
+
+
+def main():
+    # (5) SCORE_TO_ERROR_RATE bit patterns, read back through PerTileQuality
+    bits = []
+    for q in range(94):
+        p = _qc.PerTileQuality()
+        p.add_read(_qc.FastqRecordView("a:b:c:d:7:x", "A", chr(q + 33)))
+        bits.append(int(np.float64(p.get_tile_counts()[0][1][0]).view(np.uint64)))
+    with open(os.path.join(HERE, "error_table.json"), "wt") as f:
+        json.dump(["0x%016x" % b for b in bits], f, indent=0)
+
+    # (1) the reference's own test data
+    single_end_case("ref_simple", read_file("simple.fastq"), ILLUMINA_PROBES)
+    single_end_case("ref_100_illumina_adapters", read_file("100_illumina_adapters.fastq"), ILLUMINA_PROBES)
+    single_end_case("ref_100_nanopore", read_file("100_nanopore_reads.fastq.gz"), NANOPORE_PROBES)
+    for small in ("empty.fastq", "empty_read.fastq", "single_nuc.fastq",
+                  "single_illumina_metadata.fastq"):
+        single_end_case("ref_" + small.replace(".fastq", ""), read_file(small), ILLUMINA_PROBES)
+
+    t1 = read_file("LTB-A-BC001_S1_L003_R1_001.fastq.gz")
+    t2 = read_file("LTB-A-BC001_S1_L003_R2_001.fastq.gz")
+    a1, a2 = paired_arrays(t1, t2)
+    out = {"fastq1": np.frombuffer(t1, np.uint8), "fastq2": np.frombuffer(t2, np.uint8)}
+    out.update(qc_outputs(a1, prefix="qc1_"))
+    out.update(qc_outputs(a2, prefix="qc2_"))
+    out.update(pertile_outputs(a1, prefix="pt1_"))
+    out.update(pertile_outputs(a2, prefix="pt2_"))
+    out.update(overrep_outputs(a1, prefix="ov1_"))
+    out.update(overrep_outputs(a2, prefix="ov2_"))
+    out.update(adapter_outputs(a1, ILLUMINA_PROBES, prefix="ad1_"))
+    out.update(dedup_outputs(a1, a2, prefix="dd_", front_sequence_offset=0, back_sequence_offset=0))
+    out.update(dedup_outputs(a1, a2, prefix="ddcap_", max_stored_fingerprints=100,
+                             front_sequence_offset=0, back_sequence_offset=0))
+    out.update(insert_outputs(a1, a2))
+    out.update(insert_outputs(a1, a2, prefix="iscap_", max_adapters=16))
+    out["is_mate"] = np.array([x.is_mate(y) for x, y in zip(a1, a2)])
+    save("ref_LTB_paired", **out)
+
+    # (2) inline cases of the reference's tests, re-expressed as data
+    cases = [
+        ("A" * 10 + "C" * 10 + "G" * 10 + "T" * 10 + "N" * 10, chr(43) * 25 + chr(63) * 25),
+        ("A" * 50, chr(34) * 25 + chr(38) * 25),
+        (4096 * "A" + 4096 * "C", 2048 * chr(33) + 2048 * chr(43) + 2048 * chr(53) + 2048 * chr(63)),
+        ("acgtnACGTNKkRr-*", "!\"#$%&'()*+,-./~"),
+        ("", ""),
+    ]
+    for ea in (15, 50, 100, 0):
+        for i, (s, q) in enumerate(cases):
+            text = fastq_text([("name", s, q)])
+            save(f"inline_qc_{i}_ea{ea}", fastq=np.frombuffer(text, np.uint8),
+                 **qc_outputs(arrays_of(text), end_anchor=ea))
+
+    # test_average_long_quality (tests/test_qc_metrics.py:162-173), scaled to 2 Mbp
+    # to keep the fixture small; the 20 Mbp original runs in the live comparison
+    n = 2_000_000
+    text = fastq_text([("name", n * "A", 1000 * chr(33) + (n - 1000) * chr(83))])
+    o = qc_outputs(arrays_of(text, 8 * 1024 * 1024))
+    save("inline_qc_long_quality", n=np.uint64(n), qc_gc=o["qc_gc"],
+         qc_phred_scores=o["qc_phred_scores"], qc_error_rates=o["qc_error_rates"])
+
+    # (4) H1 grid: uniform-quality reads, 94 qualities x 7 lengths
+    lengths = [1, 2, 5, 36, 100, 150, 151]
+    grid = np.zeros((94, len(lengths)), np.int64)
+    errs = np.zeros((94, len(lengths)), np.float64)
+    for q in range(94):
+        for j, L in enumerate(lengths):
+            text = fastq_text([("n", "A" * L, chr(q + 33) * L)])
+            o = qc_outputs(arrays_of(text))
+            grid[q, j] = int(np.nonzero(o["qc_phred_scores"])[0][0])
+            errs[q, j] = o["qc_error_rates"][0]
+    save("h1_uniform_quality_grid", lengths=np.array(lengths), bins=grid, error_rates=errs)
+
+    # adapter counter: multi-word cases (tests/test_adapter_counter.py:98-166)
+    for i, probes in enumerate([
+            ["A" * 64, "C" * 64, "G" * 64, "T" * 64],
+            ["A" * 64, "C" * 64, "G" * 64],
+            ["A" * 64, "C" * 64],
+            ["A" * 64, "C" * 64, "G" * 64, "T" * 64, "N" * 64]]):
+        seq = ("GATTACA" * 20).join(probes)
+        text = fastq_text([("name", seq, "H" * len(seq))])
+        save(f"inline_adapter_words_{i}", fastq=np.frombuffer(text, np.uint8),
+             **adapter_outputs(arrays_of(text), probes))
+    mixed = ["TATAAATATAAATATAAA", "GATTACAGATTACAGATTACA", "AAAAAAAAAAAA", "TTTTTTTTTTTT",
+             "CACGTCAGTTACCGGATAGA", "GGTCAAGGGGTAAATGATAT", "AGGTAGATTTATTTTATTTAT", "GGGTGGGAGGCC"]
+    seqs = ["NNNNN".join(mixed[i] for i in range(8)),
+            "NNNNNNN".join(mixed[i] for i in (1, 2, 4, 5, 6, 7)),
+            "NNN".join(mixed[i] for i in (7, 2, 6, 3, 4, 7)),
+            "AAGATTACAAAAAGATTACAGGGGAACGAGGGG", "nnnnKKKKggtcaaggggtaaatgatat"]
+    text = fastq_text([("name", s, "H" * len(s)) for s in seqs])
+    save("inline_adapter_mixed", fastq=np.frombuffer(text, np.uint8),
+         **adapter_outputs(arrays_of(text), mixed + ["GATTACA", "GGGG", "TTTTT", "NNNN", "KK"]))
+
+    # per tile: malformed headers (tests/test_per_tile_quality.py:66-85) after good ones
+    good = [(f"SIM:1:FCX:1:{t}:6329:1045:GATTACT+GTCTTAAC 1:N:0:ATCCGA", "ACGT" * (1 + t % 3), "ABCD" * (1 + t % 3))
+            for t in list(range(100)) + [1234, 99239]]
+    bad_headers = ["SIMULATED_NAME", "SIM:1:FCX:1::6329:1045:GATTACT+GTCTTAAC 1:N:0:ATCCGA",
+                   "SIM:1:FCX:1:abc:6329:1045:GATTACT+GTCTTAAC 1:N:0:ATCCGA",
+                   "SIM:1:FCX:1:0x1a3:6329:1045:GATTACT+GTCTTAAC 1:N:0:ATCCGA",
+                   "SIM:1:FCX:1", "SIM:1:FCX:1:1045", "a:b:c:d:1234567890123456789:e"]
+    save("inline_pertile_good", fastq=np.frombuffer(fastq_text(good), np.uint8),
+         **pertile_outputs(arrays_of(fastq_text(good))))
+    for i, h in enumerate(bad_headers):
+        recs = good[:7] + [(h, "AAAA", "ABCD")] + good[7:20]
+        text = fastq_text(recs)
+        save(f"inline_pertile_bad_{i}", fastq=np.frombuffer(text, np.uint8),
+             **pertile_outputs(arrays_of(text)))
+
+    # overrepresented: the small parametrised cases (tests/test_overrepresented_sequences.py:147-208)
+    for i, s in enumerate(["GATTACAGATTACA", "GATTACAAA", "GA", "GATT", "GATTACGATTAC", "ACT", "KKK", "ACGTN"]):
+        text = fastq_text([("name", s, "A" * len(s))])
+        save(f"inline_overrep_k3_{i}", fastq=np.frombuffer(text, np.uint8),
+             **overrep_outputs(arrays_of(text), fragment_length=3, sample_every=1))
+    text = fastq_text([("name", "AACCGGTTTTGGCCAA", "A" * 16)])
+    for i, (bs, be) in enumerate([(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (1, 0), (0, 1), (100, 100), (-1, -1)]):
+        save(f"inline_overrep_ends_{i}", fastq=np.frombuffer(text, np.uint8),
+             **overrep_outputs(arrays_of(text), fragment_length=3, sample_every=1,
+                               bases_from_start=bs, bases_from_end=be))
+    # cap crossing (tests/test_overrepresented_sequences.py:33-60, scaled: 4^6 reads, cap 1000)
+    recs = [("n", "".join(c) + 25 * "A", "H" * 31) for c in itertools.product("ACGT", repeat=6)]
+    recs.append(("n", 31 * "A", 31 * "A"))
+    text = fastq_text(recs)
+    save("inline_overrep_cap", fastq=np.frombuffer(text, np.uint8),
+         **overrep_outputs(arrays_of(text), max_unique_fragments=1000, fragment_length=31, sample_every=1))
+
+    # dedup: modulo switching (tests/test_dedup_estimator.py:41-53)
+    ten = [string.ascii_letters] * 10
+    seqs = ["".join(x) for _, x in zip(range(10000), itertools.product(*ten))]
+    text = fastq_text([("n", s, "A" * len(s)) for s in seqs])
+    for cap in (100, 137, 179, 500):
+        save(f"inline_dedup_cap{cap}", fastq=np.frombuffer(text, np.uint8),
+             **dedup_outputs(arrays_of(text), max_stored_fingerprints=cap))
+    six = ["123456AC TA123451", "234561AC AA234561", "345612AC TA345611",
+           "456123AG AA456121", "561234AG TA561231", "612345AG AA612341"]
+    text = fastq_text([("n", s, "A" * len(s)) for s in six])
+    text1 = fastq_text([("n", s.split()[0], "A" * 8) for s in six])
+    text2 = fastq_text([("n", s.split()[1], "A" * 8) for s in six])
+    a1, a2 = paired_arrays(text1, text2)
+    for i, (fl, fo, bl, bo) in enumerate([(8, 0, 8, 0), (0, 0, 6, 0), (1, 6, 1, 6), (2, 6, 1, 6),
+                                          (2, 6, 2, 6), (1, 0, 0, 0), (0, 0, 1, 0), (1, 6, 1, 1),
+                                          (2, 6, 2, 0), (0, 0, 1, 7)]):
+        kw = dict(front_sequence_length=fl, front_sequence_offset=fo, back_sequence_length=bl,
+                  back_sequence_offset=bo, max_stored_fingerprints=100)
+        save(f"inline_dedup_geom_{i}", fastq=np.frombuffer(text, np.uint8),
+             fastq1=np.frombuffer(text1, np.uint8), fastq2=np.frombuffer(text2, np.uint8),
+             **dedup_outputs(arrays_of(text), **kw),
+             **dedup_outputs(a1, a2, prefix="ddp_", **kw))
+
+    # insert size (tests/test_insert_size_metrics.py:24-80)
+    R1, R2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+    pairs = [("ATATATATATATATAT", "ATATATATATATATAT"),
+             ("ATATATATATATATATNNNNNNNNNN", "ATATATATATATATATNNNNNNNNNN"),
+             ("NNNNNNNNNNATATATATATATATAT", "ATATATATATATATATNNNNNNNNNN"),
+             ("ACGTTGCAGCTATCGA" + R1, "TCGATAGCTGCAACGT" + R2),
+             ("GTACACGTTGCAGCTATCGA" + R1, "TCGATAGCTGCAACGTGTAC" + R2),
+             ("GTACACGTTGCAGCTATCGA" + R1, "tcgatagctgcaacgtgtac" + R2),
+             ("GTACACGTTGCAGCTATCGA" + R1, "tcGatagCTgcaAcgtGtac" + R2),
+             ("gtacacgttgcagctatcga" + R1, "TCGATAGCTGCAACGTGTAC" + R2),   # lowercase R1 (Q8)
+             ("GTACACGTTGCAGCTATCGT" + R1, "TCGATAGCTGCAACGTGTAC" + R2),   # one mismatch
+             ("GTACACGTTGCAGCTATGGT" + R1, "TCGATAGCTGCAACGTGTAC" + R2),   # two mismatches
+             ("ACGT", "ACGT"), ("A" * 15, "T" * 40), ("", "")]
+    text1 = fastq_text([("n", a, "A" * len(a)) for a, _ in pairs])
+    text2 = fastq_text([("n", b, "A" * len(b)) for _, b in pairs])
+    for i in range(len(pairs)):
+        one1 = fastq_text([("n", pairs[i][0], "A" * len(pairs[i][0]))])
+        one2 = fastq_text([("n", pairs[i][1], "A" * len(pairs[i][1]))])
+        a1, a2 = paired_arrays(one1, one2)
+        if not a1:   # empty pair: the parser yields nothing
+            continue
+        save(f"inline_insert_{i}", fastq1=np.frombuffer(one1, np.uint8),
+             fastq2=np.frombuffer(one2, np.uint8), **insert_outputs(a1, a2))
+    a1, a2 = paired_arrays(text1, text2)
+    save("inline_insert_all", fastq1=np.frombuffer(text1, np.uint8),
+         fastq2=np.frombuffer(text2, np.uint8), **insert_outputs(a1, a2))
+
+    # is_mate (tests/test_fastq_record_array.py:22-43)
+    names = [("same", "same", True), ("same1", "same2", True),
+             ("same with comments", "same different comments", True),
+             ("same1 with comments", "same2 different comments", True),
+             ("same1", "same2 with comments", True), ("same1 with comments", "same2", True),
+             ("differnt", "diferent", False), ("different with comment", "diferent with comment", False),
+             ("same1", "same3", False), ("same2", "same1", True), ("same2", "same5", False)]
+    got = []
+    for a, b, _ in names:
+        x = _qc.FastqRecordArrayView([_qc.FastqRecordView(a, "A", "A")])
+        y = _qc.FastqRecordArrayView([_qc.FastqRecordView(b, "A", "A")])
+        got.append(x.is_mate(y))
+    with open(os.path.join(HERE, "is_mate.json"), "wt") as f:
+        json.dump([[a, b, bool(g)] for (a, b, _), g in zip(names, got)], f, indent=0)
+
+
+def synthetic():
+    """(3) slices of the build's own synthetic generator (needs libsqgpu.so's host
+    generator; run after `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    from sequali_amd import synth
+    text = synth.illumina_fastq(0, 20000, seed=synth.DEFAULT_SEED)
+    single_end_case("synth_illumina_20k", text, ILLUMINA_PROBES)
+    t1, t2 = synth.illumina_paired_fastq(0, 20000, seed=synth.DEFAULT_SEED)
+    a1, a2 = paired_arrays(t1, t2)
+    out = {"fastq1": np.frombuffer(t1, np.uint8), "fastq2": np.frombuffer(t2, np.uint8)}
+    out.update(qc_outputs(a1, prefix="qc1_"))
+    out.update(qc_outputs(a2, prefix="qc2_"))
+    out.update(pertile_outputs(a1, prefix="pt1_"))
+    out.update(pertile_outputs(a2, prefix="pt2_"))
+    out.update(dedup_outputs(a1, a2, prefix="dd_", front_sequence_offset=0, back_sequence_offset=0))
+    out.update(dedup_outputs(a1, a2, prefix="ddcap_", max_stored_fingerprints=1000,
+                             front_sequence_offset=0, back_sequence_offset=0))
+    out.update(insert_outputs(a1, a2))
+    out.update(insert_outputs(a1, a2, prefix="iscap_", max_adapters=16))
+    save("synth_illumina_paired_20k", **out)
+    text = synth.nanopore_fastq(0, 300, seed=synth.DEFAULT_SEED)
+    single_end_case("synth_nanopore_300", text, NANOPORE_PROBES)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "synthetic":
+        synthetic()
+    else:
+        main()
