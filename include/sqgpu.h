@@ -1,0 +1,254 @@
+/*
+ * sqgpu.h -- C ABI of libsqgpu.so: sequali's per-read QC accumulators on
+ * MI355X (gfx950).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Every entry point replaces a function of the reference's `_qc` extension
+ * (paths relative to src/sequali/ of rhpvorderman/sequali v1.0.2).  The
+ * reference hands each module a FastqRecordArrayView = one bytes buffer + an
+ * array of 40-byte FastqMeta structs (_qcmodule.c:337-355, 575-579); here the
+ * same pair crosses the boundary as (buf, buf_len, sq_meta*, n) with the
+ * record_start pointer turned into a byte offset into buf.
+ *
+ * Conventions (the reference's C convention, _qcmodule.c:2183-2204 etc.):
+ * functions returning int give 0 on success and a negative SQ_ERR_* code on
+ * failure; sq_last_error() then holds the message the reference would have
+ * put into the Python exception.  Work is enqueued on the context's HIP
+ * stream and is asynchronous: a deferred error (e.g. an invalid phred byte)
+ * surfaces at the module's *_flush() or at its first getter, which flush.
+ * Objects are not thread-safe (neither are the reference's).
+ */
+#ifndef SQGPU_H
+#define SQGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_ABI_VERSION 1
+
+#define SQ_OK 0
+#define SQ_ERR_HIP (-1)           /* a HIP runtime call failed (RuntimeError)            */
+#define SQ_ERR_VALUE (-2)         /* ValueError, e.g. "Not a valid phred character: %c"   */
+#define SQ_ERR_MEMORY (-3)        /* MemoryError                                          */
+#define SQ_ERR_TYPE (-4)          /* TypeError                                            */
+#define SQ_ERR_EOF (-5)           /* EOFError: incomplete record at the end of the file   */
+#define SQ_ERR_OVERFLOW (-6)      /* OverflowError                                        */
+
+#define SQ_NUMBER_OF_NUCS 5       /* NUC_TABLE_SIZE   _qcmodule.c:1766 */
+#define SQ_NUMBER_OF_PHREDS 12    /* PHRED_TABLE_SIZE _qcmodule.c:1768 */
+#define SQ_PHRED_MAX 93           /* _qcmodule.c:101  */
+#define SQ_MAX_SEQUENCE_SIZE 64   /* _qcmodule.c:2393 */
+#define SQ_ADAPTER_STORE_SIZE 31  /* INSERT_SIZE_MAX_ADAPTER_STORE_SIZE _qcmodule.c:5457 */
+
+/* struct FastqMeta, _qcmodule.c:337-355, same size and field order; the
+ * pointer is an offset so that the array is position independent. */
+typedef struct sq_meta {
+    uint64_t record_start;        /* offset of the first name byte in buf */
+    uint32_t name_length;
+    uint32_t sequence_offset;     /* relative to record_start */
+    uint32_t sequence_length;
+    uint32_t qualities_offset;    /* relative to record_start */
+    uint32_t tags_offset;
+    uint32_t tags_length;
+    double accumulated_error_rate; /* written by QCMetrics (_qcmodule.c:2126) */
+} sq_meta;
+
+typedef struct sq_ctx sq_ctx;
+typedef struct sq_batch sq_batch;
+typedef struct sq_qcmetrics sq_qcmetrics;
+typedef struct sq_adaptercounter sq_adaptercounter;
+typedef struct sq_pertile sq_pertile;
+typedef struct sq_overrep sq_overrep;
+typedef struct sq_dedup sq_dedup;
+typedef struct sq_insertsize sq_insertsize;
+
+/* ---- library / context ------------------------------------------------ */
+int sq_abi_version(void);
+const char *sq_last_error(void);
+/* One context per process and GPU: selects `device`, creates the stream all
+ * work of its modules is ordered on.  NULL on failure. */
+sq_ctx *sq_init(int device);
+void sq_shutdown(sq_ctx *ctx);
+int sq_synchronize(sq_ctx *ctx);
+/* hipStream_t of the context, for event timing / interop by the caller. */
+void *sq_stream_handle(sq_ctx *ctx);
+
+/* ---- record boundary, host side (no GPU involved) ---------------------- */
+/* The record loop of FastqParser_create_record_array, _qcmodule.c:1093-1171:
+ * split FASTQ text into records.  Writes up to `cap` metas (offsets relative
+ * to buf), stores the number of bytes consumed by complete records in
+ * *consumed.  Returns the record count or a negative SQ_ERR_* (bad '@'/'+',
+ * unequal sequence/quality length). */
+int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas, size_t cap,
+                       size_t *consumed);
+/* string_is_ascii, _qcmodule.c:203-237: index of the first byte >= 0x80 or -1 */
+int64_t sq_first_non_ascii(const uint8_t *buf, size_t len);
+/* FastqRecordArrayView_is_mate, _qcmodule.c:814-850 (fastq_names_are_mates
+ * :777-800): 1 if every pair of names matches, else 0. */
+int sq_names_are_mates(const uint8_t *buf1, const sq_meta *metas1, const uint8_t *buf2,
+                       const sq_meta *metas2, size_t n);
+
+/* ---- batches: a record array resident in HBM --------------------------- */
+/* Copies buf and metas to the device (the reference's modules borrow the
+ * array for the duration of the call, _qcmodule.c:575-607; a deferred GPU
+ * pass must own a copy). */
+sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_len,
+                          const sq_meta *metas, size_t n);
+/* Wraps memory that already lives on the device (borrowed, not freed). */
+sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len, void *d_metas,
+                               size_t n);
+void sq_batch_free(sq_batch *b);
+uint64_t sq_batch_size(const sq_batch *b);
+uint64_t sq_batch_total_bases(const sq_batch *b);
+uint64_t sq_batch_max_length(const sq_batch *b);
+uint64_t sq_batch_bytes(const sq_batch *b);
+/* Copies the batch back to the host: buf_len bytes and n metas. */
+int sq_batch_download(sq_batch *b, uint8_t *buf, size_t buf_cap, sq_meta *metas, size_t meta_cap);
+/* metas[i].accumulated_error_rate of every record, after QCMetrics ran. */
+int sq_batch_error_rates(sq_batch *b, double *out, size_t n);
+
+/* ---- QCMetrics, _qcmodule.c:1786-2385 ---------------------------------- */
+sq_qcmetrics *sq_qcmetrics_new(sq_ctx *ctx, uint64_t end_anchor_length); /* QCMetrics__new__ :1821 */
+void sq_qcmetrics_free(sq_qcmetrics *m);
+/* QCMetrics_add_record_array :2183, from host memory; also writes
+ * accumulated_error_rate into metas (synchronises). */
+int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_len, sq_meta *metas, size_t n);
+int sq_qcmetrics_add_batch(sq_qcmetrics *m, sq_batch *b);
+int sq_qcmetrics_flush(sq_qcmetrics *m);
+uint64_t sq_qcmetrics_number_of_reads(sq_qcmetrics *m);    /* members :2361-2369 */
+uint64_t sq_qcmetrics_max_length(sq_qcmetrics *m);
+uint64_t sq_qcmetrics_end_anchor_length(sq_qcmetrics *m);
+/* getters :2215-2334; each returns the element count (or <0) and fills `out`
+ * when cap is large enough: max_length*5, max_length*12, end_anchor*5,
+ * end_anchor*12, 101, 94 */
+int64_t sq_qcmetrics_base_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap);
+int64_t sq_qcmetrics_phred_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap);
+int64_t sq_qcmetrics_end_anchored_base_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap);
+int64_t sq_qcmetrics_end_anchored_phred_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap);
+int64_t sq_qcmetrics_gc_content(sq_qcmetrics *m, uint64_t *out, size_t cap);
+int64_t sq_qcmetrics_phred_scores(sq_qcmetrics *m, uint64_t *out, size_t cap);
+
+/* ---- AdapterCounter, _qcmodule.c:2391-2969 ------------------------------ */
+/* AdapterCounter__new__ :2464: n ASCII adapters, each at most 64 bytes. */
+sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *const *adapters,
+                                         const size_t *lengths, size_t n);
+void sq_adaptercounter_free(sq_adaptercounter *a);
+int sq_adaptercounter_add(sq_adaptercounter *a, const uint8_t *buf, size_t buf_len,
+                          const sq_meta *metas, size_t n);          /* :2867 */
+int sq_adaptercounter_add_batch(sq_adaptercounter *a, sq_batch *b);
+int sq_adaptercounter_flush(sq_adaptercounter *a);
+uint64_t sq_adaptercounter_number_of_sequences(sq_adaptercounter *a);
+uint64_t sq_adaptercounter_max_length(sq_adaptercounter *a);
+uint64_t sq_adaptercounter_number_of_adapters(sq_adaptercounter *a);
+/* get_counts :2902: forward and reverse arrays of adapter i, max_length each */
+int64_t sq_adaptercounter_get_counts(sq_adaptercounter *a, size_t i, uint64_t *forward,
+                                     uint64_t *reverse, size_t cap);
+
+/* ---- PerTileQuality, _qcmodule.c:2975-3397 ------------------------------ */
+sq_pertile *sq_pertile_new(sq_ctx *ctx);
+void sq_pertile_free(sq_pertile *p);
+int sq_pertile_add(sq_pertile *p, const uint8_t *buf, size_t buf_len, const sq_meta *metas, size_t n); /* :3268 */
+int sq_pertile_add_batch(sq_pertile *p, sq_batch *b);
+int sq_pertile_flush(sq_pertile *p);
+uint64_t sq_pertile_number_of_reads(sq_pertile *p);
+uint64_t sq_pertile_max_length(sq_pertile *p);
+/* skipped_reason :3377: NULL while the module is active, else
+ * "Can not parse header: <repr of the header>" (:3143) */
+const char *sq_pertile_skipped_reason(sq_pertile *p);
+uint64_t sq_pertile_number_of_tiles(sq_pertile *p);
+/* get_tile_counts :3307: ascending tile ids; errors and counts are
+ * [tiles][max_length], counts already reverse-cumulated */
+int64_t sq_pertile_get_tile_counts(sq_pertile *p, int64_t *tile_ids, double *errors,
+                                   uint64_t *counts, size_t cap_tiles, size_t cap_len);
+
+/* ---- one fused pass over a batch for the three per-base modules --------- */
+/* Any of the three may be NULL.  Same result as calling the three
+ * *_add_batch functions one after the other, with one read of the batch. */
+int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p);
+
+/* ---- OverrepresentedSequences, _qcmodule.c:3435-4236 --------------------- */
+sq_overrep *sq_overrep_new(sq_ctx *ctx, int64_t max_unique_fragments, int64_t fragment_length,
+                           int64_t sample_every, int64_t bases_from_start,
+                           int64_t bases_from_end);                  /* :3464 */
+void sq_overrep_free(sq_overrep *o);
+int sq_overrep_add(sq_overrep *o, const uint8_t *buf, size_t buf_len, const sq_meta *metas, size_t n); /* :3987 */
+int sq_overrep_add_batch(sq_overrep *o, sq_batch *b);
+int sq_overrep_flush(sq_overrep *o);
+uint64_t sq_overrep_number_of_sequences(sq_overrep *o);          /* members :4199-4220 */
+uint64_t sq_overrep_sampled_sequences(sq_overrep *o);
+uint64_t sq_overrep_collected_unique_fragments(sq_overrep *o);
+uint64_t sq_overrep_total_fragments(sq_overrep *o);
+/* Number of sampled reads that held a byte outside ACGTN (the reference
+ * raises one UserWarning per such read, :3931) and the index (counted over
+ * every record ever added) of the most recent one, or -1. */
+uint64_t sq_overrep_warning_count(sq_overrep *o);
+int64_t sq_overrep_last_warning_record(sq_overrep *o);
+/* sequence_counts :4020: k-mers (2 bits per base, first base most
+ * significant; already un-hashed) and their counts, unordered. */
+int64_t sq_overrep_get_counts(sq_overrep *o, uint64_t *kmers, uint64_t *counts, size_t cap);
+
+/* ---- DedupEstimator, _qcmodule.c:4270-4802 -------------------------------- */
+sq_dedup *sq_dedup_new(sq_ctx *ctx, int64_t max_stored_fingerprints, int64_t front_sequence_length,
+                       int64_t back_sequence_length, int64_t front_sequence_offset,
+                       int64_t back_sequence_offset);                /* :4301 */
+void sq_dedup_free(sq_dedup *d);
+int sq_dedup_add(sq_dedup *d, const uint8_t *buf, size_t buf_len, const sq_meta *metas, size_t n); /* :4531 */
+int sq_dedup_add_batch(sq_dedup *d, sq_batch *b);
+int sq_dedup_add_pair(sq_dedup *d, const uint8_t *buf1, size_t len1, const sq_meta *metas1,
+                      const uint8_t *buf2, size_t len2, const sq_meta *metas2, size_t n); /* :4572 */
+int sq_dedup_add_batch_pair(sq_dedup *d, sq_batch *b1, sq_batch *b2);
+int sq_dedup_flush(sq_dedup *d);
+uint64_t sq_dedup_modulo_bits(sq_dedup *d);                     /* members :4770-4786 */
+uint64_t sq_dedup_hash_table_size(sq_dedup *d);
+uint64_t sq_dedup_tracked_sequences(sq_dedup *d);
+/* duplication_counts :4721: the non-zero counts in slot order */
+int64_t sq_dedup_duplication_counts(sq_dedup *d, uint64_t *out, size_t cap);
+
+/* ---- InsertSizeMetrics, _qcmodule.c:5456-5982 ------------------------------ */
+sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters);  /* :5505 */
+void sq_insertsize_free(sq_insertsize *z);
+int sq_insertsize_add_pair(sq_insertsize *z, const uint8_t *buf1, size_t len1, const sq_meta *metas1,
+                           const uint8_t *buf2, size_t len2, const sq_meta *metas2, size_t n); /* :5808 */
+int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2);
+int sq_insertsize_flush(sq_insertsize *z);
+uint64_t sq_insertsize_total_reads(sq_insertsize *z);           /* members :5492-5502 */
+uint64_t sq_insertsize_number_of_adapters_read1(sq_insertsize *z);
+uint64_t sq_insertsize_number_of_adapters_read2(sq_insertsize *z);
+int64_t sq_insertsize_insert_sizes(sq_insertsize *z, uint64_t *out, size_t cap);  /* :5876 */
+/* adapters_read1/2 :5923-5944, slot order: bytes is [n][31] zero padded */
+int64_t sq_insertsize_adapters(sq_insertsize *z, int read2, uint8_t *bytes, uint8_t *lengths,
+                               uint64_t *counts, size_t cap);
+
+/* ---- multi-GPU: raw count tables for an all-reduce over RCCL --------------- */
+/* Exposes the device arrays of the additive tables (u64 counts; f64 for the
+ * per-tile error sums) so that the caller's collective can sum them in place
+ * across ranks (torch.distributed / RCCL).  Fills up to `cap` entries of
+ * (device pointer, element count); returns the number of arrays. */
+int64_t sq_qcmetrics_device_tables(sq_qcmetrics *m, void **ptrs, uint64_t *counts, size_t cap);
+int64_t sq_adaptercounter_device_tables(sq_adaptercounter *a, void **ptrs, uint64_t *counts, size_t cap);
+/* Pads the tables to `length` rows (after an all-reduce(max) of max_length)
+ * and, after the sum, sets the scalar members that are kept on the host. */
+int sq_qcmetrics_reserve(sq_qcmetrics *m, uint64_t length);
+int sq_qcmetrics_set_totals(sq_qcmetrics *m, uint64_t number_of_reads, uint64_t max_length);
+int sq_adaptercounter_reserve(sq_adaptercounter *a, uint64_t length);
+int sq_adaptercounter_set_totals(sq_adaptercounter *a, uint64_t number_of_sequences, uint64_t max_length);
+
+/* ---- synthetic FASTQ (bench / tests): counter-based, host == device bytes -- */
+#define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */
+#define SQ_SYNTH_ILLUMINA_R2 1    /* the mate of read i              */
+#define SQ_SYNTH_NANOPORE 2       /* variable length, ~10 kb          */
+/* Size in bytes of records [first, first+n) and the generators themselves.
+ * Host version writes FASTQ text + metas into caller memory; device version
+ * allocates a batch in HBM and fills it with a kernel. */
+uint64_t sq_synth_bytes(int kind, uint64_t seed, uint64_t first, uint64_t n);
+int sq_synth_host(int kind, uint64_t seed, uint64_t first, uint64_t n, uint8_t *buf,
+                  size_t buf_cap, sq_meta *metas);
+sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64_t first, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQGPU_H */

@@ -1,0 +1,872 @@
+"""Host-side mirror of the reference's ``sequali._qc`` extension for the QC hot
+path (src/sequali/_qc.pyi:45-188): same class names, constructor arguments,
+method names, return types and error behaviour, with the accumulation done by
+the HIP kernels behind libsqgpu.so (include/sqgpu.h).
+
+Deviations that follow from deferred execution on a stream:
+  * ``add_record_array`` enqueues work and returns; an invalid phred byte is
+    reported as ``ValueError`` by the next getter / ``flush()`` (``add_read`` is
+    synchronous and raises at once, like the reference);
+  * ``accumulated_error_rate`` is written into the array's metas when the
+    QCMetrics object is flushed (any getter flushes).
+"""
+from __future__ import annotations
+
+import array
+import ctypes as C
+import sys
+import warnings
+import weakref
+from typing import Dict, Iterable, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, context, lib
+
+# constants exported by the reference module (_qcmodule.c:6082-6171)
+NUMBER_OF_NUCS = 5
+NUMBER_OF_PHREDS = 12
+TABLE_SIZE = NUMBER_OF_PHREDS * NUMBER_OF_NUCS
+PHRED_MAX = 93
+A, C_, G, T, N = 0, 1, 2, 3, 4
+MAX_SEQUENCE_SIZE = 64
+DEFAULT_END_ANCHOR_LENGTH = 100
+DEFAULT_MAX_UNIQUE_FRAGMENTS = 5_000_000
+DEFAULT_DEDUP_MAX_STORED_FINGERPRINTS = 1_000_000
+DEFAULT_FRAGMENT_LENGTH = 21
+DEFAULT_UNIQUE_SAMPLE_EVERY = 8
+DEFAULT_BASES_FROM_START = 100
+DEFAULT_BASES_FROM_END = 100
+DEFAULT_FINGERPRINT_FRONT_SEQUENCE_LENGTH = 8
+DEFAULT_FINGERPRINT_BACK_SEQUENCE_LENGTH = 8
+DEFAULT_FINGERPRINT_FRONT_SEQUENCE_OFFSET = 64
+DEFAULT_FINGERPRINT_BACK_SEQUENCE_OFFSET = 64
+INSERT_SIZE_MAX_ADAPTER_STORE_SIZE = 31
+
+META_DTYPE = np.dtype([
+    ("record_start", "<u8"), ("name_length", "<u4"), ("sequence_offset", "<u4"),
+    ("sequence_length", "<u4"), ("qualities_offset", "<u4"), ("tags_offset", "<u4"),
+    ("tags_length", "<u4"), ("accumulated_error_rate", "<f8")])
+assert META_DTYPE.itemsize == 40
+
+# SCORE_TO_ERROR_RATE (score_to_error_rate.h), same recipe as its generator script
+_ERROR_RATES = np.array([10 ** -(q / 10) for q in range(PHRED_MAX + 1)], dtype=np.float64)
+
+
+def _addr(b) -> int:
+    if isinstance(b, np.ndarray):
+        return b.ctypes.data
+    if len(b) == 0:
+        return 0
+    return np.frombuffer(b, dtype=np.uint8).ctypes.data
+
+
+def _type_name(obj) -> str:
+    return repr(type(obj))
+
+
+# ---------------------------------------------------------------------------
+# record boundary
+# ---------------------------------------------------------------------------
+class FastqRecordView:
+    """FastqRecordView__new__, _qcmodule.c:372-482"""
+
+    __slots__ = ("obj", "_meta")
+
+    def __init__(self, name: str, sequence: str, qualities: str,
+                 tags: Optional[bytes] = None):
+        for label, v in (("name", name), ("sequence", sequence), ("qualities", qualities)):
+            if not isinstance(v, str):
+                raise TypeError(f"FastqRecordView() argument '{label}' must be str, "
+                                f"not {type(v).__name__}")
+        if tags is not None and not isinstance(tags, bytes):
+            raise TypeError(f"FastqRecordView() argument 'tags' must be bytes, "
+                            f"not {type(tags).__name__}")
+        if not name.isascii():
+            raise ValueError(f"name should contain only ASCII characters: {name!r}")
+        if not sequence.isascii():
+            raise ValueError(f"sequence should contain only ASCII characters: {sequence!r}")
+        if not qualities.isascii():
+            raise ValueError(f"qualities should contain only ASCII characters: {sequence!r}")
+        if len(sequence) != len(qualities):
+            raise ValueError("sequence and qualities have different lengths: "
+                             f"{len(sequence)} and {len(qualities)}")
+        tags = tags or b""
+        total = len(name) + 2 * len(sequence) + len(tags)
+        if total > 0xFFFFFFFF:
+            raise OverflowError("Total length of FASTQ record exceeds 4 GiB. "
+                                f"Record name: {name!r}")
+        qb = qualities.encode("ascii")
+        q = np.frombuffer(qb, dtype=np.uint8).astype(np.int16) - 33
+        bad = np.nonzero((q < 0) | (q > PHRED_MAX))[0]
+        if len(bad):
+            raise ValueError(f"Not a valid phred character: {qualities[int(bad[0])]}")
+        # sequential sum, as the loop at :443-451 (cumsum adds left to right)
+        err = float(np.cumsum(_ERROR_RATES[q])[-1]) if len(q) else 0.0
+        self.obj = name.encode("ascii") + sequence.encode("ascii") + qb + tags
+        m = np.zeros(1, dtype=META_DTYPE)
+        m["name_length"] = len(name)
+        m["sequence_offset"] = len(name)
+        m["sequence_length"] = len(sequence)
+        m["qualities_offset"] = len(name) + len(sequence)
+        m["tags_offset"] = len(name) + 2 * len(sequence)
+        m["tags_length"] = len(tags)
+        m["accumulated_error_rate"] = err
+        self._meta = m
+
+    @classmethod
+    def _from(cls, obj: bytes, meta: np.ndarray) -> "FastqRecordView":
+        self = cls.__new__(cls)
+        self.obj = obj
+        self._meta = meta
+        return self
+
+    def _slice(self, off_field: str, length: int) -> bytes:
+        m = self._meta[0]
+        start = int(m["record_start"]) + (int(m[off_field]) if off_field else 0)
+        return self.obj[start:start + length]
+
+    def name(self) -> str:
+        return self._slice("", int(self._meta[0]["name_length"])).decode("ascii")
+
+    def sequence(self) -> str:
+        return self._slice("sequence_offset", int(self._meta[0]["sequence_length"])).decode("ascii")
+
+    def qualities(self) -> str:
+        return self._slice("qualities_offset", int(self._meta[0]["sequence_length"])).decode("ascii")
+
+    def tags(self) -> bytes:
+        return self._slice("tags_offset", int(self._meta[0]["tags_length"]))
+
+
+class _DeviceBatch:
+    """A record array resident in HBM (sq_batch)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().sq_batch_free(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+    @property
+    def number_of_records(self) -> int:
+        return lib().sq_batch_size(self.handle)
+
+    @property
+    def total_bases(self) -> int:
+        return lib().sq_batch_total_bases(self.handle)
+
+    @property
+    def max_length(self) -> int:
+        return lib().sq_batch_max_length(self.handle)
+
+    def download(self):
+        """(bytes, metas) copied back from HBM"""
+        nbytes, n = lib().sq_batch_bytes(self.handle), self.number_of_records
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        metas = np.zeros(n, dtype=META_DTYPE)
+        check(lib().sq_batch_download(self.handle, buf.ctypes.data, nbytes, metas.ctypes.data, n))
+        return buf, metas
+
+    def error_rates(self) -> np.ndarray:
+        out = np.zeros(self.number_of_records, dtype=np.float64)
+        if len(out):
+            check(lib().sq_batch_error_rates(self.handle, out.ctypes.data, len(out)))
+        return out
+
+
+class FastqRecordArrayView:
+    """FastqRecordArrayView, _qcmodule.c:575-883: one bytes object plus the
+    40-byte metas of its records.  Built from views it copies them into one new
+    buffer (and, unlike :672-684, points the metas at that new buffer)."""
+
+    def __init__(self, view_items: Iterable[FastqRecordView]):
+        try:
+            items = list(view_items)
+        except TypeError:
+            raise TypeError("view_items should be iterable")
+        metas = np.zeros(len(items), dtype=META_DTYPE)
+        parts = []
+        pos = 0
+        for i, item in enumerate(items):
+            if not isinstance(item, FastqRecordView):
+                raise TypeError("Expected an iterable of FastqRecordView objects, but item "
+                                f"{i} is of type {type(item)!r}: {item!r}")
+            m = item._meta[0]
+            nl, sl, tl = int(m["name_length"]), int(m["sequence_length"]), int(m["tags_length"])
+            start = int(m["record_start"])
+            parts.append(item.obj[start:start + nl])
+            so, qo, to = (int(m["sequence_offset"]), int(m["qualities_offset"]), int(m["tags_offset"]))
+            parts.append(item.obj[start + so:start + so + sl])
+            parts.append(item.obj[start + qo:start + qo + sl])
+            parts.append(item.obj[start + to:start + to + tl])
+            metas[i] = (pos, nl, nl, sl, nl + sl, nl + 2 * sl, tl, m["accumulated_error_rate"])
+            pos += nl + 2 * sl + tl
+        self.obj = b"".join(parts)
+        self._metas = metas
+        self._batch: Optional[_DeviceBatch] = None
+        self._writeback = None  # weakref to the QCMetrics that owes this array its error rates
+
+    @classmethod
+    def _from_buffer(cls, obj, metas: np.ndarray) -> "FastqRecordArrayView":
+        self = cls.__new__(cls)
+        self.obj = obj
+        self._metas = metas
+        self._batch = None
+        self._writeback = None
+        return self
+
+    @classmethod
+    def _from_device(cls, batch: _DeviceBatch) -> "FastqRecordArrayView":
+        """An array whose records only live in HBM (synthetic data, GPU-side parsers)."""
+        self = cls.__new__(cls)
+        self.obj = None
+        self._metas = None
+        self._batch = batch
+        self._writeback = None
+        return self
+
+    def __len__(self) -> int:
+        if self._metas is None:
+            return self._batch.number_of_records
+        return len(self._metas)
+
+    def __getitem__(self, i: int) -> FastqRecordView:
+        n = len(self)
+        if i < 0:
+            i += n
+        if i < 0 or i >= n:
+            raise IndexError("array index out of range")
+        if self._metas is None:
+            raise TypeError("this record array lives on the device only")
+        return FastqRecordView._from(self.obj, self._metas[i:i + 1])
+
+    def is_mate(self, other) -> bool:
+        """FastqRecordArrayView_is_mate, _qcmodule.c:814-850"""
+        if not isinstance(other, FastqRecordArrayView):
+            raise TypeError(f"other must be of type FastqRecordArrayView, got {type(other)!r}")
+        if len(self) != len(other):
+            raise ValueError("other is not the same length as this record array view. "
+                             f"This length: {len(self)}, other length: {len(other)}")
+        return bool(lib().sq_names_are_mates(_addr(self.obj), self._metas.ctypes.data,
+                                             _addr(other.obj), other._metas.ctypes.data,
+                                             len(self)))
+
+    # -- device side ---------------------------------------------------------
+    def _device(self) -> _DeviceBatch:
+        if self._batch is None:
+            h = lib().sq_batch_upload(context(), _addr(self.obj), len(self.obj),
+                                      self._metas.ctypes.data, len(self._metas))
+            if not h:
+                raise MemoryError(_lib.last_error())
+            self._batch = _DeviceBatch(h)
+        return self._batch
+
+    def _release_device(self) -> None:
+        self._batch = None
+
+    def accumulated_error_rates(self) -> np.ndarray:
+        """FastqMeta.accumulated_error_rate of every record (what NanoStats reads,
+        _qcmodule.c:5314); flushes the QCMetrics pass that computes it."""
+        if self._writeback is not None:
+            qcm = self._writeback()
+            if qcm is not None:
+                qcm.flush()
+        if self._metas is None:
+            return self._batch.error_rates()
+        return self._metas["accumulated_error_rate"].copy()
+
+
+def _require_array(obj, what="record_array") -> FastqRecordArrayView:
+    if not isinstance(obj, FastqRecordArrayView):
+        raise TypeError(f"{what} should be a FastqRecordArrayView object, got {type(obj)!r}")
+    return obj
+
+
+def _require_view(obj) -> FastqRecordView:
+    if not isinstance(obj, FastqRecordView):
+        raise TypeError(f"read should be a FastqRecordView object, got {type(obj)!r}")
+    return obj
+
+
+def _array_of_sequences(seqs: List[str]) -> FastqRecordArrayView:
+    """records that only carry a sequence (add_sequence / add_sequence_pair)"""
+    metas = np.zeros(len(seqs), dtype=META_DTYPE)
+    parts, pos = [], 0
+    for i, s in enumerate(seqs):
+        b = s.encode("ascii")
+        parts.append(b)
+        metas[i] = (pos, 0, 0, len(b), 0, len(b), 0, 0.0)
+        pos += len(b)
+    return FastqRecordArrayView._from_buffer(b"".join(parts), metas)
+
+
+class FastqParser:
+    """FastqParser, _qcmodule.c:889-1244: iterates record arrays over a binary
+    file object, ``initial_buffersize`` bytes at a time (memchr record split on
+    the host, sq_fastq_split)."""
+
+    def __init__(self, fileobj, initial_buffersize: int = 128 * 1024):
+        if initial_buffersize < 1:
+            raise ValueError(f"initial_buffersize must be at least 1, got {initial_buffersize}")
+        self._file = fileobj
+        self._read_in_size = int(initial_buffersize)
+        self._leftover = b""
+
+    def __iter__(self) -> "FastqParser":
+        return self
+
+    def __next__(self) -> FastqRecordArrayView:
+        arr = self._create(1, sys.maxsize)
+        if len(arr) == 0:
+            raise StopIteration
+        return arr
+
+    def read(self, number_of_records: int) -> FastqRecordArrayView:
+        if number_of_records < 1:
+            raise ValueError(f"number_of_records should be greater than 1, got {number_of_records}")
+        return self._create(number_of_records, number_of_records)
+
+    def _create(self, min_records: int, max_records: int) -> FastqRecordArrayView:
+        """FastqParser_create_record_array, _qcmodule.c:964-1184: a new buffer of
+        ``initial_buffersize`` bytes seeded with the leftover of the previous call,
+        enlarged by the same amount until ``min_records`` records fit."""
+        buf = bytearray(self._leftover)
+        first, eof = True, False
+        metas = np.zeros(0, dtype=META_DTYPE)
+        consumed = 0
+        while True:
+            want = max(self._read_in_size - len(buf), 0) if first else self._read_in_size
+            first = False
+            if want > 0:
+                chunk = bytearray(want)
+                got = self._file.readinto(chunk) or 0
+                if got:
+                    new = bytes(chunk[:got])
+                    bad = lib().sq_first_non_ascii(_addr(new), got)
+                    if bad >= 0:  # :1055-1067
+                        raise ValueError(f"Found non-ASCII character in file: {chr(new[bad])}")
+                    buf += new
+                else:
+                    eof = True
+            if len(buf) == 0:
+                break  # :1069 entire file is read
+            if eof and buf.count(b"\n") < 4:  # :1073-1081
+                raise EOFError(f"Incomplete record at the end of file {bytes(buf)!r}")
+            cap = len(buf) // 64 + 16
+            while True:
+                tmp = np.zeros(cap, dtype=META_DTYPE)
+                c = C.c_size_t(0)
+                view = np.frombuffer(buf, dtype=np.uint8)
+                n = lib().sq_fastq_split(view.ctypes.data, len(buf), tmp.ctypes.data,
+                                         min(cap, max_records), C.byref(c))
+                del view
+                check(n)
+                if n == cap and cap < max_records:
+                    cap *= 4
+                    continue
+                break
+            metas, consumed = tmp[:n].copy(), c.value
+            if n >= min_records:
+                break
+            if eof:
+                if n == 0:
+                    raise EOFError(f"Incomplete record at the end of file {bytes(buf)!r}")
+                break
+        obj = bytes(buf)
+        self._leftover = obj[consumed:]
+        return FastqRecordArrayView._from_buffer(obj, metas)
+
+
+# ---------------------------------------------------------------------------
+# modules
+# ---------------------------------------------------------------------------
+def _u64_array(fn, handle, n_hint: Optional[int] = None) -> array.array:
+    n = check(fn(handle, None, 0))
+    out = np.zeros(n, dtype=np.uint64)
+    if n:
+        check(fn(handle, out.ctypes.data, n))
+    a = array.array("Q")
+    a.frombytes(out.tobytes())
+    return a
+
+
+class QCMetrics:
+    """_qcmodule.c:1786-2385"""
+
+    def __init__(self, end_anchor_length: int = DEFAULT_END_ANCHOR_LENGTH):
+        if end_anchor_length < 0 or end_anchor_length > 0xFFFFFFFF:
+            raise ValueError(f"end_anchor_length must be between 0 and {0xFFFFFFFF}, "
+                             f"got {end_anchor_length}")
+        self._h = lib().sq_qcmetrics_new(context(), end_anchor_length)
+        if not self._h:
+            raise MemoryError(_lib.last_error())
+        self._pending: List[FastqRecordArrayView] = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_qcmetrics_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        check(lib().sq_qcmetrics_add_batch(self._h, arr._device().handle))
+        self._track(arr)
+
+    def _track(self, arr: FastqRecordArrayView) -> None:
+        arr._writeback = weakref.ref(self)
+        self._pending.append(arr)
+        if len(self._pending) > 64:
+            self.flush()
+
+    def add_read(self, read: FastqRecordView) -> None:
+        view = _require_view(read)
+        arr = FastqRecordArrayView([view])
+        self.add_record_array(arr)
+        try:
+            self.flush()
+        except ValueError:
+            q = view.qualities()
+            bad = next((c for c in q if not 33 <= ord(c) <= 33 + PHRED_MAX), "?")
+            raise ValueError(f"Not a valid phred character: {bad}") from None
+        view._meta["accumulated_error_rate"] = arr._metas["accumulated_error_rate"]
+
+    def flush(self) -> None:
+        """Waits for the enqueued passes, writes accumulated_error_rate back into the
+        arrays that went through (:2126) and raises a deferred ValueError."""
+        pending, self._pending = self._pending, []
+        rc = lib().sq_qcmetrics_flush(self._h)
+        for arr in pending:
+            if arr._metas is not None and arr._batch is not None and len(arr._metas):
+                arr._metas["accumulated_error_rate"] = arr._batch.error_rates()
+            arr._writeback = None
+        if rc < 0:
+            msg = _lib.last_error()
+            # find the character the reference would name (:2102-2105)
+            for arr in pending:
+                if arr._metas is None:
+                    continue
+                for m in arr._metas:
+                    s = int(m["record_start"]) + int(m["qualities_offset"])
+                    q = np.frombuffer(arr.obj, dtype=np.uint8, count=int(m["sequence_length"]), offset=s)
+                    bad = np.nonzero((q < 33) | (q > 33 + PHRED_MAX))[0]
+                    if len(bad):
+                        raise ValueError(f"Not a valid phred character: {chr(q[int(bad[0])])}")
+            raise ValueError(msg)
+
+    @property
+    def number_of_reads(self) -> int:
+        return lib().sq_qcmetrics_number_of_reads(self._h)
+
+    @property
+    def max_length(self) -> int:
+        return lib().sq_qcmetrics_max_length(self._h)
+
+    @property
+    def end_anchor_length(self) -> int:
+        return lib().sq_qcmetrics_end_anchor_length(self._h)
+
+    def _table(self, fn) -> array.array:
+        self.flush()
+        return _u64_array(fn, self._h)
+
+    def base_count_table(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_base_count_table)
+
+    def phred_count_table(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_phred_count_table)
+
+    def end_anchored_base_count_table(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_end_anchored_base_count_table)
+
+    def end_anchored_phred_count_table(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_end_anchored_phred_count_table)
+
+    def gc_content(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_gc_content)
+
+    def phred_scores(self) -> array.array:
+        return self._table(lib().sq_qcmetrics_phred_scores)
+
+
+class AdapterCounter:
+    """_qcmodule.c:2391-2969"""
+
+    def __init__(self, adapters: Iterable[str]):
+        try:
+            adapters = tuple(adapters)
+        except TypeError:
+            raise TypeError(f"{type(adapters).__name__!r} object is not iterable")
+        if len(adapters) < 1:
+            raise ValueError("At least one adapter is expected")
+        for a in adapters:
+            if type(a) is not str:
+                raise TypeError("All adapter sequences must be of type str, "
+                                f"got {type(a)!r}, for {a!r}")
+            if not a.isascii():
+                raise ValueError(f"Adapter must contain only ASCII characters: {a!r}")
+            if len(a) > MAX_SEQUENCE_SIZE:
+                raise ValueError(f"Maximum adapter size is {MAX_SEQUENCE_SIZE}, "
+                                 f"got {len(a)} for {a!r}")
+        self.adapters = adapters
+        enc = [a.encode("ascii") for a in adapters]
+        ptrs = (C.c_char_p * len(enc))(*enc)
+        lens = (C.c_size_t * len(enc))(*[len(e) for e in enc])
+        self._h = lib().sq_adaptercounter_new(context(), C.cast(ptrs, C.c_void_p),
+                                              C.cast(lens, C.c_void_p), len(enc))
+        if not self._h:
+            raise ValueError(_lib.last_error())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_adaptercounter_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        check(lib().sq_adaptercounter_add_batch(self._h, arr._device().handle))
+
+    def add_read(self, read: FastqRecordView) -> None:
+        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+
+    def flush(self) -> None:
+        check(lib().sq_adaptercounter_flush(self._h))
+
+    @property
+    def number_of_sequences(self) -> int:
+        return lib().sq_adaptercounter_number_of_sequences(self._h)
+
+    @property
+    def max_length(self) -> int:
+        return lib().sq_adaptercounter_max_length(self._h)
+
+    def get_counts(self) -> List[Tuple[str, array.array, array.array]]:
+        ml = self.max_length
+        out = []
+        for i, a in enumerate(self.adapters):
+            f = np.zeros(ml, dtype=np.uint64)
+            r = np.zeros(ml, dtype=np.uint64)
+            check(lib().sq_adaptercounter_get_counts(self._h, i, f.ctypes.data, r.ctypes.data, ml))
+            fa, ra = array.array("Q"), array.array("Q")
+            fa.frombytes(f.tobytes())
+            ra.frombytes(r.tobytes())
+            out.append((a, fa, ra))
+        return out
+
+
+class PerTileQuality:
+    """_qcmodule.c:2975-3397"""
+
+    def __init__(self):
+        self._h = lib().sq_pertile_new(context())
+        if not self._h:
+            raise MemoryError(_lib.last_error())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_pertile_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        if self.skipped_reason is not None:
+            return
+        arr = _require_array(record_array)
+        check(lib().sq_pertile_add_batch(self._h, arr._device().handle))
+
+    def add_read(self, read: FastqRecordView) -> None:
+        if self.skipped_reason is not None:
+            return
+        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+
+    def flush(self) -> None:
+        check(lib().sq_pertile_flush(self._h))
+
+    @property
+    def number_of_reads(self) -> int:
+        return lib().sq_pertile_number_of_reads(self._h)
+
+    @property
+    def max_length(self) -> int:
+        return lib().sq_pertile_max_length(self._h)
+
+    @property
+    def skipped_reason(self) -> Optional[str]:
+        r = lib().sq_pertile_skipped_reason(self._h)
+        return None if r is None else r.decode("ascii", "replace")
+
+    def get_tile_counts(self) -> List[Tuple[int, List[float], List[int]]]:
+        nt = lib().sq_pertile_number_of_tiles(self._h)
+        ml = self.max_length
+        ids = np.zeros(nt, dtype=np.int64)
+        err = np.zeros((nt, ml), dtype=np.float64)
+        cnt = np.zeros((nt, ml), dtype=np.uint64)
+        if nt:
+            check(lib().sq_pertile_get_tile_counts(self._h, ids.ctypes.data, err.ctypes.data,
+                                                   cnt.ctypes.data, nt, ml))
+        return [(int(ids[i]), err[i].tolist(), [int(x) for x in cnt[i]]) for i in range(nt)]
+
+
+class FusedPass:
+    """One pass over each record array for any of QCMetrics / AdapterCounter /
+    PerTileQuality (sq_fused_add_batch): the same results as calling the three
+    add_record_array methods in turn, with the records read from HBM once."""
+
+    def __init__(self, qc_metrics: Optional[QCMetrics] = None,
+                 adapter_counter: Optional[AdapterCounter] = None,
+                 per_tile_quality: Optional[PerTileQuality] = None):
+        self.qc_metrics = qc_metrics
+        self.adapter_counter = adapter_counter
+        self.per_tile_quality = per_tile_quality
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        m, a, p = self.qc_metrics, self.adapter_counter, self.per_tile_quality
+        check(lib().sq_fused_add_batch(arr._device().handle, m._h if m else None,
+                                       a._h if a else None, p._h if p else None))
+        if m is not None:
+            m._track(arr)
+
+
+def _kmer_to_sequence(kmer: int, k: int) -> str:
+    """kmer_to_sequence, _qcmodule.c:3405-3414"""
+    return "".join("ACGT"[(kmer >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+class OverrepresentedSequences:
+    """_qcmodule.c:3435-4236"""
+
+    def __init__(self, max_unique_fragments: int = DEFAULT_MAX_UNIQUE_FRAGMENTS,
+                 fragment_length: int = DEFAULT_FRAGMENT_LENGTH,
+                 sample_every: int = DEFAULT_UNIQUE_SAMPLE_EVERY,
+                 bases_from_start: int = DEFAULT_BASES_FROM_START,
+                 bases_from_end: int = DEFAULT_BASES_FROM_END):
+        self._h = lib().sq_overrep_new(context(), max_unique_fragments, fragment_length,
+                                       sample_every, bases_from_start, bases_from_end)
+        if not self._h:
+            raise ValueError(_lib.last_error())
+        self.max_unique_fragments = max_unique_fragments
+        self.fragment_length = fragment_length
+        self.sample_every = sample_every
+        self._warned = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_overrep_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        before = self.number_of_sequences
+        check(lib().sq_overrep_add_batch(self._h, arr._device().handle))
+        count = lib().sq_overrep_warning_count(self._h)
+        if count != self._warned:  # :3931-3938, once per array here
+            self._warned = count
+            idx = lib().sq_overrep_last_warning_record(self._h) - before
+            culprit = arr[idx].sequence() if arr._metas is not None and 0 <= idx < len(arr) else "?"
+            warnings.warn("Sequence contains a chacter that is not A, C, G, T or N: "
+                          f"{culprit!r}", UserWarning, stacklevel=2)
+
+    def add_read(self, read: FastqRecordView) -> None:
+        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+
+    def flush(self) -> None:
+        check(lib().sq_overrep_flush(self._h))
+
+    @property
+    def number_of_sequences(self) -> int:
+        return lib().sq_overrep_number_of_sequences(self._h)
+
+    @property
+    def sampled_sequences(self) -> int:
+        return lib().sq_overrep_sampled_sequences(self._h)
+
+    @property
+    def collected_unique_fragments(self) -> int:
+        return lib().sq_overrep_collected_unique_fragments(self._h)
+
+    @property
+    def total_fragments(self) -> int:
+        return lib().sq_overrep_total_fragments(self._h)
+
+    def _counts(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = check(lib().sq_overrep_get_counts(self._h, None, None, 0))
+        km = np.zeros(n, dtype=np.uint64)
+        ct = np.zeros(n, dtype=np.uint64)
+        if n:
+            check(lib().sq_overrep_get_counts(self._h, km.ctypes.data, ct.ctypes.data, n))
+        return km, ct
+
+    def sequence_counts(self) -> Dict[str, int]:
+        km, ct = self._counts()
+        k = self.fragment_length
+        return {_kmer_to_sequence(int(a), k): int(b) for a, b in zip(km, ct)}
+
+    def overrepresented_sequences(self, threshold_fraction: float = 0.0001,
+                                  min_threshold: int = 1,
+                                  max_threshold: int = sys.maxsize
+                                  ) -> List[Tuple[int, float, str]]:
+        """:4091-4180"""
+        import math
+        if threshold_fraction < 0.0 or threshold_fraction > 1.0:
+            raise ValueError("threshold_fraction must be between 0.0 and 1.0 got, "
+                             f"{threshold_fraction!r}")
+        if min_threshold < 1:
+            raise ValueError(f"min_threshold must be at least 1, got {min_threshold}")
+        if max_threshold < 1:
+            raise ValueError(f"max_threshold must be at least 1, got {max_threshold}")
+        if max_threshold < min_threshold:
+            raise ValueError(f"max_threshold ({max_threshold}) must be greater than "
+                             f"min_threshold ({min_threshold})")
+        sampled = self.sampled_sequences
+        hits = min(max_threshold, max(min_threshold, math.ceil(threshold_fraction * sampled)))
+        km, ct = self._counts()
+        k = self.fragment_length
+        res = [(int(c), int(c) / sampled, _kmer_to_sequence(int(a), k))
+               for a, c in zip(km, ct) if c >= hits]
+        res.sort(reverse=True)
+        return res
+
+
+class DedupEstimator:
+    """_qcmodule.c:4270-4802"""
+
+    def __init__(self, max_stored_fingerprints: int = DEFAULT_DEDUP_MAX_STORED_FINGERPRINTS, *,
+                 front_sequence_length: int = DEFAULT_FINGERPRINT_FRONT_SEQUENCE_LENGTH,
+                 back_sequence_length: int = DEFAULT_FINGERPRINT_BACK_SEQUENCE_LENGTH,
+                 front_sequence_offset: int = DEFAULT_FINGERPRINT_FRONT_SEQUENCE_OFFSET,
+                 back_sequence_offset: int = DEFAULT_FINGERPRINT_BACK_SEQUENCE_OFFSET):
+        self._h = lib().sq_dedup_new(context(), max_stored_fingerprints, front_sequence_length,
+                                     back_sequence_length, front_sequence_offset,
+                                     back_sequence_offset)
+        if not self._h:
+            raise ValueError(_lib.last_error())
+        self.front_sequence_length = front_sequence_length
+        self.back_sequence_length = back_sequence_length
+        self.front_sequence_offset = front_sequence_offset
+        self.back_sequence_offset = back_sequence_offset
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_dedup_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        check(lib().sq_dedup_add_batch(self._h, arr._device().handle))
+
+    def add_record_array_pair(self, record_array1, record_array2) -> None:
+        a1 = _require_array(record_array1, "record_array1")
+        a2 = _require_array(record_array2, "record_array2")
+        if len(a1) != len(a2):
+            raise ValueError("record_array1 and record_array2 must be of the same size. "
+                             f"Got {len(a1)} and {len(a2)} respectively.")
+        check(lib().sq_dedup_add_batch_pair(self._h, a1._device().handle, a2._device().handle))
+
+    def add_sequence(self, sequence: str) -> None:
+        if type(sequence) is not str:
+            raise TypeError(f"sequence should be a str object, got {type(sequence)!r}")
+        if not sequence.isascii():
+            raise ValueError("sequence should consist only of ASCII characters.")
+        self.add_record_array(_array_of_sequences([sequence]))
+
+    def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
+        for s in (sequence1, sequence2):
+            if not isinstance(s, str):
+                raise TypeError(f"add_sequence_pair() argument must be str, not {type(s).__name__}")
+            if not s.isascii():
+                raise ValueError("sequence should consist only of ASCII characters.")
+        self.add_record_array_pair(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
+
+    @property
+    def _modulo_bits(self) -> int:
+        return lib().sq_dedup_modulo_bits(self._h)
+
+    @property
+    def _hash_table_size(self) -> int:
+        return lib().sq_dedup_hash_table_size(self._h)
+
+    @property
+    def tracked_sequences(self) -> int:
+        return lib().sq_dedup_tracked_sequences(self._h)
+
+    def duplication_counts(self) -> array.array:
+        return _u64_array(lib().sq_dedup_duplication_counts, self._h)
+
+
+class InsertSizeMetrics:
+    """_qcmodule.c:5456-5982"""
+
+    def __init__(self, max_adapters: int = 10000):
+        self._h = lib().sq_insertsize_new(context(), max_adapters)
+        if not self._h:
+            raise ValueError(_lib.last_error())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_insertsize_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array_pair(self, record_array1, record_array2) -> None:
+        a1 = _require_array(record_array1, "record_array1")
+        a2 = _require_array(record_array2, "record_array2")
+        if len(a1) != len(a2):
+            raise ValueError("record_array1 and record_array2 must be of the same size. "
+                             f"Got {len(a1)} and {len(a2)} respectively.")
+        check(lib().sq_insertsize_add_batch_pair(self._h, a1._device().handle, a2._device().handle))
+
+    def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
+        for label, s in (("sequence1", sequence1), ("sequence2", sequence2)):
+            if not isinstance(s, str):
+                raise TypeError(f"add_sequence_pair() argument must be str, not {type(s).__name__}")
+            if not s.isascii():
+                raise ValueError(f"{label} should consist only of ASCII characters.")
+        self.add_record_array_pair(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
+
+    @property
+    def total_reads(self) -> int:
+        return lib().sq_insertsize_total_reads(self._h)
+
+    @property
+    def number_of_adapters_read1(self) -> int:
+        return lib().sq_insertsize_number_of_adapters_read1(self._h)
+
+    @property
+    def number_of_adapters_read2(self) -> int:
+        return lib().sq_insertsize_number_of_adapters_read2(self._h)
+
+    def insert_sizes(self) -> array.array:
+        return _u64_array(lib().sq_insertsize_insert_sizes, self._h)
+
+    def _adapters(self, read2: int) -> List[Tuple[str, int]]:
+        n = check(lib().sq_insertsize_adapters(self._h, read2, None, None, None, 0))
+        by = np.zeros((n, INSERT_SIZE_MAX_ADAPTER_STORE_SIZE), dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint8)
+        ct = np.zeros(n, dtype=np.uint64)
+        if n:
+            check(lib().sq_insertsize_adapters(self._h, read2, by.ctypes.data, ln.ctypes.data,
+                                               ct.ctypes.data, n))
+        return [(bytes(by[i, :ln[i]]).decode("ascii"), int(ct[i])) for i in range(n)]
+
+    def adapters_read1(self) -> List[Tuple[str, int]]:
+        return self._adapters(0)
+
+    def adapters_read2(self) -> List[Tuple[str, int]]:
+        return self._adapters(1)

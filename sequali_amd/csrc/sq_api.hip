@@ -1,0 +1,452 @@
+/* sq_api.hip -- context, batches, host-side record boundary, synthetic FASTQ */
+#include "sq_common.h"
+#include "sq_synth_core.h"
+
+static thread_local std::string g_last_error;
+
+void sq_set_error(const char *fmt, ...)
+{
+    char tmp[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_end(ap);
+    g_last_error = tmp;
+}
+
+SQ_EXPORT int sq_abi_version(void) { return SQ_ABI_VERSION; }
+SQ_EXPORT const char *sq_last_error(void) { return g_last_error.c_str(); }
+
+SQ_EXPORT sq_ctx *sq_init(int device)
+{
+    int count = 0;
+    SQ_HIP_NULL(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        sq_set_error("sq_init: device %d not available (%d visible)", device, count);
+        return nullptr;
+    }
+    SQ_HIP_NULL(hipSetDevice(device));
+    sq_ctx *ctx = new sq_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    SQ_HIP_NULL(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
+    return ctx;
+}
+
+SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
+
+SQ_EXPORT int sq_synchronize(sq_ctx *ctx)
+{
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SQ_OK;
+}
+
+SQ_EXPORT void *sq_stream_handle(sq_ctx *ctx) { return (void *)ctx->stream; }
+
+/* ---- host-side record boundary ------------------------------------------- */
+
+/* FastqParser_create_record_array, the record loop _qcmodule.c:1093-1171 */
+SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas, size_t cap,
+                                 size_t *consumed)
+{
+    const uint8_t *end = buf + len;
+    const uint8_t *rec = buf;
+    int64_t n = 0;
+    while ((size_t)n < cap) {
+        if (rec + 2 >= end) break; /* :1094 */
+        if (rec[0] != '@') {
+            sq_set_error("Record does not start with @ but with %c", rec[0]);
+            return SQ_ERR_VALUE;
+        }
+        const uint8_t *name = rec + 1;
+        /* the reference searches (end - rec) bytes from name, one past the end;
+           the buffer is a bytes object there so the extra byte is its NUL */
+        const uint8_t *name_end = (const uint8_t *)memchr(name, '\n', end - name);
+        if (!name_end) break;
+        const uint8_t *seq = name_end + 1;
+        const uint8_t *seq_end = (const uint8_t *)memchr(seq, '\n', end - seq);
+        if (!seq_end) break;
+        const uint8_t *plus = seq_end + 1;
+        if (plus < end && plus[0] != '+') {
+            sq_set_error("Record second header does not start with + but with %c", plus[0]);
+            return SQ_ERR_VALUE;
+        }
+        const uint8_t *plus_end = (const uint8_t *)memchr(plus, '\n', end - plus);
+        if (!plus_end) break;
+        const uint8_t *qual = plus_end + 1;
+        const uint8_t *qual_end = (const uint8_t *)memchr(qual, '\n', end - qual);
+        if (!qual_end) break;
+        if (seq_end - seq != qual_end - qual) {
+            std::string nm((const char *)name, name_end - name);
+            sq_set_error("Record sequence and qualities do not have equal length, '%s'", nm.c_str());
+            return SQ_ERR_VALUE;
+        }
+        if ((uint64_t)(qual_end - name) > UINT32_MAX) {
+            sq_set_error("Total length of FASTQ record exceeds 4 GiB");
+            return SQ_ERR_OVERFLOW;
+        }
+        sq_meta *m = &metas[n++];
+        m->record_start = (uint64_t)(name - buf);
+        m->name_length = (uint32_t)(name_end - name);
+        m->sequence_offset = (uint32_t)(seq - name);
+        m->sequence_length = (uint32_t)(seq_end - seq);
+        m->qualities_offset = (uint32_t)(qual - name);
+        m->tags_offset = (uint32_t)(qual_end - name);
+        m->tags_length = 0;
+        m->accumulated_error_rate = 0.0;
+        rec = qual_end + 1;
+    }
+    if (consumed) *consumed = (size_t)(rec - buf);
+    return n;
+}
+
+SQ_EXPORT int64_t sq_first_non_ascii(const uint8_t *buf, size_t len)
+{
+    size_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t w;
+        memcpy(&w, buf + i, 8);
+        if (w & 0x8080808080808080ULL) break;
+    }
+    for (; i < len; i++)
+        if (buf[i] & 0x80) return (int64_t)i;
+    return -1;
+}
+
+/* fastq_names_are_mates, _qcmodule.c:777-800 */
+static bool names_are_mates(const uint8_t *n1, size_t l1, const uint8_t *n2, size_t l2)
+{
+    size_t id = 0;
+    while (id < l1 && n1[id] != ' ' && n1[id] != '\t') id++;
+    if (l2 < id) return false;
+    if (l2 > id && !(n2[id] == ' ' || n2[id] == '\t')) return false;
+    if (id > 0) {
+        uint8_t a = n1[id - 1], b = n2[id - 1];
+        if ((a == '1' || a == '2') && (b == '1' || b == '2')) id -= 1;
+    }
+    return memcmp(n1, n2, id) == 0;
+}
+
+SQ_EXPORT int sq_names_are_mates(const uint8_t *buf1, const sq_meta *metas1, const uint8_t *buf2,
+                                 const sq_meta *metas2, size_t n)
+{
+    for (size_t i = 0; i < n; i++)
+        if (!names_are_mates(buf1 + metas1[i].record_start, metas1[i].name_length,
+                             buf2 + metas2[i].record_start, metas2[i].name_length))
+            return 0;
+    return 1;
+}
+
+/* ---- batches ----------------------------------------------------------------- */
+
+/* per-batch statistics on the device: [0] total bases [1] max length
+ * [2] max name length [3] max record span (name start .. quality end) */
+__global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long *out)
+{
+    unsigned long long bases = 0, maxlen = 0, maxname = 0, maxspan = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        sq_meta m = metas[i];
+        bases += m.sequence_length;
+        if (m.sequence_length > maxlen) maxlen = m.sequence_length;
+        if (m.name_length > maxname) maxname = m.name_length;
+        unsigned long long span = (unsigned long long)m.qualities_offset + m.sequence_length;
+        if (span > maxspan) maxspan = span;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bases += __shfl_down(bases, off);
+        unsigned long long a = __shfl_down(maxlen, off), b = __shfl_down(maxname, off),
+                           c = __shfl_down(maxspan, off);
+        maxlen = a > maxlen ? a : maxlen;
+        maxname = b > maxname ? b : maxname;
+        maxspan = c > maxspan ? c : maxspan;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], bases);
+        atomicMax(&out[1], maxlen);
+        atomicMax(&out[2], maxname);
+        atomicMax(&out[3], maxspan);
+    }
+}
+
+SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_len,
+                                    const sq_meta *metas, size_t n)
+{
+    sq_batch *b = new sq_batch();
+    b->ctx = ctx;
+    b->buf_len = buf_len;
+    b->n = n;
+    b->owns = true;
+    for (size_t i = 0; i < n; i++) {
+        const sq_meta &m = metas[i];
+        uint64_t span = (uint64_t)m.qualities_offset + m.sequence_length;
+        uint64_t seq_end = (uint64_t)m.sequence_offset + m.sequence_length;
+        if (m.record_start + span > buf_len || m.record_start + seq_end > buf_len ||
+            m.record_start + m.name_length > buf_len) {
+            sq_set_error("sq_batch_upload: record %zu lies outside the buffer", i);
+            delete b;
+            return nullptr;
+        }
+        b->total_bases += m.sequence_length;
+        if (m.sequence_length > b->max_length) b->max_length = m.sequence_length;
+        if (m.name_length > b->max_name_length) b->max_name_length = m.name_length;
+        if (span > b->max_record_span) b->max_record_span = span;
+    }
+    /* 64 spare bytes so that wide loads near the end stay inside the allocation */
+    if (hipMalloc((void **)&b->d_buf, buf_len + 64) != hipSuccess ||
+        hipMalloc((void **)&b->d_metas, (n ? n : 1) * sizeof(sq_meta)) != hipSuccess) {
+        sq_set_error("sq_batch_upload: out of device memory");
+        if (b->d_buf) (void)hipFree(b->d_buf);
+        delete b;
+        return nullptr;
+    }
+    b->h_buf.assign(buf, buf + buf_len);
+    b->h_metas.assign(metas, metas + n);
+    if (buf_len) SQ_HIP_NULL(hipMemcpyAsync(b->d_buf, b->h_buf.data(), buf_len, hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(b->d_buf + buf_len, 0, 64, ctx->stream));
+    if (n) SQ_HIP_NULL(hipMemcpyAsync(b->d_metas, b->h_metas.data(), n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream));
+    return b;
+}
+
+SQ_EXPORT sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len,
+                                         void *d_metas, size_t n)
+{
+    sq_batch *b = new sq_batch();
+    b->ctx = ctx;
+    b->d_buf = (uint8_t *)d_buf;
+    b->d_metas = (sq_meta *)d_metas;
+    b->buf_len = buf_len;
+    b->n = n;
+    b->owns = false;
+    if (n) {
+        unsigned long long *d_out = nullptr;
+        SQ_HIP_NULL(hipMalloc((void **)&d_out, 4 * sizeof(unsigned long long)));
+        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_batch_stats, dim3(blocks), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
+        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_out);
+        b->total_bases = ctx->pinned[0];
+        b->max_length = ctx->pinned[1];
+        b->max_name_length = ctx->pinned[2];
+        b->max_record_span = ctx->pinned[3];
+    }
+    return b;
+}
+
+SQ_EXPORT void sq_batch_free(sq_batch *b)
+{
+    if (!b) return;
+    if (b->owns) {
+        (void)hipStreamSynchronize(b->ctx->stream);
+        if (b->d_buf) (void)hipFree(b->d_buf);
+        if (b->d_metas) (void)hipFree(b->d_metas);
+    }
+    delete b;
+}
+
+SQ_EXPORT uint64_t sq_batch_size(const sq_batch *b) { return b->n; }
+SQ_EXPORT uint64_t sq_batch_total_bases(const sq_batch *b) { return b->total_bases; }
+SQ_EXPORT uint64_t sq_batch_max_length(const sq_batch *b) { return b->max_length; }
+
+SQ_EXPORT uint64_t sq_batch_bytes(const sq_batch *b) { return b->buf_len; }
+
+SQ_EXPORT int sq_batch_download(sq_batch *b, uint8_t *buf, size_t buf_cap, sq_meta *metas, size_t meta_cap)
+{
+    if (buf_cap < b->buf_len || meta_cap < b->n) {
+        sq_set_error("sq_batch_download: destination too small");
+        return SQ_ERR_VALUE;
+    }
+    SQ_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->buf_len) SQ_HIP(hipMemcpy(buf, b->d_buf, b->buf_len, hipMemcpyDeviceToHost));
+    if (b->n) SQ_HIP(hipMemcpy(metas, b->d_metas, b->n * sizeof(sq_meta), hipMemcpyDeviceToHost));
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_batch_error_rates(sq_batch *b, double *out, size_t n)
+{
+    if (n > b->n) n = b->n;
+    if (!n) return SQ_OK;
+    /* strided 8 of every 40 bytes */
+    SQ_HIP(hipMemcpy2DAsync(out, sizeof(double),
+                            (const uint8_t *)b->d_metas + offsetof(sq_meta, accumulated_error_rate),
+                            sizeof(sq_meta), sizeof(double), n, hipMemcpyDeviceToHost,
+                            b->ctx->stream));
+    SQ_HIP(hipStreamSynchronize(b->ctx->stream));
+    return SQ_OK;
+}
+
+/* ---- synthetic FASTQ ------------------------------------------------------------ */
+
+__host__ __device__ static inline void synth_write_record(int kind, uint64_t seed, uint64_t i,
+                                                          uint8_t *dst, uint32_t lane,
+                                                          uint32_t nlanes)
+{
+    /* lanes stride over the bytes of one record */
+    int mate = kind == SQ_SYNTH_ILLUMINA_R2 ? 1 : 0;
+    uint32_t nl = sqs_name_length(kind);
+    uint32_t L = sqs_read_length(kind, seed, i);
+    uint64_t src = 0;
+    uint32_t flen = 0;
+    if (kind != SQ_SYNTH_NANOPORE) {
+        src = sqs_source_pair(seed, i);
+        flen = sqs_fragment_length(seed, src);
+    }
+    if (lane == 0) {
+        dst[0] = '@';
+        if (kind == SQ_SYNTH_NANOPORE) sqs_nanopore_name(seed, i, dst + 1);
+        else sqs_illumina_name(seed, i, mate, dst + 1);
+        dst[1 + nl] = '\n';
+        dst[2 + nl + L] = '\n';
+        dst[3 + nl + L] = '+';
+        dst[4 + nl + L] = '\n';
+        dst[5 + nl + 2 * (uint64_t)L] = '\n';
+    }
+    uint8_t *seq = dst + 2 + nl;
+    uint8_t *qual = dst + 5 + nl + L;
+    for (uint32_t p = lane; p < L; p += nlanes) {
+        if (kind == SQ_SYNTH_NANOPORE) {
+            seq[p] = sqs_nanopore_base(seed, i, p);
+            qual[p] = sqs_nanopore_qual(seed, i, p);
+        } else {
+            seq[p] = sqs_illumina_base(seed, i, src, flen, mate, p);
+            qual[p] = sqs_illumina_qual(seed, i, mate, p);
+        }
+    }
+}
+
+__host__ __device__ static inline void synth_fill_meta(int kind, uint64_t seed, uint64_t i,
+                                                       uint64_t rec_off, sq_meta *m)
+{
+    uint32_t nl = sqs_name_length(kind), L = sqs_read_length(kind, seed, i);
+    m->record_start = rec_off + 1;
+    m->name_length = nl;
+    m->sequence_offset = nl + 1;
+    m->sequence_length = L;
+    m->qualities_offset = nl + 1 + L + 3;
+    m->tags_offset = nl + 1 + L + 3 + L;
+    m->tags_length = 0;
+    m->accumulated_error_rate = 0.0;
+}
+
+SQ_EXPORT uint64_t sq_synth_bytes(int kind, uint64_t seed, uint64_t first, uint64_t n)
+{
+    if (kind != SQ_SYNTH_NANOPORE) return n * sqs_record_bytes(kind, seed, 0);
+    uint64_t t = 0;
+    for (uint64_t i = 0; i < n; i++) t += sqs_record_bytes(kind, seed, first + i);
+    return t;
+}
+
+SQ_EXPORT int sq_synth_host(int kind, uint64_t seed, uint64_t first, uint64_t n, uint8_t *buf,
+                            size_t buf_cap, sq_meta *metas)
+{
+    uint64_t off = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        uint64_t sz = sqs_record_bytes(kind, seed, first + k);
+        if (off + sz > buf_cap) {
+            sq_set_error("sq_synth_host: buffer too small");
+            return SQ_ERR_VALUE;
+        }
+        synth_write_record(kind, seed, first + k, buf + off, 0, 1);
+        if (metas) synth_fill_meta(kind, seed, first + k, off, &metas[k]);
+        off += sz;
+    }
+    return SQ_OK;
+}
+
+__global__ void k_synth_sizes(int kind, uint64_t seed, uint64_t first, uint64_t n, uint64_t *sizes)
+{
+    uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (k < n) sizes[k] = sqs_record_bytes(kind, seed, first + k);
+}
+
+/* one wave per record; offs[k] = byte offset of record k (NULL: fixed size) */
+__global__ void k_synth_fill(int kind, uint64_t seed, uint64_t first, uint64_t n,
+                             const uint64_t *offs, uint64_t fixed, uint8_t *buf, sq_meta *metas)
+{
+    uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t lane = threadIdx.x & 63;
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        uint64_t off = offs ? offs[k] : k * fixed;
+        synth_write_record(kind, seed, first + k, buf + off, lane, 64);
+        if (lane == 0) synth_fill_meta(kind, seed, first + k, off, &metas[k]);
+    }
+}
+
+SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64_t first, uint64_t n)
+{
+    sq_batch *b = new sq_batch();
+    b->ctx = ctx;
+    b->n = n;
+    b->owns = true;
+    uint64_t *d_offs = nullptr;
+    uint64_t fixed = 0, total = 0;
+    if (kind == SQ_SYNTH_NANOPORE) {
+        /* sizes on the device, exclusive scan on the host (n is ~1e6) */
+        std::vector<uint64_t> sizes(n);
+        SQ_HIP_NULL(hipMalloc((void **)&d_offs, (n ? n : 1) * sizeof(uint64_t)));
+        if (n) {
+            hipLaunchKernelGGL(k_synth_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               ctx->stream, kind, seed, first, n, d_offs);
+            SQ_HIP_NULL(hipMemcpyAsync(sizes.data(), d_offs, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+        }
+        for (uint64_t k = 0; k < n; k++) {
+            uint64_t s = sizes[k];
+            sizes[k] = total;
+            total += s;
+        }
+        if (n) SQ_HIP_NULL(hipMemcpyAsync(d_offs, sizes.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+    } else {
+        fixed = sqs_record_bytes(kind, seed, 0);
+        total = fixed * n;
+    }
+    b->buf_len = total;
+    if (hipMalloc((void **)&b->d_buf, total + 64) != hipSuccess ||
+        hipMalloc((void **)&b->d_metas, (n ? n : 1) * sizeof(sq_meta)) != hipSuccess) {
+        sq_set_error("sq_synth_device: out of device memory (%llu bytes)", (unsigned long long)total);
+        if (b->d_buf) (void)hipFree(b->d_buf);
+        if (d_offs) (void)hipFree(d_offs);
+        delete b;
+        return nullptr;
+    }
+    SQ_HIP_NULL(hipMemsetAsync(b->d_buf + total, 0, 64, ctx->stream));
+    if (n) {
+        uint64_t waves = n < 65536 ? n : 65536;
+        unsigned blocks = (unsigned)((waves + 3) / 4);
+        hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, ctx->stream, kind, seed, first,
+                           n, d_offs, fixed, b->d_buf, b->d_metas);
+        unsigned long long *d_out = nullptr;
+        SQ_HIP_NULL(hipMalloc((void **)&d_out, 32));
+        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 32, ctx->stream));
+        int sb = (int)((n + 255) / 256);
+        if (sb > 4096) sb = 4096;
+        hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
+        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_out);
+        b->total_bases = ctx->pinned[0];
+        b->max_length = ctx->pinned[1];
+        b->max_name_length = ctx->pinned[2];
+        b->max_record_span = ctx->pinned[3];
+    }
+    if (d_offs) (void)hipFree(d_offs);
+    return b;
+}

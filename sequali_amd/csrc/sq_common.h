@@ -1,0 +1,111 @@
+/* sq_common.h -- internals shared by the translation units of libsqgpu.so */
+#ifndef SQ_COMMON_H
+#define SQ_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sqgpu.h"
+
+#define SQ_EXPORT extern "C" __attribute__((visibility("default")))
+
+/* thread-local message of the last failing call */
+void sq_set_error(const char *fmt, ...);
+
+#define SQ_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            sq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                     \
+            return SQ_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define SQ_HIP_NULL(call)                                                               \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            sq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                     \
+            return nullptr;                                                             \
+        }                                                                               \
+    } while (0)
+
+struct sq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    /* small pinned scratch for scalar read-backs */
+    uint64_t *pinned = nullptr; /* 64 words */
+};
+
+struct sq_batch {
+    sq_ctx *ctx = nullptr;
+    uint8_t *d_buf = nullptr;
+    sq_meta *d_metas = nullptr;
+    size_t buf_len = 0;
+    size_t n = 0;
+    bool owns = false;
+    uint64_t total_bases = 0;
+    uint64_t max_length = 0;
+    uint64_t max_name_length = 0;
+    uint64_t max_record_span = 0;
+    /* host copies kept by sq_batch_upload for rare host-side follow-ups
+       (error messages, skipped_reason); empty for wrapped device memory */
+    std::vector<uint8_t> h_buf;
+    std::vector<sq_meta> h_metas;
+};
+
+/* grow a device array of T to at least `want` elements, zero-filling the new
+ * tail and preserving the old contents; *cap is the current element count */
+template <typename T>
+int sq_grow_device(sq_ctx *ctx, T **ptr, size_t *cap, size_t want)
+{
+    if (want <= *cap) return SQ_OK;
+    T *n = nullptr;
+    SQ_HIP(hipMalloc((void **)&n, want * sizeof(T)));
+    SQ_HIP(hipMemsetAsync(n, 0, want * sizeof(T), ctx->stream));
+    if (*ptr && *cap)
+        SQ_HIP(hipMemcpyAsync(n, *ptr, *cap * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    if (*ptr) {
+        SQ_HIP(hipStreamSynchronize(ctx->stream));
+        SQ_HIP(hipFree(*ptr));
+    }
+    *ptr = n;
+    *cap = want;
+    return SQ_OK;
+}
+
+/* device-side helpers -------------------------------------------------------- */
+#ifdef __HIPCC__
+/* NUCLEOTIDE_TO_INDEX, _qcmodule.c:1748-1763: A/a 0 C/c 1 G/g 2 T/t 3 else 4 */
+__device__ __forceinline__ unsigned sq_base_class(unsigned c)
+{
+    unsigned l = c | 0x20u;
+    return l == 'a' ? 0u : l == 'c' ? 1u : l == 'g' ? 2u : l == 't' ? 3u : 4u;
+}
+
+__device__ __forceinline__ uint32_t sq_load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t sq_load_u64_unaligned(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+#endif
+
+#endif

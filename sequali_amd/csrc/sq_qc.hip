@@ -1,0 +1,1198 @@
+/*
+ * sq_qc.hip -- the per-base pass: QCMetrics, AdapterCounter, PerTileQuality.
+ *
+ * One kernel template, k_pass<QC, AD, PT>, reads a batch once and feeds up to
+ * three modules (reference: three separate C loops over the same record
+ * array, _qcmodule.c:1966-2139, 2786-2823, 3123-3222).
+ *
+ * Work decomposition (wave64; a workgroup is 4 independent waves that share
+ * the LDS histograms):
+ *   - a wave owns 64 consecutive reads at a time ("group") and walks them in
+ *     chunks of 64 positions;
+ *   - STAGE: the 64x64-byte sequence and quality tiles of the chunk are
+ *     fetched with 16-byte loads (4 lanes per read, so every 64-byte segment
+ *     of a read is one request) and written to LDS, XOR-swizzled so that both
+ *     orientations below are bank-conflict free; bytes past the end of a read
+ *     become 0x80, a value FASTQ text cannot contain;
+ *   - phase S (lane = read): everything that is sequential inside a read --
+ *     the four interleaved f64 error-rate chains in the reference's exact
+ *     order, and the adapter automaton;
+ *   - phase H (lane = position): the per-position histograms.  All 64 lanes
+ *     hit different positions, so the LDS atomics never collide inside an
+ *     instruction (a lane=read layout would send 64 lanes to <= 5 counters);
+ *     per-read GC/AT totals fall out of two ballots per row;
+ *   - per-read epilogue (lane = read): the 1-4 trailing qualities in order,
+ *     GC% and mean-phred bins, accumulated_error_rate write-back.
+ *   LDS histograms are merged into the u64 tables in HBM once per workgroup.
+ */
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "sq_common.h"
+#include "sq_error_table.h"
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int WAVES = WG_THREADS / 64;
+constexpr uint32_t PAD4 = 0x80808080u;
+constexpr uint32_t LDS_HIST_MAX = 512;  /* positions kept in LDS histograms */
+constexpr uint32_t LDS_EA_MAX = 256;    /* end-anchor rows kept in LDS */
+constexpr uint32_t DFA_LDS_MAX_STATES = 1024; /* 16 KB of LDS */
+constexpr uint32_t BASE_COLS = 8, PHRED_COLS = 16;
+constexpr int64_t TILE_EMPTY = -1;
+constexpr uint32_t TILE_MAP_SIZE = 1u << 16;
+
+/* SCORE_TO_ERROR_RATE as bit patterns (score_to_error_rate.h:4-99) */
+__constant__ unsigned long long c_error_rate_bits[94] = {SQ_ERROR_RATE_BITS_LIST};
+
+struct PassParams {
+    const uint8_t *buf;
+    uint64_t buf_len;
+    sq_meta *metas;
+    uint64_t n;
+    uint64_t first_read_index; /* index of record 0 over everything the module saw */
+    uint32_t lds_len;          /* positions covered by the LDS histograms */
+    /* QCMetrics */
+    unsigned long long *qc_base, *qc_phred, *qc_ea_base, *qc_ea_phred, *qc_gc, *qc_ps;
+    uint32_t ea_len;
+    uint32_t ea_in_lds;
+    const double *thresholds; /* [94], see phred_thresholds() */
+    unsigned long long *qc_first_bad;
+    /* AdapterCounter */
+    const uint16_t *dfa;      /* [states][8] */
+    uint32_t dfa_states;
+    const unsigned long long *dfa_out; /* [states] adapters ending in that state */
+    const uint8_t *ad_len;    /* [n_adapters] */
+    unsigned long long *ad_fwd, *ad_rev; /* [n_adapters][ad_cap] */
+    uint64_t ad_cap;
+    /* PerTileQuality */
+    const int32_t *pt_slot;   /* per record, from k_tile_prepass */
+    unsigned long long *pt_len_counts;
+    double *pt_errors;
+    uint64_t pt_cap;          /* row length of the two tables */
+    uint64_t pt_first_bad;    /* records >= this are ignored */
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+/* 16 bytes from an arbitrary byte address; falls back to byte loads when the
+ * 16-byte window would leave the buffer */
+__device__ __forceinline__ uint4 load16(const uint8_t *buf, uint64_t off, uint64_t buf_len)
+{
+    uint4 v;
+    if (off + 16 <= buf_len) {
+        __builtin_memcpy(&v, buf + off, 16);
+    } else {
+        uint32_t w[4] = {PAD4, PAD4, PAD4, PAD4};
+        for (int k = 0; k < 16; k++) {
+            if (off + k < buf_len) {
+                uint32_t sh = 8 * (k & 3);
+                w[k >> 2] = (w[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)buf[off + k] << sh);
+            }
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+/* keep the first `nvalid` (0..4) bytes of w, the rest become 0x80 */
+__device__ __forceinline__ uint32_t pad_tail(uint32_t w, int nvalid)
+{
+    if (nvalid >= 4) return w;
+    if (nvalid <= 0) return PAD4;
+    uint32_t keep = (1u << (8 * nvalid)) - 1u;
+    return (w & keep) | (PAD4 & ~keep);
+}
+
+template <bool QC, bool AD, bool PT, bool DFA_LDS>
+__global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    /* ---- LDS carve-up (every region 16-byte aligned) ---- */
+    double *l_err = (double *)smem;                        /* [256] by raw quality byte */
+    double *l_thr = l_err + 256;                           /* [96] */
+    uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
+    uint32_t *l_ps = l_gc + 104;                           /* [96] */
+    uint8_t *l_cls = (uint8_t *)(l_ps + 96);               /* [256] */
+    uint32_t *l_wave = (uint32_t *)(l_cls + 256);          /* per wave: seq tile, qual tile, offsets, lengths */
+    constexpr uint32_t WAVE_WORDS = 1024 + 1024 + 128 + 128 + 64;
+    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [lds_len][8] */
+    uint32_t *l_hist_phred = l_hist_base + (QC ? P.lds_len * BASE_COLS : 0);
+    uint32_t *l_ea_base = l_hist_phred + (QC ? P.lds_len * PHRED_COLS : 0);
+    uint32_t ea_rows = (QC && P.ea_in_lds) ? P.ea_len : 0;
+    uint32_t *l_ea_phred = l_ea_base + ea_rows * BASE_COLS;
+    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + ea_rows * PHRED_COLS);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    /* ---- fill tables ---- */
+    for (int i = tid; i < 256; i += WG_THREADS) {
+        double e;
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) {
+            unsigned long long bits = c_error_rate_bits[i - 33];
+            e = __longlong_as_double((long long)bits);
+        } else if (i >= 128) {
+            e = 0.0; /* padding past the end of a read adds nothing */
+        } else {
+            e = __longlong_as_double(0x7FF8000000000000LL); /* invalid phred byte poisons the sum */
+        }
+        l_err[i] = e;
+        l_cls[i] = i >= 128 ? 5 : (uint8_t)sq_base_class((unsigned)i);
+    }
+    if (QC) {
+        for (int i = tid; i < 96; i += WG_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+        for (int i = tid; i < 104; i += WG_THREADS) l_gc[i] = 0;
+        for (int i = tid; i < 96; i += WG_THREADS) l_ps[i] = 0;
+        uint32_t nh = P.lds_len * (BASE_COLS + PHRED_COLS) + ea_rows * (BASE_COLS + PHRED_COLS);
+        for (uint32_t i = tid; i < nh; i += WG_THREADS) l_hist_base[i] = 0;
+    }
+    if (AD && DFA_LDS) {
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+    }
+    __syncthreads();
+
+    uint32_t *w_seq = l_wave + wave * WAVE_WORDS;
+    uint32_t *w_qual = w_seq + 1024;
+    unsigned long long *w_soff = (unsigned long long *)(w_qual + 1024);
+    unsigned long long *w_qoff = w_soff + 64;
+    uint32_t *w_len = (uint32_t *)(w_qoff + 64);
+
+    const uint64_t ngroups = (P.n + 63) / 64;
+    const uint32_t my_swz = (lane >> 1) & 15;
+
+    for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g < ngroups;
+         g += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t r = g * 64 + lane;
+        const bool valid = r < P.n;
+        sq_meta m;
+        if (valid) m = P.metas[r];
+        const uint32_t L = valid ? m.sequence_length : 0;
+        const uint64_t soff = valid ? m.record_start + m.sequence_offset : 0;
+        const uint64_t qoff = valid ? m.record_start + m.qualities_offset : 0;
+        w_soff[lane] = soff;
+        w_qoff[lane] = qoff;
+        w_len[lane] = L;
+        const uint32_t maxL = wave_max_u32(L);
+        const uint32_t Lmain = L > 0 ? 4 * ((L - 1) / 4) : 0; /* _qcmodule.c:2062,2068 */
+
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        uint32_t st = 0;                 /* automaton state as a byte offset of its row */
+        unsigned long long found = 0;    /* adapters already seen in this read */
+        uint32_t gc_cnt = 0, acgt_cnt = 0;
+        bool pt_on = false;
+        int32_t pt_slot = -1;
+        if (PT) {
+            pt_slot = valid ? P.pt_slot[r] : -1;
+            pt_on = valid && pt_slot >= 0 && (P.first_read_index + r) < P.pt_first_bad;
+        }
+        /* the staging lanes of other rows read w_soff / w_qoff / w_len */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t c0 = 0; c0 < maxL; c0 += 64) {
+            /* ---------------- STAGE ---------------- */
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const uint32_t row = it * 16 + (lane >> 2), piece = lane & 3;
+                const uint32_t Lr = w_len[row];
+                const uint32_t p0 = c0 + piece * 16;
+                uint4 sv = make_uint4(PAD4, PAD4, PAD4, PAD4), qv = sv;
+                if (p0 < Lr) {
+                    const int nv = (int)min(16u, Lr - p0);
+                    if (QC || AD) sv = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                    if (QC || PT) qv = load16(P.buf, w_qoff[row] + p0, P.buf_len);
+                    if (nv < 16) {
+                        sv.x = pad_tail(sv.x, nv); sv.y = pad_tail(sv.y, nv - 4);
+                        sv.z = pad_tail(sv.z, nv - 8); sv.w = pad_tail(sv.w, nv - 12);
+                        qv.x = pad_tail(qv.x, nv); qv.y = pad_tail(qv.y, nv - 4);
+                        qv.z = pad_tail(qv.z, nv - 8); qv.w = pad_tail(qv.w, nv - 12);
+                    }
+                }
+                const uint32_t swz = (row >> 1) & 15, base = row * 16, d0 = piece * 4;
+                if (QC || AD) {
+                    w_seq[base + ((d0 + 0) ^ swz)] = sv.x;
+                    w_seq[base + ((d0 + 1) ^ swz)] = sv.y;
+                    w_seq[base + ((d0 + 2) ^ swz)] = sv.z;
+                    w_seq[base + ((d0 + 3) ^ swz)] = sv.w;
+                }
+                if (QC || PT) {
+                    w_qual[base + ((d0 + 0) ^ swz)] = qv.x;
+                    w_qual[base + ((d0 + 1) ^ swz)] = qv.y;
+                    w_qual[base + ((d0 + 2) ^ swz)] = qv.z;
+                    w_qual[base + ((d0 + 3) ^ swz)] = qv.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            /* ---------------- phase S: lane = read ---------------- */
+            if (QC || AD) {
+                const uint32_t rb = lane * 16;
+#pragma unroll 4
+                for (uint32_t d = 0; d < 16; d++) {
+                    const uint32_t pos0 = c0 + d * 4;
+                    if (QC) {
+                        uint32_t qd = w_qual[rb + (d ^ my_swz)];
+                        /* the reference's four chains stop four short of the end (:2068) */
+                        qd = pos0 < Lmain ? qd : PAD4;
+                        acc0 += l_err[qd & 0xFF];
+                        acc1 += l_err[(qd >> 8) & 0xFF];
+                        acc2 += l_err[(qd >> 16) & 0xFF];
+                        acc3 += l_err[qd >> 24];
+                    }
+                    if (AD) {
+                        const uint32_t sd = w_seq[rb + (d ^ my_swz)];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t cls2 = (uint32_t)l_cls[(sd >> (8 * j)) & 0xFF] * 2;
+                            uint32_t e;
+                            if (DFA_LDS) e = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
+                            else e = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
+                            st = e & 0xFFF0u;
+                            if (e & 1u) {
+                                /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+                                unsigned long long hits = P.dfa_out[st >> 4] & ~found;
+                                found |= hits;
+                                const uint32_t pos = pos0 + j;
+                                while (hits) {
+                                    const int a = __ffsll((long long)hits) - 1;
+                                    hits &= hits - 1;
+                                    const uint32_t start = pos - P.ad_len[a] + 1;
+                                    atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                                    atomicAdd(&P.ad_rev[a * P.ad_cap + (L - 1 - start)], 1ULL);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+
+            /* ---------------- phase H: lane = position ---------------- */
+            if (QC || PT) {
+                const uint32_t p = c0 + lane;
+                uint32_t gc_tmp = 0, acgt_tmp = 0;
+                for (uint32_t row = 0; row < 64; row++) {
+                    const uint32_t Lr = __builtin_amdgcn_readfirstlane(w_len[row]);
+                    if (c0 >= Lr) continue;
+                    const uint32_t widx = row * 16 + (((uint32_t)lane >> 2) ^ ((row >> 1) & 15));
+                    const uint32_t sh = 8 * (lane & 3);
+                    const bool act = p < Lr;
+                    const uint32_t qb = (w_qual[widx] >> sh) & 0xFF;
+                    if (QC) {
+                        const uint32_t cls = l_cls[(w_seq[widx] >> sh) & 0xFF];
+                        const uint32_t q = qb - 33u;
+                        const uint32_t bin = q > (uint32_t)SQ_PHRED_MAX ? 12u : (min(q, 47u) >> 2);
+                        if (act) {
+                            if (p < P.lds_len) {
+                                atomicAdd(&l_hist_base[p * BASE_COLS + cls], 1u);
+                                atomicAdd(&l_hist_phred[p * PHRED_COLS + bin], 1u);
+                            } else {
+                                atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
+                                if (bin < 12) atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
+                            }
+                            /* last min(ea, L) positions, right aligned (:1971-1972) */
+                            const uint32_t ean = min(P.ea_len, Lr);
+                            if (p >= Lr - ean) {
+                                const uint32_t e = P.ea_len - Lr + p;
+                                if (P.ea_in_lds) {
+                                    atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
+                                    atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                                } else {
+                                    atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
+                                    if (bin < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
+                                }
+                            }
+                        }
+                        const unsigned long long m_gc = __ballot(act && (cls == 1 || cls == 2));
+                        const unsigned long long m_acgt = __ballot(act && cls < 4);
+                        /* row totals land in the lane that owns the read */
+                        const bool mine = (uint32_t)lane == row;
+                        gc_tmp = mine ? (uint32_t)__popcll(m_gc) : gc_tmp;
+                        acgt_tmp = mine ? (uint32_t)__popcll(m_acgt) : acgt_tmp;
+                    }
+                    if (PT) {
+                        const int32_t slot = __builtin_amdgcn_readfirstlane(__shfl(pt_on ? pt_slot : -1, (int)row));
+                        if (slot >= 0 && act) {
+                            const double e = l_err[qb];
+                            unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                        }
+                    }
+                }
+                gc_cnt += gc_tmp;
+                acgt_cnt += acgt_tmp;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        /* ---------------- per-read epilogue: lane = read ---------------- */
+        if (QC && valid) {
+            double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099, left to right */
+            for (uint32_t pos = Lmain; pos < L; pos++)  /* :2100-2112 */
+                total += l_err[P.buf[qoff + pos]];
+            P.metas[r].accumulated_error_rate = total;  /* :2126 */
+            if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+            if (acgt_cnt > 0) { /* :2051-2058 */
+                const double pct = (double)gc_cnt * 100.0 / (double)acgt_cnt;
+                atomicAdd(&l_gc[(uint32_t)round(pct)], 1u);
+            }
+            if (L > 0) { /* :2127-2137 via the host-libm threshold table */
+                const double avg = total / (double)L;
+                uint32_t lo = 0, hi = 93; /* largest k with avg <= thr[k]; thr[0] = +inf */
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+                }
+                atomicAdd(&l_ps[lo], 1u);
+            }
+        }
+        if (PT && pt_on && L > 0)
+            atomicAdd(&P.pt_len_counts[(uint64_t)pt_slot * P.pt_cap + (L - 1)], 1ULL);
+    }
+
+    /* ---------------- merge the workgroup's histograms ---------------- */
+    if (QC) {
+        __syncthreads();
+        for (uint32_t i = tid; i < P.lds_len * BASE_COLS; i += WG_THREADS) {
+            const uint32_t v = l_hist_base[i], c = i % BASE_COLS;
+            if (v && c < 5) atomicAdd(&P.qc_base[(uint64_t)(i / BASE_COLS) * 5 + c], (unsigned long long)v);
+        }
+        for (uint32_t i = tid; i < P.lds_len * PHRED_COLS; i += WG_THREADS) {
+            const uint32_t v = l_hist_phred[i], c = i % PHRED_COLS;
+            if (v && c < 12) atomicAdd(&P.qc_phred[(uint64_t)(i / PHRED_COLS) * 12 + c], (unsigned long long)v);
+        }
+        for (uint32_t i = tid; i < ea_rows * BASE_COLS; i += WG_THREADS) {
+            const uint32_t v = l_ea_base[i], c = i % BASE_COLS;
+            if (v && c < 5) atomicAdd(&P.qc_ea_base[(uint64_t)(i / BASE_COLS) * 5 + c], (unsigned long long)v);
+        }
+        for (uint32_t i = tid; i < ea_rows * PHRED_COLS; i += WG_THREADS) {
+            const uint32_t v = l_ea_phred[i], c = i % PHRED_COLS;
+            if (v && c < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)(i / PHRED_COLS) * 12 + c], (unsigned long long)v);
+        }
+        for (uint32_t i = tid; i < 101; i += WG_THREADS)
+            if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
+        for (uint32_t i = tid; i < 94; i += WG_THREADS)
+            if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+    }
+}
+
+size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states)
+{
+    size_t b = 256 * 8 + 96 * 8 + 104 * 4 + 96 * 4 + 256;
+    b += (size_t)WAVES * (1024 + 1024 + 128 + 128 + 64) * 4;
+    if (qc) b += (size_t)(lds_len + ea_rows) * (BASE_COLS + PHRED_COLS) * 4;
+    if (dfa_lds) b += (size_t)dfa_states * 16;
+    return b + 16;
+}
+
+/* ---- PerTileQuality prepass: tile id and table slot of every record -------- */
+struct TileMap {
+    long long *keys; /* [TILE_MAP_SIZE], TILE_EMPTY when free */
+    int *vals;       /* slot numbers, -1 until published */
+    int *n_slots;
+};
+
+/* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180) */
+__device__ long long tile_id_of(const uint8_t *name, uint32_t n)
+{
+    uint32_t i = 0, colons = 0;
+    for (; i < n; i++)
+        if (name[i] == ':' && ++colons == 4) break;
+    const uint32_t start = i + 1;
+    for (uint32_t j = start; j < n; j++) {
+        if (name[j] != ':') continue;
+        const uint32_t len = j - start;
+        if (len < 1 || len > 18) return -1;
+        unsigned long long v = 0;
+        for (uint32_t k = start; k < j; k++) {
+            const uint32_t d = (uint32_t)name[k] - '0';
+            if (d > 9) return -1;
+            v = v * 10 + d;
+        }
+        return (long long)v;
+    }
+    return -1;
+}
+
+__global__ void k_tile_prepass(const uint8_t *buf, const sq_meta *metas, uint64_t n,
+                               uint64_t first_read_index, TileMap map, int32_t *slots,
+                               unsigned long long *first_bad, int *overflow)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const sq_meta m = metas[r];
+        const long long tile = tile_id_of(buf + m.record_start, m.name_length);
+        int slot = -1;
+        if (tile < 0) {
+            atomicMin(first_bad, (unsigned long long)(first_read_index + r));
+        } else {
+            uint32_t idx = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 48) & (TILE_MAP_SIZE - 1);
+            bool done = false;
+            for (uint32_t probes = 0; !done && probes < 4 * TILE_MAP_SIZE; probes++) {
+                long long k = __hip_atomic_load(&map.keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == TILE_EMPTY) {
+                    const long long old = (long long)atomicCAS((unsigned long long *)&map.keys[idx],
+                                                               (unsigned long long)TILE_EMPTY,
+                                                               (unsigned long long)tile);
+                    if (old == TILE_EMPTY) {
+                        slot = atomicAdd(map.n_slots, 1);
+                        __hip_atomic_store(&map.vals[idx], slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        done = true;
+                    } else {
+                        k = old;
+                    }
+                }
+                if (!done) {
+                    if (k == tile) {
+                        const int v = __hip_atomic_load(&map.vals[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v >= 0) { slot = v; done = true; }
+                        /* else: the inserting lane publishes it this iteration */
+                    } else {
+                        idx = (idx + 1) & (TILE_MAP_SIZE - 1);
+                    }
+                }
+            }
+            if (!done) *overflow = 1;
+        }
+        slots[r] = slot;
+    }
+}
+
+/* ---- phred_scores thresholds ----------------------------------------------------
+ * bin = floor(-10 * log10(avg))  (_qcmodule.c:2127-2136) is evaluated with the
+ * HOST libm: thr[k] is the largest double with bin >= k, found by bisection
+ * over the bit patterns, so the device only compares.   */
+int phred_bin_host(double avg) { return (int)(uint64_t)floor(-10.0 * log10(avg)); }
+
+const double *phred_thresholds()
+{
+    static double thr[94];
+    static bool ready = false;
+    if (ready) return thr;
+    thr[0] = INFINITY;
+    for (int k = 1; k < 94; k++) {
+        double lo_d = 1e-12, hi_d = 1.0; /* bin(lo) >= k, bin(hi) = 0 < k */
+        uint64_t lo, hi;
+        memcpy(&lo, &lo_d, 8);
+        memcpy(&hi, &hi_d, 8);
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            double md;
+            memcpy(&md, &mid, 8);
+            if (phred_bin_host(md) >= k) lo = mid; else hi = mid;
+        }
+        memcpy(&thr[k], &lo, 8);
+    }
+    ready = true;
+    return thr;
+}
+
+int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
+{
+    uint64_t groups = (n + 63) / 64;
+    uint64_t wgs = (groups + WAVES - 1) / WAVES;
+    uint64_t cap = (uint64_t)ctx->num_cus * wgs_per_cu;
+    if (wgs > cap) wgs = cap;
+    return (int)(wgs ? wgs : 1);
+}
+
+} // namespace
+
+/* =============================== modules =================================== */
+
+struct sq_qcmetrics {
+    sq_ctx *ctx;
+    uint64_t end_anchor, max_length = 0, number_of_reads = 0;
+    size_t cap = 0;              /* rows allocated in base/phred */
+    unsigned long long *d_base = nullptr, *d_phred = nullptr;
+    size_t cap_phred = 0;
+    unsigned long long *d_ea_base = nullptr, *d_ea_phred = nullptr, *d_gc = nullptr, *d_ps = nullptr;
+    double *d_thr = nullptr;
+    unsigned long long *d_first_bad = nullptr;
+    uint64_t records_seen = 0;
+    std::vector<sq_batch *> pending; /* batches whose host copy may be needed for the error text */
+};
+
+struct sq_adaptercounter {
+    sq_ctx *ctx;
+    std::vector<std::string> adapters;
+    uint64_t max_length = 0, number_of_sequences = 0;
+    size_t cap = 0; /* row length of fwd / rev */
+    unsigned long long *d_fwd = nullptr, *d_rev = nullptr;
+    /* adapters are matched in groups of <= 64 (one automaton each) */
+    struct Group {
+        size_t first, count;
+        uint32_t states;
+        uint16_t *d_dfa = nullptr;
+        unsigned long long *d_out = nullptr;
+        uint8_t *d_len = nullptr;
+    };
+    std::vector<Group> groups;
+};
+
+struct sq_pertile {
+    sq_ctx *ctx;
+    bool skipped = false;
+    std::string skipped_reason;
+    uint64_t number_of_reads = 0, max_length = 0, records_seen = 0;
+    TileMap map{};
+    int n_slots = 0;
+    size_t slot_cap = 0, len_cap = 0;
+    unsigned long long *d_len_counts = nullptr;
+    double *d_errors = nullptr;
+    int32_t *d_slots = nullptr;
+    size_t slots_cap = 0;
+    unsigned long long *d_first_bad = nullptr;
+    int *d_overflow = nullptr;
+    uint64_t first_bad = UINT64_MAX;
+};
+
+/* ---- QCMetrics ------------------------------------------------------------------ */
+
+SQ_EXPORT sq_qcmetrics *sq_qcmetrics_new(sq_ctx *ctx, uint64_t end_anchor_length)
+{
+    if (end_anchor_length > UINT32_MAX) { /* _qcmodule.c:1832-1837 */
+        sq_set_error("end_anchor_length must be between 0 and %lld, got %llu", (long long)UINT32_MAX,
+                     (unsigned long long)end_anchor_length);
+        return nullptr;
+    }
+    sq_qcmetrics *m = new sq_qcmetrics();
+    m->ctx = ctx;
+    m->end_anchor = end_anchor_length;
+    size_t ea = end_anchor_length ? end_anchor_length : 1;
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_ea_base, ea * 5 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_ea_phred, ea * 12 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_gc, 101 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_ps, 94 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_thr, 94 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_first_bad, 8));
+    SQ_HIP_NULL(hipMemsetAsync(m->d_ea_base, 0, ea * 5 * 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(m->d_ea_phred, 0, ea * 12 * 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(m->d_gc, 0, 101 * 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(m->d_ps, 0, 94 * 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(m->d_first_bad, 0xFF, 8, ctx->stream));
+    SQ_HIP_NULL(hipMemcpyAsync(m->d_thr, phred_thresholds(), 94 * 8, hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+    return m;
+}
+
+SQ_EXPORT void sq_qcmetrics_free(sq_qcmetrics *m)
+{
+    if (!m) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (void *p : {(void *)m->d_base, (void *)m->d_phred, (void *)m->d_ea_base, (void *)m->d_ea_phred,
+                    (void *)m->d_gc, (void *)m->d_ps, (void *)m->d_thr, (void *)m->d_first_bad})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+SQ_EXPORT int sq_qcmetrics_reserve(sq_qcmetrics *m, uint64_t length)
+{
+    /* QCMetrics_resize, _qcmodule.c:1870-1906 */
+    int rc = sq_grow_device(m->ctx, &m->d_base, &m->cap, (size_t)length * 5);
+    if (rc) return rc;
+    return sq_grow_device(m->ctx, &m->d_phred, &m->cap_phred, (size_t)length * 12);
+}
+
+/* ---- AdapterCounter: Aho-Corasick automaton over the 5 base classes ------------ */
+namespace {
+
+/* The reference scans with bit-parallel shift-AND words (_qcmodule.c:2675-2770);
+ * what it reports is, per position, the set of adapters that end there.  A
+ * dense automaton gives the same set with one table step per base however
+ * many adapters there are.  Row = 8 u16: next-row byte offset | 1 when some
+ * adapter ends in the target state; class 5 (padding) returns to the root. */
+int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
+              std::vector<uint16_t> &dfa, std::vector<unsigned long long> &out, uint32_t *n_states)
+{
+    struct Node { int next[5]; int fail; unsigned long long out; };
+    std::vector<Node> t(1);
+    for (int c = 0; c < 5; c++) t[0].next[c] = -1;
+    t[0].fail = 0;
+    t[0].out = 0;
+    for (size_t a = 0; a < count; a++) {
+        const std::string &s = ads[first + a];
+        if (s.empty() || s.find('\0') != std::string::npos)
+            continue; /* can never match (populate_bitmask skips NUL, :2455) */
+        int cur = 0;
+        for (unsigned char ch : s) {
+            unsigned l = ch | 0x20u;
+            int c = l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : l == 't' ? 3 : 4;
+            if (t[cur].next[c] < 0) {
+                Node nn;
+                for (int k = 0; k < 5; k++) nn.next[k] = -1;
+                nn.fail = 0;
+                nn.out = 0;
+                t[cur].next[c] = (int)t.size();
+                t.push_back(nn);
+            }
+            cur = t[cur].next[c];
+        }
+        t[cur].out |= 1ULL << a;
+    }
+    if (t.size() > 4095) return -1;
+    /* breadth first: failure links, merged outputs, completed transitions */
+    std::vector<int> queue;
+    for (int c = 0; c < 5; c++) {
+        int v = t[0].next[c];
+        if (v < 0) t[0].next[c] = 0;
+        else { t[v].fail = 0; queue.push_back(v); }
+    }
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        int u = queue[qi];
+        t[u].out |= t[t[u].fail].out;
+        for (int c = 0; c < 5; c++) {
+            int v = t[u].next[c];
+            if (v < 0) t[u].next[c] = t[t[u].fail].next[c];
+            else { t[v].fail = t[t[u].fail].next[c]; queue.push_back(v); }
+        }
+    }
+    /* outputs of a node are final only after its fail chain is: BFS order guarantees it */
+    dfa.assign(t.size() * 8, 0);
+    out.assign(t.size(), 0);
+    for (size_t s = 0; s < t.size(); s++) {
+        out[s] = t[s].out;
+        for (int c = 0; c < 5; c++) {
+            int v = t[s].next[c];
+            dfa[s * 8 + c] = (uint16_t)((v << 4) | (t[v].out ? 1 : 0));
+        }
+    }
+    *n_states = (uint32_t)t.size();
+    return 0;
+}
+
+} // namespace
+
+SQ_EXPORT sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *const *adapters,
+                                                   const size_t *lengths, size_t n)
+{
+    if (n < 1) { /* :2484 */
+        sq_set_error("At least one adapter is expected");
+        return nullptr;
+    }
+    sq_adaptercounter *a = new sq_adaptercounter();
+    a->ctx = ctx;
+    for (size_t i = 0; i < n; i++) {
+        if (lengths[i] > SQ_MAX_SEQUENCE_SIZE) { /* :2506 */
+            sq_set_error("Maximum adapter size is %d, got %zu for '%.*s'", SQ_MAX_SEQUENCE_SIZE,
+                         lengths[i], (int)lengths[i], adapters[i]);
+            delete a;
+            return nullptr;
+        }
+        a->adapters.emplace_back(adapters[i], lengths[i]);
+    }
+    for (size_t first = 0; first < n;) {
+        size_t count = 0, chars = 0;
+        while (first + count < n && count < 64 && chars + lengths[first + count] <= 4000) {
+            chars += lengths[first + count];
+            count++;
+        }
+        sq_adaptercounter::Group g;
+        g.first = first;
+        g.count = count;
+        std::vector<uint16_t> dfa;
+        std::vector<unsigned long long> out;
+        if (build_dfa(a->adapters, first, count, dfa, out, &g.states) != 0) {
+            sq_set_error("adapter automaton too large");
+            delete a;
+            return nullptr;
+        }
+        std::vector<uint8_t> lens(64, 0);
+        for (size_t k = 0; k < count; k++) lens[k] = (uint8_t)lengths[first + k];
+        SQ_HIP_NULL(hipMalloc((void **)&g.d_dfa, dfa.size() * 2));
+        SQ_HIP_NULL(hipMalloc((void **)&g.d_out, out.size() * 8));
+        SQ_HIP_NULL(hipMalloc((void **)&g.d_len, 64));
+        SQ_HIP_NULL(hipMemcpy(g.d_dfa, dfa.data(), dfa.size() * 2, hipMemcpyHostToDevice));
+        SQ_HIP_NULL(hipMemcpy(g.d_out, out.data(), out.size() * 8, hipMemcpyHostToDevice));
+        SQ_HIP_NULL(hipMemcpy(g.d_len, lens.data(), 64, hipMemcpyHostToDevice));
+        a->groups.push_back(g);
+        first += count;
+    }
+    return a;
+}
+
+SQ_EXPORT void sq_adaptercounter_free(sq_adaptercounter *a)
+{
+    if (!a) return;
+    (void)hipStreamSynchronize(a->ctx->stream);
+    for (auto &g : a->groups) {
+        (void)hipFree(g.d_dfa);
+        (void)hipFree(g.d_out);
+        (void)hipFree(g.d_len);
+    }
+    if (a->d_fwd) (void)hipFree(a->d_fwd);
+    if (a->d_rev) (void)hipFree(a->d_rev);
+    delete a;
+}
+
+/* row-major [rows][old_len] -> [rows][new_len], zero filled */
+template <typename T>
+static int regrow_rows(sq_ctx *ctx, T **ptr, size_t rows_old, size_t rows_new, size_t len_old,
+                       size_t len_new)
+{
+    T *n = nullptr;
+    SQ_HIP(hipMalloc((void **)&n, rows_new * len_new * sizeof(T)));
+    SQ_HIP(hipMemsetAsync(n, 0, rows_new * len_new * sizeof(T), ctx->stream));
+    if (*ptr && rows_old && len_old)
+        SQ_HIP(hipMemcpy2DAsync(n, len_new * sizeof(T), *ptr, len_old * sizeof(T), len_old * sizeof(T),
+                                rows_old, hipMemcpyDeviceToDevice, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (*ptr) SQ_HIP(hipFree(*ptr));
+    *ptr = n;
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_adaptercounter_reserve(sq_adaptercounter *a, uint64_t length)
+{
+    /* AdapterCounter_resize, _qcmodule.c:2611-2641 */
+    if (length <= a->cap) return SQ_OK;
+    size_t want = std::max<size_t>(length, a->cap * 2);
+    size_t rows = a->adapters.size();
+    int rc = regrow_rows(a->ctx, &a->d_fwd, rows, rows, a->cap, want);
+    if (rc) return rc;
+    rc = regrow_rows(a->ctx, &a->d_rev, rows, rows, a->cap, want);
+    if (rc) return rc;
+    a->cap = want;
+    return SQ_OK;
+}
+
+/* ---- PerTileQuality ---------------------------------------------------------------- */
+
+SQ_EXPORT sq_pertile *sq_pertile_new(sq_ctx *ctx)
+{
+    sq_pertile *p = new sq_pertile();
+    p->ctx = ctx;
+    SQ_HIP_NULL(hipMalloc((void **)&p->map.keys, TILE_MAP_SIZE * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&p->map.vals, TILE_MAP_SIZE * 4));
+    SQ_HIP_NULL(hipMalloc((void **)&p->map.n_slots, 4));
+    SQ_HIP_NULL(hipMalloc((void **)&p->d_first_bad, 8));
+    SQ_HIP_NULL(hipMalloc((void **)&p->d_overflow, 4));
+    SQ_HIP_NULL(hipMemsetAsync(p->map.keys, 0xFF, TILE_MAP_SIZE * 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(p->map.vals, 0xFF, TILE_MAP_SIZE * 4, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(p->map.n_slots, 0, 4, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(p->d_first_bad, 0xFF, 8, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(p->d_overflow, 0, 4, ctx->stream));
+    SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
+    return p;
+}
+
+SQ_EXPORT void sq_pertile_free(sq_pertile *p)
+{
+    if (!p) return;
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void *q : {(void *)p->map.keys, (void *)p->map.vals, (void *)p->map.n_slots,
+                    (void *)p->d_first_bad, (void *)p->d_overflow, (void *)p->d_len_counts,
+                    (void *)p->d_errors, (void *)p->d_slots})
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+namespace {
+
+/* Python's repr() of an ASCII str, as %R prints it in _qcmodule.c:3144 */
+std::string py_repr(const std::string &s)
+{
+    bool has_sq = s.find('\'') != std::string::npos, has_dq = s.find('"') != std::string::npos;
+    char quote = (has_sq && !has_dq) ? '"' : '\'';
+    std::string r(1, quote);
+    for (unsigned char c : s) {
+        if (c == (unsigned char)quote || c == '\\') { r += '\\'; r += (char)c; }
+        else if (c == '\t') r += "\\t";
+        else if (c == '\n') r += "\\n";
+        else if (c == '\r') r += "\\r";
+        else if (c < 0x20 || c == 0x7F) { char t[8]; snprintf(t, sizeof t, "\\x%02x", c); r += t; }
+        else r += (char)c;
+    }
+    r += quote;
+    return r;
+}
+
+int fetch_bytes(sq_batch *b, uint64_t off, uint64_t len, std::string &out)
+{
+    out.resize(len);
+    if (!len) return SQ_OK;
+    if (!b->h_buf.empty()) {
+        memcpy(&out[0], b->h_buf.data() + off, len);
+        return SQ_OK;
+    }
+    SQ_HIP(hipMemcpy(&out[0], b->d_buf + off, len, hipMemcpyDeviceToHost));
+    return SQ_OK;
+}
+
+int fetch_meta(sq_batch *b, uint64_t i, sq_meta *m)
+{
+    if (!b->h_metas.empty()) { *m = b->h_metas[i]; return SQ_OK; }
+    SQ_HIP(hipMemcpy(m, b->d_metas + i, sizeof(sq_meta), hipMemcpyDeviceToHost));
+    return SQ_OK;
+}
+
+/* stage 1 of a PerTileQuality add: tile ids, slots, first unparsable header */
+int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
+{
+    *active = false;
+    if (p->skipped || b->n == 0) return SQ_OK; /* :3126 */
+    sq_ctx *ctx = p->ctx;
+    if (b->n > p->slots_cap) {
+        if (p->d_slots) SQ_HIP(hipFree(p->d_slots));
+        SQ_HIP(hipMalloc((void **)&p->d_slots, b->n * 4));
+        p->slots_cap = b->n;
+    }
+    int blocks = (int)std::min<uint64_t>((b->n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_tile_prepass, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, b->d_metas,
+                       (uint64_t)b->n, p->records_seen, p->map, p->d_slots, p->d_first_bad,
+                       p->d_overflow);
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[1], p->map.n_slots, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[2], p->d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    p->first_bad = ctx->pinned[0];
+    p->n_slots = (int)(uint32_t)ctx->pinned[1];
+    if ((uint32_t)ctx->pinned[2]) {
+        sq_set_error("PerTileQuality: more than %u distinct tile ids", TILE_MAP_SIZE / 2);
+        return SQ_ERR_MEMORY;
+    }
+    uint64_t counted = b->n; /* records of this batch in front of the first bad header */
+    if (p->first_bad != UINT64_MAX) {
+        counted = p->first_bad - p->records_seen;
+        sq_meta m;
+        std::string name;
+        int rc = fetch_meta(b, counted, &m);
+        if (rc) return rc;
+        rc = fetch_bytes(b, m.record_start, m.name_length, name);
+        if (rc) return rc;
+        p->skipped = true; /* :3137-3148 */
+        p->skipped_reason = "Can not parse header: " + py_repr(name);
+    }
+    p->number_of_reads += counted;
+    /* max_length only moves for records that are counted (:3150) */
+    uint64_t maxlen = b->max_length;
+    if (counted < b->n) {
+        maxlen = 0;
+        if (!b->h_metas.empty()) {
+            for (uint64_t i = 0; i < counted; i++) maxlen = std::max<uint64_t>(maxlen, b->h_metas[i].sequence_length);
+        } else if (counted) {
+            std::vector<sq_meta> tmp(counted);
+            SQ_HIP(hipMemcpy(tmp.data(), b->d_metas, counted * sizeof(sq_meta), hipMemcpyDeviceToHost));
+            for (auto &mm : tmp) maxlen = std::max<uint64_t>(maxlen, mm.sequence_length);
+        }
+    }
+    p->max_length = std::max(p->max_length, maxlen);
+    if (counted == 0) return SQ_OK;
+    /* tables: [slot][len] */
+    size_t need_slots = (size_t)p->n_slots, need_len = (size_t)std::max<uint64_t>(p->max_length, 1);
+    if (need_slots > p->slot_cap || need_len > p->len_cap) {
+        size_t ns = std::max(need_slots, p->slot_cap), nl = std::max(need_len, p->len_cap);
+        if (need_slots > p->slot_cap) ns = std::max<size_t>(need_slots, p->slot_cap * 2);
+        int rc = regrow_rows(ctx, &p->d_len_counts, p->slot_cap, ns, p->len_cap, nl);
+        if (rc) return rc;
+        rc = regrow_rows(ctx, &p->d_errors, p->slot_cap, ns, p->len_cap, nl);
+        if (rc) return rc;
+        p->slot_cap = ns;
+        p->len_cap = nl;
+    }
+    *active = true;
+    return SQ_OK;
+}
+
+template <bool QC, bool AD, bool PT>
+void launch_pass(sq_ctx *ctx, const PassParams &P, bool dfa_lds, int grid, size_t lds)
+{
+    if (dfa_lds)
+        hipLaunchKernelGGL((k_pass<QC, AD, PT, true>), dim3(grid), dim3(WG_THREADS), lds, ctx->stream, P);
+    else
+        hipLaunchKernelGGL((k_pass<QC, AD, PT, false>), dim3(grid), dim3(WG_THREADS), lds, ctx->stream, P);
+}
+
+void dispatch_pass(sq_ctx *ctx, const PassParams &P, bool qc, bool ad, bool pt, bool dfa_lds, int grid,
+                   size_t lds)
+{
+    int key = (qc ? 4 : 0) | (ad ? 2 : 0) | (pt ? 1 : 0);
+    switch (key) {
+        case 1: launch_pass<false, false, true>(ctx, P, dfa_lds, grid, lds); break;
+        case 2: launch_pass<false, true, false>(ctx, P, dfa_lds, grid, lds); break;
+        case 3: launch_pass<false, true, true>(ctx, P, dfa_lds, grid, lds); break;
+        case 4: launch_pass<true, false, false>(ctx, P, dfa_lds, grid, lds); break;
+        case 5: launch_pass<true, false, true>(ctx, P, dfa_lds, grid, lds); break;
+        case 6: launch_pass<true, true, false>(ctx, P, dfa_lds, grid, lds); break;
+        case 7: launch_pass<true, true, true>(ctx, P, dfa_lds, grid, lds); break;
+        default: break;
+    }
+}
+
+} // namespace
+
+SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
+{
+    sq_ctx *ctx = b->ctx;
+    bool pt_active = false;
+    if (p) {
+        int rc = pertile_prepare(p, b, &pt_active);
+        if (rc) return rc;
+    }
+    if (b->n == 0) return SQ_OK;
+    PassParams P{};
+    P.buf = b->d_buf;
+    P.buf_len = b->buf_len;
+    P.metas = b->d_metas;
+    P.n = b->n;
+    if (m) {
+        if (b->max_length > m->max_length) {
+            int rc = sq_qcmetrics_reserve(m, std::max<uint64_t>(b->max_length, m->max_length * 2));
+            if (rc) return rc;
+            m->max_length = b->max_length;
+        }
+        P.first_read_index = m->records_seen;
+        P.qc_base = m->d_base; P.qc_phred = m->d_phred;
+        P.qc_ea_base = m->d_ea_base; P.qc_ea_phred = m->d_ea_phred;
+        P.qc_gc = m->d_gc; P.qc_ps = m->d_ps;
+        P.ea_len = (uint32_t)m->end_anchor;
+        P.ea_in_lds = m->end_anchor <= LDS_EA_MAX;
+        P.thresholds = m->d_thr;
+        P.qc_first_bad = m->d_first_bad;
+    }
+    if (p) {
+        /* the pass compares first_read_index + r with pt_first_bad; both modules
+           count records from their own creation, so carry the difference */
+        P.pt_slot = p->d_slots;
+        P.pt_len_counts = p->d_len_counts;
+        P.pt_errors = p->d_errors;
+        P.pt_cap = p->len_cap;
+        uint64_t fb = p->first_bad == UINT64_MAX ? UINT64_MAX : p->first_bad - p->records_seen;
+        P.pt_first_bad = fb == UINT64_MAX ? UINT64_MAX : fb + P.first_read_index;
+    }
+    P.lds_len = m ? (uint32_t)std::min<uint64_t>(b->max_length, LDS_HIST_MAX) : 0;
+    const uint32_t ea_rows = (m && P.ea_in_lds) ? P.ea_len : 0;
+    if (a) {
+        if (b->max_length > a->max_length) {
+            int rc = sq_adaptercounter_reserve(a, b->max_length);
+            if (rc) return rc;
+            a->max_length = b->max_length;
+        }
+        P.ad_cap = a->cap;
+    }
+    /* first automaton rides with the other modules; further groups get a pass of their own */
+    size_t ngroups = a ? a->groups.size() : 0;
+    for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
+        bool qc = m && gi == 0, pt = pt_active && gi == 0, ad = a != nullptr;
+        bool dfa_lds = false;
+        uint32_t states = 0;
+        if (ad) {
+            auto &g = a->groups[gi];
+            P.dfa = g.d_dfa; P.dfa_states = g.states; P.dfa_out = g.d_out; P.ad_len = g.d_len;
+            P.ad_fwd = a->d_fwd + g.first * a->cap;
+            P.ad_rev = a->d_rev + g.first * a->cap;
+            states = g.states;
+            dfa_lds = states <= DFA_LDS_MAX_STATES;
+        }
+        if (!qc && !pt && !ad) break;
+        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states);
+        int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+        int grid = grid_for(ctx, b->n, wgs_per_cu);
+        dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);
+        SQ_HIP(hipGetLastError());
+    }
+    if (m) { m->number_of_reads += b->n; m->records_seen += b->n; }
+    if (a) a->number_of_sequences += b->n;
+    if (p) p->records_seen += b->n;
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_qcmetrics_add_batch(sq_qcmetrics *m, sq_batch *b) { return sq_fused_add_batch(b, m, nullptr, nullptr); }
+SQ_EXPORT int sq_adaptercounter_add_batch(sq_adaptercounter *a, sq_batch *b) { return sq_fused_add_batch(b, nullptr, a, nullptr); }
+SQ_EXPORT int sq_pertile_add_batch(sq_pertile *p, sq_batch *b) { return sq_fused_add_batch(b, nullptr, nullptr, p); }
+
+/* ---- QCMetrics: flush, errors, getters ----------------------------------------------- */
+
+SQ_EXPORT int sq_qcmetrics_flush(sq_qcmetrics *m)
+{
+    sq_ctx *ctx = m->ctx;
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pinned[8] != UINT64_MAX) {
+        /* _qcmodule.c:2102-2105.  Deferred: the whole batch has been applied. */
+        sq_set_error("Not a valid phred character in record %llu",
+                     (unsigned long long)ctx->pinned[8]);
+        return SQ_ERR_VALUE;
+    }
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_len, sq_meta *metas, size_t n)
+{
+    sq_batch *b = sq_batch_upload(m->ctx, buf, buf_len, metas, n);
+    if (!b) return SQ_ERR_MEMORY;
+    int rc = sq_qcmetrics_add_batch(m, b);
+    if (rc == SQ_OK && n) {
+        std::vector<double> errs(n);
+        rc = sq_batch_error_rates(b, errs.data(), n);
+        for (size_t i = 0; i < n && rc == SQ_OK; i++) metas[i].accumulated_error_rate = errs[i];
+    }
+    if (rc == SQ_OK) {
+        /* surface an invalid phred byte now, with the reference's message */
+        sq_ctx *ctx = m->ctx;
+        hipError_t e = hipMemcpy(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && ctx->pinned[8] != UINT64_MAX) {
+            uint64_t idx = ctx->pinned[8] - (m->records_seen - n);
+            char bad = '?';
+            if (idx < n) {
+                const uint8_t *q = buf + metas[idx].record_start + metas[idx].qualities_offset;
+                for (uint32_t k = 0; k < metas[idx].sequence_length; k++)
+                    if ((uint8_t)(q[k] - 33) > SQ_PHRED_MAX) { bad = (char)q[k]; break; }
+            }
+            sq_set_error("Not a valid phred character: %c", bad);
+            rc = SQ_ERR_VALUE;
+        }
+    }
+    sq_batch_free(b);
+    return rc;
+}
+
+SQ_EXPORT uint64_t sq_qcmetrics_number_of_reads(sq_qcmetrics *m) { return m->number_of_reads; }
+SQ_EXPORT uint64_t sq_qcmetrics_max_length(sq_qcmetrics *m) { return m->max_length; }
+SQ_EXPORT uint64_t sq_qcmetrics_end_anchor_length(sq_qcmetrics *m) { return m->end_anchor; }
+
+static int64_t copy_out(sq_ctx *ctx, const void *d, size_t count, void *out, size_t cap, size_t elem)
+{
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sq_set_error("stream sync failed"); return SQ_ERR_HIP; }
+    if (out && cap >= count && count) {
+        if (hipMemcpy(out, d, count * elem, hipMemcpyDeviceToHost) != hipSuccess) {
+            sq_set_error("device to host copy failed");
+            return SQ_ERR_HIP;
+        }
+    }
+    return (int64_t)count;
+}
+
+SQ_EXPORT int64_t sq_qcmetrics_base_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_base, m->max_length * 5, out, cap, 8); }
+SQ_EXPORT int64_t sq_qcmetrics_phred_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_phred, m->max_length * 12, out, cap, 8); }
+SQ_EXPORT int64_t sq_qcmetrics_end_anchored_base_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_ea_base, m->end_anchor * 5, out, cap, 8); }
+SQ_EXPORT int64_t sq_qcmetrics_end_anchored_phred_count_table(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_ea_phred, m->end_anchor * 12, out, cap, 8); }
+SQ_EXPORT int64_t sq_qcmetrics_gc_content(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_gc, 101, out, cap, 8); }
+SQ_EXPORT int64_t sq_qcmetrics_phred_scores(sq_qcmetrics *m, uint64_t *out, size_t cap)
+{ return copy_out(m->ctx, m->d_ps, 94, out, cap, 8); }
+
+SQ_EXPORT int64_t sq_qcmetrics_device_tables(sq_qcmetrics *m, void **ptrs, uint64_t *counts, size_t cap)
+{
+    void *p[6] = {m->d_base, m->d_phred, m->d_ea_base, m->d_ea_phred, m->d_gc, m->d_ps};
+    uint64_t c[6] = {m->cap, m->cap_phred, m->end_anchor * 5, m->end_anchor * 12, 101, 94};
+    for (size_t i = 0; i < 6 && i < cap; i++) { ptrs[i] = p[i]; counts[i] = c[i]; }
+    return 6;
+}
+
+SQ_EXPORT int sq_qcmetrics_set_totals(sq_qcmetrics *m, uint64_t number_of_reads, uint64_t max_length)
+{
+    int rc = sq_qcmetrics_reserve(m, max_length);
+    if (rc) return rc;
+    m->number_of_reads = number_of_reads;
+    m->max_length = max_length;
+    return SQ_OK;
+}
+
+/* ---- AdapterCounter: add, getters -------------------------------------------------------- */
+
+SQ_EXPORT int sq_adaptercounter_add(sq_adaptercounter *a, const uint8_t *buf, size_t buf_len,
+                                    const sq_meta *metas, size_t n)
+{
+    sq_batch *b = sq_batch_upload(a->ctx, buf, buf_len, metas, n);
+    if (!b) return SQ_ERR_MEMORY;
+    int rc = sq_adaptercounter_add_batch(a, b);
+    sq_batch_free(b);
+    return rc;
+}
+
+SQ_EXPORT int sq_adaptercounter_flush(sq_adaptercounter *a) { return sq_synchronize(a->ctx); }
+SQ_EXPORT uint64_t sq_adaptercounter_number_of_sequences(sq_adaptercounter *a) { return a->number_of_sequences; }
+SQ_EXPORT uint64_t sq_adaptercounter_max_length(sq_adaptercounter *a) { return a->max_length; }
+SQ_EXPORT uint64_t sq_adaptercounter_number_of_adapters(sq_adaptercounter *a) { return a->adapters.size(); }
+
+SQ_EXPORT int64_t sq_adaptercounter_get_counts(sq_adaptercounter *a, size_t i, uint64_t *forward,
+                                               uint64_t *reverse, size_t cap)
+{
+    if (i >= a->adapters.size()) { sq_set_error("adapter index out of range"); return SQ_ERR_VALUE; }
+    int64_t r = copy_out(a->ctx, a->d_fwd + i * a->cap, a->max_length, forward, cap, 8);
+    if (r < 0) return r;
+    return copy_out(a->ctx, a->d_rev + i * a->cap, a->max_length, reverse, cap, 8);
+}
+
+SQ_EXPORT int64_t sq_adaptercounter_device_tables(sq_adaptercounter *a, void **ptrs, uint64_t *counts, size_t cap)
+{
+    if (cap > 0) { ptrs[0] = a->d_fwd; counts[0] = a->adapters.size() * a->cap; }
+    if (cap > 1) { ptrs[1] = a->d_rev; counts[1] = a->adapters.size() * a->cap; }
+    return 2;
+}
+
+SQ_EXPORT int sq_adaptercounter_set_totals(sq_adaptercounter *a, uint64_t number_of_sequences, uint64_t max_length)
+{
+    int rc = sq_adaptercounter_reserve(a, max_length);
+    if (rc) return rc;
+    a->number_of_sequences = number_of_sequences;
+    a->max_length = max_length;
+    return SQ_OK;
+}
+
+/* ---- PerTileQuality: add, getters ---------------------------------------------------------- */
+
+SQ_EXPORT int sq_pertile_add(sq_pertile *p, const uint8_t *buf, size_t buf_len, const sq_meta *metas, size_t n)
+{
+    if (p->skipped) { p->records_seen += n; return SQ_OK; }
+    sq_batch *b = sq_batch_upload(p->ctx, buf, buf_len, metas, n);
+    if (!b) return SQ_ERR_MEMORY;
+    int rc = sq_pertile_add_batch(p, b);
+    sq_batch_free(b);
+    return rc;
+}
+
+SQ_EXPORT int sq_pertile_flush(sq_pertile *p) { return sq_synchronize(p->ctx); }
+SQ_EXPORT uint64_t sq_pertile_number_of_reads(sq_pertile *p) { return p->number_of_reads; }
+SQ_EXPORT uint64_t sq_pertile_max_length(sq_pertile *p) { return p->max_length; }
+SQ_EXPORT const char *sq_pertile_skipped_reason(sq_pertile *p) { return p->skipped ? p->skipped_reason.c_str() : nullptr; }
+SQ_EXPORT uint64_t sq_pertile_number_of_tiles(sq_pertile *p) { return (uint64_t)p->n_slots; }
+
+SQ_EXPORT int64_t sq_pertile_get_tile_counts(sq_pertile *p, int64_t *tile_ids, double *errors,
+                                             uint64_t *counts, size_t cap_tiles, size_t cap_len)
+{
+    sq_ctx *ctx = p->ctx;
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t nt = (size_t)p->n_slots, ml = (size_t)p->max_length;
+    if (!tile_ids || cap_tiles < nt || cap_len < ml || nt == 0) return (int64_t)nt;
+    std::vector<long long> keys(TILE_MAP_SIZE);
+    std::vector<int> vals(TILE_MAP_SIZE);
+    SQ_HIP(hipMemcpy(keys.data(), p->map.keys, TILE_MAP_SIZE * 8, hipMemcpyDeviceToHost));
+    SQ_HIP(hipMemcpy(vals.data(), p->map.vals, TILE_MAP_SIZE * 4, hipMemcpyDeviceToHost));
+    std::vector<std::pair<long long, int>> order;
+    for (size_t i = 0; i < TILE_MAP_SIZE; i++)
+        if (keys[i] != TILE_EMPTY && vals[i] >= 0) order.emplace_back(keys[i], vals[i]);
+    std::sort(order.begin(), order.end()); /* :3317 ascending tile id */
+    std::vector<unsigned long long> lc(p->slot_cap * p->len_cap);
+    std::vector<double> er(p->slot_cap * p->len_cap);
+    if (!lc.empty()) {
+        SQ_HIP(hipMemcpy(lc.data(), p->d_len_counts, lc.size() * 8, hipMemcpyDeviceToHost));
+        SQ_HIP(hipMemcpy(er.data(), p->d_errors, er.size() * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t k = 0; k < order.size() && k < nt; k++) {
+        const size_t slot = (size_t)order[k].second;
+        tile_ids[k] = order[k].first;
+        uint64_t running = 0; /* :3336-3347 reads reaching position j */
+        for (size_t j = ml; j-- > 0;) {
+            running += lc[slot * p->len_cap + j];
+            errors[k * cap_len + j] = er[slot * p->len_cap + j];
+            counts[k * cap_len + j] = running;
+        }
+    }
+    return (int64_t)nt;
+}

@@ -1,0 +1,232 @@
+"""HIP path vs the CPU oracle on seeded inputs the golden files do not cover:
+ragged lengths, every byte class, several adapter group shapes, long reads,
+device-generated batches.  Needs a GPU."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def u64(a):
+    return np.array(a, dtype=np.uint64)
+
+
+def random_batch(rng, n, max_len, illumina_names=True, alphabet=b"ACGTNacgtnRYKM-", qmax=93):
+    from sequali_amd import FastqRecordArrayView
+    names, seqs, quals = [], [], []
+    alpha = np.frombuffer(alphabet, np.uint8)
+    for i in range(n):
+        L = int(rng.integers(0, max_len + 1))
+        if rng.random() < 0.1:
+            L = int(rng.integers(0, 8))
+        w = np.ones(len(alpha))
+        w[:4] = 20
+        s = rng.choice(alpha, size=L, p=w / w.sum()).tobytes().decode()
+        q = (rng.integers(0, qmax + 1, size=L) + 33).astype(np.uint8).tobytes().decode()
+        tile = int(rng.choice([1101, 1102, 2205, 7, 99239]))
+        names.append(f"M:1:F:{i % 4}:{tile}:{i}:{L} 1:N:0:X" if illumina_names else f"read{i} x")
+        seqs.append(s)
+        quals.append(q)
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    return buf, metas, FastqRecordArrayView._from_buffer(buf, metas.copy())
+
+
+def compare_qc(ref, got, metas_ref, arr):
+    assert got.number_of_reads == ref.number_of_reads
+    assert got.max_length == ref.max_length
+    np.testing.assert_array_equal(u64(got.base_count_table()), ref.base_count_table())
+    np.testing.assert_array_equal(u64(got.phred_count_table()), ref.phred_count_table())
+    np.testing.assert_array_equal(u64(got.end_anchored_base_count_table()), ref.end_anchored_base_count_table())
+    np.testing.assert_array_equal(u64(got.end_anchored_phred_count_table()), ref.end_anchored_phred_count_table())
+    np.testing.assert_array_equal(u64(got.gc_content()), ref.gc_content())
+    np.testing.assert_array_equal(u64(got.phred_scores()), ref.phred_scores())
+    np.testing.assert_array_equal(arr.accumulated_error_rates().view(np.uint64),
+                                  metas_ref["accumulated_error_rate"].view(np.uint64))
+
+
+@pytest.mark.parametrize("seed,n,max_len,ea", [(1, 2000, 151, 100), (2, 3000, 40, 100), (3, 700, 700, 15),
+                                                (4, 300, 3000, 300), (5, 64, 64, 0), (6, 65, 63, 1000)])
+def test_qc_ragged(seed, n, max_len, ea):
+    from sequali_amd import QCMetrics
+    rng = np.random.default_rng(seed)
+    buf, metas, arr = random_batch(rng, n, max_len)
+    ref, got = oracle.QCMetrics(ea), QCMetrics(ea)
+    ref.add(buf, metas)
+    got.add_record_array(arr)
+    compare_qc(ref, got, metas, arr)
+
+
+def test_qc_two_batches_growing_length():
+    from sequali_amd import QCMetrics
+    rng = np.random.default_rng(11)
+    ref, got = oracle.QCMetrics(), QCMetrics()
+    for max_len in (50, 400, 120):
+        buf, metas, arr = random_batch(rng, 500, max_len)
+        ref.add(buf, metas)
+        got.add_record_array(arr)
+    np.testing.assert_array_equal(u64(got.base_count_table()), ref.base_count_table())
+    np.testing.assert_array_equal(u64(got.phred_count_table()), ref.phred_count_table())
+    np.testing.assert_array_equal(u64(got.phred_scores()), ref.phred_scores())
+    assert got.max_length == ref.max_length
+
+
+def test_qc_invalid_phred_raises():
+    from sequali_amd import FastqRecordArrayView, QCMetrics
+    buf, metas = oracle.make_batch(["a", "b"], ["ACGT", "ACGTA"], ["IIII", "II II"])
+    m = QCMetrics()
+    m.add_record_array(FastqRecordArrayView._from_buffer(buf, metas))
+    with pytest.raises(ValueError, match="Not a valid phred character:  "):
+        m.base_count_table()
+
+
+ADAPTER_SETS = [
+    ["AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA", "GGGGGGGGGGGG", "AAAAAAAAAAAA"],
+    ["ACG", "CGT", "A", "NN", "GTAC", "TTTTTTTT"],
+    ["A" * 64, "C" * 64, "G" * 64, "ACGT" * 16, "N" * 5],
+    [("ACGT" * 16)[i:i + 7 + i % 5] for i in range(70)],   # more than 64 adapters: two automatons
+]
+
+
+@pytest.mark.parametrize("which", range(len(ADAPTER_SETS)))
+def test_adapter_ragged(which):
+    from sequali_amd import AdapterCounter
+    rng = np.random.default_rng(20 + which)
+    adapters = ADAPTER_SETS[which]
+    buf, metas, arr = random_batch(rng, 3000, 200, alphabet=b"ACGTNacgt")
+    ref, got = oracle.AdapterCounter(adapters), AdapterCounter(adapters)
+    ref.add(buf, metas)
+    got.add_record_array(arr)
+    assert got.max_length == ref.max_length
+    assert got.number_of_sequences == ref.number_of_sequences
+    for (_, f, r), (_, fr, rr) in zip(got.get_counts(), ref.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    assert sum(int(f.sum()) for _, f, _ in ref.get_counts()) > 0
+
+
+def test_pertile_ragged():
+    from sequali_amd import PerTileQuality
+    rng = np.random.default_rng(31)
+    ref, got = oracle.PerTileQuality(), PerTileQuality()
+    for _ in range(3):
+        buf, metas, arr = random_batch(rng, 2000, 151)
+        ref.add(buf, metas)
+        got.add_record_array(arr)
+    assert got.number_of_reads == ref.number_of_reads
+    assert got.max_length == ref.max_length
+    assert got.skipped_reason is None
+    for (t, e, c), (tr, er, cr) in zip(got.get_tile_counts(), ref.get_tile_counts()):
+        assert t == tr
+        np.testing.assert_allclose(np.array(e), er, rtol=1e-6)   # summation order differs
+        np.testing.assert_array_equal(u64(c), cr)
+
+
+def test_overrep_vs_oracle_with_cap_crossing():
+    from sequali_amd import OverrepresentedSequences
+    rng = np.random.default_rng(41)
+    kw = dict(max_unique_fragments=700, sample_every=3, fragment_length=21)
+    ref, got = oracle.OverrepresentedSequences(**kw), OverrepresentedSequences(**kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(4):
+            buf, metas, arr = random_batch(rng, 1500, 160, alphabet=b"ACGTACGTACGTACGTN")
+            ref.add(buf, metas)
+            got.add_record_array(arr)
+    assert got.collected_unique_fragments == ref.collected_unique_fragments == 700
+    assert got.total_fragments == ref.total_fragments
+    assert got.sampled_sequences == ref.sampled_sequences
+    assert got.sequence_counts() == ref.sequence_counts()
+    assert got.overrepresented_sequences(0.001) == ref.overrepresented_sequences(0.001)
+
+
+def test_overrep_whole_read_fragments():
+    """bases_from_start/end = -1: staging tables larger than the register path"""
+    from sequali_amd import OverrepresentedSequences
+    rng = np.random.default_rng(42)
+    kw = dict(sample_every=1, fragment_length=5, bases_from_start=-1, bases_from_end=-1)
+    ref, got = oracle.OverrepresentedSequences(**kw), OverrepresentedSequences(**kw)
+    buf, metas, arr = random_batch(rng, 400, 400, alphabet=b"ACGT")
+    ref.add(buf, metas)
+    got.add_record_array(arr)
+    assert got.sequence_counts() == ref.sequence_counts()
+    assert got.total_fragments == ref.total_fragments
+
+
+def test_dedup_vs_oracle_rebuilds():
+    from sequali_amd import DedupEstimator
+    rng = np.random.default_rng(51)
+    kw = dict(max_stored_fingerprints=300, front_sequence_offset=8, back_sequence_offset=0)
+    ref, got = oracle.DedupEstimator(**kw), DedupEstimator(**kw)
+    for _ in range(5):
+        buf, metas, arr = random_batch(rng, 2500, 80, alphabet=b"ACGT")
+        ref.add(buf, metas)
+        got.add_record_array(arr)
+    assert got._modulo_bits == ref._modulo_bits >= 3
+    assert got.tracked_sequences == ref.tracked_sequences
+    np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
+
+
+def test_dedup_pairs_with_short_reads_stale_bytes():
+    """pairs shorter than the fingerprint reuse bytes of the previous fingerprint (:4512)"""
+    from sequali_amd import DedupEstimator
+    rng = np.random.default_rng(52)
+    kw = dict(max_stored_fingerprints=200, front_sequence_offset=0, back_sequence_offset=0)
+    ref, got = oracle.DedupEstimator(**kw), DedupEstimator(**kw)
+    for _ in range(3):
+        b1, m1, a1 = random_batch(rng, 800, 20, alphabet=b"ACGT")
+        b2, m2, a2 = random_batch(rng, 800, 20, alphabet=b"ACGT")
+        ref.add_pair(b1, m1, b2, m2)
+        got.add_record_array_pair(a1, a2)
+    assert got._modulo_bits == ref._modulo_bits
+    np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
+
+
+def test_insert_size_vs_oracle():
+    from sequali_amd import InsertSizeMetrics, synth
+    ref, got = oracle.InsertSizeMetrics(50), InsertSizeMetrics(50)
+    for first in (0, 5000):
+        a1 = synth.host_array(synth.ILLUMINA, first, 5000)
+        a2 = synth.host_array(synth.ILLUMINA_R2, first, 5000)
+        ref.add_pair(a1.obj, a1._metas, a2.obj, a2._metas)
+        got.add_record_array_pair(a1, a2)
+    np.testing.assert_array_equal(u64(got.insert_sizes()), ref.insert_sizes())
+    assert got.adapters_read1() == ref.adapters_read1()
+    assert got.adapters_read2() == ref.adapters_read2()
+    assert got.number_of_adapters_read1 == ref.number_of_adapters_read1 > 0
+    assert int(ref.insert_sizes()[1:].sum()) > 1000
+
+
+def test_device_generator_matches_host_generator():
+    """the GPU-resident synthetic batches hold exactly the host generator's bytes"""
+    from sequali_amd import QCMetrics, synth
+    for kind, n in ((synth.ILLUMINA, 3000), (synth.ILLUMINA_R2, 1000), (synth.NANOPORE, 40)):
+        host = synth.host_array(kind, 17, n)
+        dev = synth.device_array(kind, 17, n)
+        assert len(dev) == n
+        a, b = QCMetrics(), QCMetrics()
+        a.add_record_array(host)
+        b.add_record_array(dev)
+        assert a.base_count_table() == b.base_count_table()
+        assert a.phred_count_table() == b.phred_count_table()
+        np.testing.assert_array_equal(host.accumulated_error_rates().view(np.uint64),
+                                      dev.accumulated_error_rates().view(np.uint64))
+
+
+def test_nanopore_long_reads_all_modules():
+    from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
+    arr = synth.host_array(synth.NANOPORE, 0, 200)
+    probes = list(synth.NANOPORE_PROBES)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    metas = arr._metas.copy()
+    rq.add(arr.obj, metas)
+    ra.add(arr.obj, metas)
+    gq, ga = QCMetrics(), AdapterCounter(probes)
+    FusedPass(gq, ga).add_record_array(arr)
+    compare_qc(rq, gq, metas, arr)
+    for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
