@@ -424,18 +424,32 @@ __device__ long long tile_id_of(const uint8_t *name, uint32_t n)
     return -1;
 }
 
-__global__ void k_tile_prepass(const uint8_t *buf, const sq_meta *metas, uint64_t n,
-                               uint64_t first_read_index, TileMap map, int32_t *slots,
-                               unsigned long long *first_bad, int *overflow)
+/* pass 1: tile id of every record, first record whose header does not parse */
+__global__ void k_tile_parse(const uint8_t *buf, const sq_meta *metas, uint64_t n,
+                             uint64_t first_read_index, long long *tiles,
+                             unsigned long long *first_bad)
 {
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
          r += (uint64_t)gridDim.x * blockDim.x) {
         const sq_meta m = metas[r];
         const long long tile = tile_id_of(buf + m.record_start, m.name_length);
+        if (tile < 0) atomicMin(first_bad, (unsigned long long)(first_read_index + r));
+        tiles[r] = tile;
+    }
+}
+
+/* pass 2: table slots, only for the records in front of the first bad header
+ * (the reference stops creating tiles there, _qcmodule.c:3126,3137-3148) */
+__global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first_read_index,
+                              TileMap map, int32_t *slots, const unsigned long long *first_bad,
+                              int *overflow)
+{
+    const unsigned long long stop = *first_bad;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const long long tile = tiles[r];
         int slot = -1;
-        if (tile < 0) {
-            atomicMin(first_bad, (unsigned long long)(first_read_index + r));
-        } else {
+        if (tile >= 0 && first_read_index + r < stop) {
             uint32_t idx = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 48) & (TILE_MAP_SIZE - 1);
             bool done = false;
             for (uint32_t probes = 0; !done && probes < 4 * TILE_MAP_SIZE; probes++) {
@@ -551,6 +565,7 @@ struct sq_pertile {
     unsigned long long *d_len_counts = nullptr;
     double *d_errors = nullptr;
     int32_t *d_slots = nullptr;
+    long long *d_tiles = nullptr;
     size_t slots_cap = 0;
     unsigned long long *d_first_bad = nullptr;
     int *d_overflow = nullptr;
@@ -792,7 +807,7 @@ SQ_EXPORT void sq_pertile_free(sq_pertile *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void *q : {(void *)p->map.keys, (void *)p->map.vals, (void *)p->map.n_slots,
                     (void *)p->d_first_bad, (void *)p->d_overflow, (void *)p->d_len_counts,
-                    (void *)p->d_errors, (void *)p->d_slots})
+                    (void *)p->d_errors, (void *)p->d_slots, (void *)p->d_tiles})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -844,11 +859,15 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
     sq_ctx *ctx = p->ctx;
     if (b->n > p->slots_cap) {
         if (p->d_slots) SQ_HIP(hipFree(p->d_slots));
+        if (p->d_tiles) SQ_HIP(hipFree(p->d_tiles));
         SQ_HIP(hipMalloc((void **)&p->d_slots, b->n * 4));
+        SQ_HIP(hipMalloc((void **)&p->d_tiles, b->n * 8));
         p->slots_cap = b->n;
     }
     int blocks = (int)std::min<uint64_t>((b->n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_tile_prepass, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, b->d_metas,
+    hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, b->d_metas,
+                       (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
+    hipLaunchKernelGGL(k_tile_assign, dim3(blocks), dim3(256), 0, ctx->stream, p->d_tiles,
                        (uint64_t)b->n, p->records_seen, p->map, p->d_slots, p->d_first_bad,
                        p->d_overflow);
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
