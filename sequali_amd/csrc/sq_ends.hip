@@ -1043,7 +1043,10 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
         hipLaunchKernelGGL(k_isz_events, dim3(blocks_for(n_ev)), dim3(256), 0, ctx->stream, d_idx, n_ev,
                            b1->d_buf, b1->d_metas, b2->d_buf, b2->d_metas, d_out, d_ev);
         std::vector<IszEvent> ev(n_ev);
-        SQ_HIP(hipMemcpy(ev.data(), d_ev, n_ev * sizeof(IszEvent), hipMemcpyDeviceToHost));
+        /* same stream as the kernel: the context stream is non-blocking, a plain
+           hipMemcpy on the null stream would not wait for it */
+        SQ_HIP(hipMemcpyAsync(ev.data(), d_ev, n_ev * sizeof(IszEvent), hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipStreamSynchronize(ctx->stream));
         (void)hipFree(d_ev);
         for (const IszEvent &e : ev) { /* :5729-5742 */
             if (e.len1) { z->n_adapters[0]++; isz_add_adapter(z, e.a1, e.len1, 0); }

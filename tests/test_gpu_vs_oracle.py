@@ -15,7 +15,8 @@ def u64(a):
     return np.array(a, dtype=np.uint64)
 
 
-def random_batch(rng, n, max_len, illumina_names=True, alphabet=b"ACGTNacgtnRYKM-", qmax=93):
+def random_batch(rng, n, max_len, illumina_names=True, alphabet=b"ACGTNacgtnRYKM-", qmax=93,
+                 splice=()):
     from sequali_amd import FastqRecordArrayView
     names, seqs, quals = [], [], []
     alpha = np.frombuffer(alphabet, np.uint8)
@@ -26,6 +27,14 @@ def random_batch(rng, n, max_len, illumina_names=True, alphabet=b"ACGTNacgtnRYKM
         w = np.ones(len(alpha))
         w[:4] = 20
         s = rng.choice(alpha, size=L, p=w / w.sum()).tobytes().decode()
+        if splice and rng.random() < 0.5:   # plant one or two of the given words
+            for _ in range(int(rng.integers(1, 3))):
+                word = splice[int(rng.integers(0, len(splice)))]
+                if rng.random() < 0.3:
+                    word = word.lower()
+                if len(word) <= L:
+                    at = int(rng.integers(0, L - len(word) + 1))
+                    s = s[:at] + word + s[at + len(word):]
         q = (rng.integers(0, qmax + 1, size=L) + 33).astype(np.uint8).tobytes().decode()
         tile = int(rng.choice([1101, 1102, 2205, 7, 99239]))
         names.append(f"M:1:F:{i % 4}:{tile}:{i}:{L} 1:N:0:X" if illumina_names else f"read{i} x")
@@ -96,7 +105,7 @@ def test_adapter_ragged(which):
     from sequali_amd import AdapterCounter
     rng = np.random.default_rng(20 + which)
     adapters = ADAPTER_SETS[which]
-    buf, metas, arr = random_batch(rng, 3000, 200, alphabet=b"ACGTNacgt")
+    buf, metas, arr = random_batch(rng, 3000, 200, alphabet=b"ACGTNacgt", splice=adapters)
     ref, got = oracle.AdapterCounter(adapters), AdapterCounter(adapters)
     ref.add(buf, metas)
     got.add_record_array(arr)
