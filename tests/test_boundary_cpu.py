@@ -1,0 +1,189 @@
+"""CPU-only tests of the drop-in boundary: the C ABI library loads and exports
+every symbol of include/sqgpu.h, the host-side record types behave like the
+reference's (golden vectors / oracle), the synthetic generator is deterministic.
+No GPU work is launched here."""
+import io
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import golden, golden_json, split_fastq
+
+
+def test_library_exports_every_declared_symbol():
+    from sequali_amd import _lib
+    lib = _lib.lib()
+    header = open(_lib.HEADER).read()
+    declared = set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 85
+    assert declared == set(_lib.PROTOTYPES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sq_abi_version() == 1
+
+
+def test_init_without_gpu_fails_loudly():
+    """no silent CPU fallback: without a device sq_init reports an error"""
+    import torch
+    from sequali_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert not _lib.lib().sq_init(0)
+    assert "hipGetDeviceCount" in _lib.last_error() or "not available" in _lib.last_error()
+
+
+def test_meta_layout_matches_fastqmeta():
+    from sequali_amd._qc import META_DTYPE
+    assert META_DTYPE.itemsize == 40
+    assert [META_DTYPE.fields[n][1] for n in META_DTYPE.names] == [0, 8, 12, 16, 20, 24, 28, 32]
+
+
+def test_constants():
+    import sequali_amd as s
+    assert (s.NUMBER_OF_NUCS, s.NUMBER_OF_PHREDS, s.TABLE_SIZE, s.PHRED_MAX) == (5, 12, 60, 93)
+    assert (s.A, s.C, s.G, s.T, s.N) == (0, 1, 2, 3, 4)
+    assert s.MAX_SEQUENCE_SIZE == 64 and s.INSERT_SIZE_MAX_ADAPTER_STORE_SIZE == 31
+    assert s.DEFAULT_MAX_UNIQUE_FRAGMENTS == 5_000_000 and s.DEFAULT_FRAGMENT_LENGTH == 21
+
+
+def test_record_view_roundtrip_and_error_rate():
+    from sequali_amd import FastqRecordView
+    v = FastqRecordView("name 1", "ACGTN", "!+5?I", b"tags")
+    assert (v.name(), v.sequence(), v.qualities(), v.tags()) == ("name 1", "ACGTN", "!+5?I", b"tags")
+    want = 0.0
+    for c in "!+5?I":
+        want += oracle.error_rate(ord(c) - 33)
+    assert v._meta["accumulated_error_rate"][0] == want
+    assert v.obj == b"name 1ACGTN!+5?Itags"
+
+
+@pytest.mark.parametrize("args,exc,match", [
+    (("n", "ACGT", "III"), ValueError, "different lengths: 4 and 3"),
+    (("n", "ACGT", "II\x7fI"), ValueError, "Not a valid phred character: \x7f"),
+    (("n", "ACGT", "II I"), ValueError, "Not a valid phred character:  "),
+    (("nä", "A", "I"), ValueError, "name should contain only ASCII"),
+    (("n", "ä", "I"), ValueError, "sequence should contain only ASCII"),
+    ((b"n", "A", "I"), TypeError, "must be str"),
+])
+def test_record_view_errors(args, exc, match):
+    from sequali_amd import FastqRecordView
+    with pytest.raises(exc, match=match):
+        FastqRecordView(*args)
+
+
+def test_record_array_from_views_points_at_own_buffer():
+    from sequali_amd import FastqRecordArrayView, FastqRecordView
+    views = [FastqRecordView(f"r{i}", "ACGT" * i, "IIII" * i) for i in range(5)]
+    arr = FastqRecordArrayView(views)
+    assert len(arr) == 5
+    for i in range(5):
+        assert arr[i].name() == f"r{i}" and arr[i].sequence() == "ACGT" * i
+        assert arr[i].obj is arr.obj   # not the source view's buffer
+    assert arr[-1].qualities() == "IIII" * 4
+    with pytest.raises(IndexError):
+        arr[5]
+    with pytest.raises(TypeError, match="FastqRecordView"):
+        FastqRecordArrayView([views[0], "no"])
+
+
+def test_is_mate_golden_and_errors():
+    from sequali_amd import FastqRecordArrayView, FastqRecordView
+    for a, b, want in golden_json("is_mate"):
+        x = FastqRecordArrayView([FastqRecordView(a, "A", "A")])
+        y = FastqRecordArrayView([FastqRecordView(b, "A", "A")])
+        assert x.is_mate(y) is want
+        assert oracle.names_are_mates(a, b) is want
+    with pytest.raises(TypeError, match="FastqRecordArrayView"):
+        x.is_mate("nope")
+    with pytest.raises(ValueError, match="same length"):
+        x.is_mate(FastqRecordArrayView([]))
+
+
+@pytest.mark.parametrize("name", ["ref_simple", "ref_100_illumina_adapters", "ref_100_nanopore"])
+@pytest.mark.parametrize("buffersize", [1, 7, 100, 4096, 128 * 1024, 1 << 24])
+def test_fastq_parser_chunking(name, buffersize):
+    """tests/test_fastq_parser.py:49-174 of the reference: any buffer size gives the
+    same records; offsets follow FastqParser's layout"""
+    from sequali_amd import FastqParser
+    text = golden(name)["fastq"].tobytes()
+    if buffersize < 100 and len(text) > 100_000:
+        pytest.skip("quadratic for a tiny buffer on a large file")
+    buf, metas = split_fastq(text)
+    got = []
+    for arr in FastqParser(io.BytesIO(text), buffersize):
+        assert len(arr) > 0
+        for i in range(len(arr)):
+            v = arr[i]
+            got.append((v.name(), v.sequence(), v.qualities()))
+    assert len(got) == len(metas)
+    for (n, s, q), m in zip(got, metas):
+        st = int(m["record_start"])
+        assert n == text[st:st + int(m["name_length"])].decode()
+        assert s == text[st + int(m["sequence_offset"]):st + int(m["sequence_offset"]) + int(m["sequence_length"])].decode()
+        assert q == text[st + int(m["qualities_offset"]):st + int(m["qualities_offset"]) + int(m["sequence_length"])].decode()
+
+
+def test_fastq_parser_read_lockstep_and_errors():
+    from sequali_amd import FastqParser
+    text = golden("ref_100_illumina_adapters")["fastq"].tobytes()
+    p = FastqParser(io.BytesIO(text), 500)
+    sizes = []
+    while True:
+        arr = p.read(7)
+        if len(arr) == 0:
+            break
+        sizes.append(len(arr))
+    assert sum(sizes) == 100 and all(s == 7 for s in sizes[:-1])
+    assert list(FastqParser(io.BytesIO(b""))) == []
+    with pytest.raises(EOFError, match="Incomplete record"):
+        list(FastqParser(io.BytesIO(b"@a\nACGT\n+\nII")))
+    with pytest.raises(ValueError, match="does not start with @"):
+        list(FastqParser(io.BytesIO(b"a\nACGT\n+\nIIII\n")))
+    with pytest.raises(ValueError, match="does not start with \\+"):
+        list(FastqParser(io.BytesIO(b"@a\nACGT\n-\nIIII\n")))
+    with pytest.raises(ValueError, match="equal length"):
+        list(FastqParser(io.BytesIO(b"@a\nACGT\n+\nIII\n")))
+    with pytest.raises(ValueError, match="non-ASCII"):
+        list(FastqParser(io.BytesIO("@a\nACGä\n+\nIIII\n".encode("latin-1"))))
+    with pytest.raises(ValueError):
+        FastqParser(io.BytesIO(b""), 0)
+
+
+def test_synthetic_generator_is_counter_based():
+    """any slice of the stream can be generated on its own (what lets every rank
+    generate its shard) and the text parses back to the same metas"""
+    from sequali_amd import synth
+    whole, metas = synth.host_records(synth.ILLUMINA, 0, 300)
+    part, _ = synth.host_records(synth.ILLUMINA, 100, 50)
+    assert whole[100 * 348:150 * 348] == part
+    buf, parsed = split_fastq(whole)
+    for f in ("record_start", "name_length", "sequence_offset", "sequence_length", "qualities_offset"):
+        np.testing.assert_array_equal(parsed[f], metas[f])
+    assert len(set(whole[i * 348:(i + 1) * 348] for i in range(300))) == 300
+    r1, _ = synth.host_records(synth.ILLUMINA, 0, 200)
+    r2, m2 = synth.host_records(synth.ILLUMINA_R2, 0, 200)
+    n1 = [r1[i * 348 + 1:i * 348 + 30] for i in range(200)]
+    n2 = [r2[i * 348 + 1:i * 348 + 30] for i in range(200)]
+    assert n1 == n2    # mates share the id part of the header
+    nano, mn = synth.host_records(synth.NANOPORE, 5, 40)
+    assert 200 <= mn["sequence_length"].min() and mn["sequence_length"].max() <= 100000
+    assert len(np.unique(mn["sequence_length"])) > 30
+    _, again = synth.host_records(synth.NANOPORE, 5, 40)
+    np.testing.assert_array_equal(mn, again)
+
+
+def test_synthetic_data_has_the_intended_features():
+    """duplicates, adapter read-through, N bases, four quality values, 96 tiles"""
+    from sequali_amd import synth
+    text, metas = synth.host_records(synth.ILLUMINA, 0, 5000)
+    seqs = [text[int(m["record_start"]) + int(m["sequence_offset"]):][:150] for m in metas]
+    assert 0.03 < sum(b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"[:20] in s for s in seqs) / 5000 < 0.15
+    assert 4000 < len(set(s[20:60] for s in seqs)) < 4900     # ~10 % duplicated fragments
+    allbytes = b"".join(seqs)
+    assert 0.0005 < allbytes.count(b"N") / len(allbytes) < 0.002
+    quals = set(b"".join(text[int(m["record_start"]) + int(m["qualities_offset"]):][:150] for m in metas[:200]))
+    assert quals == set(b"F:,#")
+    tiles = set(oracle.tile_id(text[int(m["record_start"]):][:int(m["name_length"])].decode()) for m in metas)
+    assert len(tiles) == 96 and min(tiles) == 1101 and max(tiles) == 2224
