@@ -153,10 +153,11 @@ SQ_EXPORT int sq_names_are_mates(const uint8_t *buf1, const sq_meta *metas1, con
 /* ---- batches ----------------------------------------------------------------- */
 
 /* per-batch statistics on the device: [0] total bases [1] max length
- * [2] max name length [3] max record span (name start .. quality end) */
+ * [2] max name length [3] max record span (name start .. quality end)
+ * [4] ~min length (kept as a max so that one memset(0) initialises all) */
 __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long *out)
 {
-    unsigned long long bases = 0, maxlen = 0, maxname = 0, maxspan = 0;
+    unsigned long long bases = 0, maxlen = 0, maxname = 0, maxspan = 0, minlen_inv = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         sq_meta m = metas[i];
@@ -165,20 +166,24 @@ __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long
         if (m.name_length > maxname) maxname = m.name_length;
         unsigned long long span = (unsigned long long)m.qualities_offset + m.sequence_length;
         if (span > maxspan) maxspan = span;
+        unsigned long long inv = ~(unsigned long long)m.sequence_length;
+        if (inv > minlen_inv) minlen_inv = inv;
     }
     for (int off = 32; off > 0; off >>= 1) {
         bases += __shfl_down(bases, off);
         unsigned long long a = __shfl_down(maxlen, off), b = __shfl_down(maxname, off),
-                           c = __shfl_down(maxspan, off);
+                           c = __shfl_down(maxspan, off), d = __shfl_down(minlen_inv, off);
         maxlen = a > maxlen ? a : maxlen;
         maxname = b > maxname ? b : maxname;
         maxspan = c > maxspan ? c : maxspan;
+        minlen_inv = d > minlen_inv ? d : minlen_inv;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], bases);
         atomicMax(&out[1], maxlen);
         atomicMax(&out[2], maxname);
         atomicMax(&out[3], maxspan);
+        atomicMax(&out[4], minlen_inv);
     }
 }
 
@@ -202,6 +207,7 @@ SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_
         }
         b->total_bases += m.sequence_length;
         if (m.sequence_length > b->max_length) b->max_length = m.sequence_length;
+        if (i == 0 || m.sequence_length < b->min_length) b->min_length = m.sequence_length;
         if (m.name_length > b->max_name_length) b->max_name_length = m.name_length;
         if (span > b->max_record_span) b->max_record_span = span;
     }
@@ -233,18 +239,19 @@ SQ_EXPORT sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t 
     b->owns = false;
     if (n) {
         unsigned long long *d_out = nullptr;
-        SQ_HIP_NULL(hipMalloc((void **)&d_out, 4 * sizeof(unsigned long long)));
-        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        SQ_HIP_NULL(hipMalloc((void **)&d_out, 8 * sizeof(unsigned long long)));
+        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 8 * sizeof(unsigned long long), ctx->stream));
         int blocks = (int)((n + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_batch_stats, dim3(blocks), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
-        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
         (void)hipFree(d_out);
         b->total_bases = ctx->pinned[0];
         b->max_length = ctx->pinned[1];
         b->max_name_length = ctx->pinned[2];
         b->max_record_span = ctx->pinned[3];
+        b->min_length = ~ctx->pinned[4];
     }
     return b;
 }
@@ -434,18 +441,19 @@ SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64
         hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, ctx->stream, kind, seed, first,
                            n, d_offs, fixed, b->d_buf, b->d_metas);
         unsigned long long *d_out = nullptr;
-        SQ_HIP_NULL(hipMalloc((void **)&d_out, 32));
-        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 32, ctx->stream));
+        SQ_HIP_NULL(hipMalloc((void **)&d_out, 64));
+        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 64, ctx->stream));
         int sb = (int)((n + 255) / 256);
         if (sb > 4096) sb = 4096;
         hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
-        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
         (void)hipFree(d_out);
         b->total_bases = ctx->pinned[0];
         b->max_length = ctx->pinned[1];
         b->max_name_length = ctx->pinned[2];
         b->max_record_span = ctx->pinned[3];
+        b->min_length = ~ctx->pinned[4];
     }
     if (d_offs) (void)hipFree(d_offs);
     return b;

@@ -56,6 +56,7 @@ struct sq_batch {
     bool owns = false;
     uint64_t total_bases = 0;
     uint64_t max_length = 0;
+    uint64_t min_length = 0;
     uint64_t max_name_length = 0;
     uint64_t max_record_span = 0;
     /* host copies kept by sq_batch_upload for rare host-side follow-ups

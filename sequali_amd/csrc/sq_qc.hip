@@ -37,11 +37,11 @@ namespace {
 
 constexpr int WG_THREADS = 256;
 constexpr int WAVES = WG_THREADS / 64;
-constexpr uint32_t PAD4 = 0x80808080u;
+constexpr uint32_t PAD4 = 0x80808080u;   /* quality tile: past the end of the read */
 constexpr uint32_t LDS_HIST_MAX = 512;  /* positions kept in LDS histograms */
 constexpr uint32_t LDS_EA_MAX = 256;    /* end-anchor rows kept in LDS */
 constexpr uint32_t DFA_LDS_MAX_STATES = 1024; /* 16 KB of LDS */
-constexpr uint32_t BASE_COLS = 8, PHRED_COLS = 16;
+constexpr uint32_t BASE_COLS = 7, PHRED_COLS = 13; /* odd strides: conflict-free LDS atomics; 1 spare column each for padding / invalid */
 constexpr int64_t TILE_EMPTY = -1;
 constexpr uint32_t TILE_MAP_SIZE = 1u << 16;
 
@@ -59,6 +59,7 @@ struct PassParams {
     unsigned long long *qc_base, *qc_phred, *qc_ea_base, *qc_ea_phred, *qc_gc, *qc_ps;
     uint32_t ea_len;
     uint32_t ea_in_lds;
+    uint32_t uniform_len;     /* != 0: every record of the batch has this length (<= lds_len) */
     const double *thresholds; /* [94], see phred_thresholds() */
     unsigned long long *qc_first_bad;
     /* AdapterCounter */
@@ -105,38 +106,59 @@ __device__ __forceinline__ uint4 load16(const uint8_t *buf, uint64_t off, uint64
     return v;
 }
 
-/* keep the first `nvalid` (0..4) bytes of w, the rest become 0x80 */
-__device__ __forceinline__ uint32_t pad_tail(uint32_t w, int nvalid)
+/* keep the first `nvalid` (0..4) bytes of w, the rest become `pad` */
+__device__ __forceinline__ uint32_t pad_tail(uint32_t w, int nvalid, uint32_t pad)
 {
     if (nvalid >= 4) return w;
-    if (nvalid <= 0) return PAD4;
+    if (nvalid <= 0) return pad;
     uint32_t keep = (1u << (8 * nvalid)) - 1u;
-    return (w & keep) | (PAD4 & ~keep);
+    return (w & keep) | (pad & ~keep);
 }
+
+/* Four sequence bytes -> four class codes, doubled (A 0, C 2, G 4, T 6, other 8),
+ * without a table in memory.  The low three bits of A/C/G/T (either case) are
+ * 1/3/7/4 (the observation the reference cites from fastp, _qcmodule.c:1731-1739)
+ * and index two 8-byte LUTs held in registers (v_perm_b32): the class and the
+ * upper-case letter that class requires.  A byte whose upper-cased value is not
+ * that letter is class 4 like in NUCLEOTIDE_TO_INDEX (:1748-1763).  Bytes must be
+ * 7-bit ASCII (the parser guarantees it, :1055). */
+constexpr uint32_t CLS2_PAD4 = 0x0A0A0A0Au; /* class 5 = past the end of the read */
+__device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
+{
+    const uint32_t idx = w & 0x07070707u;
+    const uint32_t lut = __builtin_amdgcn_perm(0x04080806u, 0x02080008u, idx);
+    const uint32_t want = __builtin_amdgcn_perm(0x47000054u, 0x43004100u, idx);
+    const uint32_t d = (w & 0xDFDFDFDFu) ^ want;
+    const uint32_t ne = ((d + 0x7F7F7F7Fu) & 0x80808080u) >> 7; /* 1 where it is not that letter */
+    const uint32_t mask = (ne << 8) - ne;                        /* 0xFF per such byte */
+    return (mask & 0x08080808u) | (~mask & lut);
+}
+
+/* LDS words one workgroup needs in front of its histograms */
+constexpr uint32_t WAVE_WORDS = 1024 + 1024 + 128 + 128 + 64;
+constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
 
 template <bool QC, bool AD, bool PT, bool DFA_LDS>
 __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     /* ---- LDS carve-up (every region 16-byte aligned) ---- */
-    double *l_err = (double *)smem;                        /* [256] by raw quality byte */
-    double *l_thr = l_err + 256;                           /* [96] */
+    double *l_err = (double *)smem;                        /* [136] by raw quality byte, 128 = padding */
+    double *l_thr = l_err + 136;                           /* [96] */
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
-    uint8_t *l_cls = (uint8_t *)(l_ps + 96);               /* [256] */
-    uint32_t *l_wave = (uint32_t *)(l_cls + 256);          /* per wave: seq tile, qual tile, offsets, lengths */
-    constexpr uint32_t WAVE_WORDS = 1024 + 1024 + 128 + 128 + 64;
+    uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
     uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [lds_len][8] */
     uint32_t *l_hist_phred = l_hist_base + (QC ? P.lds_len * BASE_COLS : 0);
     uint32_t *l_ea_base = l_hist_phred + (QC ? P.lds_len * PHRED_COLS : 0);
-    uint32_t ea_rows = (QC && P.ea_in_lds) ? P.ea_len : 0;
+    const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
     uint32_t *l_ea_phred = l_ea_base + ea_rows * BASE_COLS;
     uint16_t *l_dfa = (uint16_t *)(l_ea_phred + ea_rows * PHRED_COLS);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     /* ---- fill tables ---- */
-    for (int i = tid; i < 256; i += WG_THREADS) {
+    for (int i = tid; i < 136; i += WG_THREADS) {
         double e;
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) {
             unsigned long long bits = c_error_rate_bits[i - 33];
@@ -147,13 +169,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             e = __longlong_as_double(0x7FF8000000000000LL); /* invalid phred byte poisons the sum */
         }
         l_err[i] = e;
-        l_cls[i] = i >= 128 ? 5 : (uint8_t)sq_base_class((unsigned)i);
     }
     if (QC) {
         for (int i = tid; i < 96; i += WG_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
         for (int i = tid; i < 104; i += WG_THREADS) l_gc[i] = 0;
         for (int i = tid; i < 96; i += WG_THREADS) l_ps[i] = 0;
-        uint32_t nh = P.lds_len * (BASE_COLS + PHRED_COLS) + ea_rows * (BASE_COLS + PHRED_COLS);
+        uint32_t nh = (P.lds_len + ea_rows) * (BASE_COLS + PHRED_COLS);
         for (uint32_t i = tid; i < nh; i += WG_THREADS) l_hist_base[i] = 0;
     }
     if (AD && DFA_LDS) {
@@ -169,6 +190,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
 
     const uint64_t ngroups = (P.n + 63) / 64;
     const uint32_t my_swz = (lane >> 1) & 15;
+    const bool ea_atomics = QC && !P.uniform_len;
 
     for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g < ngroups;
          g += (uint64_t)gridDim.x * WAVES) {
@@ -186,7 +208,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
         const uint32_t Lmain = L > 0 ? 4 * ((L - 1) / 4) : 0; /* _qcmodule.c:2062,2068 */
 
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        uint32_t st = 0;                 /* automaton state as a byte offset of its row */
+        uint32_t st = 0;                 /* automaton state as the byte offset of its row */
         unsigned long long found = 0;    /* adapters already seen in this read */
         uint32_t gc_cnt = 0, acgt_cnt = 0;
         bool pt_on = false;
@@ -206,16 +228,21 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 const uint32_t row = it * 16 + (lane >> 2), piece = lane & 3;
                 const uint32_t Lr = w_len[row];
                 const uint32_t p0 = c0 + piece * 16;
-                uint4 sv = make_uint4(PAD4, PAD4, PAD4, PAD4), qv = sv;
+                uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4);
+                uint4 qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
                 if (p0 < Lr) {
                     const int nv = (int)min(16u, Lr - p0);
-                    if (QC || AD) sv = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                    if (QC || AD) {
+                        sv = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                        sv.x = cls2_of_dword(sv.x); sv.y = cls2_of_dword(sv.y);
+                        sv.z = cls2_of_dword(sv.z); sv.w = cls2_of_dword(sv.w);
+                    }
                     if (QC || PT) qv = load16(P.buf, w_qoff[row] + p0, P.buf_len);
                     if (nv < 16) {
-                        sv.x = pad_tail(sv.x, nv); sv.y = pad_tail(sv.y, nv - 4);
-                        sv.z = pad_tail(sv.z, nv - 8); sv.w = pad_tail(sv.w, nv - 12);
-                        qv.x = pad_tail(qv.x, nv); qv.y = pad_tail(qv.y, nv - 4);
-                        qv.z = pad_tail(qv.z, nv - 8); qv.w = pad_tail(qv.w, nv - 12);
+                        sv.x = pad_tail(sv.x, nv, CLS2_PAD4); sv.y = pad_tail(sv.y, nv - 4, CLS2_PAD4);
+                        sv.z = pad_tail(sv.z, nv - 8, CLS2_PAD4); sv.w = pad_tail(sv.w, nv - 12, CLS2_PAD4);
+                        qv.x = pad_tail(qv.x, nv, PAD4); qv.y = pad_tail(qv.y, nv - 4, PAD4);
+                        qv.z = pad_tail(qv.z, nv - 8, PAD4); qv.w = pad_tail(qv.w, nv - 12, PAD4);
                     }
                 }
                 const uint32_t swz = (row >> 1) & 15, base = row * 16, d0 = piece * 4;
@@ -238,30 +265,36 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             /* ---------------- phase S: lane = read ---------------- */
             if (QC || AD) {
                 const uint32_t rb = lane * 16;
-#pragma unroll 4
-                for (uint32_t d = 0; d < 16; d++) {
+                const uint32_t nd = min(16u, (maxL - c0 + 3) / 4); /* dwords any read still has */
+                for (uint32_t d = 0; d < nd; d++) {
                     const uint32_t pos0 = c0 + d * 4;
                     if (QC) {
                         uint32_t qd = w_qual[rb + (d ^ my_swz)];
                         /* the reference's four chains stop four short of the end (:2068) */
                         qd = pos0 < Lmain ? qd : PAD4;
-                        acc0 += l_err[qd & 0xFF];
-                        acc1 += l_err[(qd >> 8) & 0xFF];
-                        acc2 += l_err[(qd >> 16) & 0xFF];
-                        acc3 += l_err[qd >> 24];
+                        const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
+                        const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
+                        acc0 += e0;
+                        acc1 += e1;
+                        acc2 += e2;
+                        acc3 += e3;
                     }
                     if (AD) {
                         const uint32_t sd = w_seq[rb + (d ^ my_swz)];
+                        uint32_t e[4];
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const uint32_t cls2 = (uint32_t)l_cls[(sd >> (8 * j)) & 0xFF] * 2;
-                            uint32_t e;
-                            if (DFA_LDS) e = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
-                            else e = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
-                            st = e & 0xFFF0u;
-                            if (e & 1u) {
-                                /* update_adapter_count_array, _qcmodule.c:2643-2672 */
-                                unsigned long long hits = P.dfa_out[st >> 4] & ~found;
+                            const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
+                            if (DFA_LDS) e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
+                            else e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
+                            st = e[j] & 0xFFF0u;
+                        }
+                        if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
+                            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                if (!(e[j] & 1u)) continue;
+                                unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
                                 found |= hits;
                                 const uint32_t pos = pos0 + j;
                                 while (hits) {
@@ -280,51 +313,66 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             /* ---------------- phase H: lane = position ---------------- */
             if (QC || PT) {
                 const uint32_t p = c0 + lane;
+                const uint32_t sh = 8 * (lane & 3);
+                const bool in_lds = p < P.lds_len;
                 uint32_t gc_tmp = 0, acgt_tmp = 0;
-                for (uint32_t row = 0; row < 64; row++) {
-                    const uint32_t Lr = __builtin_amdgcn_readfirstlane(w_len[row]);
-                    if (c0 >= Lr) continue;
-                    const uint32_t widx = row * 16 + (((uint32_t)lane >> 2) ^ ((row >> 1) & 15));
-                    const uint32_t sh = 8 * (lane & 3);
-                    const bool act = p < Lr;
-                    const uint32_t qb = (w_qual[widx] >> sh) & 0xFF;
-                    if (QC) {
-                        const uint32_t cls = l_cls[(w_seq[widx] >> sh) & 0xFF];
-                        const uint32_t q = qb - 33u;
-                        const uint32_t bin = q > (uint32_t)SQ_PHRED_MAX ? 12u : (min(q, 47u) >> 2);
-                        if (act) {
-                            if (p < P.lds_len) {
-                                atomicAdd(&l_hist_base[p * BASE_COLS + cls], 1u);
-                                atomicAdd(&l_hist_phred[p * PHRED_COLS + bin], 1u);
-                            } else {
-                                atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
-                                if (bin < 12) atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
-                            }
-                            /* last min(ea, L) positions, right aligned (:1971-1972) */
-                            const uint32_t ean = min(P.ea_len, Lr);
-                            if (p >= Lr - ean) {
-                                const uint32_t e = P.ea_len - Lr + p;
-                                if (P.ea_in_lds) {
-                                    atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
-                                    atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                const uint32_t nrows = 64;
+                for (uint32_t row0 = 0; row0 < nrows; row0 += 4) {
+                    uint32_t sw[4], qw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t row = row0 + k;
+                        const uint32_t widx = row * 16 + (((uint32_t)lane >> 2) ^ ((row >> 1) & 15));
+                        if (QC) sw[k] = w_seq[widx];
+                        qw[k] = w_qual[widx];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t row = row0 + k;
+                        const uint32_t Lr = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)row);
+                        const bool act = p < Lr;
+                        const uint32_t qb = (qw[k] >> sh) & 0xFF;
+                        if (QC) {
+                            const uint32_t cls2 = (sw[k] >> sh) & 0xFF;
+                            const uint32_t q = qb - 33u;
+                            const uint32_t bin = q > (uint32_t)SQ_PHRED_MAX ? 12u : (min(q, 47u) >> 2);
+                            if (act) {
+                                if (in_lds) {
+                                    atomicAdd(&l_hist_base[p * BASE_COLS + (cls2 >> 1)], 1u);
+                                    atomicAdd(&l_hist_phred[p * PHRED_COLS + bin], 1u);
                                 } else {
-                                    atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
-                                    if (bin < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
+                                    atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls2 >> 1, 4u)], 1ULL);
+                                    if (bin < 12) atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
+                                }
+                                if (ea_atomics) {
+                                    /* last min(ea, L) positions, right aligned (:1971-1972) */
+                                    const uint32_t ean = min(P.ea_len, Lr);
+                                    if (p >= Lr - ean) {
+                                        const uint32_t e = P.ea_len - Lr + p;
+                                        if (P.ea_in_lds) {
+                                            atomicAdd(&l_ea_base[e * BASE_COLS + (cls2 >> 1)], 1u);
+                                            atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                                        } else {
+                                            atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls2 >> 1, 4u)], 1ULL);
+                                            if (bin < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
+                                        }
+                                    }
                                 }
                             }
+                            /* padding has class 5, so no need to mask with act */
+                            const unsigned long long m_gc = __ballot(cls2 == 2 || cls2 == 4);
+                            const unsigned long long m_acgt = __ballot(cls2 < 8);
+                            /* row totals land in the lane that owns the read */
+                            const bool mine = (uint32_t)lane == row;
+                            gc_tmp = mine ? (uint32_t)__popcll(m_gc) : gc_tmp;
+                            acgt_tmp = mine ? (uint32_t)__popcll(m_acgt) : acgt_tmp;
                         }
-                        const unsigned long long m_gc = __ballot(act && (cls == 1 || cls == 2));
-                        const unsigned long long m_acgt = __ballot(act && cls < 4);
-                        /* row totals land in the lane that owns the read */
-                        const bool mine = (uint32_t)lane == row;
-                        gc_tmp = mine ? (uint32_t)__popcll(m_gc) : gc_tmp;
-                        acgt_tmp = mine ? (uint32_t)__popcll(m_acgt) : acgt_tmp;
-                    }
-                    if (PT) {
-                        const int32_t slot = __builtin_amdgcn_readfirstlane(__shfl(pt_on ? pt_slot : -1, (int)row));
-                        if (slot >= 0 && act) {
-                            const double e = l_err[qb];
-                            unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                        if (PT) {
+                            const int32_t slot = __builtin_amdgcn_readlane(pt_on ? pt_slot : -1, (int)row);
+                            if (slot >= 0 && act) {
+                                const double e = l_err[qb];
+                                unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                            }
                         }
                     }
                 }
@@ -338,8 +386,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
         /* ---------------- per-read epilogue: lane = read ---------------- */
         if (QC && valid) {
             double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099, left to right */
-            for (uint32_t pos = Lmain; pos < L; pos++)  /* :2100-2112 */
-                total += l_err[P.buf[qoff + pos]];
+            for (uint32_t pos = Lmain; pos < L; pos++) { /* :2100-2112 */
+                const uint32_t qb = P.buf[qoff + pos];
+                total += l_err[qb < 128 ? qb : 0];
+            }
             P.metas[r].accumulated_error_rate = total;  /* :2126 */
             if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
             if (acgt_cnt > 0) { /* :2051-2058 */
@@ -364,12 +414,30 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     if (QC) {
         __syncthreads();
         for (uint32_t i = tid; i < P.lds_len * BASE_COLS; i += WG_THREADS) {
-            const uint32_t v = l_hist_base[i], c = i % BASE_COLS;
-            if (v && c < 5) atomicAdd(&P.qc_base[(uint64_t)(i / BASE_COLS) * 5 + c], (unsigned long long)v);
+            const uint32_t v = l_hist_base[i], c = i % BASE_COLS, pos = i / BASE_COLS;
+            if (v && c < 5) {
+                atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
+                if (P.uniform_len) {
+                    /* every read has the same length: the end-anchored table is a
+                       window of the positional one (:1971-1972, 2034-2043) */
+                    const uint32_t ean = min(P.ea_len, P.uniform_len);
+                    if (pos >= P.uniform_len - ean)
+                        atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - P.uniform_len + pos) * 5 + c],
+                                  (unsigned long long)v);
+                }
+            }
         }
         for (uint32_t i = tid; i < P.lds_len * PHRED_COLS; i += WG_THREADS) {
-            const uint32_t v = l_hist_phred[i], c = i % PHRED_COLS;
-            if (v && c < 12) atomicAdd(&P.qc_phred[(uint64_t)(i / PHRED_COLS) * 12 + c], (unsigned long long)v);
+            const uint32_t v = l_hist_phred[i], c = i % PHRED_COLS, pos = i / PHRED_COLS;
+            if (v && c < 12) {
+                atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
+                if (P.uniform_len) {
+                    const uint32_t ean = min(P.ea_len, P.uniform_len);
+                    if (pos >= P.uniform_len - ean)
+                        atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - P.uniform_len + pos) * 12 + c],
+                                  (unsigned long long)v);
+                }
+            }
         }
         for (uint32_t i = tid; i < ea_rows * BASE_COLS; i += WG_THREADS) {
             const uint32_t v = l_ea_base[i], c = i % BASE_COLS;
@@ -388,8 +456,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
 
 size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states)
 {
-    size_t b = 256 * 8 + 96 * 8 + 104 * 4 + 96 * 4 + 256;
-    b += (size_t)WAVES * (1024 + 1024 + 128 + 128 + 64) * 4;
+    size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
     if (qc) b += (size_t)(lds_len + ea_rows) * (BASE_COLS + PHRED_COLS) * 4;
     if (dfa_lds) b += (size_t)dfa_states * 16;
     return b + 16;
@@ -990,7 +1057,9 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         P.pt_first_bad = fb == UINT64_MAX ? UINT64_MAX : fb + P.first_read_index;
     }
     P.lds_len = m ? (uint32_t)std::min<uint64_t>(b->max_length, LDS_HIST_MAX) : 0;
-    const uint32_t ea_rows = (m && P.ea_in_lds) ? P.ea_len : 0;
+    if (m && b->min_length == b->max_length && b->max_length > 0 && b->max_length <= LDS_HIST_MAX)
+        P.uniform_len = (uint32_t)b->max_length;
+    const uint32_t ea_rows = (m && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
     if (a) {
         if (b->max_length > a->max_length) {
             int rc = sq_adaptercounter_reserve(a, b->max_length);
