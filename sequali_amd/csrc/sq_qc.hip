@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t pad_tail(uint32_t w, int nvalid, uint32_t pa
  * upper-case letter that class requires.  A byte whose upper-cased value is not
  * that letter is class 4 like in NUCLEOTIDE_TO_INDEX (:1748-1763).  Bytes must be
  * 7-bit ASCII (the parser guarantees it, :1055). */
-constexpr uint32_t CLS2_PAD4 = 0x0A0A0A0Au; /* class 5 = past the end of the read */
+constexpr uint32_t CLS2_PAD4 = 0x0E0E0E0Eu; /* class 7 = past the end of the read */
 __device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
 {
     const uint32_t idx = w & 0x07070707u;
@@ -134,9 +134,21 @@ __device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
     return (mask & 0x08080808u) | (~mask & lut);
 }
 
-/* LDS words one workgroup needs in front of its histograms */
-constexpr uint32_t WAVE_WORDS = 1024 + 1024 + 128 + 128 + 64;
+/* A wave walks its 64 reads in chunks of CW positions. */
+constexpr uint32_t CW = 32;               /* positions per chunk */
+constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
+constexpr uint32_t TILE_WORDS = 64 * ROW_WORDS;
+constexpr uint32_t WAVE_WORDS = 2 * TILE_WORDS + 128 + 128 + 64;
 constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
+
+/* tile address of dword d of row r: rows are ROW_WORDS = 8 dwords, the dword index
+ * is XOR-ed with bits of the row so that "lane = row, same dword" (phase S),
+ * "lane = position, one or two rows" (phase H) and the staging writes all spread
+ * over the 32 banks */
+__device__ __forceinline__ uint32_t tile_idx(uint32_t row, uint32_t d)
+{
+    return row * ROW_WORDS + (d ^ ((row >> 2) & 7));
+}
 
 template <bool QC, bool AD, bool PT, bool DFA_LDS>
 __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
@@ -148,7 +160,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
     uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
-    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [lds_len][8] */
+    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [lds_len][BASE_COLS] */
     uint32_t *l_hist_phred = l_hist_base + (QC ? P.lds_len * BASE_COLS : 0);
     uint32_t *l_ea_base = l_hist_phred + (QC ? P.lds_len * PHRED_COLS : 0);
     const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
@@ -183,14 +195,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     __syncthreads();
 
     uint32_t *w_seq = l_wave + wave * WAVE_WORDS;
-    uint32_t *w_qual = w_seq + 1024;
-    unsigned long long *w_soff = (unsigned long long *)(w_qual + 1024);
+    uint32_t *w_qual = w_seq + TILE_WORDS;
+    unsigned long long *w_soff = (unsigned long long *)(w_qual + TILE_WORDS);
     unsigned long long *w_qoff = w_soff + 64;
     uint32_t *w_len = (uint32_t *)(w_qoff + 64);
 
     const uint64_t ngroups = (P.n + 63) / 64;
-    const uint32_t my_swz = (lane >> 1) & 15;
     const bool ea_atomics = QC && !P.uniform_len;
+    /* phase H: lanes 0-31 take an even row, lanes 32-63 the odd row after it */
+    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
 
     for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g < ngroups;
          g += (uint64_t)gridDim.x * WAVES) {
@@ -216,16 +230,17 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
         if (PT) {
             pt_slot = valid ? P.pt_slot[r] : -1;
             pt_on = valid && pt_slot >= 0 && (P.first_read_index + r) < P.pt_first_bad;
+            if (!pt_on) pt_slot = -1;
         }
         /* the staging lanes of other rows read w_soff / w_qoff / w_len */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        for (uint32_t c0 = 0; c0 < maxL; c0 += 64) {
-            /* ---------------- STAGE ---------------- */
+        for (uint32_t c0 = 0; c0 < maxL; c0 += CW) {
+            /* ---------------- STAGE: 2 lanes x 16 bytes per row ---------------- */
 #pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const uint32_t row = it * 16 + (lane >> 2), piece = lane & 3;
+            for (int it = 0; it < 2; it++) {
+                const uint32_t row = it * 32 + ((uint32_t)lane >> 1), piece = (uint32_t)lane & 1;
                 const uint32_t Lr = w_len[row];
                 const uint32_t p0 = c0 + piece * 16;
                 uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4);
@@ -245,18 +260,18 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                         qv.z = pad_tail(qv.z, nv - 8, PAD4); qv.w = pad_tail(qv.w, nv - 12, PAD4);
                     }
                 }
-                const uint32_t swz = (row >> 1) & 15, base = row * 16, d0 = piece * 4;
+                const uint32_t d0 = piece * 4;
                 if (QC || AD) {
-                    w_seq[base + ((d0 + 0) ^ swz)] = sv.x;
-                    w_seq[base + ((d0 + 1) ^ swz)] = sv.y;
-                    w_seq[base + ((d0 + 2) ^ swz)] = sv.z;
-                    w_seq[base + ((d0 + 3) ^ swz)] = sv.w;
+                    w_seq[tile_idx(row, d0 + 0)] = sv.x;
+                    w_seq[tile_idx(row, d0 + 1)] = sv.y;
+                    w_seq[tile_idx(row, d0 + 2)] = sv.z;
+                    w_seq[tile_idx(row, d0 + 3)] = sv.w;
                 }
                 if (QC || PT) {
-                    w_qual[base + ((d0 + 0) ^ swz)] = qv.x;
-                    w_qual[base + ((d0 + 1) ^ swz)] = qv.y;
-                    w_qual[base + ((d0 + 2) ^ swz)] = qv.z;
-                    w_qual[base + ((d0 + 3) ^ swz)] = qv.w;
+                    w_qual[tile_idx(row, d0 + 0)] = qv.x;
+                    w_qual[tile_idx(row, d0 + 1)] = qv.y;
+                    w_qual[tile_idx(row, d0 + 2)] = qv.z;
+                    w_qual[tile_idx(row, d0 + 3)] = qv.w;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -264,12 +279,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
 
             /* ---------------- phase S: lane = read ---------------- */
             if (QC || AD) {
-                const uint32_t rb = lane * 16;
-                const uint32_t nd = min(16u, (maxL - c0 + 3) / 4); /* dwords any read still has */
+                const uint32_t nd = min(ROW_WORDS, (maxL - c0 + 3) / 4); /* dwords any read still has */
                 for (uint32_t d = 0; d < nd; d++) {
                     const uint32_t pos0 = c0 + d * 4;
+                    const uint32_t ti = tile_idx((uint32_t)lane, d);
+                    const uint32_t sd = w_seq[ti];
                     if (QC) {
-                        uint32_t qd = w_qual[rb + (d ^ my_swz)];
+                        uint32_t qd = w_qual[ti];
                         /* the reference's four chains stop four short of the end (:2068) */
                         qd = pos0 < Lmain ? qd : PAD4;
                         const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
@@ -278,9 +294,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                         acc1 += e1;
                         acc2 += e2;
                         acc3 += e3;
+                        /* class codes are 0 2 4 6 (ACGT) 8 (other) 14 (padding): G/C have
+                           bit1 != bit2, non-ACGT have bit 3 (:1997-2049 counts) */
+                        gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                        acgt_cnt += __popc(~sd & 0x08080808u);
                     }
                     if (AD) {
-                        const uint32_t sd = w_seq[rb + (d ^ my_swz)];
                         uint32_t e[4];
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -310,74 +329,61 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 }
             }
 
-            /* ---------------- phase H: lane = position ---------------- */
+            /* ---------------- phase H: lane = position, two rows at a time ---------------- */
             if (QC || PT) {
-                const uint32_t p = c0 + lane;
-                const uint32_t sh = 8 * (lane & 3);
+                const uint32_t p = c0 + pl;
                 const bool in_lds = p < P.lds_len;
-                uint32_t gc_tmp = 0, acgt_tmp = 0;
-                const uint32_t nrows = 64;
-                for (uint32_t row0 = 0; row0 < nrows; row0 += 4) {
-                    uint32_t sw[4], qw[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t row = row0 + k;
-                        const uint32_t widx = row * 16 + (((uint32_t)lane >> 2) ^ ((row >> 1) & 15));
-                        if (QC) sw[k] = w_seq[widx];
-                        qw[k] = w_qual[widx];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t row = row0 + k;
-                        const uint32_t Lr = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)row);
-                        const bool act = p < Lr;
-                        const uint32_t qb = (qw[k] >> sh) & 0xFF;
-                        if (QC) {
-                            const uint32_t cls2 = (sw[k] >> sh) & 0xFF;
-                            const uint32_t q = qb - 33u;
-                            const uint32_t bin = q > (uint32_t)SQ_PHRED_MAX ? 12u : (min(q, 47u) >> 2);
-                            if (act) {
-                                if (in_lds) {
-                                    atomicAdd(&l_hist_base[p * BASE_COLS + (cls2 >> 1)], 1u);
-                                    atomicAdd(&l_hist_phred[p * PHRED_COLS + bin], 1u);
-                                } else {
-                                    atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls2 >> 1, 4u)], 1ULL);
-                                    if (bin < 12) atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
-                                }
-                                if (ea_atomics) {
-                                    /* last min(ea, L) positions, right aligned (:1971-1972) */
-                                    const uint32_t ean = min(P.ea_len, Lr);
-                                    if (p >= Lr - ean) {
-                                        const uint32_t e = P.ea_len - Lr + p;
-                                        if (P.ea_in_lds) {
-                                            atomicAdd(&l_ea_base[e * BASE_COLS + (cls2 >> 1)], 1u);
-                                            atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
-                                        } else {
-                                            atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls2 >> 1, 4u)], 1ULL);
-                                            if (bin < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
-                                        }
+                uint32_t *hb = l_hist_base + p * BASE_COLS;
+                uint32_t *hp = l_hist_phred + p * PHRED_COLS;
+#pragma unroll 4
+                for (uint32_t rp = 0; rp < 32; rp++) {
+                    const uint32_t row = 2 * rp + half;
+                    /* both rows of the pair share (row >> 2), so the swizzle term is uniform */
+                    const uint32_t ti = row * ROW_WORDS + (h_dw ^ ((rp >> 1) & 7));
+                    const uint32_t L_even = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp));
+                    const uint32_t L_odd = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp + 1));
+                    if (c0 >= max(L_even, L_odd)) continue; /* both reads ended before this chunk */
+                    const uint32_t Lr = half ? L_odd : L_even;
+                    const bool act = p < Lr;
+                    const uint32_t qb = (w_qual[ti] >> h_sh) & 0xFF;
+                    if (QC) {
+                        const uint32_t cls = ((w_seq[ti] >> h_sh) & 0xFF) >> 1;
+                        /* an invalid byte makes the pass fail anyway, so it may land in any bin */
+                        const uint32_t bin = min(qb - 33u, 47u) >> 2;
+                        if (act) {
+                            if (in_lds) {
+                                atomicAdd(&hb[cls], 1u);
+                                atomicAdd(&hp[bin], 1u);
+                            } else {
+                                atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
+                                atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
+                            }
+                            if (ea_atomics) {
+                                /* last min(ea, L) positions, right aligned (:1971-1972) */
+                                const uint32_t ean = min(P.ea_len, Lr);
+                                if (p >= Lr - ean) {
+                                    const uint32_t e = P.ea_len - Lr + p;
+                                    if (P.ea_in_lds) {
+                                        atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
+                                        atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                                    } else {
+                                        atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
+                                        atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
                                     }
                                 }
                             }
-                            /* padding has class 5, so no need to mask with act */
-                            const unsigned long long m_gc = __ballot(cls2 == 2 || cls2 == 4);
-                            const unsigned long long m_acgt = __ballot(cls2 < 8);
-                            /* row totals land in the lane that owns the read */
-                            const bool mine = (uint32_t)lane == row;
-                            gc_tmp = mine ? (uint32_t)__popcll(m_gc) : gc_tmp;
-                            acgt_tmp = mine ? (uint32_t)__popcll(m_acgt) : acgt_tmp;
                         }
-                        if (PT) {
-                            const int32_t slot = __builtin_amdgcn_readlane(pt_on ? pt_slot : -1, (int)row);
-                            if (slot >= 0 && act) {
-                                const double e = l_err[qb];
-                                unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
-                            }
+                    }
+                    if (PT) {
+                        const int32_t s_even = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp));
+                        const int32_t s_odd = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp + 1));
+                        const int32_t slot = half ? s_odd : s_even;
+                        if (slot >= 0 && act) {
+                            const double e = l_err[qb < 128 ? qb : 0];
+                            unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
                         }
                     }
                 }
-                gc_cnt += gc_tmp;
-                acgt_cnt += acgt_tmp;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
