@@ -236,6 +236,24 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+        /* global loads of a chunk are issued one chunk ahead and sit in registers
+           while the previous chunk is being counted */
+        uint4 pf_s[2], pf_q[2];
+        auto prefetch = [&](uint32_t c0) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const uint32_t row = it * 32 + ((uint32_t)lane >> 1), piece = (uint32_t)lane & 1;
+                const uint32_t p0 = c0 + piece * 16;
+                pf_s[it] = make_uint4(0, 0, 0, 0);
+                pf_q[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (p0 < w_len[row]) {
+                    if (QC || AD) pf_s[it] = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                    if (QC || PT) pf_q[it] = load16(P.buf, w_qoff[row] + p0, P.buf_len);
+                }
+            }
+        };
+        if (maxL > 0) prefetch(0);
+
         for (uint32_t c0 = 0; c0 < maxL; c0 += CW) {
             /* ---------------- STAGE: 2 lanes x 16 bytes per row ---------------- */
 #pragma unroll
@@ -244,15 +262,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 const uint32_t Lr = w_len[row];
                 const uint32_t p0 = c0 + piece * 16;
                 uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4);
-                uint4 qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                uint4 qv = pf_q[it];
                 if (p0 < Lr) {
                     const int nv = (int)min(16u, Lr - p0);
                     if (QC || AD) {
-                        sv = load16(P.buf, w_soff[row] + p0, P.buf_len);
-                        sv.x = cls2_of_dword(sv.x); sv.y = cls2_of_dword(sv.y);
-                        sv.z = cls2_of_dword(sv.z); sv.w = cls2_of_dword(sv.w);
+                        sv.x = cls2_of_dword(pf_s[it].x); sv.y = cls2_of_dword(pf_s[it].y);
+                        sv.z = cls2_of_dword(pf_s[it].z); sv.w = cls2_of_dword(pf_s[it].w);
                     }
-                    if (QC || PT) qv = load16(P.buf, w_qoff[row] + p0, P.buf_len);
                     if (nv < 16) {
                         sv.x = pad_tail(sv.x, nv, CLS2_PAD4); sv.y = pad_tail(sv.y, nv - 4, CLS2_PAD4);
                         sv.z = pad_tail(sv.z, nv - 8, CLS2_PAD4); sv.w = pad_tail(sv.w, nv - 12, CLS2_PAD4);
@@ -276,6 +292,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (c0 + CW < maxL) prefetch(c0 + CW);
 
             /* ---------------- phase S: lane = read ---------------- */
             if (QC || AD) {
@@ -332,55 +349,89 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             /* ---------------- phase H: lane = position, two rows at a time ---------------- */
             if (QC || PT) {
                 const uint32_t p = c0 + pl;
-                const bool in_lds = p < P.lds_len;
                 uint32_t *hb = l_hist_base + p * BASE_COLS;
                 uint32_t *hp = l_hist_phred + p * PHRED_COLS;
-#pragma unroll 4
-                for (uint32_t rp = 0; rp < 32; rp++) {
-                    const uint32_t row = 2 * rp + half;
-                    /* both rows of the pair share (row >> 2), so the swizzle term is uniform */
-                    const uint32_t ti = row * ROW_WORDS + (h_dw ^ ((rp >> 1) & 7));
-                    const uint32_t L_even = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp));
-                    const uint32_t L_odd = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp + 1));
-                    if (c0 >= max(L_even, L_odd)) continue; /* both reads ended before this chunk */
-                    const uint32_t Lr = half ? L_odd : L_even;
-                    const bool act = p < Lr;
-                    const uint32_t qb = (w_qual[ti] >> h_sh) & 0xFF;
-                    if (QC) {
-                        const uint32_t cls = ((w_seq[ti] >> h_sh) & 0xFF) >> 1;
-                        /* an invalid byte makes the pass fail anyway, so it may land in any bin */
-                        const uint32_t bin = min(qb - 33u, 47u) >> 2;
-                        if (act) {
-                            if (in_lds) {
+                const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
+                if (QC && !PT && P.uniform_len) {
+                    /* every read has P.uniform_len bases, all of them inside the LDS
+                       histograms, and the end-anchored tables are derived at the merge:
+                       nothing in the loop depends on the row but its two tile words */
+                    if (p < P.uniform_len) {
+#pragma unroll
+                        for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                            uint32_t sw[4], qw[4];
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t rp = rp0 + k;
+                                const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                                sw[k] = w_seq[ti];
+                                qw[k] = w_qual[ti];
+                            }
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
+                                const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
                                 atomicAdd(&hb[cls], 1u);
                                 atomicAdd(&hp[bin], 1u);
-                            } else {
-                                atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
-                                atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
-                            }
-                            if (ea_atomics) {
-                                /* last min(ea, L) positions, right aligned (:1971-1972) */
-                                const uint32_t ean = min(P.ea_len, Lr);
-                                if (p >= Lr - ean) {
-                                    const uint32_t e = P.ea_len - Lr + p;
-                                    if (P.ea_in_lds) {
-                                        atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
-                                        atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
-                                    } else {
-                                        atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
-                                        atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
-                                    }
-                                }
                             }
                         }
                     }
-                    if (PT) {
-                        const int32_t s_even = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp));
-                        const int32_t s_odd = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp + 1));
-                        const int32_t slot = half ? s_odd : s_even;
-                        if (slot >= 0 && act) {
-                            const double e = l_err[qb < 128 ? qb : 0];
-                            unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                } else {
+                    const bool in_lds = p < P.lds_len;
+                    for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                        uint32_t sw[4], qw[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t rp = rp0 + k;
+                            const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                            sw[k] = QC ? w_seq[ti] : 0;
+                            qw[k] = w_qual[ti];
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t rp = rp0 + k;
+                            const uint32_t L_even = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp));
+                            const uint32_t L_odd = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp + 1));
+                            const uint32_t Lr = half ? L_odd : L_even;
+                            const bool act = p < Lr;
+                            const uint32_t qb = (qw[k] >> h_sh) & 0xFF;
+                            if (QC) {
+                                const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
+                                /* an invalid byte makes the pass fail anyway, so it may land in any bin */
+                                const uint32_t bin = min(qb - 33u, 47u) >> 2;
+                                if (act) {
+                                    if (in_lds) {
+                                        atomicAdd(&hb[cls], 1u);
+                                        atomicAdd(&hp[bin], 1u);
+                                    } else {
+                                        atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
+                                        atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
+                                    }
+                                    if (ea_atomics) {
+                                        /* last min(ea, L) positions, right aligned (:1971-1972) */
+                                        const uint32_t ean = min(P.ea_len, Lr);
+                                        if (p >= Lr - ean) {
+                                            const uint32_t e = P.ea_len - Lr + p;
+                                            if (P.ea_in_lds) {
+                                                atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
+                                                atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                                            } else {
+                                                atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
+                                                atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            if (PT) {
+                                const int32_t s_even = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp));
+                                const int32_t s_odd = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp + 1));
+                                const int32_t slot = half ? s_odd : s_even;
+                                if (slot >= 0 && act) {
+                                    const double e = l_err[qb < 128 ? qb : 0];
+                                    unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                                }
+                            }
                         }
                     }
                 }
