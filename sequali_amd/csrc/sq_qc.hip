@@ -352,8 +352,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 uint32_t *hb = l_hist_base + p * BASE_COLS;
                 uint32_t *hp = l_hist_phred + p * PHRED_COLS;
                 const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
-                if (QC && !PT && P.uniform_len) {
-                    /* every read has P.uniform_len bases, all of them inside the LDS
+                if (QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n) {
+                    /* a full group whose reads all have P.uniform_len bases, every one inside the LDS
                        histograms, and the end-anchored tables are derived at the merge:
                        nothing in the loop depends on the row but its two tile words */
                     if (p < P.uniform_len) {
