@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000,
                     help="records of the CPU baseline sample (0 = skip)")
     ap.add_argument("--modules", default="qc,adapter", help="qc,adapter[,pertile]")
+    ap.add_argument("--kind", default="illumina", choices=["illumina", "nanopore"],
+                    help="illumina: 150 bp (configs 2/5); nanopore: ~10 kb variable length (config 4)")
     return ap.parse_args()
 
 
@@ -136,7 +138,8 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ   # launched by torch.distributed.run, even with 1 rank
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -147,8 +150,10 @@ def main():
     lib, ctx = _lib.lib(), _lib.context()
 
     mods = set(args.modules.split(","))
+    kind = synth.NANOPORE if args.kind == "nanopore" else synth.ILLUMINA
+    probes = synth.NANOPORE_PROBES if args.kind == "nanopore" else synth.ILLUMINA_PROBES
     qc = QCMetrics() if "qc" in mods else None
-    ad = AdapterCounter(list(synth.ILLUMINA_PROBES)) if "adapter" in mods else None
+    ad = AdapterCounter(list(probes)) if "adapter" in mods else None
     pt = PerTileQuality() if "pertile" in mods else None
 
     # ---- the rank's shard, generated straight into HBM (not timed) ----
@@ -157,32 +162,12 @@ def main():
     done = 0
     while done < args.reads:
         n = min(args.batch_reads, args.reads - done)
-        batches.append(synth.device_array(synth.ILLUMINA, first + done, n))
+        batches.append(synth.device_array(kind, first + done, n))
         done += n
     total_bases = sum(b._batch.total_bases for b in batches)
 
-    def tables_as_tensors():
-        """device arrays of the additive tables, aliased as torch int64 tensors"""
-        out = []
-        for getter, h in ((lib.sq_qcmetrics_device_tables, qc), (lib.sq_adaptercounter_device_tables, ad)):
-            if h is None:
-                continue
-            ptrs = (ctypes.c_void_p * 8)()
-            counts = (ctypes.c_uint64 * 8)()
-            k = getter(h._h, ptrs, counts, 8)
-            for i in range(k):
-                if not ptrs[i] or not counts[i]:
-                    continue
-
-                class _Alias:
-                    pass
-                a = _Alias()
-                a.__cuda_array_interface__ = {"shape": (int(counts[i]),), "typestr": "<i8",
-                                              "data": (int(ptrs[i]), False), "version": 2}
-                out.append(torch.as_tensor(a, device=f"cuda:{local_rank}"))
-        return out
-
-    scratch = None
+    device = f"cuda:{local_rank}"
+    scratch = []
 
     def step(events=None):
         for b in batches:
@@ -192,23 +177,22 @@ def main():
                                               ad._h if ad else None, pt._h if pt else None))
             if events is not None:
                 events.stop()
-        if world > 1:
-            # the job's exchange step: sum the count tables of all ranks over RCCL.
-            # (on a copy, so that repeated steps keep accumulating local counts)
-            nonlocal scratch
-            _lib.synchronize()
-            tensors = tables_as_tensors()
-            flat = torch.cat([t.reshape(-1) for t in tensors])
-            if scratch is None or scratch.numel() != flat.numel():
-                scratch = torch.empty_like(flat)
-            scratch.copy_(flat)
-            dist.all_reduce(scratch)
+        _lib.synchronize()
+        if use_dist:
+            # the job's one exchange step: sum the count tables of all ranks over RCCL
+            # (on copies, so that repeated steps keep accumulating the local counts)
+            from sequali_amd import dist as sqdist
+            tables = (sqdist.qcmetrics_tables(qc, device) if qc else []) + \
+                     (sqdist.adaptercounter_tables(ad, device) if ad else [])
+            if not scratch:
+                scratch.extend(torch.empty_like(t) for t in tables)
+            for dst, src in zip(scratch, tables):
+                dst.copy_(src)
+            sqdist.sum_tables(scratch)
             torch.cuda.synchronize()
-        else:
-            _lib.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         _lib.synchronize()
@@ -224,7 +208,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms = events.durations_ms()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -237,7 +221,8 @@ def main():
         phred = np.array(qc.phred_count_table(), dtype=np.uint64)
         checks["base_table_sum_ok"] = bool(int(base.sum()) == total_bases * passes)
         checks["phred_table_sum_ok"] = bool(int(phred.sum()) == total_bases * passes)
-        checks["per_position_ok"] = bool((base.reshape(-1, 5).sum(axis=1) == args.reads * passes).all())
+        if args.kind == "illumina":
+            checks["per_position_ok"] = bool((base.reshape(-1, 5).sum(axis=1) == args.reads * passes).all())
         checks["gc_hist_sum_ok"] = bool(int(np.array(qc.gc_content(), dtype=np.uint64).sum())
                                         <= args.reads * passes)
         checks["phred_scores_sum_ok"] = bool(int(np.array(qc.phred_scores(), dtype=np.uint64).sum())
@@ -252,7 +237,16 @@ def main():
         value = world * total_bases * args.steps / elapsed / 1e9
         avg_ms = sum(launch_ms) / max(len(launch_ms), 1)
         reads_per_launch = sum(len(b) for b in batches) / len(batches)
-        algo_bytes = reads_per_launch * ALGO_BYTES_PER_READ
+        # 2 B/base + 40 B/read meta + 8 B/read error-rate write-back
+        algo_bytes = (2 * total_bases + 48 * args.reads) / len(batches)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):   # PMC passes cannot run inside this process; see profiles/README.md
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("reads_per_launch") == int(reads_per_launch) and tj.get("kind") == args.kind \
+                    and tj.get("modules") == sorted(mods):
+                traffic = tj.get("hbm_bytes_per_launch")
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "Gbases/s processed (1/2/4/8 GPU) + achieved HBM GB/s fraction",
@@ -260,12 +254,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"{args.reads} x {READ_LEN} bp synthetic single-end FASTQ per GPU, "
+            "config": {"workload": f"{args.reads} x {READ_LEN if args.kind == 'illumina' else '~10 kb'} bp synthetic single-end {args.kind} FASTQ per GPU, "
                                    f"{'+'.join(sorted(mods))} fused pass, records resident in HBM",
                        "reads_per_gpu": args.reads, "reads_per_launch": int(reads_per_launch),
                        "modules": sorted(mods), "sharding": f"records x{world}, RCCL all-reduce of count tables"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "k_pass<QC,AD> (fused per-base pass)",
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launch_ms)},
@@ -279,7 +273,7 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
