@@ -45,6 +45,8 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (void *p : ctx->scratch)
+        if (p) (void)hipFree(p);
     delete ctx;
 }
 

@@ -45,7 +45,29 @@ struct sq_ctx {
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */
+    /* grow-only device scratch buffers (sorting), reused across batches so that no
+       hipFree (a device-wide sync) sits between launches */
+    void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
 };
+
+inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)
+{
+    if (ctx->scratch_bytes[i] < bytes) {
+        if (ctx->scratch[i]) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->scratch[i]);
+        }
+        size_t want = bytes + bytes / 4;
+        if (hipMalloc(&ctx->scratch[i], want) != hipSuccess) {
+            ctx->scratch[i] = nullptr;
+            ctx->scratch_bytes[i] = 0;
+            return nullptr;
+        }
+        ctx->scratch_bytes[i] = want;
+    }
+    return ctx->scratch[i];
+}
 
 struct sq_batch {
     sq_ctx *ctx = nullptr;

@@ -26,6 +26,7 @@
  *   LDS histograms are merged into the u64 tables in HBM once per workgroup.
  */
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -55,6 +56,9 @@ struct PassParams {
     uint64_t n;
     uint64_t first_read_index; /* index of record 0 over everything the module saw */
     uint32_t lds_len;          /* positions covered by the LDS histograms */
+    uint32_t window;           /* != 0: positions >= lds_len go through a per-wave LDS window
+                                  that is merged into the u64 tables after every chunk */
+    const uint32_t *order;     /* processing order of the records (NULL: as stored) */
     /* QCMetrics */
     unsigned long long *qc_base, *qc_phred, *qc_ea_base, *qc_ea_phred, *qc_gc, *qc_ps;
     uint32_t ea_len;
@@ -139,6 +143,8 @@ constexpr uint32_t CW = 32;               /* positions per chunk */
 constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
 constexpr uint32_t TILE_WORDS = 64 * ROW_WORDS;
 constexpr uint32_t WAVE_WORDS = 2 * TILE_WORDS + 128 + 128 + 64;
+constexpr uint32_t WIN_STRIDE = BASE_COLS + PHRED_COLS + 1;   /* odd: conflict-free */
+constexpr uint32_t WIN_WORDS = CW * WIN_STRIDE;
 constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
 
 /* tile address of dword d of row r: rows are ROW_WORDS = 8 dwords, the dword index
@@ -160,7 +166,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
     uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
-    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [lds_len][BASE_COLS] */
+    uint32_t *l_win = l_wave + WAVES * WAVE_WORDS;         /* per wave [CW][WIN_STRIDE] when P.window */
+    uint32_t *l_hist_base = l_win + (P.window ? WAVES * WIN_WORDS : 0); /* [lds_len][BASE_COLS] */
     uint32_t *l_hist_phred = l_hist_base + (QC ? P.lds_len * BASE_COLS : 0);
     uint32_t *l_ea_base = l_hist_phred + (QC ? P.lds_len * PHRED_COLS : 0);
     const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
@@ -192,6 +199,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     if (AD && DFA_LDS) {
         for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
     }
+    if (P.window)
+        for (uint32_t i = tid; i < WAVES * WIN_WORDS; i += WG_THREADS) l_win[i] = 0;
     __syncthreads();
 
     uint32_t *w_seq = l_wave + wave * WAVE_WORDS;
@@ -199,6 +208,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     unsigned long long *w_soff = (unsigned long long *)(w_qual + TILE_WORDS);
     unsigned long long *w_qoff = w_soff + 64;
     uint32_t *w_len = (uint32_t *)(w_qoff + 64);
+    uint32_t *w_win = l_win + wave * WIN_WORDS;
 
     const uint64_t ngroups = (P.n + 63) / 64;
     const bool ea_atomics = QC && !P.uniform_len;
@@ -208,8 +218,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
 
     for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g < ngroups;
          g += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t r = g * 64 + lane;
-        const bool valid = r < P.n;
+        const uint64_t slot_index = g * 64 + lane;
+        const bool valid = slot_index < P.n;
+        const uint64_t r = (valid && P.order) ? P.order[slot_index] : slot_index;
         sq_meta m;
         if (valid) m = P.metas[r];
         const uint32_t L = valid ? m.sequence_length : 0;
@@ -378,7 +389,25 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                     }
                 } else {
                     const bool in_lds = p < P.lds_len;
+                    uint32_t *wb = w_win + pl * WIN_STRIDE;
+                    /* PerTileQuality: the records come sorted by tile (P.order), so a lane
+                       keeps the running error sum of its position in a register and only
+                       touches memory when the tile changes */
+                    int32_t run_slot = -1;
+                    double run_sum = 0.0;
                     for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                        /* rows of this group that are still inside their read (uniform) */
+                        {
+                            const uint32_t La = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0));
+                            const uint32_t Lb = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 1));
+                            const uint32_t Lc = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 2));
+                            const uint32_t Ld = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 3));
+                            const uint32_t Le = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 4));
+                            const uint32_t Lf = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 5));
+                            const uint32_t Lg = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 6));
+                            const uint32_t Lh = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp0 + 7));
+                            if (c0 >= max(max(max(La, Lb), max(Lc, Ld)), max(max(Le, Lf), max(Lg, Lh)))) continue;
+                        }
                         uint32_t sw[4], qw[4];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) {
@@ -403,6 +432,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                                     if (in_lds) {
                                         atomicAdd(&hb[cls], 1u);
                                         atomicAdd(&hp[bin], 1u);
+                                    } else if (P.window) {
+                                        atomicAdd(&wb[cls], 1u);
+                                        atomicAdd(&wb[BASE_COLS + bin], 1u);
                                     } else {
                                         atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
                                         atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
@@ -426,12 +458,33 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                             if (PT) {
                                 const int32_t s_even = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp));
                                 const int32_t s_odd = __builtin_amdgcn_readlane(pt_slot, (int)(2 * rp + 1));
-                                const int32_t slot = half ? s_odd : s_even;
-                                if (slot >= 0 && act) {
-                                    const double e = l_err[qb < 128 ? qb : 0];
-                                    unsafeAtomicAdd(&P.pt_errors[(uint64_t)slot * P.pt_cap + p], e);
+                                const int32_t slot = (half ? s_odd : s_even);
+                                if (act && slot >= 0) {
+                                    if (slot != run_slot) {
+                                        if (run_slot >= 0)
+                                            unsafeAtomicAdd(&P.pt_errors[(uint64_t)run_slot * P.pt_cap + p], run_sum);
+                                        run_slot = slot;
+                                        run_sum = 0.0;
+                                    }
+                                    run_sum += l_err[qb < 128 ? qb : 0];
                                 }
                             }
+                        }
+                    }
+                    if (PT && run_slot >= 0)
+                        unsafeAtomicAdd(&P.pt_errors[(uint64_t)run_slot * P.pt_cap + p], run_sum);
+                    if (QC && P.window && c0 + CW > P.lds_len) {
+                        /* merge this chunk's window into the u64 tables and clear it */
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t i = lane; i < WIN_WORDS; i += 64) {
+                            const uint32_t v = w_win[i];
+                            if (!v) continue;
+                            w_win[i] = 0;
+                            const uint32_t pos = c0 + i / WIN_STRIDE, col = i % WIN_STRIDE;
+                            if (col < 5) atomicAdd(&P.qc_base[(uint64_t)pos * 5 + col], (unsigned long long)v);
+                            else if (col >= BASE_COLS && col < BASE_COLS + 12)
+                                atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + (col - BASE_COLS)], (unsigned long long)v);
                         }
                     }
                 }
@@ -511,9 +564,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     }
 }
 
-size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states)
+size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states,
+                      bool window)
 {
     size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
+    if (window) b += (size_t)WAVES * WIN_WORDS * 4;
     if (qc) b += (size_t)(lds_len + ea_rows) * (BASE_COLS + PHRED_COLS) * 4;
     if (dfa_lds) b += (size_t)dfa_states * 16;
     return b + 16;
@@ -633,6 +688,49 @@ const double *phred_thresholds()
     }
     ready = true;
     return thr;
+}
+
+/* ---- processing order --------------------------------------------------------
+ * The tables are sums over records, so the pass may visit the records in any
+ * order.  Two orders pay: by length when a batch is ragged (a wave's 64 reads
+ * then end together instead of idling until the longest is done), and by tile
+ * for PerTileQuality (a lane then carries its position's error sum in a
+ * register while the tile stays the same). */
+__global__ void k_order_keys(const sq_meta *metas, const int32_t *slots, uint32_t missing_key,
+                             uint64_t n, uint32_t *keys, uint32_t *vals)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t k;
+        if (slots) k = slots[i] < 0 ? missing_key : (uint32_t)slots[i];
+        else k = metas[i].sequence_length;
+        keys[i] = k;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+/* returns the device array of record indices sorted by key (owned by the context) */
+const uint32_t *sorted_order(sq_ctx *ctx, const sq_batch *b, const int32_t *slots, uint32_t max_key)
+{
+    const uint64_t n = b->n;
+    uint32_t *keys_in = (uint32_t *)sq_scratch(ctx, 0, n * 4), *keys_out = (uint32_t *)sq_scratch(ctx, 1, n * 4);
+    uint32_t *vals_in = (uint32_t *)sq_scratch(ctx, 2, n * 4), *vals_out = (uint32_t *)sq_scratch(ctx, 3, n * 4);
+    if (!keys_in || !keys_out || !vals_in || !vals_out) return nullptr;
+    int blocks = (int)std::min<uint64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_order_keys, dim3(blocks), dim3(256), 0, ctx->stream, b->d_metas, slots,
+                       max_key, n, keys_in, vals_in);
+    int bits = 1;
+    while ((1ull << bits) <= max_key) bits++;
+    size_t temp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                           (int)n, 0, bits, ctx->stream) != hipSuccess)
+        return nullptr;
+    void *temp = sq_scratch(ctx, 4, temp_bytes ? temp_bytes : 8);
+    if (!temp) return nullptr;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                           (int)n, 0, bits, ctx->stream) != hipSuccess)
+        return nullptr;
+    return vals_out;
 }
 
 int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
@@ -1113,9 +1211,21 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         uint64_t fb = p->first_bad == UINT64_MAX ? UINT64_MAX : p->first_bad - p->records_seen;
         P.pt_first_bad = fb == UINT64_MAX ? UINT64_MAX : fb + P.first_read_index;
     }
-    P.lds_len = m ? (uint32_t)std::min<uint64_t>(b->max_length, LDS_HIST_MAX) : 0;
-    if (m && b->min_length == b->max_length && b->max_length > 0 && b->max_length <= LDS_HIST_MAX)
-        P.uniform_len = (uint32_t)b->max_length;
+    if (m) {
+        if (b->max_length <= LDS_HIST_MAX) {
+            P.lds_len = (uint32_t)b->max_length; /* every position has its LDS counters */
+            if (b->min_length == b->max_length && b->max_length > 0) P.uniform_len = P.lds_len;
+        } else {
+            P.lds_len = 0;  /* long reads: a per-wave window of one chunk, merged chunk by chunk */
+            P.window = 1;
+        }
+    }
+    if (b->n >= 4096 && b->n < (1ull << 31)) {
+        if (pt_active)
+            P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
+        else if ((m || a) && b->max_length > 2 * b->min_length + 64)
+            P.order = sorted_order(ctx, b, nullptr, (uint32_t)b->max_length);
+    }
     const uint32_t ea_rows = (m && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
     if (a) {
         if (b->max_length > a->max_length) {
@@ -1127,8 +1237,10 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
     }
     /* first automaton rides with the other modules; further groups get a pass of their own */
     size_t ngroups = a ? a->groups.size() : 0;
+    const uint32_t window_regime = P.window;
     for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
         bool qc = m && gi == 0, pt = pt_active && gi == 0, ad = a != nullptr;
+        P.window = qc ? window_regime : 0;
         bool dfa_lds = false;
         uint32_t states = 0;
         if (ad) {
@@ -1140,7 +1252,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             dfa_lds = states <= DFA_LDS_MAX_STATES;
         }
         if (!qc && !pt && !ad) break;
-        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states);
+        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, qc && P.window);
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         int grid = grid_for(ctx, b->n, wgs_per_cu);
         dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);

@@ -121,8 +121,8 @@ def test_pertile_ragged():
     from sequali_amd import PerTileQuality
     rng = np.random.default_rng(31)
     ref, got = oracle.PerTileQuality(), PerTileQuality()
-    for _ in range(3):
-        buf, metas, arr = random_batch(rng, 2000, 151)
+    for n in (2000, 6000, 5000):   # >= 4096 records: the tile-sorted processing order
+        buf, metas, arr = random_batch(rng, n, 151)
         ref.add(buf, metas)
         got.add_record_array(arr)
     assert got.number_of_reads == ref.number_of_reads
@@ -223,6 +223,32 @@ def test_device_generator_matches_host_generator():
         assert a.phred_count_table() == b.phred_count_table()
         np.testing.assert_array_equal(host.accumulated_error_rates().view(np.uint64),
                                       dev.accumulated_error_rates().view(np.uint64))
+
+
+def test_ragged_batch_in_sorted_order_fused():
+    """>= 4096 ragged records: processed in length-sorted order; with PerTileQuality
+    in the pass, in tile-sorted order"""
+    from sequali_amd import AdapterCounter, FusedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(77)
+    probes = ADAPTER_SETS[0]
+    buf, metas, arr = random_batch(rng, 9000, 700, alphabet=b"ACGTNacgt", splice=probes)
+    rq, ra, rp = oracle.QCMetrics(), oracle.AdapterCounter(probes), oracle.PerTileQuality()
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    rp.add(buf, metas)
+    for with_pt in (False, True):
+        gq, ga, gp = QCMetrics(), AdapterCounter(probes), PerTileQuality()
+        FusedPass(gq, ga, gp if with_pt else None).add_record_array(arr)
+        compare_qc(rq, gq, metas, arr)
+        for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(f), fr)
+            np.testing.assert_array_equal(u64(r), rr)
+        if with_pt:
+            assert gp.number_of_reads == rp.number_of_reads
+            for (t, e, c), (tr, er, cr) in zip(gp.get_tile_counts(), rp.get_tile_counts()):
+                assert t == tr
+                np.testing.assert_allclose(np.array(e), er, rtol=1e-6)
+                np.testing.assert_array_equal(u64(c), cr)
 
 
 def test_nanopore_long_reads_all_modules():
