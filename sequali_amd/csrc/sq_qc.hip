@@ -42,7 +42,11 @@ constexpr uint32_t PAD4 = 0x80808080u;   /* quality tile: past the end of the re
 constexpr uint32_t LDS_HIST_MAX = 512;  /* positions kept in LDS histograms */
 constexpr uint32_t LDS_EA_MAX = 256;    /* end-anchor rows kept in LDS */
 constexpr uint32_t DFA_LDS_MAX_STATES = 1024; /* 16 KB of LDS */
-constexpr uint32_t BASE_COLS = 7, PHRED_COLS = 13; /* odd strides: conflict-free LDS atomics; 1 spare column each for padding / invalid */
+/* LDS histograms are class-major, [class][position] with the position stride rounded
+ * up to 32 words: the lanes of one atomic instruction hold consecutive positions, so
+ * whatever their classes they fall into 32 different banks */
+constexpr uint32_t BASE_COLS = 5, PHRED_COLS = 12;
+__host__ __device__ inline uint32_t hist_stride(uint32_t rows) { return (rows + 31u) & ~31u; }
 constexpr int64_t TILE_EMPTY = -1;
 constexpr uint32_t TILE_MAP_SIZE = 1u << 16;
 
@@ -59,6 +63,8 @@ struct PassParams {
     uint32_t window;           /* != 0: positions >= lds_len go through a per-wave LDS window
                                   that is merged into the u64 tables after every chunk */
     const uint32_t *order;     /* processing order of the records (NULL: as stored) */
+    uint32_t blocked;          /* != 0: a wave takes a contiguous run of groups (tile-sorted order:
+                                  concurrent waves then sit in different tiles) */
     /* QCMetrics */
     unsigned long long *qc_base, *qc_phred, *qc_ea_base, *qc_ea_phred, *qc_gc, *qc_ps;
     uint32_t ea_len;
@@ -143,8 +149,7 @@ constexpr uint32_t CW = 32;               /* positions per chunk */
 constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
 constexpr uint32_t TILE_WORDS = 64 * ROW_WORDS;
 constexpr uint32_t WAVE_WORDS = 2 * TILE_WORDS + 128 + 128 + 64;
-constexpr uint32_t WIN_STRIDE = BASE_COLS + PHRED_COLS + 1;   /* odd: conflict-free */
-constexpr uint32_t WIN_WORDS = CW * WIN_STRIDE;
+constexpr uint32_t WIN_WORDS = (BASE_COLS + PHRED_COLS) * CW; /* [class][CW positions] */
 constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
 
 /* tile address of dword d of row r: rows are ROW_WORDS = 8 dwords, the dword index
@@ -167,12 +172,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
     uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
     uint32_t *l_win = l_wave + WAVES * WAVE_WORDS;         /* per wave [CW][WIN_STRIDE] when P.window */
-    uint32_t *l_hist_base = l_win + (P.window ? WAVES * WIN_WORDS : 0); /* [lds_len][BASE_COLS] */
-    uint32_t *l_hist_phred = l_hist_base + (QC ? P.lds_len * BASE_COLS : 0);
-    uint32_t *l_ea_base = l_hist_phred + (QC ? P.lds_len * PHRED_COLS : 0);
+    const uint32_t hs = QC ? hist_stride(P.lds_len) : 0;   /* words per class row */
+    uint32_t *l_hist_base = l_win + (P.window ? WAVES * WIN_WORDS : 0); /* [5][hs] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;               /* [12][hs] */
+    uint32_t *l_ea_base = l_hist_phred + hs * PHRED_COLS;
     const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
-    uint32_t *l_ea_phred = l_ea_base + ea_rows * BASE_COLS;
-    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + ea_rows * PHRED_COLS);
+    const uint32_t es = hist_stride(ea_rows);
+    uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
+    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + es * PHRED_COLS);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
         for (int i = tid; i < 96; i += WG_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
         for (int i = tid; i < 104; i += WG_THREADS) l_gc[i] = 0;
         for (int i = tid; i < 96; i += WG_THREADS) l_ps[i] = 0;
-        uint32_t nh = (P.lds_len + ea_rows) * (BASE_COLS + PHRED_COLS);
+        uint32_t nh = (hs + es) * (BASE_COLS + PHRED_COLS);
         for (uint32_t i = tid; i < nh; i += WG_THREADS) l_hist_base[i] = 0;
     }
     if (AD && DFA_LDS) {
@@ -216,8 +223,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
 
-    for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g < ngroups;
-         g += (uint64_t)gridDim.x * WAVES) {
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES, wave_id = (uint64_t)blockIdx.x * WAVES + wave;
+    const uint64_t per_wave = (ngroups + n_waves - 1) / n_waves;
+    const uint64_t g_begin = P.blocked ? wave_id * per_wave : wave_id;
+    const uint64_t g_end = P.blocked ? min(ngroups, g_begin + per_wave) : ngroups;
+    const uint64_t g_step = P.blocked ? 1 : n_waves;
+    for (uint64_t g = g_begin; g < g_end; g += g_step) {
         const uint64_t slot_index = g * 64 + lane;
         const bool valid = slot_index < P.n;
         const uint64_t r = (valid && P.order) ? P.order[slot_index] : slot_index;
@@ -360,8 +371,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             /* ---------------- phase H: lane = position, two rows at a time ---------------- */
             if (QC || PT) {
                 const uint32_t p = c0 + pl;
-                uint32_t *hb = l_hist_base + p * BASE_COLS;
-                uint32_t *hp = l_hist_phred + p * PHRED_COLS;
+                uint32_t *hb = l_hist_base + p;   /* + class * hs */
+                uint32_t *hp = l_hist_phred + p;
                 const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
                 if (QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n) {
                     /* a full group whose reads all have P.uniform_len bases, every one inside the LDS
@@ -382,14 +393,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                             for (uint32_t k = 0; k < 4; k++) {
                                 const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
                                 const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
-                                atomicAdd(&hb[cls], 1u);
-                                atomicAdd(&hp[bin], 1u);
+                                atomicAdd(&hb[cls * hs], 1u);
+                                atomicAdd(&hp[bin * hs], 1u);
                             }
                         }
                     }
                 } else {
                     const bool in_lds = p < P.lds_len;
-                    uint32_t *wb = w_win + pl * WIN_STRIDE;
+                    uint32_t *wb = w_win + pl;        /* + class * CW */
                     /* PerTileQuality: the records come sorted by tile (P.order), so a lane
                        keeps the running error sum of its position in a register and only
                        touches memory when the tile changes */
@@ -430,11 +441,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                                 const uint32_t bin = min(qb - 33u, 47u) >> 2;
                                 if (act) {
                                     if (in_lds) {
-                                        atomicAdd(&hb[cls], 1u);
-                                        atomicAdd(&hp[bin], 1u);
+                                        atomicAdd(&hb[cls * hs], 1u);
+                                        atomicAdd(&hp[bin * hs], 1u);
                                     } else if (P.window) {
-                                        atomicAdd(&wb[cls], 1u);
-                                        atomicAdd(&wb[BASE_COLS + bin], 1u);
+                                        atomicAdd(&wb[min(cls, 4u) * CW], 1u);
+                                        atomicAdd(&wb[(BASE_COLS + bin) * CW], 1u);
                                     } else {
                                         atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
                                         atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
@@ -445,8 +456,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                                         if (p >= Lr - ean) {
                                             const uint32_t e = P.ea_len - Lr + p;
                                             if (P.ea_in_lds) {
-                                                atomicAdd(&l_ea_base[e * BASE_COLS + cls], 1u);
-                                                atomicAdd(&l_ea_phred[e * PHRED_COLS + bin], 1u);
+                                                atomicAdd(&l_ea_base[cls * es + e], 1u);
+                                                atomicAdd(&l_ea_phred[bin * es + e], 1u);
                                             } else {
                                                 atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
                                                 atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
@@ -481,10 +492,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                             const uint32_t v = w_win[i];
                             if (!v) continue;
                             w_win[i] = 0;
-                            const uint32_t pos = c0 + i / WIN_STRIDE, col = i % WIN_STRIDE;
-                            if (col < 5) atomicAdd(&P.qc_base[(uint64_t)pos * 5 + col], (unsigned long long)v);
-                            else if (col >= BASE_COLS && col < BASE_COLS + 12)
-                                atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + (col - BASE_COLS)], (unsigned long long)v);
+                            const uint32_t pos = c0 + i % CW, col = i / CW;
+                            if (col < BASE_COLS) atomicAdd(&P.qc_base[(uint64_t)pos * 5 + col], (unsigned long long)v);
+                            else atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + (col - BASE_COLS)], (unsigned long long)v);
                         }
                     }
                 }
@@ -523,9 +533,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     /* ---------------- merge the workgroup's histograms ---------------- */
     if (QC) {
         __syncthreads();
-        for (uint32_t i = tid; i < P.lds_len * BASE_COLS; i += WG_THREADS) {
-            const uint32_t v = l_hist_base[i], c = i % BASE_COLS, pos = i / BASE_COLS;
-            if (v && c < 5) {
+        for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
+            const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
+            if (v) {
                 atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
                 if (P.uniform_len) {
                     /* every read has the same length: the end-anchored table is a
@@ -537,9 +547,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 }
             }
         }
-        for (uint32_t i = tid; i < P.lds_len * PHRED_COLS; i += WG_THREADS) {
-            const uint32_t v = l_hist_phred[i], c = i % PHRED_COLS, pos = i / PHRED_COLS;
-            if (v && c < 12) {
+        for (uint32_t i = tid; i < hs * PHRED_COLS; i += WG_THREADS) {
+            const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
+            if (v) {
                 atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
                 if (P.uniform_len) {
                     const uint32_t ean = min(P.ea_len, P.uniform_len);
@@ -549,13 +559,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                 }
             }
         }
-        for (uint32_t i = tid; i < ea_rows * BASE_COLS; i += WG_THREADS) {
-            const uint32_t v = l_ea_base[i], c = i % BASE_COLS;
-            if (v && c < 5) atomicAdd(&P.qc_ea_base[(uint64_t)(i / BASE_COLS) * 5 + c], (unsigned long long)v);
+        for (uint32_t i = tid; i < es * BASE_COLS; i += WG_THREADS) {
+            const uint32_t v = l_ea_base[i];
+            if (v) atomicAdd(&P.qc_ea_base[(uint64_t)(i % es) * 5 + i / es], (unsigned long long)v);
         }
-        for (uint32_t i = tid; i < ea_rows * PHRED_COLS; i += WG_THREADS) {
-            const uint32_t v = l_ea_phred[i], c = i % PHRED_COLS;
-            if (v && c < 12) atomicAdd(&P.qc_ea_phred[(uint64_t)(i / PHRED_COLS) * 12 + c], (unsigned long long)v);
+        for (uint32_t i = tid; i < es * PHRED_COLS; i += WG_THREADS) {
+            const uint32_t v = l_ea_phred[i];
+            if (v) atomicAdd(&P.qc_ea_phred[(uint64_t)(i % es) * 12 + i / es], (unsigned long long)v);
         }
         for (uint32_t i = tid; i < 101; i += WG_THREADS)
             if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
@@ -569,7 +579,7 @@ size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds,
 {
     size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
     if (window) b += (size_t)WAVES * WIN_WORDS * 4;
-    if (qc) b += (size_t)(lds_len + ea_rows) * (BASE_COLS + PHRED_COLS) * 4;
+    if (qc) b += (size_t)(hist_stride(lds_len) + hist_stride(ea_rows)) * (BASE_COLS + PHRED_COLS) * 4;
     if (dfa_lds) b += (size_t)dfa_states * 16;
     return b + 16;
 }
@@ -581,26 +591,36 @@ struct TileMap {
     int *n_slots;
 };
 
-/* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180) */
+/* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180): the decimal number
+ * between the 4th and the 5th ':' of the header.  Colons are found eight bytes at a
+ * time (headers are 7-bit ASCII, so x + 0x7F sets bit 7 of every non-zero byte). */
 __device__ long long tile_id_of(const uint8_t *name, uint32_t n)
 {
-    uint32_t i = 0, colons = 0;
-    for (; i < n; i++)
-        if (name[i] == ':' && ++colons == 4) break;
-    const uint32_t start = i + 1;
-    for (uint32_t j = start; j < n; j++) {
-        if (name[j] != ':') continue;
-        const uint32_t len = j - start;
-        if (len < 1 || len > 18) return -1;
-        unsigned long long v = 0;
-        for (uint32_t k = start; k < j; k++) {
-            const uint32_t d = (uint32_t)name[k] - '0';
-            if (d > 9) return -1;
-            v = v * 10 + d;
+    uint32_t colons = 0, c4 = n, c5 = n;
+    for (uint32_t off = 0; off < n && c5 == n; off += 8) {
+        /* the sequence follows the name inside the same buffer: reading 8 bytes is safe */
+        uint64_t w = sq_load_u64_unaligned(name + off);
+        if (n - off < 8) w |= ~0ULL << (8 * (n - off)); /* bytes past the name never match */
+        const uint64_t x = w ^ 0x3A3A3A3A3A3A3A3AULL;
+        uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
+        while (m) {
+            const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
+            m &= m - 1;
+            colons++;
+            if (colons == 4) c4 = at;
+            else if (colons == 5) { c5 = at; break; }
         }
-        return (long long)v;
     }
-    return -1;
+    if (c5 == n) return -1;           /* fewer than five colons */
+    const uint32_t start = c4 + 1, len = c5 - start;
+    if (len < 1 || len > 18) return -1;
+    unsigned long long v = 0;
+    for (uint32_t k = start; k < c5; k++) {
+        const uint32_t d = (uint32_t)name[k] - '0';
+        if (d > 9) return -1;
+        v = v * 10 + d;
+    }
+    return (long long)v;
 }
 
 /* pass 1: tile id of every record, first record whose header does not parse */
@@ -1221,8 +1241,10 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         }
     }
     if (b->n >= 4096 && b->n < (1ull << 31)) {
-        if (pt_active)
+        if (pt_active) {
             P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
+            P.blocked = P.order != nullptr;
+        }
         else if ((m || a) && b->max_length > 2 * b->min_length + 64)
             P.order = sorted_order(ctx, b, nullptr, (uint32_t)b->max_length);
     }
