@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000_000, help="records per GPU")
-    ap.add_argument("--batch-reads", type=int, default=10_000_000, help="records per launch")
+    ap.add_argument("--batch-reads", type=int, default=25_000_000, help="records per launch")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000,
                     help="records of the CPU baseline sample (0 = skip)")
     ap.add_argument("--modules", default="qc,adapter", help="qc,adapter[,pertile]")
