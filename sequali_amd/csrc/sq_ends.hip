@@ -329,16 +329,80 @@ __device__ __forceinline__ uint8_t complement_or_zero(uint8_t c)
     return l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : l == 't' ? 'A' : 0;
 }
 
+/* Adapter remainders (InsertSizeMetrics_add_adapter, _qcmodule.c:5570-5611) are
+ * counted in a device hash table keyed by the zero-padded 32-byte record
+ * {length, bytes[31]}.  Besides the count every key keeps the rank of its first
+ * occurrence (pair index over the whole run, read 1 before read 2), which is all
+ * the reference's first-come, linear-probing table depends on: at read-out the
+ * keys are replayed in rank order into a table of the reference's geometry. */
+constexpr uint32_t ISZ_TABLE_BITS = 18;
+constexpr uint64_t ISZ_TABLE_SIZE = 1ull << ISZ_TABLE_BITS;
+
+struct IszTable {
+    unsigned long long *hash;   /* 0 = free */
+    unsigned long long *count;
+    unsigned long long *rank;
+    unsigned int *ready;        /* key bytes published */
+    unsigned long long *key;    /* [size][4] */
+    unsigned long long *n_distinct, *n_events;
+    int *overflow;
+};
+
 struct IszParams {
     const uint8_t *buf1, *buf2;
     const sq_meta *metas1, *metas2;
     uint64_t n;
     unsigned long long *insert_sizes; /* [cap] */
-    unsigned int *sizes_out;          /* [n] insert size per pair */
     unsigned long long *max_insert;
+    IszTable tab[2];
+    uint64_t rank_base;               /* pairs seen before this batch */
+    int closed;                       /* the first-come cap was reached in an earlier batch */
 };
 
-/* calculate_insert_size, _qcmodule.c:5667-5707 */
+__device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t len,
+                                  unsigned long long rank, int closed)
+{
+    unsigned long long key[4] = {0, 0, 0, 0};
+    key[0] = len;
+    for (uint32_t i = 0; i < len; i++) key[(i + 1) >> 3] |= (unsigned long long)a[i] << (8 * ((i + 1) & 7));
+    unsigned long long h = murmur3_x64_64([&](uint64_t i) { return a[i]; }, len, 0);
+    if (h == 0) h = 1; /* 0 marks a free slot */
+    atomicAdd(T.n_events, 1ULL);
+    uint64_t idx = h & (ISZ_TABLE_SIZE - 1);
+    bool mine = false;
+    for (uint64_t spins = 0; spins < (1ull << 22); spins++) {
+        unsigned long long cur = __hip_atomic_load(&T.hash[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            if (closed) return; /* a new key cannot be among the first max_adapters any more */
+            cur = atomicCAS(&T.hash[idx], 0ULL, h);
+            if (cur == 0) {
+                for (int k = 0; k < 4; k++) T.key[idx * 4 + k] = key[k];
+                __threadfence();
+                __hip_atomic_store(&T.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicAdd(T.n_distinct, 1ULL) > (ISZ_TABLE_SIZE / 4) * 3) *T.overflow = 1;
+                cur = h;
+                mine = true;
+            }
+        }
+        if (cur == h) {
+            if (!mine && __hip_atomic_load(&T.ready[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                continue; /* the inserting lane publishes the key in this very iteration */
+            bool same = true;
+            if (!mine)
+                for (int k = 0; k < 4; k++) same &= T.key[idx * 4 + k] == key[k];
+            if (same) {
+                atomicAdd(&T.count[idx], 1ULL);
+                atomicMin(&T.rank[idx], rank);
+                return;
+            }
+        }
+        idx = (idx + 1) & (ISZ_TABLE_SIZE - 1);
+    }
+    *T.overflow = 1;
+}
+
+/* calculate_insert_size, _qcmodule.c:5667-5707, and the bookkeeping of
+ * InsertSizeMetrics_add_sequence_pair_ptr :5709-5744 */
 __global__ void k_insert_size(IszParams P)
 {
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n;
@@ -382,48 +446,27 @@ __global__ void k_insert_size(IszParams P)
                 }
             }
         }
-        P.sizes_out[r] = result;
         atomicAdd(&P.insert_sizes[result], 1ULL);
-        if (result) atomicMax(P.max_insert, (unsigned long long)result);
+        if (result) {
+            atomicMax(P.max_insert, (unsigned long long)result);
+            const unsigned long long rank = 2 * (P.rank_base + r);
+            if (L1 > result) /* :5729-5735 */
+                isz_count_adapter(P.tab[0], s1 + result, min(L1 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank, P.closed);
+            if (L2 > result) /* :5736-5742 */
+                isz_count_adapter(P.tab[1], s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank + 1, P.closed);
+        }
     }
 }
 
-struct IszHasAdapter {
-    const unsigned int *sizes;
-    const sq_meta *metas1, *metas2;
-    __device__ bool operator()(const unsigned long long &idx) const
-    {
-        const unsigned int sz = sizes[idx];
-        return sz != 0 && (metas1[idx].sequence_length > sz || metas2[idx].sequence_length > sz);
-    }
-};
-
-struct IszEvent { /* what the ordered tail needs of one pair */
-    unsigned int size, len1, len2, pad;
-    uint8_t a1[32], a2[32];
-};
-
-__global__ void k_isz_events(const unsigned long long *idx, uint64_t n_events, const uint8_t *buf1,
-                             const sq_meta *metas1, const uint8_t *buf2, const sq_meta *metas2,
-                             const unsigned int *sizes, IszEvent *out)
+/* survivors only travel to the host: hash and the "needs the host" flag of every kept index */
+__global__ void k_dedup_gather(const unsigned long long *idx, uint64_t n_keep,
+                               const unsigned long long *hashes, const unsigned char *special,
+                               unsigned long long *out_hash, unsigned char *out_special)
 {
-    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_events;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_keep;
          e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = idx[e];
-        const sq_meta m1 = metas1[r], m2 = metas2[r];
-        const unsigned int sz = sizes[r];
-        IszEvent ev;
-        ev.size = sz;
-        ev.pad = 0;
-        ev.len1 = m1.sequence_length > sz ? min(m1.sequence_length - sz, (unsigned)SQ_ADAPTER_STORE_SIZE) : 0;
-        ev.len2 = m2.sequence_length > sz ? min(m2.sequence_length - sz, (unsigned)SQ_ADAPTER_STORE_SIZE) : 0;
-        const uint8_t *s1 = buf1 + m1.record_start + m1.sequence_offset + sz;
-        const uint8_t *s2 = buf2 + m2.record_start + m2.sequence_offset + sz;
-        for (unsigned i = 0; i < 32; i++) {
-            ev.a1[i] = i < ev.len1 ? s1[i] : 0;
-            ev.a2[i] = i < ev.len2 ? s2[i] : 0;
-        }
-        out[e] = ev;
+        out_hash[e] = hashes[idx[e]];
+        out_special[e] = special[idx[e]];
     }
 }
 
@@ -852,17 +895,34 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
     uint64_t n_keep = 0;
     int rc = ordered_select(ctx, n, keep, &d_idx, &n_keep);
     if (rc) return rc;
-    std::vector<unsigned long long> idx(n_keep), hashes(n);
-    std::vector<unsigned char> special(n);
-    if (n_keep) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_keep * 8, hipMemcpyDeviceToHost));
-    SQ_HIP(hipMemcpy(hashes.data(), d_hashes, n * 8, hipMemcpyDeviceToHost));
-    SQ_HIP(hipMemcpy(special.data(), d_special, n, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> idx(n_keep), hashes(n_keep);
+    std::vector<unsigned char> special(n_keep);
+    if (n_keep) {
+        unsigned long long *d_kh = nullptr;
+        unsigned char *d_ks = nullptr;
+        SQ_HIP(hipMalloc((void **)&d_kh, n_keep * 8));
+        SQ_HIP(hipMalloc((void **)&d_ks, n_keep));
+        hipLaunchKernelGGL(k_dedup_gather, dim3(blocks_for(n_keep)), dim3(256), 0, ctx->stream, d_idx,
+                           n_keep, d_hashes, d_special, d_kh, d_ks);
+        SQ_HIP(hipMemcpyAsync(idx.data(), d_idx, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(hashes.data(), d_kh, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(special.data(), d_ks, n_keep, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_kh);
+        (void)hipFree(d_ks);
+    }
     (void)hipFree(d_idx); (void)hipFree(d_hashes); (void)hipFree(d_special);
     const uint64_t fp_len = d->front_len + d->back_len;
     for (uint64_t e = 0; e < n_keep; e++) {
+        if (e + 12 < n_keep) { /* the slot a hash lands in is known ahead: hide the table's cache misses */
+            const uint64_t hn = hashes[e + 12];
+            const uint64_t slot = (hn >> d->modulo_bits) & (d->table_size - 1);
+            __builtin_prefetch(&d->count[slot]);
+            __builtin_prefetch(&d->hash[slot]);
+        }
         const uint64_t r = idx[e];
-        uint64_t h = hashes[r];
-        if (special[r]) {
+        uint64_t h = hashes[e];
+        if (special[e]) {
             std::vector<uint8_t> store;
             rc = store_after_pair(d, b1, b2, r, store);
             if (rc) return rc;
@@ -949,11 +1009,15 @@ struct sq_adapter_entry {
 struct sq_insertsize {
     sq_ctx *ctx;
     uint64_t max_adapters, table_size;
-    uint64_t total_reads = 0, n_adapters[2] = {0, 0}, entries[2] = {0, 0};
-    std::vector<sq_adapter_entry> table[2];
+    uint64_t total_reads = 0;
+    IszTable tab[2];
+    bool closed = false;
     size_t cap = 0; /* device histogram length */
     unsigned long long *d_sizes = nullptr, *d_max = nullptr;
     uint64_t max_insert = 0;
+    /* read-out: the reference's tables, rebuilt from the device tables */
+    uint64_t entries[2] = {0, 0};
+    std::vector<sq_adapter_entry> table[2];
 };
 
 SQ_EXPORT sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters)
@@ -966,10 +1030,25 @@ SQ_EXPORT sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters)
     z->ctx = ctx;
     z->max_adapters = max_adapters;
     z->table_size = 1ULL << (uint64_t)(log2(max_adapters * 1.5) + 1); /* :5525 */
-    z->table[0].resize(z->table_size);
-    z->table[1].resize(z->table_size);
     SQ_HIP_NULL(hipMalloc((void **)&z->d_max, 8));
     SQ_HIP_NULL(hipMemset(z->d_max, 0, 8));
+    for (int w = 0; w < 2; w++) {
+        IszTable &T = z->tab[w];
+        SQ_HIP_NULL(hipMalloc((void **)&T.hash, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMalloc((void **)&T.count, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMalloc((void **)&T.rank, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMalloc((void **)&T.ready, ISZ_TABLE_SIZE * 4));
+        SQ_HIP_NULL(hipMalloc((void **)&T.key, ISZ_TABLE_SIZE * 32));
+        SQ_HIP_NULL(hipMalloc((void **)&T.n_distinct, 16));
+        SQ_HIP_NULL(hipMalloc((void **)&T.overflow, 4));
+        T.n_events = T.n_distinct + 1;
+        SQ_HIP_NULL(hipMemset(T.hash, 0, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMemset(T.count, 0, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMemset(T.rank, 0xFF, ISZ_TABLE_SIZE * 8));
+        SQ_HIP_NULL(hipMemset(T.ready, 0, ISZ_TABLE_SIZE * 4));
+        SQ_HIP_NULL(hipMemset(T.n_distinct, 0, 16));
+        SQ_HIP_NULL(hipMemset(T.overflow, 0, 4));
+    }
     return z;
 }
 
@@ -979,13 +1058,20 @@ SQ_EXPORT void sq_insertsize_free(sq_insertsize *z)
     (void)hipStreamSynchronize(z->ctx->stream);
     if (z->d_sizes) (void)hipFree(z->d_sizes);
     if (z->d_max) (void)hipFree(z->d_max);
+    for (int w = 0; w < 2; w++) {
+        IszTable &T = z->tab[w];
+        for (void *p : {(void *)T.hash, (void *)T.count, (void *)T.rank, (void *)T.ready, (void *)T.key,
+                        (void *)T.n_distinct, (void *)T.overflow})
+            if (p) (void)hipFree(p);
+    }
     delete z;
 }
 
 namespace {
 
-/* InsertSizeMetrics_add_adapter, _qcmodule.c:5570-5611 */
-void isz_add_adapter(sq_insertsize *z, const uint8_t *a, size_t len, int which)
+/* InsertSizeMetrics_add_adapter, _qcmodule.c:5570-5611, for a key that brings its
+ * whole count along (keys are replayed in the order of their first occurrence) */
+void isz_replay_adapter(sq_insertsize *z, const uint8_t *a, size_t len, uint64_t count, int which)
 {
     const uint64_t h = murmur3_x64_64([&](uint64_t i) { return a[i]; }, len, 0);
     const bool full = z->entries[which] == z->max_adapters;
@@ -994,10 +1080,10 @@ void isz_add_adapter(sq_insertsize *z, const uint8_t *a, size_t len, int which)
     for (;;) {
         sq_adapter_entry &e = z->table[which][i];
         if (e.hash == h) {
-            if (len == e.len && memcmp(a, e.bytes, len) == 0) { e.count++; return; }
+            if (len == e.len && memcmp(a, e.bytes, len) == 0) { e.count += count; return; }
         } else if (e.count == 0) {
             if (!full) {
-                e.hash = h; e.len = (uint8_t)len; e.count = 1;
+                e.hash = h; e.len = (uint8_t)len; e.count = count;
                 memcpy(e.bytes, a, len);
                 z->entries[which]++;
             }
@@ -1005,6 +1091,32 @@ void isz_add_adapter(sq_insertsize *z, const uint8_t *a, size_t len, int which)
         }
         i = (i + 1) & mask;
     }
+}
+
+int isz_rebuild_tables(sq_insertsize *z)
+{
+    sq_ctx *ctx = z->ctx;
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    for (int w = 0; w < 2; w++) {
+        const IszTable &T = z->tab[w];
+        std::vector<unsigned long long> hash(ISZ_TABLE_SIZE), count(ISZ_TABLE_SIZE), rank(ISZ_TABLE_SIZE);
+        std::vector<unsigned long long> key(ISZ_TABLE_SIZE * 4);
+        SQ_HIP(hipMemcpy(hash.data(), T.hash, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
+        SQ_HIP(hipMemcpy(count.data(), T.count, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
+        SQ_HIP(hipMemcpy(rank.data(), T.rank, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
+        SQ_HIP(hipMemcpy(key.data(), T.key, ISZ_TABLE_SIZE * 32, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> used;
+        for (uint64_t i = 0; i < ISZ_TABLE_SIZE; i++)
+            if (hash[i] && count[i]) used.push_back(i);
+        std::sort(used.begin(), used.end(), [&](uint64_t x, uint64_t y) { return rank[x] < rank[y]; });
+        z->table[w].assign(z->table_size, sq_adapter_entry());
+        z->entries[w] = 0;
+        for (uint64_t i : used) {
+            const uint8_t *rec = (const uint8_t *)&key[i * 4];
+            isz_replay_adapter(z, rec + 1, rec[0], count[i], w);
+        }
+    }
+    return SQ_OK;
 }
 
 } // namespace
@@ -1023,38 +1135,30 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     const size_t need = (size_t)(b1->max_length + b2->max_length + 17);
     int rc = sq_grow_device(ctx, &z->d_sizes, &z->cap, need);
     if (rc) return rc;
-    unsigned int *d_out = nullptr;
-    SQ_HIP(hipMalloc((void **)&d_out, n * 4));
     IszParams P{};
     P.buf1 = b1->d_buf; P.buf2 = b2->d_buf; P.metas1 = b1->d_metas; P.metas2 = b2->d_metas;
-    P.n = n; P.insert_sizes = z->d_sizes; P.sizes_out = d_out; P.max_insert = z->d_max;
+    P.n = n; P.insert_sizes = z->d_sizes; P.max_insert = z->d_max;
+    P.tab[0] = z->tab[0]; P.tab[1] = z->tab[1];
+    P.rank_base = z->total_reads;
+    P.closed = z->closed ? 1 : 0;
     hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, P);
     SQ_HIP(hipGetLastError());
     z->total_reads += n;
-    /* pairs that report an adapter remainder, in order, for the first-come tables */
-    IszHasAdapter pred{d_out, b1->d_metas, b2->d_metas};
-    unsigned long long *d_idx = nullptr;
-    uint64_t n_ev = 0;
-    rc = ordered_select(ctx, n, pred, &d_idx, &n_ev);
-    if (rc) return rc;
-    if (n_ev) {
-        IszEvent *d_ev = nullptr;
-        SQ_HIP(hipMalloc((void **)&d_ev, n_ev * sizeof(IszEvent)));
-        hipLaunchKernelGGL(k_isz_events, dim3(blocks_for(n_ev)), dim3(256), 0, ctx->stream, d_idx, n_ev,
-                           b1->d_buf, b1->d_metas, b2->d_buf, b2->d_metas, d_out, d_ev);
-        std::vector<IszEvent> ev(n_ev);
-        /* same stream as the kernel: the context stream is non-blocking, a plain
-           hipMemcpy on the null stream would not wait for it */
-        SQ_HIP(hipMemcpyAsync(ev.data(), d_ev, n_ev * sizeof(IszEvent), hipMemcpyDeviceToHost, ctx->stream));
+    if (!z->closed) {
+        /* once max_adapters distinct remainders exist in both tables, later batches can
+           only add to keys that are already there (first come, :5583,5599) */
+        SQ_HIP(hipMemcpyAsync(&ctx->pinned[32], z->tab[0].n_distinct, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(&ctx->pinned[33], z->tab[1].n_distinct, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(&ctx->pinned[34], z->tab[0].overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(&ctx->pinned[35], z->tab[1].overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_ev);
-        for (const IszEvent &e : ev) { /* :5729-5742 */
-            if (e.len1) { z->n_adapters[0]++; isz_add_adapter(z, e.a1, e.len1, 0); }
-            if (e.len2) { z->n_adapters[1]++; isz_add_adapter(z, e.a2, e.len2, 1); }
+        if ((uint32_t)ctx->pinned[34] || (uint32_t)ctx->pinned[35]) {
+            sq_set_error("InsertSizeMetrics: more than %llu distinct adapter remainders in flight",
+                         (unsigned long long)(ISZ_TABLE_SIZE / 4 * 3));
+            return SQ_ERR_MEMORY;
         }
+        if (ctx->pinned[32] >= z->max_adapters && ctx->pinned[33] >= z->max_adapters) z->closed = true;
     }
-    (void)hipFree(d_idx);
-    (void)hipFree(d_out);
     return SQ_OK;
 }
 
@@ -1071,8 +1175,15 @@ SQ_EXPORT int sq_insertsize_add_pair(sq_insertsize *z, const uint8_t *buf1, size
 
 SQ_EXPORT int sq_insertsize_flush(sq_insertsize *z) { return sq_synchronize(z->ctx); }
 SQ_EXPORT uint64_t sq_insertsize_total_reads(sq_insertsize *z) { return z->total_reads; }
-SQ_EXPORT uint64_t sq_insertsize_number_of_adapters_read1(sq_insertsize *z) { return z->n_adapters[0]; }
-SQ_EXPORT uint64_t sq_insertsize_number_of_adapters_read2(sq_insertsize *z) { return z->n_adapters[1]; }
+static uint64_t isz_events(sq_insertsize *z, int w)
+{
+    unsigned long long v = 0;
+    (void)hipStreamSynchronize(z->ctx->stream);
+    (void)hipMemcpy(&v, z->tab[w].n_events, 8, hipMemcpyDeviceToHost);
+    return v;
+}
+SQ_EXPORT uint64_t sq_insertsize_number_of_adapters_read1(sq_insertsize *z) { return isz_events(z, 0); }
+SQ_EXPORT uint64_t sq_insertsize_number_of_adapters_read2(sq_insertsize *z) { return isz_events(z, 1); }
 
 SQ_EXPORT int64_t sq_insertsize_insert_sizes(sq_insertsize *z, uint64_t *out, size_t cap)
 {
@@ -1092,6 +1203,7 @@ SQ_EXPORT int64_t sq_insertsize_insert_sizes(sq_insertsize *z, uint64_t *out, si
 SQ_EXPORT int64_t sq_insertsize_adapters(sq_insertsize *z, int read2, uint8_t *bytes, uint8_t *lengths,
                                          uint64_t *counts, size_t cap)
 {
+    if (isz_rebuild_tables(z) != SQ_OK) return SQ_ERR_HIP;
     size_t n = 0;
     for (const sq_adapter_entry &e : z->table[read2 ? 1 : 0]) { /* :5894-5910 slot order */
         if (!e.count) continue;
