@@ -353,6 +353,7 @@ struct IszParams {
     const sq_meta *metas1, *metas2;
     uint64_t n;
     unsigned long long *insert_sizes; /* [cap] */
+    uint32_t lds_sizes;               /* histogram entries privatised in LDS (0: straight to HBM) */
     unsigned long long *max_insert;
     IszTable tab[2];
     uint64_t rank_base;               /* pairs seen before this batch */
@@ -405,6 +406,11 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
  * InsertSizeMetrics_add_sequence_pair_ptr :5709-5744 */
 __global__ void k_insert_size(IszParams P)
 {
+    /* most pairs report the same few sizes (0 = no overlap found): count per workgroup first */
+    extern __shared__ unsigned int l_sizes[];
+    for (uint32_t i = threadIdx.x; i < P.lds_sizes; i += blockDim.x) l_sizes[i] = 0;
+    __syncthreads();
+    unsigned long long local_max = 0;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n;
          r += (uint64_t)gridDim.x * blockDim.x) {
         const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
@@ -446,9 +452,10 @@ __global__ void k_insert_size(IszParams P)
                 }
             }
         }
-        atomicAdd(&P.insert_sizes[result], 1ULL);
+        if (result < P.lds_sizes) atomicAdd(&l_sizes[result], 1u);
+        else atomicAdd(&P.insert_sizes[result], 1ULL);
         if (result) {
-            atomicMax(P.max_insert, (unsigned long long)result);
+            if (result > local_max) local_max = result;
             const unsigned long long rank = 2 * (P.rank_base + r);
             if (L1 > result) /* :5729-5735 */
                 isz_count_adapter(P.tab[0], s1 + result, min(L1 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank, P.closed);
@@ -456,6 +463,10 @@ __global__ void k_insert_size(IszParams P)
                 isz_count_adapter(P.tab[1], s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank + 1, P.closed);
         }
     }
+    if (local_max) atomicMax(P.max_insert, local_max);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P.lds_sizes; i += blockDim.x)
+        if (l_sizes[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_sizes[i]);
 }
 
 /* survivors only travel to the host: hash and the "needs the host" flag of every kept index */
@@ -1141,7 +1152,8 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     P.tab[0] = z->tab[0]; P.tab[1] = z->tab[1];
     P.rank_base = z->total_reads;
     P.closed = z->closed ? 1 : 0;
-    hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, P);
+    P.lds_sizes = (uint32_t)std::min<size_t>(z->cap, 8192);
+    hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(n, 2048)), dim3(256), P.lds_sizes * 4, ctx->stream, P);
     SQ_HIP(hipGetLastError());
     z->total_reads += n;
     if (!z->closed) {
