@@ -63,6 +63,9 @@ struct PassParams {
     uint32_t window;           /* != 0: positions >= lds_len go through a per-wave LDS window
                                   that is merged into the u64 tables after every chunk */
     const uint32_t *order;     /* processing order of the records (NULL: as stored) */
+    unsigned long long *win_base, *win_phred; /* window regime: [n_copies][win_rows][5] / [12] */
+    uint32_t n_copies;         /* private copies of the two tables the windows merge into */
+    uint64_t win_rows;
     uint32_t blocked;          /* != 0: a wave takes a contiguous run of groups (tile-sorted order:
                                   concurrent waves then sit in different tiles) */
     /* QCMetrics */
@@ -493,8 +496,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                             if (!v) continue;
                             w_win[i] = 0;
                             const uint32_t pos = c0 + i % CW, col = i / CW;
-                            if (col < BASE_COLS) atomicAdd(&P.qc_base[(uint64_t)pos * 5 + col], (unsigned long long)v);
-                            else atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + (col - BASE_COLS)], (unsigned long long)v);
+                            /* thousands of waves walk the same positions at about the same time:
+                               spread them over private copies of the tables (summed afterwards) */
+                            const uint64_t copy = wave_id % P.n_copies;
+                            if (col < BASE_COLS)
+                                atomicAdd(&P.win_base[(copy * P.win_rows + pos) * 5 + col], (unsigned long long)v);
+                            else
+                                atomicAdd(&P.win_phred[(copy * P.win_rows + pos) * 12 + (col - BASE_COLS)], (unsigned long long)v);
                         }
                     }
                 }
@@ -751,6 +759,18 @@ const uint32_t *sorted_order(sq_ctx *ctx, const sq_batch *b, const int32_t *slot
                                            (int)n, 0, bits, ctx->stream) != hipSuccess)
         return nullptr;
     return vals_out;
+}
+
+/* dst[i] += sum over copies of src[copy][i] */
+__global__ void k_sum_copies(unsigned long long *dst, const unsigned long long *src, uint64_t cells,
+                             uint32_t n_copies)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cells;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long t = 0;
+        for (uint32_t c = 0; c < n_copies; c++) t += src[c * cells + i];
+        if (t) dst[i] += t;
+    }
 }
 
 int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
@@ -1258,6 +1278,19 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         P.ad_cap = a->cap;
     }
     /* first automaton rides with the other modules; further groups get a pass of their own */
+    if (m && P.window) {
+        /* private copies of the positional tables for the window merges: as many as fit
+           in about 1 GB, at most 64 */
+        const uint64_t rows = b->max_length, cells = rows * 17;
+        uint32_t copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (1ull << 30) / (cells * 8)));
+        unsigned long long *priv = (unsigned long long *)sq_scratch(ctx, 5, (size_t)copies * cells * 8);
+        if (!priv) { sq_set_error("out of device memory for the long-read tables"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemsetAsync(priv, 0, (size_t)copies * cells * 8, ctx->stream));
+        P.win_base = priv;
+        P.win_phred = priv + (size_t)copies * rows * 5;
+        P.n_copies = copies;
+        P.win_rows = rows;
+    }
     size_t ngroups = a ? a->groups.size() : 0;
     const uint32_t window_regime = P.window;
     for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
@@ -1275,10 +1308,18 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         }
         if (!qc && !pt && !ad) break;
         size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, qc && P.window);
+        if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         int grid = grid_for(ctx, b->n, wgs_per_cu);
         dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);
         SQ_HIP(hipGetLastError());
+        if (qc && P.window) {
+            const uint64_t rows = P.win_rows;
+            hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 5 + 255) / 256, 4096)),
+                               dim3(256), 0, ctx->stream, m->d_base, P.win_base, rows * 5, P.n_copies);
+            hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 12 + 255) / 256, 4096)),
+                               dim3(256), 0, ctx->stream, m->d_phred, P.win_phred, rows * 12, P.n_copies);
+        }
     }
     if (m) { m->number_of_reads += b->n; m->records_seen += b->n; }
     if (a) a->number_of_sequences += b->n;
