@@ -42,14 +42,21 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="records per GPU")
-    ap.add_argument("--batch-reads", type=int, default=25_000_000, help="records per launch")
+    ap.add_argument("--reads", type=int, default=None,
+                    help="records per GPU (default 100 M illumina / 1 M nanopore)")
+    ap.add_argument("--batch-reads", type=int, default=None,
+                    help="records per launch (default 25 M illumina / 1 M nanopore)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000,
                     help="records of the CPU baseline sample (0 = skip)")
     ap.add_argument("--modules", default="qc,adapter", help="qc,adapter[,pertile]")
     ap.add_argument("--kind", default="illumina", choices=["illumina", "nanopore"],
                     help="illumina: 150 bp (configs 2/5); nanopore: ~10 kb variable length (config 4)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.reads is None:
+        args.reads = 100_000_000 if args.kind == "illumina" else 1_000_000
+    if args.batch_reads is None:
+        args.batch_reads = 25_000_000 if args.kind == "illumina" else 1_000_000
+    return args
 
 
 class HipEvents:

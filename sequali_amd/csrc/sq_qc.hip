@@ -731,7 +731,7 @@ __global__ void k_order_keys(const sq_meta *metas, const int32_t *slots, uint32_
          i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t k;
         if (slots) k = slots[i] < 0 ? missing_key : (uint32_t)slots[i];
-        else k = metas[i].sequence_length;
+        else k = missing_key - metas[i].sequence_length; /* longest first: the long tail starts early */
         keys[i] = k;
         vals[i] = (uint32_t)i;
     }
