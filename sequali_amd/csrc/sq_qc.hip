@@ -582,6 +582,248 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     }
 }
 
+/* ---- k_coop: the fused pass for the common case, one group per WORKGROUP -------------
+ * Conditions (checked by the host): QCMetrics (+ AdapterCounter) without
+ * PerTileQuality, every read of the batch has the same length U <= 512, records in
+ * stored order, automaton in LDS.  Everything else runs k_pass.
+ *
+ * k_pass gives every wave its own 64 reads, so a read's consecutive 32-position
+ * chunks are fetched ~12 us apart and a 64-byte sector shared by two chunks has
+ * left the L2 by then: each sector is requested about twice and the pass is
+ * bound by that request rate.  Here the four waves of a workgroup
+ * share ONE group: a chunk is finished ~4x sooner, the sector's second touch hits
+ * the L2, and the waves specialise:
+ *     every wave   loads one quarter of each chunk (stream = wave / 2, rows = wave % 2),
+ *                  two chunks ahead in registers, converts / pads, writes the LDS tile
+ *     wave 0       the f64 error-rate chains in the reference's order   (lane = read)
+ *     wave 1       GC / ACGT counts and the adapter automaton            (lane = read)
+ *     waves 2, 3   the per-position histograms, 16 row pairs each        (lane = position)
+ * Tiles are double buffered, so one workgroup barrier per chunk is enough. */
+constexpr uint32_t COOP_FIXED_WORDS = (136 * 8 + 96 * 8) / 4 + 104 + 96;
+
+template <bool AD>
+__global__ void __launch_bounds__(WG_THREADS) k_coop(PassParams P)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    double *l_err = (double *)smem;                        /* [136] */
+    double *l_thr = l_err + 136;                           /* [96] */
+    uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
+    uint32_t *l_ps = l_gc + 104;                           /* [96] */
+    uint32_t *l_tiles = l_ps + 96;                         /* [2 buffers][seq, qual][TILE_WORDS] */
+    unsigned long long *l_off = (unsigned long long *)(l_tiles + 4 * TILE_WORDS); /* [seq, qual][64] */
+    uint32_t *l_cnt = (uint32_t *)(l_off + 128);           /* [gc, acgt][64], wave 1 -> wave 0 */
+    const uint32_t U = P.uniform_len, hs = hist_stride(U);
+    uint32_t *l_hist_base = l_cnt + 128;                   /* [5][hs] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12][hs] */
+    uint16_t *l_dfa = (uint16_t *)(l_hist_phred + hs * PHRED_COLS);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 136; i += WG_THREADS) {
+        double e;
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
+        else if (i >= 128) e = 0.0;
+        else e = __longlong_as_double(0x7FF8000000000000LL);
+        l_err[i] = e;
+    }
+    for (int i = tid; i < 96; i += WG_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+    for (int i = tid; i < 104; i += WG_THREADS) l_gc[i] = 0;
+    for (int i = tid; i < 96; i += WG_THREADS) l_ps[i] = 0;
+    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += WG_THREADS) l_hist_base[i] = 0;
+    if (AD)
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+    __syncthreads();
+
+    const uint32_t nchunks = (U + CW - 1) / CW;
+    const uint32_t Lmain = 4 * ((U - 1) / 4);
+    /* loader: this lane's 16 bytes of every chunk */
+    const uint32_t ld_stream = (uint32_t)wave >> 1;
+    const uint32_t ld_row = ((uint32_t)wave & 1) * 32 + ((uint32_t)lane >> 1), ld_piece = (uint32_t)lane & 1;
+    /* histogram waves: lanes 0-31 an even row, lanes 32-63 the odd row after it */
+    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2, row_base = half * ROW_WORDS;
+    const uint32_t pair0 = wave >= 2 ? ((uint32_t)wave - 2) * 16 : 0;
+    const uint64_t ngroups = P.n / 64;
+
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t r = g * 64 + lane;
+        uint64_t qoff = 0;
+        if (wave == 0) {
+            const sq_meta m = P.metas[r];
+            qoff = m.record_start + m.qualities_offset;
+            l_off[lane] = m.record_start + m.sequence_offset;
+            l_off[64 + lane] = qoff;
+        }
+        __syncthreads();
+        const uint64_t my_off = l_off[ld_stream * 64 + ld_row];
+        const uint4 pad4 = ld_stream ? make_uint4(PAD4, PAD4, PAD4, PAD4)
+                                     : make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4);
+        auto issue = [&](uint32_t c) -> uint4 {
+            const uint32_t p0 = c * CW + ld_piece * 16;
+            if (p0 < U) return load16(P.buf, my_off + p0, P.buf_len);
+            return pad4;
+        };
+        uint4 pf_even = issue(0), pf_odd = nchunks > 1 ? issue(1) : pad4;
+
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; /* wave 0 */
+        uint32_t st = 0, gc_cnt = 0, acgt_cnt = 0;             /* wave 1 */
+        unsigned long long found = 0;
+
+        for (uint32_t c = 0; c < nchunks; c++) {
+            uint32_t *t_seq = l_tiles + (c & 1) * 2 * TILE_WORDS, *t_qual = t_seq + TILE_WORDS;
+            /* ---- stage this lane's 16 bytes of chunk c ---- */
+            {
+                uint4 v = (c & 1) ? pf_odd : pf_even;
+                const uint32_t p0 = c * CW + ld_piece * 16;
+                if (p0 < U) {
+                    if (ld_stream == 0) {
+                        v.x = cls2_of_dword(v.x); v.y = cls2_of_dword(v.y);
+                        v.z = cls2_of_dword(v.z); v.w = cls2_of_dword(v.w);
+                    }
+                    const int nv = (int)min(16u, U - p0);
+                    if (nv < 16) {
+                        v.x = pad_tail(v.x, nv, pad4.x); v.y = pad_tail(v.y, nv - 4, pad4.x);
+                        v.z = pad_tail(v.z, nv - 8, pad4.x); v.w = pad_tail(v.w, nv - 12, pad4.x);
+                    }
+                }
+                uint32_t *t = ld_stream ? t_qual : t_seq;
+                const uint32_t d0 = ld_piece * 4;
+                t[tile_idx(ld_row, d0 + 0)] = v.x;
+                t[tile_idx(ld_row, d0 + 1)] = v.y;
+                t[tile_idx(ld_row, d0 + 2)] = v.z;
+                t[tile_idx(ld_row, d0 + 3)] = v.w;
+                if (c + 2 < nchunks) { /* refill the register that was just consumed */
+                    const uint4 nx = issue(c + 2);
+                    if (c & 1) pf_odd = nx; else pf_even = nx;
+                }
+            }
+            __syncthreads();
+
+            const uint32_t nd = min(ROW_WORDS, (U - c * CW + 3) / 4);
+            if (wave == 0) {
+                /* the four interleaved chains of _qcmodule.c:2062-2097 */
+                for (uint32_t d = 0; d < nd; d++) {
+                    uint32_t qd = t_qual[tile_idx((uint32_t)lane, d)];
+                    qd = c * CW + d * 4 < Lmain ? qd : PAD4;
+                    const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
+                    const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
+                    acc0 += e0;
+                    acc1 += e1;
+                    acc2 += e2;
+                    acc3 += e3;
+                }
+            } else if (wave == 1) {
+                for (uint32_t d = 0; d < nd; d++) {
+                    const uint32_t sd = t_seq[tile_idx((uint32_t)lane, d)];
+                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                    acgt_cnt += __popc(~sd & 0x08080808u);
+                    if (AD) {
+                        uint32_t e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
+                            e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
+                            st = e[j] & 0xFFF0u;
+                        }
+                        if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
+                            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                if (!(e[j] & 1u)) continue;
+                                unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                                found |= hits;
+                                const uint32_t pos = c * CW + d * 4 + j;
+                                while (hits) {
+                                    const int a = __ffsll((long long)hits) - 1;
+                                    hits &= hits - 1;
+                                    const uint32_t start = pos - P.ad_len[a] + 1;
+                                    atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                                    atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                const uint32_t p = c * CW + pl;
+                if (p < U) {
+                    uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
+#pragma unroll
+                    for (uint32_t rp0 = 0; rp0 < 16; rp0 += 4) {
+                        uint32_t sw[4], qw[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t rp = pair0 + rp0 + k;
+                            const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                            sw[k] = t_seq[ti];
+                            qw[k] = t_qual[ti];
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
+                            const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
+                            atomicAdd(&hb[cls * hs], 1u);
+                            atomicAdd(&hp[bin * hs], 1u);
+                        }
+                    }
+                }
+            }
+        }
+
+        /* ---- per-read epilogue (wave 0), with wave 1's base counts ---- */
+        if (wave == 1) {
+            l_cnt[lane] = gc_cnt;
+            l_cnt[64 + lane] = acgt_cnt;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099 */
+            for (uint32_t pos = Lmain; pos < U; pos++) { /* :2100-2112 */
+                const uint32_t qb = P.buf[qoff + pos];
+                total += l_err[qb < 128 ? qb : 0];
+            }
+            P.metas[r].accumulated_error_rate = total; /* :2126 */
+            if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+            const uint32_t gc = l_cnt[lane], acgt = l_cnt[64 + lane];
+            if (acgt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc * 100.0 / (double)acgt)], 1u);
+            const double avg = total / (double)U;
+            uint32_t lo = 0, hi = 93;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+            }
+            atomicAdd(&l_ps[lo], 1u);
+        }
+    }
+
+    /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
+    __syncthreads();
+    const uint32_t ean = min(P.ea_len, U);
+    for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
+        const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
+        if (!v) continue;
+        atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
+        if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + c], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < hs * PHRED_COLS; i += WG_THREADS) {
+        const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
+        if (!v) continue;
+        atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
+        if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + c], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < 101; i += WG_THREADS)
+        if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
+    for (uint32_t i = tid; i < 94; i += WG_THREADS)
+        if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+}
+
+size_t coop_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
+{
+    size_t b = COOP_FIXED_WORDS * 4 + 4 * TILE_WORDS * 4 + 128 * 8 + 128 * 4;
+    b += (size_t)hist_stride(uniform_len) * (BASE_COLS + PHRED_COLS) * 4;
+    if (ad) b += (size_t)dfa_states * 16;
+    return b + 16;
+}
+
 size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states,
                       bool window)
 {
@@ -1307,12 +1549,32 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             dfa_lds = states <= DFA_LDS_MAX_STATES;
         }
         if (!qc && !pt && !ad) break;
+        /* the common case (uniform short reads, QCMetrics with or without AdapterCounter)
+           runs one group per workgroup; a trailing partial group goes through k_pass */
+        const bool coop = qc && !pt && P.uniform_len && !P.order && (!ad || dfa_lds) && b->n >= 64 &&
+                          !getenv("SQ_NO_COOP");
+        PassParams Pfull = P;
+        if (coop) {
+            PassParams C = P;
+            C.n = (b->n / 64) * 64;
+            const size_t clds = coop_lds_bytes(P.uniform_len, ad, states);
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, (160 * 1024) / clds));
+            const int cgrid = (int)std::min<uint64_t>(C.n / 64, (uint64_t)ctx->num_cus * per_cu);
+            if (ad) hipLaunchKernelGGL((k_coop<true>), dim3(cgrid), dim3(WG_THREADS), clds, ctx->stream, C);
+            else hipLaunchKernelGGL((k_coop<false>), dim3(cgrid), dim3(WG_THREADS), clds, ctx->stream, C);
+            SQ_HIP(hipGetLastError());
+            if (C.n == b->n) continue;
+            P.metas = b->d_metas + C.n;
+            P.first_read_index += C.n;
+            P.n = b->n - C.n;
+        }
         size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, qc && P.window);
         if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         int grid = grid_for(ctx, b->n, wgs_per_cu);
         dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);
         SQ_HIP(hipGetLastError());
+        if (coop) P = Pfull;
         if (qc && P.window) {
             const uint64_t rows = P.win_rows;
             hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 5 + 255) / 256, 4096)),
