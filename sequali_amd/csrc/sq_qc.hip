@@ -696,7 +696,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_coop(PassParams P)
                     if (c & 1) pf_odd = nx; else pf_even = nx;
                 }
             }
-            __syncthreads();
+            /* workgroup barrier for the LDS tile only: __syncthreads() would also wait for
+               vmcnt(0) and drain the loads that were just issued for chunk c + 2 */
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
 
             const uint32_t nd = min(ROW_WORDS, (U - c * CW + 3) / 4);
             if (wave == 0) {
@@ -1549,10 +1553,12 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             dfa_lds = states <= DFA_LDS_MAX_STATES;
         }
         if (!qc && !pt && !ad) break;
-        /* the common case (uniform short reads, QCMetrics with or without AdapterCounter)
-           runs one group per workgroup; a trailing partial group goes through k_pass */
-        const bool coop = qc && !pt && P.uniform_len && !P.order && (!ad || dfa_lds) && b->n >= 64 &&
-                          !getenv("SQ_NO_COOP");
+        /* QCMetrics alone on uniform short reads runs one group per workgroup (k_coop, +22 %);
+           with the automaton in the pass its dependent table steps want a sequential chain
+           per wave, 16 per CU, and k_pass wins (302 vs 680 Gbases/s measured; SQ_COOP=1 forces
+           k_coop for experiments).  A trailing partial group goes through k_pass. */
+        const bool coop = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && !getenv("SQ_NO_COOP") &&
+                          (!ad || (dfa_lds && getenv("SQ_COOP")));
         PassParams Pfull = P;
         if (coop) {
             PassParams C = P;
