@@ -265,3 +265,34 @@ def test_nanopore_long_reads_all_modules():
     for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
         np.testing.assert_array_equal(u64(f), fr)
         np.testing.assert_array_equal(u64(r), rr)
+
+
+def test_two_million_reads_all_tables_equal_oracle():
+    """bench-shaped input at a size the oracle still finishes in seconds: 2 M x 150 bp
+    generated in HBM, one fused launch (k_pass) and one QCMetrics-only launch (k_coop)"""
+    from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
+    n = 2_000_000
+    dev = synth.device_array(synth.ILLUMINA, 12345, n)
+    buf, metas = dev._batch.download()
+    probes = list(synth.ILLUMINA_PROBES)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    gq, ga, gq2 = QCMetrics(), AdapterCounter(probes), QCMetrics()
+    FusedPass(gq, ga).add_record_array(dev)
+    errs = dev.accumulated_error_rates()
+    gq2.add_record_array(dev)
+    for g in (gq, gq2):
+        np.testing.assert_array_equal(u64(g.base_count_table()), rq.base_count_table())
+        np.testing.assert_array_equal(u64(g.phred_count_table()), rq.phred_count_table())
+        np.testing.assert_array_equal(u64(g.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
+        np.testing.assert_array_equal(u64(g.end_anchored_phred_count_table()), rq.end_anchored_phred_count_table())
+        np.testing.assert_array_equal(u64(g.gc_content()), rq.gc_content())
+        np.testing.assert_array_equal(u64(g.phred_scores()), rq.phred_scores())
+    np.testing.assert_array_equal(errs.view(np.uint64), metas["accumulated_error_rate"].view(np.uint64))
+    np.testing.assert_array_equal(dev.accumulated_error_rates().view(np.uint64),
+                                  metas["accumulated_error_rate"].view(np.uint64))
+    for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 50_000
