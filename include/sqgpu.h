@@ -100,12 +100,25 @@ sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_len,
 /* Wraps memory that already lives on the device (borrowed, not freed). */
 sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len, void *d_metas,
                                size_t n);
+/* FastqParser's record split on the GPU (FastqParser_create_record_array, the loop at
+ * _qcmodule.c:1093-1171, and the ASCII check :203-237, :1055-1067): finds every
+ * complete 4-line record of `text`, builds the metas in HBM and returns the batch.
+ * *consumed = bytes covered by complete records (the tail is the caller's leftover).
+ * NULL + sq_last_error() for the reference's ValueErrors ("Record does not start
+ * with @ ...", "... second header does not start with + ...", unequal sequence /
+ * quality lengths, non-ASCII byte).  The text is copied to the device (host variant)
+ * or borrowed (device variant). */
+sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed);
+sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len, size_t *consumed);
 void sq_batch_free(sq_batch *b);
 uint64_t sq_batch_size(const sq_batch *b);
 uint64_t sq_batch_total_bases(const sq_batch *b);
 uint64_t sq_batch_max_length(const sq_batch *b);
 uint64_t sq_batch_bytes(const sq_batch *b);
-/* Copies the batch back to the host: buf_len bytes and n metas. */
+/* Device addresses of the batch's text and of its 40-byte metas (interop: torch, RCCL). */
+void *sq_batch_device_text(const sq_batch *b);
+void *sq_batch_device_metas(const sq_batch *b);
+/* Copies the batch back to the host: buf_len bytes (skipped when buf is NULL) and n metas. */
 int sq_batch_download(sq_batch *b, uint8_t *buf, size_t buf_cap, sq_meta *metas, size_t meta_cap);
 /* metas[i].accumulated_error_rate of every record, after QCMetrics ran. */
 int sq_batch_error_rates(sq_batch *b, double *out, size_t n);

@@ -72,7 +72,7 @@ def lib() -> C.CDLL:
 
 
 def last_error() -> str:
-    return (lib().sq_last_error() or b"").decode("utf-8", "replace")
+    return (lib().sq_last_error() or b"").decode("latin-1")  # bytes echoed from the input -> code points, like %c
 
 
 _EXC = {-1: RuntimeError, -2: ValueError, -3: MemoryError, -4: TypeError, -5: EOFError,

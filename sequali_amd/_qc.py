@@ -174,6 +174,11 @@ class _DeviceBatch:
         check(lib().sq_batch_download(self.handle, buf.ctypes.data, nbytes, metas.ctypes.data, n))
         return buf, metas
 
+    def download_metas(self) -> np.ndarray:
+        metas = np.zeros(self.number_of_records, dtype=META_DTYPE)
+        check(lib().sq_batch_download(self.handle, None, 0, metas.ctypes.data, len(metas)))
+        return metas
+
     def error_rates(self) -> np.ndarray:
         out = np.zeros(self.number_of_records, dtype=np.float64)
         if len(out):
@@ -243,9 +248,14 @@ class FastqRecordArrayView:
             i += n
         if i < 0 or i >= n:
             raise IndexError("array index out of range")
+        return FastqRecordView._from(self.obj, self._host_metas()[i:i + 1])
+
+    def _host_metas(self) -> np.ndarray:
         if self._metas is None:
-            raise TypeError("this record array lives on the device only")
-        return FastqRecordView._from(self.obj, self._metas[i:i + 1])
+            if self.obj is None:
+                raise TypeError("this record array lives on the device only")
+            self._metas = self._batch.download_metas()  # split on the device: fetched once
+        return self._metas
 
     def is_mate(self, other) -> bool:
         """FastqRecordArrayView_is_mate, _qcmodule.c:814-850"""
@@ -254,8 +264,8 @@ class FastqRecordArrayView:
         if len(self) != len(other):
             raise ValueError("other is not the same length as this record array view. "
                              f"This length: {len(self)}, other length: {len(other)}")
-        return bool(lib().sq_names_are_mates(_addr(self.obj), self._metas.ctypes.data,
-                                             _addr(other.obj), other._metas.ctypes.data,
+        return bool(lib().sq_names_are_mates(_addr(self.obj), self._host_metas().ctypes.data,
+                                             _addr(other.obj), other._host_metas().ctypes.data,
                                              len(self)))
 
     # -- device side ---------------------------------------------------------
@@ -269,7 +279,8 @@ class FastqRecordArrayView:
         return self._batch
 
     def _release_device(self) -> None:
-        self._batch = None
+        if self._metas is not None:
+            self._batch = None
 
     def accumulated_error_rates(self) -> np.ndarray:
         """FastqMeta.accumulated_error_rate of every record (what NanoStats reads,
@@ -312,18 +323,22 @@ class FastqParser:
     file object, ``initial_buffersize`` bytes at a time (memchr record split on
     the host, sq_fastq_split)."""
 
-    def __init__(self, fileobj, initial_buffersize: int = 128 * 1024):
+    def __init__(self, fileobj, initial_buffersize: int = 128 * 1024, split_on_device: bool = False):
         if initial_buffersize < 1:
             raise ValueError(f"initial_buffersize must be at least 1, got {initial_buffersize}")
         self._file = fileobj
         self._read_in_size = int(initial_buffersize)
         self._leftover = b""
+        # extension: iterate with the record split done on the GPU (sq_batch_from_fastq);
+        # the text is uploaded once and the metas never exist on the host unless a
+        # record is indexed.  read(n) keeps the host splitter.
+        self._split_on_device = bool(split_on_device)
 
     def __iter__(self) -> "FastqParser":
         return self
 
     def __next__(self) -> FastqRecordArrayView:
-        arr = self._create(1, sys.maxsize)
+        arr = self._create_on_device() if self._split_on_device else self._create(1, sys.maxsize)
         if len(arr) == 0:
             raise StopIteration
         return arr
@@ -332,6 +347,40 @@ class FastqParser:
         if number_of_records < 1:
             raise ValueError(f"number_of_records should be greater than 1, got {number_of_records}")
         return self._create(number_of_records, number_of_records)
+
+    def _create_on_device(self) -> FastqRecordArrayView:
+        """The loop of FastqParser_create_record_array (_qcmodule.c:964-1184) with the
+        ASCII check and the record split done by sq_batch_from_fastq."""
+        buf = bytearray(self._leftover)
+        first, eof = True, False
+        while True:
+            want = max(self._read_in_size - len(buf), 0) if first else self._read_in_size
+            first = False
+            if want > 0:
+                chunk = self._file.read(want)
+                if chunk:
+                    buf += chunk
+                else:
+                    eof = True
+            if len(buf) == 0:
+                self._leftover = b""
+                return FastqRecordArrayView._from_buffer(b"", np.zeros(0, dtype=META_DTYPE))
+            if eof and buf.count(b"\n") < 4:  # :1073-1081
+                raise EOFError("Incomplete record at the end of file " + bytes(buf).decode("latin-1"))
+            obj = bytes(buf)
+            consumed = C.c_size_t(0)
+            h = lib().sq_batch_from_fastq(context(), _addr(obj), len(obj), C.byref(consumed))
+            if not h:
+                raise ValueError(_lib.last_error())
+            batch = _DeviceBatch(h)
+            if batch.number_of_records >= 1:
+                break
+            if eof:
+                raise EOFError("Incomplete record at the end of file " + obj.decode("latin-1"))
+        self._leftover = obj[consumed.value:]
+        arr = FastqRecordArrayView._from_device(batch)
+        arr.obj = obj
+        return arr
 
     def _create(self, min_records: int, max_records: int) -> FastqRecordArrayView:
         """FastqParser_create_record_array, _qcmodule.c:964-1184: a new buffer of
@@ -358,7 +407,7 @@ class FastqParser:
             if len(buf) == 0:
                 break  # :1069 entire file is read
             if eof and buf.count(b"\n") < 4:  # :1073-1081
-                raise EOFError(f"Incomplete record at the end of file {bytes(buf)!r}")
+                raise EOFError("Incomplete record at the end of file " + bytes(buf).decode("latin-1"))
             cap = len(buf) // 64 + 16
             while True:
                 tmp = np.zeros(cap, dtype=META_DTYPE)
@@ -377,7 +426,7 @@ class FastqParser:
                 break
             if eof:
                 if n == 0:
-                    raise EOFError(f"Incomplete record at the end of file {bytes(buf)!r}")
+                    raise EOFError("Incomplete record at the end of file " + bytes(buf).decode("latin-1"))
                 break
         obj = bytes(buf)
         self._leftover = obj[consumed:]

@@ -1,4 +1,6 @@
 /* sq_api.hip -- context, batches, host-side record boundary, synthetic FASTQ */
+#include <hipcub/hipcub.hpp>
+
 #include "sq_common.h"
 #include "sq_synth_core.h"
 
@@ -258,14 +260,310 @@ SQ_EXPORT sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t 
     return b;
 }
 
+/* ---- FASTQ record split on the device ----------------------------------------------
+ * pass 1: newlines per 16 KiB block (+ first non-ASCII byte), exclusive scan of the
+ * block counts; pass 2: every thread rescans its 64 bytes and writes the positions of
+ * its newlines at (block prefix + in-block prefix); pass 3: one thread per record turns
+ * four consecutive newline positions into a FastqMeta and checks '@', '+' and the
+ * equal-length rule. */
+namespace {
+
+constexpr uint32_t SPLIT_THREADS = 256, SPLIT_BYTES_PER_THREAD = 64;
+constexpr uint64_t SPLIT_BLOCK_BYTES = (uint64_t)SPLIT_THREADS * SPLIT_BYTES_PER_THREAD;
+
+/* bit 8k+7 set for every byte k of w that equals `c` (exact for any byte value) */
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t c4)
+{
+    const uint32_t x = w ^ c4;
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+__device__ __forceinline__ void load_segment(const uint8_t *text, uint64_t len, uint64_t off, uint32_t w[16])
+{
+    if (off + 64 <= len) {
+        const uint4 *p = (const uint4 *)(text + off);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint4 v;
+            __builtin_memcpy(&v, p + i, 16);
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) {
+                const uint64_t at = off + 4 * i + k;
+                if (at < len) v |= (uint32_t)text[at] << (8 * k);
+            }
+            w[i] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SPLIT_THREADS)
+k_split_count(const uint8_t *text, uint64_t len, unsigned long long *block_counts,
+              unsigned long long *first_non_ascii)
+{
+    typedef hipcub::BlockReduce<uint32_t, SPLIT_THREADS> Reduce;
+    __shared__ typename Reduce::TempStorage tmp;
+    const uint64_t off = (uint64_t)blockIdx.x * SPLIT_BLOCK_BYTES + (uint64_t)threadIdx.x * SPLIT_BYTES_PER_THREAD;
+    uint32_t count = 0;
+    if (off < len) {
+        uint32_t w[16];
+        load_segment(text, len, off, w);
+        uint32_t high = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            count += __popc(eq_bytes(w[i], 0x0A0A0A0Au));
+            high |= w[i];
+        }
+        if (high & 0x80808080u) { /* string_is_ascii :203-237 */
+            for (int i = 0; i < 16; i++)
+                for (int k = 0; k < 4; k++)
+                    if ((w[i] >> (8 * k)) & 0x80) {
+                        atomicMin(first_non_ascii, (unsigned long long)(off + 4 * i + k));
+                        i = 16;
+                        break;
+                    }
+        }
+    }
+    const uint32_t total = Reduce(tmp).Sum(count);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SPLIT_THREADS)
+k_split_positions(const uint8_t *text, uint64_t len, const unsigned long long *block_prefix,
+                  unsigned long long *positions)
+{
+    typedef hipcub::BlockScan<uint32_t, SPLIT_THREADS> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const uint64_t off = (uint64_t)blockIdx.x * SPLIT_BLOCK_BYTES + (uint64_t)threadIdx.x * SPLIT_BYTES_PER_THREAD;
+    uint32_t w[16], count = 0;
+    if (off < len) {
+        load_segment(text, len, off, w);
+#pragma unroll
+        for (int i = 0; i < 16; i++) count += __popc(eq_bytes(w[i], 0x0A0A0A0Au));
+    }
+    uint32_t before = 0;
+    Scan(tmp).ExclusiveSum(count, before);
+    if (count) {
+        unsigned long long *out = positions + block_prefix[blockIdx.x] + before;
+        for (int i = 0; i < 16; i++) {
+            uint32_t m = eq_bytes(w[i], 0x0A0A0A0Au);
+            while (m) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1;
+                *out++ = off + 4 * i + (bit >> 3);
+            }
+        }
+    }
+}
+
+enum { SPLIT_OK = 0, SPLIT_NO_AT = 1, SPLIT_NO_PLUS = 2, SPLIT_LENGTHS = 3, SPLIT_TOO_LONG = 4 };
+
+__global__ void k_split_metas(const uint8_t *text, const unsigned long long *nl, uint64_t n_records,
+                              sq_meta *metas, unsigned long long *first_bad)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_records;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t start = r ? nl[4 * r - 1] + 1 : 0;
+        const uint64_t e1 = nl[4 * r], e2 = nl[4 * r + 1], e3 = nl[4 * r + 2], e4 = nl[4 * r + 3];
+        const uint64_t name = start + 1, seq = e1 + 1, plus = e2 + 1, qual = e3 + 1;
+        unsigned long long bad = 0;
+        if (text[start] != '@') bad = SPLIT_NO_AT;                 /* :1097-1103 */
+        else if (e1 < name) bad = SPLIT_NO_AT;
+        else if (text[plus] != '+') bad = SPLIT_NO_PLUS;            /* :1119-1127 */
+        else if (e2 - seq != e4 - qual) bad = SPLIT_LENGTHS;        /* :1140-1150 */
+        else if (e4 - name > 0xFFFFFFFFull) bad = SPLIT_TOO_LONG;
+        if (bad) atomicMin(first_bad, (unsigned long long)((r << 3) | bad));
+        sq_meta m;
+        m.record_start = name;
+        m.name_length = (uint32_t)(e1 - name);
+        m.sequence_offset = (uint32_t)(seq - name);
+        m.sequence_length = (uint32_t)(e2 - seq);
+        m.qualities_offset = (uint32_t)(qual - name);
+        m.tags_offset = (uint32_t)(e4 - name);
+        m.tags_length = 0;
+        m.accumulated_error_rate = 0.0;
+        metas[r] = m;
+    }
+}
+
+sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const uint8_t *h_text, size_t len,
+                          size_t *consumed)
+{
+    auto fail = [&](sq_batch *b) -> sq_batch * {
+        if (owns_text && d_text && !b) (void)hipFree(d_text);
+        if (b) sq_batch_free(b);
+        return nullptr;
+    };
+    if (consumed) *consumed = 0;
+    const uint64_t n_blocks = (len + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
+    unsigned long long *d_counts = nullptr, *d_prefix = nullptr, *d_flags = nullptr, *d_nl = nullptr;
+    sq_batch *b = new sq_batch();
+    b->ctx = ctx;
+    b->d_buf = d_text;
+    b->buf_len = len;
+    b->owns = owns_text;
+    if (len == 0 || n_blocks == 0) {
+        if (hipMalloc((void **)&b->d_metas, sizeof(sq_meta)) != hipSuccess) return fail(b);
+        b->owns_metas = true;
+        return b;
+    }
+    if (hipMalloc((void **)&d_counts, (n_blocks + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&d_prefix, (n_blocks + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&d_flags, 16) != hipSuccess) {
+        sq_set_error("sq_batch_from_fastq: out of device memory");
+        return fail(b);
+    }
+    (void)hipMemsetAsync(d_flags, 0xFF, 16, ctx->stream);
+    (void)hipMemsetAsync(d_counts + n_blocks, 0, 8, ctx->stream);
+    hipLaunchKernelGGL(k_split_count, dim3((unsigned)n_blocks), dim3(SPLIT_THREADS), 0, ctx->stream, d_text,
+                       (uint64_t)len, d_counts, d_flags);
+    size_t temp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_counts, d_prefix, (int)(n_blocks + 1), ctx->stream);
+    void *d_temp = nullptr;
+    (void)hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8);
+    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_prefix, (int)(n_blocks + 1), ctx->stream);
+    unsigned long long h[3] = {0, 0, 0};
+    (void)hipMemcpyAsync(&ctx->pinned[40], d_prefix + n_blocks, 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(&ctx->pinned[41], d_flags, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sq_set_error("FASTQ split failed on the device"); return fail(b); }
+    h[0] = ctx->pinned[40];
+    h[1] = ctx->pinned[41];
+    (void)hipFree(d_temp);
+    if (h[1] != ~0ULL) { /* :1055-1067 */
+        uint8_t c = 0;
+        if (h_text) c = h_text[h[1]];
+        else (void)hipMemcpy(&c, d_text + h[1], 1, hipMemcpyDeviceToHost);
+        sq_set_error("Found non-ASCII character in file: %c", (char)c);
+        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags);
+        return fail(b);
+    }
+    const uint64_t n_newlines = h[0], n_records = n_newlines / 4;
+    b->n = n_records;
+    b->owns_metas = true;
+    if (hipMalloc((void **)&b->d_metas, (n_records ? n_records : 1) * sizeof(sq_meta)) != hipSuccess ||
+        hipMalloc((void **)&d_nl, (n_newlines ? n_newlines : 1) * 8) != hipSuccess) {
+        sq_set_error("sq_batch_from_fastq: out of device memory");
+        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags);
+        return fail(b);
+    }
+    auto byte_at = [&](uint64_t at) -> uint8_t {
+        uint8_t c = 0;
+        if (h_text) return h_text[at];
+        (void)hipMemcpy(&c, d_text + at, 1, hipMemcpyDeviceToHost);
+        return c;
+    };
+    auto release = [&]() {
+        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags); (void)hipFree(d_nl);
+    };
+    if (n_newlines)
+        hipLaunchKernelGGL(k_split_positions, dim3((unsigned)n_blocks), dim3(SPLIT_THREADS), 0, ctx->stream,
+                           d_text, (uint64_t)len, d_prefix, d_nl);
+    uint64_t tail_start = 0;
+    if (n_records) {
+        const int blocks = (int)((n_records + 255) / 256 > 65535 ? 65535 : (n_records + 255) / 256);
+        hipLaunchKernelGGL(k_split_metas, dim3(blocks), dim3(256), 0, ctx->stream, d_text, d_nl, n_records,
+                           b->d_metas, d_flags + 1);
+        unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 5, 64);
+        if (!d_out) { sq_set_error("sq_batch_from_fastq: out of device memory"); release(); return fail(b); }
+        (void)hipMemsetAsync(d_out, 0, 64, ctx->stream);
+        const int sb = (int)((n_records + 255) / 256 > 4096 ? 4096 : (n_records + 255) / 256);
+        hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, (size_t)n_records, d_out);
+        (void)hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(&ctx->pinned[42], d_flags + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(&ctx->pinned[43], d_nl + 4 * n_records - 1, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sq_set_error("FASTQ split failed on the device");
+            release();
+            return fail(b);
+        }
+        b->total_bases = ctx->pinned[0];
+        b->max_length = ctx->pinned[1];
+        b->max_name_length = ctx->pinned[2];
+        b->max_record_span = ctx->pinned[3];
+        b->min_length = ~ctx->pinned[4];
+        tail_start = ctx->pinned[43] + 1;
+        const unsigned long long bad = ctx->pinned[42];
+        if (bad != ~0ULL) {
+            const uint64_t r = bad >> 3;
+            sq_meta m;
+            (void)hipMemcpy(&m, b->d_metas + r, sizeof(sq_meta), hipMemcpyDeviceToHost);
+            switch (bad & 7) {
+                case SPLIT_NO_AT:
+                    sq_set_error("Record does not start with @ but with %c", (char)byte_at(m.record_start - 1));
+                    break;
+                case SPLIT_NO_PLUS:
+                    sq_set_error("Record second header does not start with + but with %c",
+                                 (char)byte_at(m.record_start + m.sequence_offset + m.sequence_length + 1));
+                    break;
+                case SPLIT_LENGTHS: {
+                    std::string name(m.name_length, ' ');
+                    if (m.name_length)
+                        (void)hipMemcpy(&name[0], d_text + m.record_start, m.name_length, hipMemcpyDeviceToHost);
+                    sq_set_error("Record sequence and qualities do not have equal length, '%s'", name.c_str());
+                    break;
+                }
+                default:
+                    sq_set_error("Total length of FASTQ record exceeds 4 GiB");
+            }
+            release();
+            return fail(b);
+        }
+    }
+    /* the incomplete record after the last complete one: the reference looks at its
+       '@' (:1097) and, when two of its lines are complete, at its '+' (:1119) before it
+       finds out that the record is incomplete */
+    if (tail_start + 2 < len) {
+        const uint8_t c = byte_at(tail_start);
+        if (c != '@') {
+            sq_set_error("Record does not start with @ but with %c", (char)c);
+            release();
+            return fail(b);
+        }
+        if (n_newlines % 4 >= 2) {
+            unsigned long long second = 0;
+            (void)hipMemcpyAsync(&second, d_nl + 4 * n_records + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (second + 1 < len && byte_at(second + 1) != '+') {
+                sq_set_error("Record second header does not start with + but with %c", (char)byte_at(second + 1));
+                release();
+                return fail(b);
+            }
+        }
+    }
+    if (consumed) *consumed = (size_t)tail_start;
+    (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags); (void)hipFree(d_nl);
+    return b;
+}
+
+} // namespace
+
+SQ_EXPORT sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed)
+{
+    uint8_t *d_text = nullptr;
+    if (hipMalloc((void **)&d_text, len + 64) != hipSuccess) {
+        sq_set_error("sq_batch_from_fastq: out of device memory");
+        return nullptr;
+    }
+    if (len) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->stream));
+    return split_on_device(ctx, d_text, true, text, len, consumed);
+}
+
+SQ_EXPORT sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len, size_t *consumed)
+{
+    return split_on_device(ctx, (uint8_t *)d_text, false, nullptr, len, consumed);
+}
+
 SQ_EXPORT void sq_batch_free(sq_batch *b)
 {
     if (!b) return;
-    if (b->owns) {
-        (void)hipStreamSynchronize(b->ctx->stream);
-        if (b->d_buf) (void)hipFree(b->d_buf);
-        if (b->d_metas) (void)hipFree(b->d_metas);
-    }
+    if (b->owns || b->owns_metas) (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->owns && b->d_buf) (void)hipFree(b->d_buf);
+    if ((b->owns || b->owns_metas) && b->d_metas) (void)hipFree(b->d_metas);
     delete b;
 }
 
@@ -274,15 +572,17 @@ SQ_EXPORT uint64_t sq_batch_total_bases(const sq_batch *b) { return b->total_bas
 SQ_EXPORT uint64_t sq_batch_max_length(const sq_batch *b) { return b->max_length; }
 
 SQ_EXPORT uint64_t sq_batch_bytes(const sq_batch *b) { return b->buf_len; }
+SQ_EXPORT void *sq_batch_device_text(const sq_batch *b) { return b->d_buf; }
+SQ_EXPORT void *sq_batch_device_metas(const sq_batch *b) { return b->d_metas; }
 
 SQ_EXPORT int sq_batch_download(sq_batch *b, uint8_t *buf, size_t buf_cap, sq_meta *metas, size_t meta_cap)
 {
-    if (buf_cap < b->buf_len || meta_cap < b->n) {
+    if ((buf && buf_cap < b->buf_len) || meta_cap < b->n) {
         sq_set_error("sq_batch_download: destination too small");
         return SQ_ERR_VALUE;
     }
     SQ_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (b->buf_len) SQ_HIP(hipMemcpy(buf, b->d_buf, b->buf_len, hipMemcpyDeviceToHost));
+    if (buf && b->buf_len) SQ_HIP(hipMemcpy(buf, b->d_buf, b->buf_len, hipMemcpyDeviceToHost));
     if (b->n) SQ_HIP(hipMemcpy(metas, b->d_metas, b->n * sizeof(sq_meta), hipMemcpyDeviceToHost));
     return SQ_OK;
 }

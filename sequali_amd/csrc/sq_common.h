@@ -75,7 +75,8 @@ struct sq_batch {
     sq_meta *d_metas = nullptr;
     size_t buf_len = 0;
     size_t n = 0;
-    bool owns = false;
+    bool owns = false;       /* frees d_buf (and d_metas) */
+    bool owns_metas = false; /* frees d_metas although d_buf is borrowed */
     uint64_t total_bases = 0;
     uint64_t max_length = 0;
     uint64_t min_length = 0;

@@ -420,8 +420,88 @@ def synthetic():
     single_end_case("synth_nanopore_300", text, NANOPORE_PROBES)
 
 
+def metas_of(arr) -> np.ndarray:
+    """The FastqMeta structs of a reference array object as (n, 7) integers with
+    record_start made relative to the array's bytes object."""
+    n = len(arr)
+    raw = bytes((ctypes.c_char * (n * 40)).from_address(id(arr) + 32))
+    dt = np.dtype([("record_start", "<u8"), ("name_length", "<u4"), ("sequence_offset", "<u4"),
+                   ("sequence_length", "<u4"), ("qualities_offset", "<u4"), ("tags_offset", "<u4"),
+                   ("tags_length", "<u4"), ("err", "<f8")])
+    m = np.frombuffer(raw, dtype=dt)
+    base = ctypes.cast(ctypes.c_char_p(arr.obj), ctypes.c_void_p).value
+    out = np.zeros((n, 7), dtype=np.int64)
+    out[:, 0] = m["record_start"].astype(np.int64) - base
+    for k, f in enumerate(dt.names[1:7], 1):
+        out[:, k] = m[f]
+    return out
+
+
+def parser():
+    """(4) what the reference's FastqParser does with a text at a buffer size: the
+    arrays it yields (bytes object, FastqMeta structs) or the exception it raises.
+    -> parser_cases.npz / parser_errors.json, the oracle of the GPU record split."""
+    good = {
+        "simple": read_file("simple.fastq"),
+        "illumina100": read_file("100_illumina_adapters.fastq"),
+        "nanopore100": read_file("100_nanopore_reads.fastq.gz"),
+        "crlf": b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nAC\r\n+\r\nII\r\n",
+        "empty_lines": b"@\n\n+\n\n@x\n\n+\n\n@y y\nA\n+y\n!\n",
+        "at_in_quals": b"@r1\nACGT\n+\n@@@@\n@r2\nAC\n+r2\n+@\n@r3\n@\n+\n+\n",
+        "empty": b"",
+    }
+    out = {}
+    names = []
+    for name, text in good.items():
+        for bs in (1, 7, 64, 300, 4096, 128 * 1024):
+            if bs < 64 and len(text) > 50_000:
+                continue
+            arrays = arrays_of(text, bs)
+            key = f"{name}_{bs}"
+            names.append(key)
+            out[name + "_text"] = np.frombuffer(text, np.uint8)
+            out[key + "_buffersize"] = np.int64(bs)
+            out[key + "_sizes"] = np.array([len(a) for a in arrays], np.int64)
+            out[key + "_objlens"] = np.array([len(a.obj) for a in arrays], np.int64)
+            out[key + "_metas"] = (np.concatenate([metas_of(a) for a in arrays])
+                                   if arrays else np.zeros((0, 7), np.int64))
+    out["names"] = np.array(names)
+    save("parser_cases", **out)
+
+    rec = b"@SOMEHEADER METADATA MOREMETADATA\nAGA\n+\nGGG\n"
+    body = b"".join(b"@r%d\nACGTACGT\n+\nIIIIIIII\n" % i for i in range(40))
+    bad = [b"not a record", b"@correctname\nSEQ\n-\n", b"@correctname\nAGA\n+\nGG\n",
+           "@n\u00c4m\u00e9 \nAGC\n+\nHHH\n".encode("latin-1"),
+           body + b"r40\nAC\n+\nII\n" + body,
+           body + b"@r40\nAC\n-\nII\n" + body,
+           body + b"@r40\nACG\n+\nII\n" + body,
+           body + b"@r40\nACG\n+\nII\n" + b"x41\nAC\n-\nI\n" + body,       # first error wins
+           body + b"@r40\nAC\n-\nIII\n" + body,                                # '+' before lengths
+           body + b"\n" + body,                                                 # blank line
+           body + b"@tail\nAC\nX",                                              # bad '+' in the tail
+           body + b"tail",                                                      # bad '@' in the tail
+           body + b"ta",                                                        # too short to look at
+           body + b"@tail\nAC\n",                                               # tail ends before '+'
+           body + "@r\nAC\n+\nI\u00ff\n".encode("latin-1") + body,
+           body + b"x\nAC\n+\nII\n" + "\u00e9".encode("latin-1")]           # ASCII check first
+    bad += [rec[:end] for end in range(1, len(rec))]
+    errors = []
+    for text in bad:
+        for bs in (8, 100, 128 * 1024):
+            try:
+                arrays = arrays_of(text, bs)
+                res = {"sizes": [len(a) for a in arrays]}
+            except Exception as e:  # noqa: BLE001
+                res = {"error": type(e).__name__, "message": str(e)}
+            errors.append({"text": text.decode("latin-1"), "buffersize": bs, **res})
+    with open(os.path.join(HERE, "parser_errors.json"), "wt") as f:
+        json.dump(errors, f, indent=0)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "synthetic":
         synthetic()
+    elif len(sys.argv) > 1 and sys.argv[1] == "parser":
+        parser()
     else:
         main()
