@@ -235,6 +235,57 @@ int64_t sq_insertsize_insert_sizes(sq_insertsize *z, uint64_t *out, size_t cap);
 int64_t sq_insertsize_adapters(sq_insertsize *z, int read2, uint8_t *bytes, uint8_t *lengths,
                                uint64_t *counts, size_t cap);
 
+/* ---- multi-GPU: the order-dependent modules across shards ------ */
+/* One rank owns a contiguous range of the job's records.  What the reference makes
+ * depend on the order of the reads is decided exactly as in one sequential run:
+ *
+ * OverrepresentedSequences (first-come cap, :3553): in shard mode the table is uncapped
+ * and every key keeps the rank (sampled read of the job, staging slot) of its first
+ * occurrence; sampling follows the job-wide record index (:3833).  Merge = all-gather
+ * the shards' candidates -> select -> per-shard lookup -> sum -> install. */
+int sq_overrep_set_shard(sq_overrep *o, uint64_t first_record_index);
+/* first min(distinct, max_unique_fragments) keys by rank; DEVICE arrays; returns the
+ * number (only the number when d_hashes is NULL or cap is too small) */
+int64_t sq_overrep_shard_candidates(sq_overrep *o, uint64_t *d_hashes, uint64_t *d_ranks, size_t cap);
+/* first max_unique_fragments distinct hashes of the concatenated candidates by rank */
+int64_t sq_overrep_shard_select(sq_overrep *o, const uint64_t *d_hashes, const uint64_t *d_ranks,
+                                size_t n, uint64_t *d_selected, size_t cap);
+int sq_overrep_shard_lookup(sq_overrep *o, const uint64_t *d_hashes, size_t n, uint64_t *d_counts);
+/* totals = {number_of_sequences, sampled_sequences, total_fragments, warning_count,
+ * last_warning_record}; afterwards the object holds the job's state, not a shard's */
+int sq_overrep_shard_install(sq_overrep *o, const uint64_t *d_hashes, const uint64_t *d_counts, size_t n,
+                             const uint64_t *totals);
+
+/* DedupEstimator (insertion order decides the modulo bits, :4430-4459): deferred mode
+ * only hashes (the hashes stay in HBM); the insertion tail runs shard after shard:
+ * import the state of the shard in front, resolve, export. */
+int sq_dedup_set_deferred(sq_dedup *d, int on);
+uint64_t sq_dedup_pending(sq_dedup *d);
+int sq_dedup_resolve(sq_dedup *d);
+uint64_t sq_dedup_state_bytes(sq_dedup *d);
+int sq_dedup_export_state(sq_dedup *d, void *out, size_t cap);
+int sq_dedup_import_state(sq_dedup *d, const void *in, size_t len);
+
+/* InsertSizeMetrics adapter tables (first-come cap, :5583,5599): ranks count the pairs
+ * of the whole job and the shard's tables (2^table_bits slots) never close.  Keys are
+ * 32 bytes {length, bytes[31]}; HOST arrays.  The histogram is a plain sum. */
+int sq_insertsize_set_shard(sq_insertsize *z, uint64_t first_pair_index, uint32_t table_bits);
+int64_t sq_insertsize_shard_candidates(sq_insertsize *z, int read2, uint8_t *keys, uint64_t *ranks, size_t cap);
+int64_t sq_insertsize_shard_select(sq_insertsize *z, const uint8_t *keys, const uint64_t *ranks, size_t n,
+                                   uint8_t *out_keys, uint64_t *out_ranks, size_t cap);
+int sq_insertsize_shard_lookup(sq_insertsize *z, int read2, const uint8_t *keys, size_t n, uint64_t *counts);
+int sq_insertsize_shard_install(sq_insertsize *z, int read2, const uint8_t *keys, const uint64_t *ranks,
+                                const uint64_t *counts, size_t n, uint64_t n_events);
+int sq_insertsize_shard_set_totals(sq_insertsize *z, uint64_t total_reads, const uint64_t *insert_sizes,
+                                   size_t len);
+
+/* PerTileQuality: sums per tile over the union of the shards' tiles; a shard behind the
+ * job's first unparsable header contributes nothing (:3126). */
+int64_t sq_pertile_first_unparsable(sq_pertile *p);
+int sq_pertile_install(sq_pertile *p, const int64_t *tile_ids, size_t n_tiles, const double *errors,
+                       const uint64_t *length_counts, size_t len, uint64_t number_of_reads,
+                       const char *skipped_reason);
+
 /* ---- multi-GPU: raw count tables for an all-reduce over RCCL --------------- */
 /* Exposes the device arrays of the additive tables (u64 counts; f64 for the
  * per-tile error sums) so that the caller's collective can sum them in place

@@ -17,7 +17,7 @@ HEADER = os.path.join(HERE, "..", "include", "sqgpu.h")
 
 _SCALARS = {
     "int": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "size_t": C.c_size_t,
-    "double": C.c_double, "void": None,
+    "double": C.c_double, "void": None, "uint32_t": C.c_uint32,
 }
 
 

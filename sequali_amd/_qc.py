@@ -709,6 +709,13 @@ class OverrepresentedSequences:
         self.fragment_length = fragment_length
         self.sample_every = sample_every
         self._warned = 0
+        self._first_record = 0
+
+    def set_shard(self, first_record_index: int) -> None:
+        """This object sees records [first_record_index, ...) of a job that other ranks
+        share (sequali_amd.dist.merge_overrepresented joins them)."""
+        check(lib().sq_overrep_set_shard(self._h, first_record_index))
+        self._first_record = first_record_index
 
     def __del__(self):
         try:
@@ -719,7 +726,7 @@ class OverrepresentedSequences:
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        before = self.number_of_sequences
+        before = self._first_record + self.number_of_sequences
         check(lib().sq_overrep_add_batch(self._h, arr._device().handle))
         count = lib().sq_overrep_warning_count(self._h)
         if count != self._warned:  # :3931-3938, once per array here
@@ -815,6 +822,11 @@ class DedupEstimator:
         except Exception:
             pass
 
+    def set_deferred(self, on: bool = True) -> None:
+        """Shard of a multi-rank job: only hash now, insert when the shard in front is done
+        (sequali_amd.dist.merge_dedup)."""
+        check(lib().sq_dedup_set_deferred(self._h, 1 if on else 0))
+
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
         check(lib().sq_dedup_add_batch(self._h, arr._device().handle))
@@ -833,6 +845,11 @@ class DedupEstimator:
         if not sequence.isascii():
             raise ValueError("sequence should consist only of ASCII characters.")
         self.add_record_array(_array_of_sequences([sequence]))
+
+    def set_shard(self, first_pair_index: int, table_bits: int = 22) -> None:
+        """This object sees pairs [first_pair_index, ...) of a job that other ranks share
+        (sequali_amd.dist.merge_insertsize joins them)."""
+        check(lib().sq_insertsize_set_shard(self._h, first_pair_index, table_bits))
 
     def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
         for s in (sequence1, sequence2):

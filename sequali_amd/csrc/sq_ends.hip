@@ -114,7 +114,7 @@ __device__ long long canonical_kmer(const uint8_t *s, uint32_t k)
     return (long long)(rc > kmer ? kmer : rc);
 }
 
-enum { OVR_NORMAL = 0, OVR_FULL = 1, OVR_CROSSING = 2 };
+enum { OVR_NORMAL = 0, OVR_FULL = 1, OVR_CROSSING = 2, OVR_RANKED = 3 };
 constexpr unsigned long long RANK_NONE = ~0ULL;
 
 struct OvrParams {
@@ -124,6 +124,7 @@ struct OvrParams {
     uint64_t first_sample;    /* record index of the first sampled record */
     uint64_t n_samples;       /* sampled records in this launch */
     uint64_t sample_base;     /* samples of this batch in front of this launch */
+    uint64_t rank_base;       /* sample number of the launch's first sample in the rank order */
     uint64_t record_base;     /* records seen before this batch */
     uint32_t k, sample_every;
     long long frags_start, frags_end;
@@ -160,7 +161,7 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
             } else {
                 atomicAdd(&P.counts[i], 1u);
                 /* keys from earlier launches carry rank 0 and stay there */
-                if (P.mode == OVR_CROSSING) atomicMin(&P.ranks[i], rank + 1);
+                if (P.mode >= OVR_CROSSING) atomicMin(&P.ranks[i], rank + 1);
             }
             return;
         }
@@ -214,7 +215,7 @@ __global__ void k_overrep(OvrParams P)
             }
         }
         for (uint64_t i = 0; i < size; i++) /* flushed in slot order (:3925-3930) */
-            if (stage[i]) ovr_insert(P, stage[i], ((P.sample_base + s) << 24) | i);
+            if (stage[i]) ovr_insert(P, stage[i], ((P.rank_base + s) << 24) | i);
         local_frags += valid;
         if (warn) {
             atomicAdd(P.warn_count, 1ULL);
@@ -252,6 +253,99 @@ __global__ void k_ovr_kill(unsigned int *counts, const unsigned long long *slots
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x)
         counts[slots[i]] = 0;
+}
+
+/* ---- shard mode (one rank of a multi-GPU job) ------------------------------
+ * The table is uncapped and every key keeps the rank of its first occurrence over the
+ * whole job, (sampled read number << 24 | staging slot).  The reference's table holds
+ * the first max_unique distinct hashes of the job in that order with all their
+ * occurrences counted, so the merge is: candidates = every shard's first max_unique
+ * keys -> first max_unique distinct of the union -> per-shard counts of those -> sum. */
+__global__ void k_ovr_rehash(const unsigned long long *oh, const unsigned int *oc, const unsigned long long *orank,
+                             uint64_t old_size, unsigned long long *nh, unsigned int *nc,
+                             unsigned long long *nrank, uint64_t new_mask)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < old_size;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = oh[i];
+        if (!h) continue;
+        uint64_t j = h & new_mask;
+        while (atomicCAS(&nh[j], 0ULL, h) != 0ULL) j = (j + 1) & new_mask; /* keys are distinct */
+        nc[j] = oc[i];
+        if (nrank) nrank[j] = orank[i];
+    }
+}
+
+__global__ void k_ovr_collect_all(const unsigned long long *hashes, const unsigned long long *ranks,
+                                  uint64_t table_size, unsigned long long *out_rank,
+                                  unsigned long long *out_hash, unsigned long long *n_out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < table_size;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        if (hashes[i]) {
+            const unsigned long long o = atomicAdd(n_out, 1ULL);
+            out_rank[o] = ranks[i];
+            out_hash[o] = hashes[i];
+        }
+    }
+}
+
+/* position of the first occurrence of every hash of a rank-sorted list */
+__global__ void k_ovr_first_pos(const unsigned long long *hashes, uint64_t n, unsigned long long *keys,
+                                unsigned long long *pos, uint64_t mask)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = hashes[i];
+        uint64_t j = h & mask;
+        for (;;) {
+            unsigned long long cur = atomicCAS(&keys[j], 0ULL, h);
+            if (cur == 0 || cur == h) { atomicMin(&pos[j], (unsigned long long)i); break; }
+            j = (j + 1) & mask;
+        }
+    }
+}
+
+__global__ void k_ovr_flag_first(const unsigned long long *hashes, uint64_t n, const unsigned long long *keys,
+                                 const unsigned long long *pos, uint64_t mask, unsigned char *flags)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = hashes[i];
+        uint64_t j = h & mask;
+        while (keys[j] != h) j = (j + 1) & mask;
+        flags[i] = pos[j] == i;
+    }
+}
+
+__global__ void k_ovr_lookup(const unsigned long long *table, const unsigned int *counts, uint64_t mask,
+                             const unsigned long long *hashes, uint64_t n, unsigned long long *out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = hashes[i];
+        uint64_t j = h & mask;
+        unsigned long long c = 0;
+        for (;;) {
+            const unsigned long long cur = table[j];
+            if (cur == h) { c = counts[j]; break; }
+            if (cur == 0) break;
+            j = (j + 1) & mask;
+        }
+        out[i] = c;
+    }
+}
+
+__global__ void k_ovr_install(unsigned long long *table, unsigned int *counts, uint64_t mask,
+                              const unsigned long long *hashes, const unsigned long long *in_counts, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = hashes[i];
+        uint64_t j = h & mask;
+        while (atomicCAS(&table[j], 0ULL, h) != 0ULL) j = (j + 1) & mask;
+        counts[j] = (unsigned int)in_counts[i]; /* the reference's counts are u32 as well (:3452) */
+    }
 }
 
 /* ================================ DedupEstimator ================================ */
@@ -316,8 +410,13 @@ struct DedupKeep {
     const unsigned char *special;
     __device__ bool operator()(const unsigned long long &idx) const
     {
-        return special[idx] || (hashes[idx] & ignore_mask) == 0;
+        return (special && special[idx]) || (hashes[idx] & ignore_mask) == 0;
     }
+};
+
+struct DedupSpecialOnly {
+    const unsigned char *special;
+    __device__ bool operator()(const unsigned long long &idx) const { return special[idx] != 0; }
 };
 
 /* ================================ InsertSizeMetrics ============================== */
@@ -336,7 +435,6 @@ __device__ __forceinline__ uint8_t complement_or_zero(uint8_t c)
  * the reference's first-come, linear-probing table depends on: at read-out the
  * keys are replayed in rank order into a table of the reference's geometry. */
 constexpr uint32_t ISZ_TABLE_BITS = 18;
-constexpr uint64_t ISZ_TABLE_SIZE = 1ull << ISZ_TABLE_BITS;
 
 struct IszTable {
     unsigned long long *hash;   /* 0 = free */
@@ -346,6 +444,7 @@ struct IszTable {
     unsigned long long *key;    /* [size][4] */
     unsigned long long *n_distinct, *n_events;
     int *overflow;
+    uint64_t mask;              /* slots - 1 */
 };
 
 struct IszParams {
@@ -369,7 +468,7 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
     unsigned long long h = murmur3_x64_64([&](uint64_t i) { return a[i]; }, len, 0);
     if (h == 0) h = 1; /* 0 marks a free slot */
     atomicAdd(T.n_events, 1ULL);
-    uint64_t idx = h & (ISZ_TABLE_SIZE - 1);
+    uint64_t idx = h & T.mask;
     bool mine = false;
     for (uint64_t spins = 0; spins < (1ull << 22); spins++) {
         unsigned long long cur = __hip_atomic_load(&T.hash[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -380,7 +479,7 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
                 for (int k = 0; k < 4; k++) T.key[idx * 4 + k] = key[k];
                 __threadfence();
                 __hip_atomic_store(&T.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicAdd(T.n_distinct, 1ULL) > (ISZ_TABLE_SIZE / 4) * 3) *T.overflow = 1;
+                if (atomicAdd(T.n_distinct, 1ULL) > ((T.mask + 1) / 4) * 3) *T.overflow = 1;
                 cur = h;
                 mine = true;
             }
@@ -397,7 +496,7 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
                 return;
             }
         }
-        idx = (idx + 1) & (ISZ_TABLE_SIZE - 1);
+        idx = (idx + 1) & T.mask;
     }
     *T.overflow = 1;
 }
@@ -469,6 +568,52 @@ __global__ void k_insert_size(IszParams P)
         if (l_sizes[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_sizes[i]);
 }
 
+/* used slots of an adapter table, unordered */
+__global__ void k_isz_collect(IszTable T, unsigned long long *out_slot, unsigned long long *n_out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= T.mask;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        if (T.hash[i] && T.count[i]) out_slot[atomicAdd(n_out, 1ULL)] = i;
+}
+
+__global__ void k_isz_gather(IszTable T, const unsigned long long *slots, uint64_t n, unsigned long long *key,
+                             unsigned long long *count, unsigned long long *rank)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = slots[e];
+        for (int k = 0; k < 4; k++) key[e * 4 + k] = T.key[i * 4 + k];
+        count[e] = T.count[i];
+        rank[e] = T.rank[i];
+    }
+}
+
+/* counts of given 32-byte keys {length, bytes[31]} in a table (0: absent) */
+__global__ void k_isz_lookup(IszTable T, const unsigned long long *keys, uint64_t n, unsigned long long *out)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long *key = keys + e * 4;
+        const uint8_t *rec = (const uint8_t *)key;
+        const uint32_t len = rec[0];
+        unsigned long long h = murmur3_x64_64([&](uint64_t i) { return rec[1 + i]; }, len, 0);
+        if (h == 0) h = 1;
+        uint64_t idx = h & T.mask;
+        unsigned long long c = 0;
+        for (;;) {
+            const unsigned long long cur = T.hash[idx];
+            if (cur == 0) break;
+            if (cur == h) {
+                bool same = true;
+                for (int k = 0; k < 4; k++) same &= T.key[idx * 4 + k] == key[k];
+                if (same) { c = T.count[idx]; break; }
+            }
+            idx = (idx + 1) & T.mask;
+        }
+        out[e] = c;
+    }
+}
+
 /* survivors only travel to the host: hash and the "needs the host" flag of every kept index */
 __global__ void k_dedup_gather(const unsigned long long *idx, uint64_t n_keep,
                                const unsigned long long *hashes, const unsigned char *special,
@@ -537,6 +682,9 @@ struct sq_overrep {
     unsigned int *d_counts = nullptr;
     unsigned long long *d_scalars = nullptr; /* [0] n_unique [1] total_fragments [2] warn_count [3] warn_last */
     uint64_t n_unique_host = 0;              /* value after the last synchronised batch */
+    /* shard mode: uncapped, ranked table over records [first_record, ...) of the job */
+    bool shard = false;
+    uint64_t first_record = 0;
 };
 
 SQ_EXPORT sq_overrep *sq_overrep_new(sq_ctx *ctx, int64_t max_unique_fragments, int64_t fragment_length,
@@ -591,15 +739,42 @@ SQ_EXPORT void sq_overrep_free(sq_overrep *o)
     delete o;
 }
 
+/* shard mode: room for `keys` distinct hashes at <= 70 % load (the table doubles) */
+static int ovr_reserve(sq_overrep *o, uint64_t keys)
+{
+    sq_ctx *ctx = o->ctx;
+    uint64_t size = o->table_size;
+    while (keys > size / 10 * 7) size <<= 1;
+    if (size == o->table_size) return SQ_OK;
+    if (size > (1ULL << 32)) { sq_set_error("OverrepresentedSequences: shard table beyond 2^32 slots"); return SQ_ERR_MEMORY; }
+    unsigned long long *nh = nullptr, *nr = nullptr;
+    unsigned int *nc = nullptr;
+    SQ_HIP(hipMalloc((void **)&nh, size * 8));
+    SQ_HIP(hipMalloc((void **)&nc, size * 4));
+    SQ_HIP(hipMalloc((void **)&nr, size * 8));
+    SQ_HIP(hipMemsetAsync(nh, 0, size * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(nc, 0, size * 4, ctx->stream));
+    SQ_HIP(hipMemsetAsync(nr, 0xFF, size * 8, ctx->stream));
+    hipLaunchKernelGGL(k_ovr_rehash, dim3(blocks_for(o->table_size)), dim3(256), 0, ctx->stream, o->d_hashes,
+                       o->d_counts, o->d_ranks, o->table_size, nh, nc, nr, size - 1);
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(o->d_hashes); (void)hipFree(o->d_counts); (void)hipFree(o->d_ranks);
+    o->d_hashes = nh; o->d_counts = nc; o->d_ranks = nr;
+    o->table_size = size;
+    return SQ_OK;
+}
+
 SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
 {
     sq_ctx *ctx = o->ctx;
     const uint64_t n = b->n;
     /* records with (number_of_sequences + r) % sample_every == 0 are sampled (:3833) */
-    const uint64_t phase = o->number_of_sequences % o->sample_every;
+    const uint64_t record_base = o->first_record + o->number_of_sequences;
+    const uint64_t phase = record_base % o->sample_every;
     const uint64_t first = phase == 0 ? 0 : o->sample_every - phase;
     const uint64_t n_samples = first < n ? (n - first + o->sample_every - 1) / o->sample_every : 0;
-    const uint64_t record_base = o->number_of_sequences;
+    /* sampled records of the job in front of this batch */
+    const uint64_t samples_before = (record_base + o->sample_every - 1) / o->sample_every;
     o->number_of_sequences += n;
     o->sampled_sequences += n_samples;
     if (n_samples == 0) return SQ_OK;
@@ -629,7 +804,12 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
     while (done < n_samples) {
         uint64_t chunk = n_samples - done;
         int mode;
-        if (o->full) {
+        if (o->shard) {
+            mode = OVR_RANKED;
+            int rc = ovr_reserve(o, o->n_unique_host + chunk * per_read);
+            if (rc) return rc;
+            P.hashes = o->d_hashes; P.counts = o->d_counts; P.table_mask = o->table_size - 1;
+        } else if (o->full) {
             mode = OVR_FULL;
         } else {
             /* keys this launch can add at most; keep the open-addressing table under ~80 % */
@@ -653,6 +833,7 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         P.mode = mode;
         P.ranks = o->d_ranks;
         P.sample_base = done;
+        P.rank_base = o->shard ? samples_before + done : done;
         P.n_samples = chunk;
         hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk)), dim3(256), 0, ctx->stream, P);
         SQ_HIP(hipGetLastError());
@@ -697,8 +878,148 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         } else {
             o->n_unique_host = n_after;
         }
-        if (o->n_unique_host >= o->max_unique) o->full = true;
+        if (!o->shard && o->n_unique_host >= o->max_unique) o->full = true;
     }
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_overrep_set_shard(sq_overrep *o, uint64_t first_record_index)
+{
+    if (o->number_of_sequences) {
+        sq_set_error("sq_overrep_set_shard: call it before the first record array");
+        return SQ_ERR_VALUE;
+    }
+    o->shard = true;
+    o->first_record = first_record_index;
+    if (!o->d_ranks) SQ_HIP(hipMalloc((void **)&o->d_ranks, o->table_size * 8));
+    SQ_HIP(hipMemsetAsync(o->d_ranks, 0xFF, o->table_size * 8, o->ctx->stream));
+    return SQ_OK;
+}
+
+/* first min(unique keys, max_unique) keys of this shard in rank order, device arrays */
+SQ_EXPORT int64_t sq_overrep_shard_candidates(sq_overrep *o, uint64_t *d_hashes, uint64_t *d_ranks, size_t cap)
+{
+    sq_ctx *ctx = o->ctx;
+    if (!o->shard) { sq_set_error("sq_overrep_shard_candidates: not in shard mode"); return SQ_ERR_VALUE; }
+    const uint64_t n = o->n_unique_host, m = std::min<uint64_t>(n, o->max_unique);
+    if (!d_hashes || cap < m || m == 0) return (int64_t)m;
+    unsigned long long *d_buf = nullptr, *d_n = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_buf, 4 * n * 8));
+    SQ_HIP(hipMalloc((void **)&d_n, 8));
+    SQ_HIP(hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    unsigned long long *rank_in = d_buf, *hash_in = d_buf + n, *rank_out = d_buf + 2 * n, *hash_out = d_buf + 3 * n;
+    hipLaunchKernelGGL(k_ovr_collect_all, dim3(blocks_for(o->table_size)), dim3(256), 0, ctx->stream,
+                       o->d_hashes, o->d_ranks, o->table_size, rank_in, hash_in, d_n);
+    size_t temp_bytes = 0;
+    void *d_temp = nullptr;
+    SQ_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, rank_in, rank_out, hash_in, hash_out, (int)n, 0,
+                                              64, ctx->stream));
+    SQ_HIP(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8));
+    SQ_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, rank_in, rank_out, hash_in, hash_out, (int)n, 0,
+                                              64, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(d_hashes, hash_out, m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(d_ranks, rank_out, m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_temp); (void)hipFree(d_buf); (void)hipFree(d_n);
+    return (int64_t)m;
+}
+
+/* the job's table keys: the first max_unique distinct hashes of the shards' candidates
+ * (concatenated in any order) by rank; device arrays in, device array out */
+SQ_EXPORT int64_t sq_overrep_shard_select(sq_overrep *o, const uint64_t *d_hashes, const uint64_t *d_ranks,
+                                          size_t n, uint64_t *d_selected, size_t cap)
+{
+    sq_ctx *ctx = o->ctx;
+    if (n == 0) return 0;
+    uint64_t tsize = 1;
+    while (tsize < 2 * n) tsize <<= 1;
+    unsigned long long *d_buf = nullptr, *d_keys = nullptr, *d_pos = nullptr, *d_num = nullptr;
+    unsigned char *d_flags = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_buf, 3 * n * 8));
+    SQ_HIP(hipMalloc((void **)&d_keys, tsize * 8));
+    SQ_HIP(hipMalloc((void **)&d_pos, tsize * 8));
+    SQ_HIP(hipMalloc((void **)&d_flags, n));
+    SQ_HIP(hipMalloc((void **)&d_num, 8));
+    unsigned long long *rank_out = d_buf, *hash_out = d_buf + n, *sel = d_buf + 2 * n;
+    size_t temp_bytes = 0, temp2 = 0;
+    void *d_temp = nullptr;
+    SQ_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long *)d_ranks, rank_out,
+                                              (const unsigned long long *)d_hashes, hash_out, (int)n, 0, 64,
+                                              ctx->stream));
+    SQ_HIP(hipcub::DeviceSelect::Flagged(nullptr, temp2, hash_out, d_flags, sel, d_num, (int)n, ctx->stream));
+    temp_bytes = std::max(temp_bytes, temp2);
+    SQ_HIP(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8));
+    SQ_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const unsigned long long *)d_ranks, rank_out,
+                                              (const unsigned long long *)d_hashes, hash_out, (int)n, 0, 64,
+                                              ctx->stream));
+    SQ_HIP(hipMemsetAsync(d_keys, 0, tsize * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(d_pos, 0xFF, tsize * 8, ctx->stream));
+    hipLaunchKernelGGL(k_ovr_first_pos, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, hash_out, (uint64_t)n,
+                       d_keys, d_pos, tsize - 1);
+    hipLaunchKernelGGL(k_ovr_flag_first, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, hash_out, (uint64_t)n,
+                       d_keys, d_pos, tsize - 1, d_flags);
+    SQ_HIP(hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, hash_out, d_flags, sel, d_num, (int)n, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[25], d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t m = std::min<uint64_t>(ctx->pinned[25], o->max_unique);
+    int64_t result = (int64_t)m;
+    if (d_selected && cap >= m) {
+        if (m) SQ_HIP(hipMemcpy(d_selected, sel, m * 8, hipMemcpyDeviceToDevice));
+    } else if (d_selected) {
+        sq_set_error("sq_overrep_shard_select: destination too small");
+        result = SQ_ERR_VALUE;
+    }
+    (void)hipFree(d_temp); (void)hipFree(d_buf); (void)hipFree(d_keys); (void)hipFree(d_pos);
+    (void)hipFree(d_flags); (void)hipFree(d_num);
+    return result;
+}
+
+/* this shard's count of every selected hash (0 when the shard never saw it) */
+SQ_EXPORT int sq_overrep_shard_lookup(sq_overrep *o, const uint64_t *d_hashes, size_t n, uint64_t *d_counts)
+{
+    if (n == 0) return SQ_OK;
+    hipLaunchKernelGGL(k_ovr_lookup, dim3(blocks_for(n)), dim3(256), 0, o->ctx->stream, o->d_hashes, o->d_counts,
+                       o->table_size - 1, (const unsigned long long *)d_hashes, (uint64_t)n,
+                       (unsigned long long *)d_counts);
+    SQ_HIP(hipGetLastError());
+    SQ_HIP(hipStreamSynchronize(o->ctx->stream));
+    return SQ_OK;
+}
+
+/* replaces the shard's state by the job's: the selected keys with their summed counts and
+ * totals = {number_of_sequences, sampled_sequences, total_fragments, warning count,
+ * last warning record (-1: none)}; the object leaves shard mode */
+SQ_EXPORT int sq_overrep_shard_install(sq_overrep *o, const uint64_t *d_hashes, const uint64_t *d_counts, size_t n,
+                                       const uint64_t *totals)
+{
+    sq_ctx *ctx = o->ctx;
+    if (n > o->max_unique) { sq_set_error("sq_overrep_shard_install: more keys than max_unique_fragments"); return SQ_ERR_VALUE; }
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t want = 2 * o->max_unique + (1u << 16), size = 1;
+    while (size < want) size <<= 1;
+    if (size != o->table_size) {
+        (void)hipFree(o->d_hashes); (void)hipFree(o->d_counts);
+        o->d_hashes = nullptr; o->d_counts = nullptr;
+        o->table_size = size;
+        SQ_HIP(hipMalloc((void **)&o->d_hashes, size * 8));
+        SQ_HIP(hipMalloc((void **)&o->d_counts, size * 4));
+    }
+    if (o->d_ranks) { (void)hipFree(o->d_ranks); o->d_ranks = nullptr; }
+    SQ_HIP(hipMemsetAsync(o->d_hashes, 0, size * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(o->d_counts, 0, size * 4, ctx->stream));
+    if (n)
+        hipLaunchKernelGGL(k_ovr_install, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, o->d_hashes, o->d_counts,
+                           size - 1, (const unsigned long long *)d_hashes, (const unsigned long long *)d_counts,
+                           (uint64_t)n);
+    const unsigned long long scalars[4] = {n, totals[2], totals[3], totals[4]};
+    SQ_HIP(hipMemcpyAsync(o->d_scalars, scalars, 32, hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    o->number_of_sequences = totals[0];
+    o->sampled_sequences = totals[1];
+    o->n_unique_host = n;
+    o->full = n >= o->max_unique;
+    o->shard = false;
+    o->first_record = 0;
     return SQ_OK;
 }
 
@@ -756,6 +1077,20 @@ struct sq_dedup {
     std::vector<uint64_t> hash;
     std::vector<uint32_t> count;
     std::vector<uint8_t> store; /* the fingerprint buffer the reference reuses */
+    /* deferred mode (a shard of a multi-GPU job): add_* only hashes; the hashes
+       stay in HBM until sq_dedup_resolve() runs the insertion tail over them, after the
+       state of the shard in front has been imported */
+    bool deferred = false;
+    unsigned long long *d_stream = nullptr;
+    size_t stream_cap = 0;
+    uint64_t stream_n = 0;
+    std::vector<uint8_t> store_known; /* store bytes written since the shard began */
+    std::vector<uint8_t> store_in;    /* the store the shard starts from */
+    struct Unresolved {               /* a short pair whose fingerprint shows bytes of store_in */
+        uint64_t pos, seed;
+        std::vector<uint8_t> bytes, known;
+    };
+    std::vector<Unresolved> unresolved;
 };
 
 SQ_EXPORT sq_dedup *sq_dedup_new(sq_ctx *ctx, int64_t max_stored_fingerprints, int64_t front_sequence_length,
@@ -791,10 +1126,20 @@ SQ_EXPORT sq_dedup *sq_dedup_new(sq_ctx *ctx, int64_t max_stored_fingerprints, i
     d->hash.assign(d->table_size, 0);
     d->count.assign(d->table_size, 0);
     d->store.assign(d->front_len + d->back_len, 0);
+    d->store_known.assign(d->front_len + d->back_len, 1);
+    d->store_in = d->store;
     return d;
 }
 
-SQ_EXPORT void sq_dedup_free(sq_dedup *d) { delete d; }
+SQ_EXPORT void sq_dedup_free(sq_dedup *d)
+{
+    if (!d) return;
+    if (d->d_stream) {
+        (void)hipStreamSynchronize(d->ctx->stream);
+        (void)hipFree(d->d_stream);
+    }
+    delete d;
+}
 
 namespace {
 
@@ -849,7 +1194,8 @@ int fetch_sequence(sq_batch *b, uint64_t r, std::vector<uint8_t> &out)
 }
 
 /* what pair r writes into the fingerprint store (:4503-4514); returns bytes written */
-int pair_store_bytes(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::vector<uint8_t> &bytes)
+int pair_store_bytes(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::vector<uint8_t> &bytes,
+                     uint64_t *total_length = nullptr)
 {
     std::vector<uint8_t> s1, s2;
     int rc = fetch_sequence(b1, r, s1);
@@ -857,6 +1203,7 @@ int pair_store_bytes(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::v
     rc = fetch_sequence(b2, r, s2);
     if (rc) return rc;
     const uint64_t L1 = s1.size(), L2 = s2.size();
+    if (total_length) *total_length = L1 + L2;
     const uint64_t fl = std::min<uint64_t>(d->front_len, L1), fo = std::min<uint64_t>(d->front_off, L1 - fl);
     const uint64_t bl = std::min<uint64_t>(d->back_len, L2), bo = std::min<uint64_t>(d->back_off, L2 - bl);
     bytes.assign(s1.begin() + fo, s1.begin() + fo + fl);
@@ -881,33 +1228,20 @@ int store_after_pair(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::v
     return SQ_OK;
 }
 
-int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
+/* the sequential part: hashes [0,n) on the device, in read order, through the
+ * estimator.  Only hashes that pass the mask in force at the start can matter; the mask
+ * only ever gets stricter (H3). */
+int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned char *d_special, uint64_t n,
+               sq_batch *b1, sq_batch *b2)
 {
     sq_ctx *ctx = d->ctx;
-    const uint64_t n = b1->n;
-    if (n == 0) return SQ_OK;
-    unsigned long long *d_hashes = nullptr;
-    unsigned char *d_special = nullptr;
-    SQ_HIP(hipMalloc((void **)&d_hashes, n * 8));
-    SQ_HIP(hipMalloc((void **)&d_special, n));
-    DedupParams P{};
-    P.buf1 = b1->d_buf; P.metas1 = b1->d_metas;
-    P.buf2 = b2 ? b2->d_buf : nullptr; P.metas2 = b2 ? b2->d_metas : nullptr;
-    P.n = n;
-    P.front_len = d->front_len; P.back_len = d->back_len;
-    P.front_off = d->front_off; P.back_off = d->back_off;
-    P.hashes = d_hashes; P.special = d_special;
-    hipLaunchKernelGGL(k_dedup_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, P);
-    SQ_HIP(hipGetLastError());
-    /* only hashes that pass the mask in force at the start of the batch can matter;
-       the mask only ever gets stricter (H3) */
     DedupKeep keep{(1ULL << d->modulo_bits) - 1, d_hashes, d_special};
     unsigned long long *d_idx = nullptr;
     uint64_t n_keep = 0;
     int rc = ordered_select(ctx, n, keep, &d_idx, &n_keep);
     if (rc) return rc;
     std::vector<unsigned long long> idx(n_keep), hashes(n_keep);
-    std::vector<unsigned char> special(n_keep);
+    std::vector<unsigned char> special(n_keep, 0);
     if (n_keep) {
         unsigned long long *d_kh = nullptr;
         unsigned char *d_ks = nullptr;
@@ -917,12 +1251,13 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
                            n_keep, d_hashes, d_special, d_kh, d_ks);
         SQ_HIP(hipMemcpyAsync(idx.data(), d_idx, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP(hipMemcpyAsync(hashes.data(), d_kh, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SQ_HIP(hipMemcpyAsync(special.data(), d_ks, n_keep, hipMemcpyDeviceToHost, ctx->stream));
+        if (d_special)
+            SQ_HIP(hipMemcpyAsync(special.data(), d_ks, n_keep, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP(hipStreamSynchronize(ctx->stream));
         (void)hipFree(d_kh);
         (void)hipFree(d_ks);
     }
-    (void)hipFree(d_idx); (void)hipFree(d_hashes); (void)hipFree(d_special);
+    (void)hipFree(d_idx);
     const uint64_t fp_len = d->front_len + d->back_len;
     for (uint64_t e = 0; e < n_keep; e++) {
         if (e + 12 < n_keep) { /* the slot a hash lands in is known ahead: hide the table's cache misses */
@@ -949,14 +1284,103 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
         }
         dedup_insert(d, h);
     }
-    if (b2) { /* carry the store into the next batch (usually one step: the last
-                 pair rewrote all of it) */
-        std::vector<uint8_t> store;
-        rc = store_after_pair(d, b1, b2, n - 1, store);
-        if (rc) return rc;
-        d->store = store;
-    }
     return SQ_OK;
+}
+
+/* deferred mode: the batch's hashes join the resident stream.  Short pairs (their
+ * fingerprint shows bytes of the one before, :4512-4516) are hashed here when every such
+ * byte was written inside this shard, else kept until the store of the shard in front
+ * is known (sq_dedup_resolve). */
+int dedup_defer(sq_dedup *d, sq_batch *b1, sq_batch *b2, const unsigned long long *d_hashes,
+                const unsigned char *d_special, uint64_t n)
+{
+    sq_ctx *ctx = d->ctx;
+    const size_t want = d->stream_n + n;
+    if (want > d->stream_cap) {
+        int rc = sq_grow_device(ctx, &d->d_stream, &d->stream_cap, std::max(want, 2 * d->stream_cap));
+        if (rc) return rc;
+    }
+    SQ_HIP(hipMemcpyAsync(d->d_stream + d->stream_n, d_hashes, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (b2) {
+        const uint64_t fp_len = d->front_len + d->back_len;
+        unsigned long long *d_idx = nullptr;
+        uint64_t n_special = 0;
+        int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, &d_idx, &n_special);
+        if (rc) return rc;
+        std::vector<unsigned long long> idx(n_special);
+        if (n_special) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_special * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_idx);
+        std::vector<uint8_t> cur = d->store, known = d->store_known, w;
+        uint64_t prev = UINT64_MAX;
+        for (uint64_t e = 0; e < n_special; e++) {
+            const uint64_t r = idx[e];
+            if (r != 0 && prev != r - 1) { /* the pair in front rewrote the whole store */
+                rc = pair_store_bytes(d, b1, b2, r - 1, cur);
+                if (rc) return rc;
+                cur.resize(fp_len);
+                known.assign(fp_len, 1);
+            }
+            uint64_t total = 0;
+            rc = pair_store_bytes(d, b1, b2, r, w, &total);
+            if (rc) return rc;
+            for (uint64_t i = 0; i < w.size(); i++) { cur[i] = w[i]; known[i] = 1; }
+            prev = r;
+            if (std::find(known.begin(), known.end(), 0) == known.end()) {
+                const uint8_t *sp = cur.data();
+                const unsigned long long h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, total >> 6);
+                SQ_HIP(hipMemcpyAsync(d->d_stream + d->stream_n + r, &h, 8, hipMemcpyHostToDevice, ctx->stream));
+                SQ_HIP(hipStreamSynchronize(ctx->stream));
+            } else {
+                d->unresolved.push_back({d->stream_n + r, total >> 6, cur, known});
+            }
+        }
+        if (prev != n - 1) { /* the last pair rewrote the whole store */
+            rc = pair_store_bytes(d, b1, b2, n - 1, cur);
+            if (rc) return rc;
+            cur.resize(fp_len);
+            known.assign(fp_len, 1);
+        }
+        d->store = cur;
+        d->store_known = known;
+    }
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    d->stream_n += n;
+    return SQ_OK;
+}
+
+int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
+{
+    sq_ctx *ctx = d->ctx;
+    const uint64_t n = b1->n;
+    if (n == 0) return SQ_OK;
+    unsigned long long *d_hashes = nullptr;
+    unsigned char *d_special = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_hashes, n * 8));
+    SQ_HIP(hipMalloc((void **)&d_special, n));
+    DedupParams P{};
+    P.buf1 = b1->d_buf; P.metas1 = b1->d_metas;
+    P.buf2 = b2 ? b2->d_buf : nullptr; P.metas2 = b2 ? b2->d_metas : nullptr;
+    P.n = n;
+    P.front_len = d->front_len; P.back_len = d->back_len;
+    P.front_off = d->front_off; P.back_off = d->back_off;
+    P.hashes = d_hashes; P.special = d_special;
+    hipLaunchKernelGGL(k_dedup_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, P);
+    SQ_HIP(hipGetLastError());
+    int rc;
+    if (d->deferred) {
+        rc = dedup_defer(d, b1, b2, d_hashes, d_special, n);
+    } else {
+        rc = dedup_tail(d, d_hashes, d_special, n, b1, b2);
+        if (rc == SQ_OK && b2) { /* carry the store into the next batch (usually one step: the
+                                    last pair rewrote all of it) */
+            std::vector<uint8_t> store;
+            rc = store_after_pair(d, b1, b2, n - 1, store);
+            if (rc == SQ_OK) d->store = store;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_hashes); (void)hipFree(d_special);
+    return rc;
 }
 
 } // namespace
@@ -1009,6 +1433,97 @@ SQ_EXPORT int64_t sq_dedup_duplication_counts(sq_dedup *d, uint64_t *out, size_t
     return (int64_t)n;
 }
 
+/* ---- DedupEstimator across shards: hash in parallel, insert in shard order --- */
+SQ_EXPORT int sq_dedup_set_deferred(sq_dedup *d, int on)
+{
+    if (!on && d->stream_n) { sq_set_error("sq_dedup_set_deferred: unresolved hashes pending"); return SQ_ERR_VALUE; }
+    if (on && !d->deferred) {
+        d->store_in = d->store;
+        d->store_known.assign(d->store.size(), 0);
+    }
+    d->deferred = on != 0;
+    return SQ_OK;
+}
+
+SQ_EXPORT uint64_t sq_dedup_pending(sq_dedup *d) { return d->stream_n; }
+
+/* runs the insertion tail over the shard's resident hashes, in read order */
+SQ_EXPORT int sq_dedup_resolve(sq_dedup *d)
+{
+    sq_ctx *ctx = d->ctx;
+    const uint64_t fp_len = d->front_len + d->back_len;
+    for (auto &u : d->unresolved) {
+        for (uint64_t i = 0; i < fp_len; i++)
+            if (!u.known[i]) u.bytes[i] = d->store_in[i];
+        const uint8_t *sp = u.bytes.data();
+        const unsigned long long h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, u.seed);
+        SQ_HIP(hipMemcpy(d->d_stream + u.pos, &h, 8, hipMemcpyHostToDevice));
+    }
+    d->unresolved.clear();
+    for (uint64_t i = 0; i < fp_len; i++)
+        if (!d->store_known[i]) d->store[i] = d->store_in[i];
+    d->store_known.assign(fp_len, d->deferred ? 0 : 1);
+    d->store_in = d->store;
+    const uint64_t chunk = 1ull << 23;
+    for (uint64_t off = 0; off < d->stream_n; off += chunk) {
+        int rc = dedup_tail(d, d->d_stream + off, nullptr, std::min(chunk, d->stream_n - off), nullptr, nullptr);
+        if (rc) return rc;
+    }
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    d->stream_n = 0;
+    return SQ_OK;
+}
+
+/* the estimator's state as bytes: {magic, modulo_bits, stored, table_size, fp_len} u64,
+ * store[fp_len] padded to 8, hash[table_size] u64, count[table_size] u32 */
+static const uint64_t DEDUP_MAGIC = 0x3150554445445153ULL; /* "SQDEDUP1" */
+
+SQ_EXPORT uint64_t sq_dedup_state_bytes(sq_dedup *d)
+{
+    const uint64_t fp_len = d->front_len + d->back_len;
+    return 40 + (fp_len + 7) / 8 * 8 + d->table_size * 12;
+}
+
+SQ_EXPORT int sq_dedup_export_state(sq_dedup *d, void *out, size_t cap)
+{
+    if (d->stream_n) { sq_set_error("sq_dedup_export_state: resolve the pending hashes first"); return SQ_ERR_VALUE; }
+    if (cap < sq_dedup_state_bytes(d)) { sq_set_error("sq_dedup_export_state: destination too small"); return SQ_ERR_VALUE; }
+    const uint64_t fp_len = d->front_len + d->back_len, pad = (fp_len + 7) / 8 * 8;
+    uint8_t *p = (uint8_t *)out;
+    const uint64_t head[5] = {DEDUP_MAGIC, d->modulo_bits, d->stored, d->table_size, fp_len};
+    memcpy(p, head, 40); p += 40;
+    memset(p, 0, pad);
+    memcpy(p, d->store.data(), fp_len); p += pad;
+    memcpy(p, d->hash.data(), d->table_size * 8); p += d->table_size * 8;
+    memcpy(p, d->count.data(), d->table_size * 4);
+    return SQ_OK;
+}
+
+/* continues from the state another shard exported: its table, its modulo bits and its
+ * fingerprint store; to be called before sq_dedup_resolve() of this shard */
+SQ_EXPORT int sq_dedup_import_state(sq_dedup *d, const void *in, size_t len)
+{
+    const uint64_t fp_len = d->front_len + d->back_len, pad = (fp_len + 7) / 8 * 8;
+    const uint8_t *p = (const uint8_t *)in;
+    uint64_t head[5];
+    if (len < 40) { sq_set_error("sq_dedup_import_state: truncated state"); return SQ_ERR_VALUE; }
+    memcpy(head, p, 40); p += 40;
+    if (head[0] != DEDUP_MAGIC || head[3] != d->table_size || head[4] != fp_len ||
+        len < 40 + pad + d->table_size * 12) {
+        sq_set_error("sq_dedup_import_state: state of a differently configured estimator");
+        return SQ_ERR_VALUE;
+    }
+    d->modulo_bits = head[1];
+    d->stored = head[2];
+    d->store_in.assign(p, p + fp_len); p += pad;
+    memcpy(d->hash.data(), p, d->table_size * 8); p += d->table_size * 8;
+    memcpy(d->count.data(), p, d->table_size * 4);
+    if (!d->deferred || (d->stream_n == 0 && d->unresolved.empty() &&
+                         std::find(d->store_known.begin(), d->store_known.end(), 1) == d->store_known.end()))
+        d->store = d->store_in; /* nothing of this shard is pending: the store is the imported one */
+    return SQ_OK;
+}
+
 /* ---- InsertSizeMetrics ------------------------------------------------------------------ */
 
 struct sq_adapter_entry {
@@ -1029,7 +1544,40 @@ struct sq_insertsize {
     /* read-out: the reference's tables, rebuilt from the device tables */
     uint64_t entries[2] = {0, 0};
     std::vector<sq_adapter_entry> table[2];
+    /* shard mode: ranks count pairs of the whole job, tables never close */
+    bool shard = false;
+    uint64_t first_pair = 0;
 };
+
+static void isz_free_table(IszTable &T)
+{
+    for (void *p : {(void *)T.hash, (void *)T.count, (void *)T.rank, (void *)T.ready, (void *)T.key,
+                    (void *)T.n_distinct, (void *)T.overflow})
+        if (p) (void)hipFree(p);
+    T = IszTable{};
+}
+
+static int isz_alloc_table(IszTable &T, uint32_t bits)
+{
+    const uint64_t size = 1ull << bits;
+    T = IszTable{};
+    T.mask = size - 1;
+    SQ_HIP(hipMalloc((void **)&T.hash, size * 8));
+    SQ_HIP(hipMalloc((void **)&T.count, size * 8));
+    SQ_HIP(hipMalloc((void **)&T.rank, size * 8));
+    SQ_HIP(hipMalloc((void **)&T.ready, size * 4));
+    SQ_HIP(hipMalloc((void **)&T.key, size * 32));
+    SQ_HIP(hipMalloc((void **)&T.n_distinct, 16));
+    SQ_HIP(hipMalloc((void **)&T.overflow, 4));
+    T.n_events = T.n_distinct + 1;
+    SQ_HIP(hipMemset(T.hash, 0, size * 8));
+    SQ_HIP(hipMemset(T.count, 0, size * 8));
+    SQ_HIP(hipMemset(T.rank, 0xFF, size * 8));
+    SQ_HIP(hipMemset(T.ready, 0, size * 4));
+    SQ_HIP(hipMemset(T.n_distinct, 0, 16));
+    SQ_HIP(hipMemset(T.overflow, 0, 4));
+    return SQ_OK;
+}
 
 SQ_EXPORT sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters)
 {
@@ -1043,23 +1591,8 @@ SQ_EXPORT sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters)
     z->table_size = 1ULL << (uint64_t)(log2(max_adapters * 1.5) + 1); /* :5525 */
     SQ_HIP_NULL(hipMalloc((void **)&z->d_max, 8));
     SQ_HIP_NULL(hipMemset(z->d_max, 0, 8));
-    for (int w = 0; w < 2; w++) {
-        IszTable &T = z->tab[w];
-        SQ_HIP_NULL(hipMalloc((void **)&T.hash, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMalloc((void **)&T.count, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMalloc((void **)&T.rank, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMalloc((void **)&T.ready, ISZ_TABLE_SIZE * 4));
-        SQ_HIP_NULL(hipMalloc((void **)&T.key, ISZ_TABLE_SIZE * 32));
-        SQ_HIP_NULL(hipMalloc((void **)&T.n_distinct, 16));
-        SQ_HIP_NULL(hipMalloc((void **)&T.overflow, 4));
-        T.n_events = T.n_distinct + 1;
-        SQ_HIP_NULL(hipMemset(T.hash, 0, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMemset(T.count, 0, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMemset(T.rank, 0xFF, ISZ_TABLE_SIZE * 8));
-        SQ_HIP_NULL(hipMemset(T.ready, 0, ISZ_TABLE_SIZE * 4));
-        SQ_HIP_NULL(hipMemset(T.n_distinct, 0, 16));
-        SQ_HIP_NULL(hipMemset(T.overflow, 0, 4));
-    }
+    for (int w = 0; w < 2; w++)
+        if (isz_alloc_table(z->tab[w], ISZ_TABLE_BITS) != SQ_OK) return nullptr;
     return z;
 }
 
@@ -1069,12 +1602,7 @@ SQ_EXPORT void sq_insertsize_free(sq_insertsize *z)
     (void)hipStreamSynchronize(z->ctx->stream);
     if (z->d_sizes) (void)hipFree(z->d_sizes);
     if (z->d_max) (void)hipFree(z->d_max);
-    for (int w = 0; w < 2; w++) {
-        IszTable &T = z->tab[w];
-        for (void *p : {(void *)T.hash, (void *)T.count, (void *)T.rank, (void *)T.ready, (void *)T.key,
-                        (void *)T.n_distinct, (void *)T.overflow})
-            if (p) (void)hipFree(p);
-    }
+    for (int w = 0; w < 2; w++) isz_free_table(z->tab[w]);
     delete z;
 }
 
@@ -1104,21 +1632,47 @@ void isz_replay_adapter(sq_insertsize *z, const uint8_t *a, size_t len, uint64_t
     }
 }
 
-int isz_rebuild_tables(sq_insertsize *z)
+/* (key, count, rank) of every used slot of table w, unordered */
+int isz_download_used(sq_insertsize *z, int w, std::vector<unsigned long long> &key,
+                      std::vector<unsigned long long> &count, std::vector<unsigned long long> &rank)
 {
     sq_ctx *ctx = z->ctx;
+    const IszTable &T = z->tab[w];
+    unsigned long long nd = 0;
     SQ_HIP(hipStreamSynchronize(ctx->stream));
+    SQ_HIP(hipMemcpy(&nd, T.n_distinct, 8, hipMemcpyDeviceToHost));
+    key.clear(); count.clear(); rank.clear();
+    if (nd == 0) return SQ_OK;
+    unsigned long long *d_slots = nullptr, *d_n = nullptr, *d_out = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_slots, nd * 8));
+    SQ_HIP(hipMalloc((void **)&d_n, 8));
+    SQ_HIP(hipMalloc((void **)&d_out, nd * 48));
+    SQ_HIP(hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_isz_collect, dim3(blocks_for(T.mask + 1)), dim3(256), 0, ctx->stream, T, d_slots, d_n);
+    unsigned long long used = 0;
+    SQ_HIP(hipMemcpyAsync(&used, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (used) {
+        hipLaunchKernelGGL(k_isz_gather, dim3(blocks_for(used)), dim3(256), 0, ctx->stream, T, d_slots,
+                           (uint64_t)used, d_out, d_out + 4 * used, d_out + 5 * used);
+        key.resize(4 * used); count.resize(used); rank.resize(used);
+        SQ_HIP(hipMemcpyAsync(key.data(), d_out, used * 32, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(count.data(), d_out + 4 * used, used * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(rank.data(), d_out + 5 * used, used * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(d_slots); (void)hipFree(d_n); (void)hipFree(d_out);
+    return SQ_OK;
+}
+
+int isz_rebuild_tables(sq_insertsize *z)
+{
     for (int w = 0; w < 2; w++) {
-        const IszTable &T = z->tab[w];
-        std::vector<unsigned long long> hash(ISZ_TABLE_SIZE), count(ISZ_TABLE_SIZE), rank(ISZ_TABLE_SIZE);
-        std::vector<unsigned long long> key(ISZ_TABLE_SIZE * 4);
-        SQ_HIP(hipMemcpy(hash.data(), T.hash, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
-        SQ_HIP(hipMemcpy(count.data(), T.count, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
-        SQ_HIP(hipMemcpy(rank.data(), T.rank, ISZ_TABLE_SIZE * 8, hipMemcpyDeviceToHost));
-        SQ_HIP(hipMemcpy(key.data(), T.key, ISZ_TABLE_SIZE * 32, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> used;
-        for (uint64_t i = 0; i < ISZ_TABLE_SIZE; i++)
-            if (hash[i] && count[i]) used.push_back(i);
+        std::vector<unsigned long long> key, count, rank;
+        int rc = isz_download_used(z, w, key, count, rank);
+        if (rc) return rc;
+        std::vector<uint64_t> used(count.size());
+        for (uint64_t i = 0; i < used.size(); i++) used[i] = i;
         std::sort(used.begin(), used.end(), [&](uint64_t x, uint64_t y) { return rank[x] < rank[y]; });
         z->table[w].assign(z->table_size, sq_adapter_entry());
         z->entries[w] = 0;
@@ -1150,7 +1704,7 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     P.buf1 = b1->d_buf; P.buf2 = b2->d_buf; P.metas1 = b1->d_metas; P.metas2 = b2->d_metas;
     P.n = n; P.insert_sizes = z->d_sizes; P.max_insert = z->d_max;
     P.tab[0] = z->tab[0]; P.tab[1] = z->tab[1];
-    P.rank_base = z->total_reads;
+    P.rank_base = z->first_pair + z->total_reads;
     P.closed = z->closed ? 1 : 0;
     P.lds_sizes = (uint32_t)std::min<size_t>(z->cap, 8192);
     hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(n, 2048)), dim3(256), P.lds_sizes * 4, ctx->stream, P);
@@ -1166,10 +1720,11 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
         SQ_HIP(hipStreamSynchronize(ctx->stream));
         if ((uint32_t)ctx->pinned[34] || (uint32_t)ctx->pinned[35]) {
             sq_set_error("InsertSizeMetrics: more than %llu distinct adapter remainders in flight",
-                         (unsigned long long)(ISZ_TABLE_SIZE / 4 * 3));
+                         (unsigned long long)((z->tab[0].mask + 1) / 4 * 3));
             return SQ_ERR_MEMORY;
         }
-        if (ctx->pinned[32] >= z->max_adapters && ctx->pinned[33] >= z->max_adapters) z->closed = true;
+        if (!z->shard && ctx->pinned[32] >= z->max_adapters && ctx->pinned[33] >= z->max_adapters)
+            z->closed = true;
     }
     return SQ_OK;
 }
@@ -1228,4 +1783,142 @@ SQ_EXPORT int64_t sq_insertsize_adapters(sq_insertsize *z, int read2, uint8_t *b
         n++;
     }
     return (int64_t)n;
+}
+
+/* ---- InsertSizeMetrics across shards -------------------------------------- */
+SQ_EXPORT int sq_insertsize_set_shard(sq_insertsize *z, uint64_t first_pair_index, uint32_t table_bits)
+{
+    if (z->total_reads) {
+        sq_set_error("sq_insertsize_set_shard: call it before the first record arrays");
+        return SQ_ERR_VALUE;
+    }
+    if (table_bits < ISZ_TABLE_BITS) table_bits = ISZ_TABLE_BITS;
+    if (table_bits > 28) { sq_set_error("sq_insertsize_set_shard: table_bits above 28"); return SQ_ERR_VALUE; }
+    SQ_HIP(hipStreamSynchronize(z->ctx->stream));
+    for (int w = 0; w < 2; w++) {
+        if (z->tab[w].mask + 1 == (1ull << table_bits)) continue;
+        isz_free_table(z->tab[w]);
+        int rc = isz_alloc_table(z->tab[w], table_bits);
+        if (rc) return rc;
+    }
+    z->shard = true;
+    z->closed = false;
+    z->first_pair = first_pair_index;
+    return SQ_OK;
+}
+
+/* the first min(distinct, max_adapters) remainders of this shard's table by rank:
+ * keys [n][32] = {length, bytes[31]}, ranks [n]; host arrays */
+SQ_EXPORT int64_t sq_insertsize_shard_candidates(sq_insertsize *z, int read2, uint8_t *keys, uint64_t *ranks,
+                                                 size_t cap)
+{
+    std::vector<unsigned long long> key, count, rank;
+    if (isz_download_used(z, read2 ? 1 : 0, key, count, rank) != SQ_OK) return SQ_ERR_HIP;
+    std::vector<uint64_t> order(count.size());
+    for (uint64_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return rank[x] < rank[y]; });
+    const size_t m = std::min<size_t>(order.size(), z->max_adapters);
+    if (!keys || cap < m) return (int64_t)m;
+    for (size_t e = 0; e < m; e++) {
+        memcpy(keys + e * 32, &key[order[e] * 4], 32);
+        ranks[e] = rank[order[e]];
+    }
+    return (int64_t)m;
+}
+
+/* first max_adapters distinct keys of the shards' candidates by rank (host arrays) */
+SQ_EXPORT int64_t sq_insertsize_shard_select(sq_insertsize *z, const uint8_t *keys, const uint64_t *ranks, size_t n,
+                                             uint8_t *out_keys, uint64_t *out_ranks, size_t cap)
+{
+    std::vector<uint64_t> order(n);
+    for (uint64_t i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+        const int c = memcmp(keys + x * 32, keys + y * 32, 32);
+        return c != 0 ? c < 0 : ranks[x] < ranks[y];
+    });
+    std::vector<uint64_t> firsts; /* per distinct key the entry with the smallest rank */
+    for (uint64_t e = 0; e < n; e++)
+        if (e == 0 || memcmp(keys + order[e] * 32, keys + order[e - 1] * 32, 32) != 0) firsts.push_back(order[e]);
+    std::sort(firsts.begin(), firsts.end(), [&](uint64_t x, uint64_t y) { return ranks[x] < ranks[y]; });
+    const size_t m = std::min<size_t>(firsts.size(), z->max_adapters);
+    if (!out_keys || cap < m) return (int64_t)m;
+    for (size_t e = 0; e < m; e++) {
+        memcpy(out_keys + e * 32, keys + firsts[e] * 32, 32);
+        out_ranks[e] = ranks[firsts[e]];
+    }
+    return (int64_t)m;
+}
+
+/* this shard's count of every selected key (host arrays) */
+SQ_EXPORT int sq_insertsize_shard_lookup(sq_insertsize *z, int read2, const uint8_t *keys, size_t n, uint64_t *counts)
+{
+    if (n == 0) return SQ_OK;
+    sq_ctx *ctx = z->ctx;
+    unsigned long long *d_keys = nullptr, *d_out = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_keys, n * 32));
+    SQ_HIP(hipMalloc((void **)&d_out, n * 8));
+    SQ_HIP(hipMemcpyAsync(d_keys, keys, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_isz_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, z->tab[read2 ? 1 : 0], d_keys,
+                       (uint64_t)n, d_out);
+    SQ_HIP(hipMemcpyAsync(counts, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_keys); (void)hipFree(d_out);
+    return SQ_OK;
+}
+
+/* replaces table `read2` by the job's: selected keys, their ranks and summed counts;
+ * n_events = the job's number_of_adapters_read{1,2} */
+SQ_EXPORT int sq_insertsize_shard_install(sq_insertsize *z, int read2, const uint8_t *keys, const uint64_t *ranks,
+                                          const uint64_t *counts, size_t n, uint64_t n_events)
+{
+    const int w = read2 ? 1 : 0;
+    uint32_t bits = ISZ_TABLE_BITS;
+    while ((1ull << bits) < 2 * n) bits++;
+    SQ_HIP(hipStreamSynchronize(z->ctx->stream));
+    isz_free_table(z->tab[w]);
+    int rc = isz_alloc_table(z->tab[w], bits);
+    if (rc) return rc;
+    IszTable &T = z->tab[w];
+    const uint64_t size = T.mask + 1;
+    std::vector<unsigned long long> hash(size, 0), count(size, 0), rank(size, ~0ULL), key(size * 4, 0);
+    std::vector<unsigned int> ready(size, 0);
+    for (size_t e = 0; e < n; e++) {
+        const uint8_t *rec = keys + e * 32;
+        unsigned long long h = murmur3_x64_64([&](uint64_t i) { return rec[1 + i]; }, rec[0], 0);
+        if (h == 0) h = 1;
+        uint64_t i = h & T.mask;
+        while (hash[i]) i = (i + 1) & T.mask;
+        hash[i] = h; count[i] = counts[e]; rank[i] = ranks[e]; ready[i] = 1;
+        memcpy(&key[i * 4], rec, 32);
+    }
+    SQ_HIP(hipMemcpy(T.hash, hash.data(), size * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(T.count, count.data(), size * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(T.rank, rank.data(), size * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(T.ready, ready.data(), size * 4, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(T.key, key.data(), size * 32, hipMemcpyHostToDevice));
+    const unsigned long long scalars[2] = {n, n_events};
+    SQ_HIP(hipMemcpy(T.n_distinct, scalars, 16, hipMemcpyHostToDevice));
+    return SQ_OK;
+}
+
+/* the job's total_reads and insert size histogram; ends shard mode */
+SQ_EXPORT int sq_insertsize_shard_set_totals(sq_insertsize *z, uint64_t total_reads, const uint64_t *insert_sizes,
+                                             size_t len)
+{
+    sq_ctx *ctx = z->ctx;
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = sq_grow_device(ctx, &z->d_sizes, &z->cap, len ? len : 1);
+    if (rc) return rc;
+    SQ_HIP(hipMemsetAsync(z->d_sizes, 0, z->cap * 8, ctx->stream));
+    if (len) SQ_HIP(hipMemcpyAsync(z->d_sizes, insert_sizes, len * 8, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned long long mx = len ? len - 1 : 0;
+    SQ_HIP(hipMemcpyAsync(z->d_max, &mx, 8, hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    z->total_reads = total_reads;
+    z->shard = false;
+    z->first_pair = 0;
+    unsigned long long nd[2] = {0, 0};
+    for (int w = 0; w < 2; w++) SQ_HIP(hipMemcpy(&nd[w], z->tab[w].n_distinct, 8, hipMemcpyDeviceToHost));
+    z->closed = nd[0] >= z->max_adapters && nd[1] >= z->max_adapters;
+    return SQ_OK;
 }

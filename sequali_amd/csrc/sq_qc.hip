@@ -1784,3 +1784,61 @@ SQ_EXPORT int64_t sq_pertile_get_tile_counts(sq_pertile *p, int64_t *tile_ids, d
     }
     return (int64_t)nt;
 }
+
+/* ---- PerTileQuality across shards ------------------------------------------ */
+/* index, among the records this object was given, of the first record whose header has no
+ * tile id (the module stopped counting there, :3137-3148); -1 while active */
+SQ_EXPORT int64_t sq_pertile_first_unparsable(sq_pertile *p)
+{
+    return p->first_bad == UINT64_MAX ? -1 : (int64_t)p->first_bad;
+}
+
+/* replaces the state by merged tables: tile k owns row k of errors / length_counts
+ * ([n_tiles][len]; length_counts[k][j] = reads of tile k that are j + 1 long, the raw form
+ * of what get_tile_counts reverse-cumulates); skipped_reason NULL keeps the module active */
+SQ_EXPORT int sq_pertile_install(sq_pertile *p, const int64_t *tile_ids, size_t n_tiles, const double *errors,
+                                 const uint64_t *length_counts, size_t len, uint64_t number_of_reads,
+                                 const char *skipped_reason)
+{
+    sq_ctx *ctx = p->ctx;
+    if (n_tiles > TILE_MAP_SIZE / 2) {
+        sq_set_error("PerTileQuality: more than %u distinct tile ids", TILE_MAP_SIZE / 2);
+        return SQ_ERR_MEMORY;
+    }
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<long long> keys(TILE_MAP_SIZE, TILE_EMPTY);
+    std::vector<int> vals(TILE_MAP_SIZE, -1);
+    for (size_t k = 0; k < n_tiles; k++) {
+        uint32_t idx = (uint32_t)(((unsigned long long)tile_ids[k] * 0x9E3779B97F4A7C15ULL) >> 48) & (TILE_MAP_SIZE - 1);
+        while (keys[idx] != TILE_EMPTY) idx = (idx + 1) & (TILE_MAP_SIZE - 1);
+        keys[idx] = tile_ids[k];
+        vals[idx] = (int)k;
+    }
+    const int n_slots = (int)n_tiles;
+    SQ_HIP(hipMemcpy(p->map.keys, keys.data(), TILE_MAP_SIZE * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(p->map.vals, vals.data(), TILE_MAP_SIZE * 4, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(p->map.n_slots, &n_slots, 4, hipMemcpyHostToDevice));
+    if (p->d_len_counts) { SQ_HIP(hipFree(p->d_len_counts)); p->d_len_counts = nullptr; }
+    if (p->d_errors) { SQ_HIP(hipFree(p->d_errors)); p->d_errors = nullptr; }
+    p->slot_cap = n_tiles;
+    p->len_cap = len;
+    if (n_tiles && len) {
+        SQ_HIP(hipMalloc((void **)&p->d_len_counts, n_tiles * len * 8));
+        SQ_HIP(hipMalloc((void **)&p->d_errors, n_tiles * len * 8));
+        SQ_HIP(hipMemcpy(p->d_len_counts, length_counts, n_tiles * len * 8, hipMemcpyHostToDevice));
+        SQ_HIP(hipMemcpy(p->d_errors, errors, n_tiles * len * 8, hipMemcpyHostToDevice));
+    } else {
+        p->slot_cap = 0;
+        p->len_cap = 0;
+    }
+    p->n_slots = n_slots;
+    p->max_length = len;
+    p->number_of_reads = number_of_reads;
+    p->records_seen = number_of_reads;
+    p->skipped = skipped_reason != nullptr;
+    p->skipped_reason = skipped_reason ? skipped_reason : "";
+    p->first_bad = p->skipped ? number_of_reads : UINT64_MAX;
+    const unsigned long long fb = p->first_bad;
+    SQ_HIP(hipMemcpy(p->d_first_bad, &fb, 8, hipMemcpyHostToDevice));
+    return SQ_OK;
+}

@@ -4,12 +4,20 @@ The per-read accumulators are sums over independent records, so records are
 sharded by contiguous ranges and the only exchange is one all-reduce of the
 count tables: RCCL (backend "nccl") on device tensors that alias
 the library's tables, gloo on CPU tensors in the tests.
+
+The modules with order-dependent state (first-come caps, the estimator's modulo
+bits) are merged so that the job's result is the one a single sequential run over
+all shards gives: see merge_overrepresented, merge_dedup, merge_insertsize,
+merge_pertile.  Each takes the shard objects this process holds, in shard order
+(normally one); with torch.distributed initialised the other ranks' shards join
+through the collectives, without it the call merges the local shards only.
 """
 from __future__ import annotations
 
 import ctypes
 from typing import List, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -106,3 +114,237 @@ def merge_adaptercounter(ad, device, group=None) -> None:
     sum_tables(tables, group)
     torch.cuda.synchronize()
     check(lib().sq_adaptercounter_set_totals(ad._h, int(seqs.item()), ml))
+
+
+# ---------------------------------------------------------------------------
+# the order-dependent modules
+# ---------------------------------------------------------------------------
+def _active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def _wire(t: torch.Tensor, group=None) -> torch.Tensor:
+    """the tensor where the backend wants it (gloo: host, nccl/RCCL: device)"""
+    return t.cpu() if dist.get_backend(group) == "gloo" else t
+
+
+def _all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:
+    if not _active(group):
+        return t
+    w = _wire(t, group).contiguous()
+    dist.all_reduce(w, op=op, group=group)
+    return w.to(t.device)
+
+
+def all_gather_ragged(t: torch.Tensor, group=None) -> torch.Tensor:
+    """concatenation over ranks, in rank order, of 1-D (or [n, k]) tensors of different n"""
+    if not _active(group):
+        return t
+    world = dist.get_world_size(group)
+    w = _wire(t, group).contiguous()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=w.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([w.shape[0]], dtype=torch.int64, device=w.device), group=group)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    padded = torch.zeros((cap,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    padded[:w.shape[0]] = w
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)]).to(t.device)
+
+
+def _broadcast_bytes(data: bytes, src: int, device, group=None) -> bytes:
+    """`data` of rank `src` on every rank"""
+    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
+    n = _wire(n, group)
+    dist.broadcast(n, src=src, group=group)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    if dist.get_rank(group) == src:
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    buf = _wire(buf, group).contiguous()
+    dist.broadcast(buf, src=src, group=group)
+    return buf.cpu().numpy().tobytes()
+
+
+def merge_overrepresented(shards: Sequence, device, group=None) -> None:
+    """OverrepresentedSequences objects in shard mode -> every one holds the job's table:
+    the first max_unique_fragments distinct fragment hashes in (sampled read, staging slot)
+    order over all shards, each with its occurrences in all shards (_qcmodule.c:3543-3568)."""
+    from ._lib import check, lib
+    L = lib()
+    hs, rs = [], []
+    for o in shards:
+        n = check(L.sq_overrep_shard_candidates(o._h, None, None, 0))
+        h = torch.zeros(max(n, 1), dtype=torch.int64, device=device)
+        r = torch.zeros(max(n, 1), dtype=torch.int64, device=device)
+        if n:
+            check(L.sq_overrep_shard_candidates(o._h, h.data_ptr(), r.data_ptr(), n))
+        hs.append(h[:n])
+        rs.append(r[:n])
+    h_all = all_gather_ragged(torch.cat(hs), group).contiguous()
+    r_all = all_gather_ragged(torch.cat(rs), group).contiguous()
+    torch.cuda.synchronize()
+    first = shards[0]
+    sel = torch.zeros(max(min(h_all.numel(), first.max_unique_fragments), 1), dtype=torch.int64, device=device)
+    m = check(L.sq_overrep_shard_select(first._h, h_all.data_ptr(), r_all.data_ptr(), h_all.numel(),
+                                        sel.data_ptr(), sel.numel())) if h_all.numel() else 0
+    sel = sel[:m].contiguous()
+    counts = torch.zeros(max(m, 1), dtype=torch.int64, device=device)
+    one = torch.zeros_like(counts)
+    for o in shards:
+        if m:
+            check(L.sq_overrep_shard_lookup(o._h, sel.data_ptr(), m, one.data_ptr()))
+            counts += one
+    sums = torch.tensor([[o.number_of_sequences, o.sampled_sequences, o.total_fragments,
+                          L.sq_overrep_warning_count(o._h)] for o in shards],
+                        dtype=torch.int64, device=device).sum(0)
+    last = torch.tensor([max(L.sq_overrep_last_warning_record(o._h) for o in shards)],
+                        dtype=torch.int64, device=device)
+    counts = _all_reduce(counts, group=group)
+    sums = _all_reduce(sums, group=group)
+    last = _all_reduce(last, dist.ReduceOp.MAX, group)
+    torch.cuda.synchronize()
+    totals = (ctypes.c_uint64 * 5)(*[int(x) for x in sums.tolist()], int(last.item()) & 0xFFFFFFFFFFFFFFFF)
+    for o in shards:
+        check(L.sq_overrep_shard_install(o._h, sel.data_ptr(), counts.data_ptr(), m, totals))
+        o._first_record = 0
+        o._warned = int(sums[3].item())
+
+
+def merge_dedup(shards: Sequence, device=None, group=None) -> None:
+    """DedupEstimator objects in deferred mode -> every one holds the job's estimator.
+    The fingerprints were hashed in parallel and are resident; the insertion tail
+    (_qcmodule.c:4426-4460) runs shard after shard, each continuing from the table, the
+    modulo bits and the fingerprint store of the one in front."""
+    from ._lib import check, lib
+    L = lib()
+
+    def export(d) -> bytes:
+        buf = (ctypes.c_uint8 * L.sq_dedup_state_bytes(d._h))()
+        check(L.sq_dedup_export_state(d._h, buf, len(buf)))
+        return bytes(buf)
+
+    def run_local(state):
+        for d in shards:
+            if state is not None:
+                check(L.sq_dedup_import_state(d._h, state, len(state)))
+            check(L.sq_dedup_resolve(d._h))
+            state = export(d)
+        return state
+
+    if _active(group):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        state = None
+        for r in range(world):
+            mine = run_local(state) if rank == r else b""
+            state = _broadcast_bytes(mine, r, device, group)
+    else:
+        state = run_local(None)
+    for d in shards:
+        check(L.sq_dedup_set_deferred(d._h, 0))
+        check(L.sq_dedup_import_state(d._h, state, len(state)))
+
+
+def merge_insertsize(shards: Sequence, device, group=None) -> None:
+    """InsertSizeMetrics objects in shard mode -> every one holds the job's histogram and
+    adapter tables (first max_adapters distinct remainders in pair order, _qcmodule.c:5570-5611)."""
+    from ._lib import check, lib
+    L = lib()
+    first = shards[0]
+    for read2 in (0, 1):
+        ks, rs = [], []
+        for z in shards:
+            n = check(L.sq_insertsize_shard_candidates(z._h, read2, None, None, 0))
+            k = np.zeros((max(n, 1), 32), dtype=np.uint8)
+            r = np.zeros(max(n, 1), dtype=np.uint64)
+            if n:
+                check(L.sq_insertsize_shard_candidates(z._h, read2, k.ctypes.data, r.ctypes.data, n))
+            ks.append(k[:n])
+            rs.append(r[:n])
+        k_all = all_gather_ragged(torch.from_numpy(np.concatenate(ks)).to(device), group).cpu().numpy()
+        r_all = all_gather_ragged(torch.from_numpy(np.concatenate(rs).view(np.int64)).to(device), group)
+        k_all = np.ascontiguousarray(k_all)
+        r_all = np.ascontiguousarray(r_all.cpu().numpy()).view(np.uint64)
+        cap = max(len(r_all), 1)
+        sk = np.zeros((cap, 32), dtype=np.uint8)
+        sr = np.zeros(cap, dtype=np.uint64)
+        m = check(L.sq_insertsize_shard_select(first._h, k_all.ctypes.data, r_all.ctypes.data, len(r_all),
+                                               sk.ctypes.data, sr.ctypes.data, cap))
+        counts = np.zeros(max(m, 1), dtype=np.uint64)
+        one = np.zeros_like(counts)
+        events = 0
+        for z in shards:
+            if m:
+                check(L.sq_insertsize_shard_lookup(z._h, read2, sk.ctypes.data, m, one.ctypes.data))
+                counts += one
+            events += z.number_of_adapters_read2 if read2 else z.number_of_adapters_read1
+        t = torch.from_numpy(np.concatenate([counts.view(np.int64), [events]])).to(device)
+        t = _all_reduce(t, group=group).cpu().numpy()
+        counts, events = np.ascontiguousarray(t[:-1]).view(np.uint64), int(t[-1])
+        for z in shards:
+            check(L.sq_insertsize_shard_install(z._h, read2, sk.ctypes.data, sr.ctypes.data, counts.ctypes.data,
+                                                m, events))
+    hists = [np.frombuffer(z.insert_sizes().tobytes(), dtype=np.uint64) for z in shards]
+    length = max(len(h) for h in hists)
+    if _active(group):
+        length = global_max(length, device if dist.get_backend(group) != "gloo" else None, group)
+    hist = np.zeros(length + 1, dtype=np.int64)
+    for h in hists:
+        hist[:len(h)] += h.view(np.int64)
+    hist[-1] = sum(z.total_reads for z in shards)
+    hist = _all_reduce(torch.from_numpy(hist).to(device), group=group).cpu().numpy()
+    sizes = np.ascontiguousarray(hist[:-1]).view(np.uint64)
+    for z in shards:
+        check(L.sq_insertsize_shard_set_totals(z._h, int(hist[-1]), sizes.ctypes.data, len(sizes)))
+
+
+def merge_pertile(shards: Sequence, first_records: Sequence[int], device, group=None) -> None:
+    """PerTileQuality objects, shard i holding the job's records from first_records[i] on ->
+    every one holds the job's tables.  The module stops for good at the job's first header
+    without a tile id (_qcmodule.c:3126,3137-3148): shards behind it contribute nothing.
+    The f64 sums are added in a different order than in one sequential run (1e-6)."""
+    from ._lib import check, lib
+    L = lib()
+    INF = (1 << 62)
+    bads = []
+    for p, f in zip(shards, first_records):
+        p.flush()
+        b = L.sq_pertile_first_unparsable(p._h)
+        bads.append(f + b if b >= 0 else INF)
+    bad = int(_all_reduce(torch.tensor([min(bads)], dtype=torch.int64, device=device), dist.ReduceOp.MIN,
+                          group).item())
+    live = [(p, f) for p, f in zip(shards, first_records) if f <= bad]
+    tables = [p.get_tile_counts() for p, _ in live]
+    tiles = sorted({t for tab in tables for t, _, _ in tab})
+    tiles = all_gather_ragged(torch.tensor(tiles, dtype=torch.int64, device=device), group)
+    tiles = sorted(set(tiles.tolist()))
+    ml = max([p.max_length for p, _ in live], default=0)
+    if _active(group):
+        ml = global_max(ml, device if dist.get_backend(group) != "gloo" else None, group)
+    index = {t: i for i, t in enumerate(tiles)}
+    errors = np.zeros((len(tiles), ml), dtype=np.float64)
+    lengths = np.zeros((len(tiles), ml), dtype=np.int64)
+    for tab in tables:
+        for t, err, cum in tab:
+            row = index[t]
+            errors[row, :len(err)] += np.asarray(err, dtype=np.float64)
+            c = np.asarray(list(cum) + [0], dtype=np.int64)
+            lengths[row, :len(cum)] += c[:-1] - c[1:]  # undo the reverse cumulation (:3336-3347)
+    reads = sum(p.number_of_reads for p, _ in live)
+    reason = b""
+    for (p, f), b in zip(zip(shards, first_records), bads):
+        if b == bad and bad != INF:
+            reason = (p.skipped_reason or "").encode()
+    rbuf = np.zeros(8192, dtype=np.int64)
+    rbuf[:len(reason)] = np.frombuffer(reason, dtype=np.uint8)[:8192]
+    errors_t = _all_reduce(torch.from_numpy(errors).to(device), group=group).cpu().numpy()
+    ints = np.concatenate([lengths.reshape(-1), [reads], rbuf])
+    ints = _all_reduce(torch.from_numpy(ints).to(device), group=group).cpu().numpy()
+    lengths = np.ascontiguousarray(ints[:lengths.size]).view(np.uint64)
+    reads = int(ints[lengths.size])
+    reason = bytes(ints[lengths.size + 1:].astype(np.uint8)).rstrip(b"\0")
+    errors_t = np.ascontiguousarray(errors_t)
+    ids = np.asarray(tiles, dtype=np.int64)
+    for p in shards:
+        check(L.sq_pertile_install(p._h, ids.ctypes.data, len(ids), errors_t.ctypes.data, lengths.ctypes.data,
+                                   ml, reads, reason if bad != INF else None))
