@@ -846,11 +846,6 @@ class DedupEstimator:
             raise ValueError("sequence should consist only of ASCII characters.")
         self.add_record_array(_array_of_sequences([sequence]))
 
-    def set_shard(self, first_pair_index: int, table_bits: int = 22) -> None:
-        """This object sees pairs [first_pair_index, ...) of a job that other ranks share
-        (sequali_amd.dist.merge_insertsize joins them)."""
-        check(lib().sq_insertsize_set_shard(self._h, first_pair_index, table_bits))
-
     def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
         for s in (sequence1, sequence2):
             if not isinstance(s, str):
@@ -897,6 +892,11 @@ class InsertSizeMetrics:
             raise ValueError("record_array1 and record_array2 must be of the same size. "
                              f"Got {len(a1)} and {len(a2)} respectively.")
         check(lib().sq_insertsize_add_batch_pair(self._h, a1._device().handle, a2._device().handle))
+
+    def set_shard(self, first_pair_index: int, table_bits: int = 22) -> None:
+        """This object sees pairs [first_pair_index, ...) of a job that other ranks share
+        (sequali_amd.dist.merge_insertsize joins them)."""
+        check(lib().sq_insertsize_set_shard(self._h, first_pair_index, table_bits))
 
     def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
         for label, s in (("sequence1", sequence1), ("sequence2", sequence2)):

@@ -622,7 +622,7 @@ __global__ void k_dedup_gather(const unsigned long long *idx, uint64_t n_keep,
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_keep;
          e += (uint64_t)gridDim.x * blockDim.x) {
         out_hash[e] = hashes[idx[e]];
-        out_special[e] = special[idx[e]];
+        out_special[e] = special ? special[idx[e]] : 0;
     }
 }
 

@@ -87,3 +87,35 @@ def test_two_rank_merge_equals_single_process(tmp_path):
         want += [f, r]
     for i, w in enumerate(want):
         np.testing.assert_array_equal(got[f"t{i}"].astype(np.uint64), w, err_msg=f"table {i}")
+
+
+def _plumbing_worker(rank: int, world: int, port: int, out_dir: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sequali_amd.dist import _all_reduce, _broadcast_bytes, all_gather_ragged
+    mine = torch.arange(3 + 4 * rank, dtype=torch.int64) + 100 * rank          # ragged lengths
+    keys = torch.full((rank + 1, 32), rank + 1, dtype=torch.uint8)              # [n, 32] rows
+    got = all_gather_ragged(mine)
+    got_keys = all_gather_ragged(keys)
+    empty = all_gather_ragged(torch.zeros(0 if rank == 0 else 2, dtype=torch.int64))
+    state = _broadcast_bytes(b"state of rank 1 \x00\xff" if rank == 1 else b"", 1, None)
+    total = _all_reduce(torch.tensor([rank + 1, 10], dtype=torch.int64))
+    low = _all_reduce(torch.tensor([5 - rank]), dist.ReduceOp.MIN)
+    np.savez(os.path.join(out_dir, f"plumbing{rank}.npz"), got=got.numpy(), keys=got_keys.numpy(),
+             empty=empty.numpy(), state=np.frombuffer(state, np.uint8), total=total.numpy(), low=low.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_merge_plumbing_two_ranks(tmp_path):
+    """the collectives the order-dependent merges are built from (dist.merge_*): ragged
+    all-gather in rank order, byte broadcast for the estimator relay, reductions"""
+    world = 2
+    mp.spawn(_plumbing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        g = np.load(tmp_path / f"plumbing{rank}.npz")
+        assert g["got"].tolist() == [0, 1, 2, 100, 101, 102, 103, 104, 105, 106]
+        assert g["keys"].shape == (3, 32) and g["keys"][:, 0].tolist() == [1, 2, 2]
+        assert g["empty"].tolist() == [0, 0]
+        assert g["state"].tobytes() == b"state of rank 1 \x00\xff"
+        assert g["total"].tolist() == [3, 20] and g["low"].tolist() == [4]
