@@ -1557,7 +1557,7 @@ static void isz_free_table(IszTable &T)
     T = IszTable{};
 }
 
-static int isz_alloc_table(IszTable &T, uint32_t bits)
+static int isz_alloc_table(sq_ctx *ctx, IszTable &T, uint32_t bits)
 {
     const uint64_t size = 1ull << bits;
     T = IszTable{};
@@ -1570,12 +1570,14 @@ static int isz_alloc_table(IszTable &T, uint32_t bits)
     SQ_HIP(hipMalloc((void **)&T.n_distinct, 16));
     SQ_HIP(hipMalloc((void **)&T.overflow, 4));
     T.n_events = T.n_distinct + 1;
-    SQ_HIP(hipMemset(T.hash, 0, size * 8));
-    SQ_HIP(hipMemset(T.count, 0, size * 8));
-    SQ_HIP(hipMemset(T.rank, 0xFF, size * 8));
-    SQ_HIP(hipMemset(T.ready, 0, size * 4));
-    SQ_HIP(hipMemset(T.n_distinct, 0, 16));
-    SQ_HIP(hipMemset(T.overflow, 0, 4));
+    SQ_HIP(hipMemsetAsync(T.hash, 0, size * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(T.count, 0, size * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(T.rank, 0xFF, size * 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(T.ready, 0, size * 4, ctx->stream));
+    SQ_HIP(hipMemsetAsync(T.n_distinct, 0, 16, ctx->stream));
+    SQ_HIP(hipMemsetAsync(T.overflow, 0, 4, ctx->stream));
+    /* the module's kernels run on ctx->stream (non-blocking): order the clears on it */
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
     return SQ_OK;
 }
 
@@ -1590,9 +1592,9 @@ SQ_EXPORT sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters)
     z->max_adapters = max_adapters;
     z->table_size = 1ULL << (uint64_t)(log2(max_adapters * 1.5) + 1); /* :5525 */
     SQ_HIP_NULL(hipMalloc((void **)&z->d_max, 8));
-    SQ_HIP_NULL(hipMemset(z->d_max, 0, 8));
+    SQ_HIP_NULL(hipMemsetAsync(z->d_max, 0, 8, ctx->stream));
     for (int w = 0; w < 2; w++)
-        if (isz_alloc_table(z->tab[w], ISZ_TABLE_BITS) != SQ_OK) return nullptr;
+        if (isz_alloc_table(ctx, z->tab[w], ISZ_TABLE_BITS) != SQ_OK) return nullptr;
     return z;
 }
 
@@ -1798,7 +1800,7 @@ SQ_EXPORT int sq_insertsize_set_shard(sq_insertsize *z, uint64_t first_pair_inde
     for (int w = 0; w < 2; w++) {
         if (z->tab[w].mask + 1 == (1ull << table_bits)) continue;
         isz_free_table(z->tab[w]);
-        int rc = isz_alloc_table(z->tab[w], table_bits);
+        int rc = isz_alloc_table(z->ctx, z->tab[w], table_bits);
         if (rc) return rc;
     }
     z->shard = true;
@@ -1876,7 +1878,7 @@ SQ_EXPORT int sq_insertsize_shard_install(sq_insertsize *z, int read2, const uin
     while ((1ull << bits) < 2 * n) bits++;
     SQ_HIP(hipStreamSynchronize(z->ctx->stream));
     isz_free_table(z->tab[w]);
-    int rc = isz_alloc_table(z->tab[w], bits);
+    int rc = isz_alloc_table(z->ctx, z->tab[w], bits);
     if (rc) return rc;
     IszTable &T = z->tab[w];
     const uint64_t size = T.mask + 1;

@@ -582,247 +582,321 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
     }
 }
 
-/* ---- k_coop: the fused pass for the common case, one group per WORKGROUP -------------
- * Conditions (checked by the host): QCMetrics (+ AdapterCounter) without
- * PerTileQuality, every read of the batch has the same length U <= 512, records in
- * stored order, automaton in LDS.  Everything else runs k_pass.
- *
- * k_pass gives every wave its own 64 reads, so a read's consecutive 32-position
- * chunks are fetched ~12 us apart and a 64-byte sector shared by two chunks has
- * left the L2 by then: each sector is requested about twice and the pass is
- * bound by that request rate.  Here the four waves of a workgroup
- * share ONE group: a chunk is finished ~4x sooner, the sector's second touch hits
- * the L2, and the waves specialise:
- *     every wave   loads one quarter of each chunk (stream = wave / 2, rows = wave % 2),
- *                  two chunks ahead in registers, converts / pads, writes the LDS tile
- *     wave 0       the f64 error-rate chains in the reference's order   (lane = read)
- *     wave 1       GC / ACGT counts and the adapter automaton            (lane = read)
- *     waves 2, 3   the per-position histograms, 16 row pairs each        (lane = position)
- * Tiles are double buffered, so one workgroup barrier per chunk is enough. */
-constexpr uint32_t COOP_FIXED_WORDS = (136 * 8 + 96 * 8) / 4 + 104 + 96;
+/* ---- k_ring: the fused pass for uniform short reads, every 64-byte sector fetched once ----
+ * k_pass fetches a read's 32-position chunk from wherever it lies: a 64-byte sector is
+ * touched by two or three chunk loads some 10 us apart, has left the L2 in between and is
+ * fetched again (17.0 GB moved for 8.7 GB of records; 32-byte aligned
+ * records run 25 % faster through the same kernel).  Here the loads follow memory, not
+ * the read:
+ *   - a row (read) and stream (sequence / quality) is cut into 32-byte ALIGNED windows;
+ *     a lane owns 16 of those bytes (two lanes per row, two row sets, two streams) and
+ *     loads the two windows of a 64-byte sector back to back, one of them a step early,
+ *     so that the sector is requested once; the later window waits in registers;
+ *   - on its way to LDS a window is rotated into position space: whole dwords by the
+ *     address it is written to, the last 0-3 bytes by v_alignbyte with the neighbouring
+ *     lane's dword (DPP), so that the tile looks exactly as in k_pass;
+ *   - the tile is a ring of two windows (64 bytes) per row and stream, because a
+ *     32-position chunk straddles two aligned windows.
+ * 512 threads share one set of LDS histograms: 8 x 8 KB of rings + 11 KB of histograms is
+ * 80 KB, two workgroups (16 waves) per CU.  Conditions (the host checks them):
+ * QCMetrics (+ AdapterCounter, automaton in LDS), no PerTileQuality, one length U <= 512 for
+ * the whole batch, stored order, full groups; the rest goes through k_pass. */
+constexpr int RING_THREADS = 512, RING_WAVES = RING_THREADS / 64;
+constexpr uint32_t RING_ROW_WORDS = 16, RING_TILE_WORDS = 64 * RING_ROW_WORDS;
+
+/* ring address of position dword m of a row: the row's 16 dwords are XOR-ed with bits of
+ * the row so that "lane = row, same dword" (phase S) hits 32 different banks */
+__device__ __forceinline__ uint32_t ring_idx(uint32_t row, uint32_t m)
+{
+    return row * RING_ROW_WORDS + ((m & 15u) ^ ((row >> 1) & 15u));
+}
+
+/* value of the neighbouring lane (lane ^ 1) */
+__device__ __forceinline__ uint32_t swap_adjacent(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+}
 
 template <bool AD>
-__global__ void __launch_bounds__(WG_THREADS) k_coop(PassParams P)
+__global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     double *l_err = (double *)smem;                        /* [136] */
     double *l_thr = l_err + 136;                           /* [96] */
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
-    uint32_t *l_tiles = l_ps + 96;                         /* [2 buffers][seq, qual][TILE_WORDS] */
-    unsigned long long *l_off = (unsigned long long *)(l_tiles + 4 * TILE_WORDS); /* [seq, qual][64] */
-    uint32_t *l_cnt = (uint32_t *)(l_off + 128);           /* [gc, acgt][64], wave 1 -> wave 0 */
+    uint32_t *l_ring = l_ps + 96;                          /* [waves][seq, qual][RING_TILE_WORDS] */
     const uint32_t U = P.uniform_len, hs = hist_stride(U);
-    uint32_t *l_hist_base = l_cnt + 128;                   /* [5][hs] */
-    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12][hs] */
+    uint32_t *l_hist_base = l_ring + RING_WAVES * 2 * RING_TILE_WORDS; /* [5][hs] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;             /* [12][hs] */
     uint16_t *l_dfa = (uint16_t *)(l_hist_phred + hs * PHRED_COLS);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 136; i += WG_THREADS) {
+    for (int i = tid; i < 136; i += RING_THREADS) {
         double e;
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
         else if (i >= 128) e = 0.0;
         else e = __longlong_as_double(0x7FF8000000000000LL);
         l_err[i] = e;
     }
-    for (int i = tid; i < 96; i += WG_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
-    for (int i = tid; i < 104; i += WG_THREADS) l_gc[i] = 0;
-    for (int i = tid; i < 96; i += WG_THREADS) l_ps[i] = 0;
-    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += WG_THREADS) l_hist_base[i] = 0;
+    for (int i = tid; i < 96; i += RING_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+    for (int i = tid; i < 104; i += RING_THREADS) l_gc[i] = 0;
+    for (int i = tid; i < 96; i += RING_THREADS) l_ps[i] = 0;
+    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += RING_THREADS) l_hist_base[i] = 0;
     if (AD)
-        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += RING_THREADS) l_dfa[i] = P.dfa[i];
     __syncthreads();
 
-    const uint32_t nchunks = (U + CW - 1) / CW;
+    uint32_t *w_seq = l_ring + wave * 2 * RING_TILE_WORDS, *w_qual = w_seq + RING_TILE_WORDS;
+    const uint32_t nch = (U + CW - 1) / CW;
     const uint32_t Lmain = 4 * ((U - 1) / 4);
-    /* loader: this lane's 16 bytes of every chunk */
-    const uint32_t ld_stream = (uint32_t)wave >> 1;
-    const uint32_t ld_row = ((uint32_t)wave & 1) * 32 + ((uint32_t)lane >> 1), ld_piece = (uint32_t)lane & 1;
-    /* histogram waves: lanes 0-31 an even row, lanes 32-63 the odd row after it */
-    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
-    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2, row_base = half * ROW_WORDS;
-    const uint32_t pair0 = wave >= 2 ? ((uint32_t)wave - 2) * 16 : 0;
     const uint64_t ngroups = P.n / 64;
+    const uint64_t bufaddr = (uint64_t)(uintptr_t)P.buf;
+    /* phase H: lanes 0-31 an even row, lanes 32-63 the odd row after it */
+    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
+    /* loader: rows st_row and st_row + 32, bytes [16 k, 16 k + 16) of every window */
+    const uint32_t st_row = (uint32_t)lane >> 1, k16 = ((uint32_t)lane & 1) * 16;
 
-    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const uint64_t n_waves = (uint64_t)gridDim.x * RING_WAVES, wave_id = (uint64_t)blockIdx.x * RING_WAVES + wave;
+    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
         const uint64_t r = g * 64 + lane;
-        uint64_t qoff = 0;
-        if (wave == 0) {
-            const sq_meta m = P.metas[r];
-            qoff = m.record_start + m.qualities_offset;
-            l_off[lane] = m.record_start + m.sequence_offset;
-            l_off[64 + lane] = qoff;
-        }
-        __syncthreads();
-        const uint64_t my_off = l_off[ld_stream * 64 + ld_row];
-        const uint4 pad4 = ld_stream ? make_uint4(PAD4, PAD4, PAD4, PAD4)
-                                     : make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4);
-        auto issue = [&](uint32_t c) -> uint4 {
-            const uint32_t p0 = c * CW + ld_piece * 16;
-            if (p0 < U) return load16(P.buf, my_off + p0, P.buf_len);
-            return pad4;
-        };
-        uint4 pf_even = issue(0), pf_odd = nchunks > 1 ? issue(1) : pad4;
+        const sq_meta m = P.metas[r];
+        const uint64_t soff = m.record_start + m.sequence_offset, qoff = m.record_start + m.qualities_offset;
 
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0; /* wave 0 */
-        uint32_t st = 0, gc_cnt = 0, acgt_cnt = 0;             /* wave 1 */
+        /* per (row set, stream): the lane's 16 bytes of the next window to load, how many
+           windows hold bytes of the read, by how much the read is off its first window
+           (s = 4 t + sb: t whole dwords, handled by the ring address; sb bytes, by
+           v_alignbyte) and whether window 0 is the second half of its 64-byte sector.
+           A window with at least one byte of the read lies in a mapped page as a whole
+           (32-byte aligned), so these loads need no bounds checks; bytes that are not
+           the read's never reach a result. */
+        const uint8_t *nextp[2][2];
+        uint32_t nwin[2][2], sb_[2][2], par[2][2];
+        int mbase[2][2]; /* position dword of y[0] for window 0 */
+        uint4 R0[2][2], R1[2][2];
+        uint32_t last3[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int row = it * 32 + (int)st_row;
+            const uint64_t off[2] = {(uint64_t)__shfl((unsigned long long)soff, row),
+                                     (uint64_t)__shfl((unsigned long long)qoff, row)};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint64_t addr = bufaddr + off[q];
+                const uint32_t s = (uint32_t)addr & 31u;
+                nextp[it][q] = (const uint8_t *)(uintptr_t)(addr - s + k16);
+                nwin[it][q] = (s + U + 31u) >> 5;
+                sb_[it][q] = s & 3u;
+                par[it][q] = (uint32_t)(addr >> 5) & 1u;
+                mbase[it][q] = (int)(k16 >> 2) - 1 - (int)(s >> 2);
+                last3[it][q] = 0;
+            }
+        }
+        /* rotate window j into position space and write it to the ring */
+        /* rotate window j into position space and write it to the ring.  Every read has U
+           bases, so what lies behind the read's end needs no masking here: phase S pads the
+           one dword that straddles the end and nothing reads further */
+        auto stage = [&](int it, int q, uint32_t j, uint4 v, bool head) {
+            const uint32_t sb = sb_[it][q];
+            if (q == 0) {
+                v.x = cls2_of_dword(v.x); v.y = cls2_of_dword(v.y);
+                v.z = cls2_of_dword(v.z); v.w = cls2_of_dword(v.w);
+            }
+            /* the dword in front of mine: the other lane's last one, of this window (k = 1)
+               or of the window before (k = 0) */
+            const uint32_t other_now = swap_adjacent(v.w), other_before = swap_adjacent(last3[it][q]);
+            const uint32_t prev = k16 ? other_now : other_before;
+            last3[it][q] = v.w;
+            uint32_t y[4];
+            y[0] = __builtin_amdgcn_alignbyte(v.x, prev, sb);
+            y[1] = __builtin_amdgcn_alignbyte(v.y, v.x, sb);
+            y[2] = __builtin_amdgcn_alignbyte(v.z, v.y, sb);
+            y[3] = __builtin_amdgcn_alignbyte(v.w, v.z, sb);
+            /* y[i] = positions 4 m .. 4 m + 3 with m = m0 + i */
+            const int m0 = (int)(8 * j) + mbase[it][q];
+            uint32_t *trow = (q ? w_qual : w_seq) + ((uint32_t)it * 32 + st_row) * RING_ROW_WORDS;
+            const uint32_t swz = (((uint32_t)it * 32 + st_row) >> 1) & 15u;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (!head || m0 + i >= 0) trow[((uint32_t)(m0 + i) ^ swz) & 15u] = y[i];
+        };
+
+        /* prologue: window 0 goes to the ring; the registers are primed so that window 1 is
+           there at step 0: in R1 when it is the second half of window 0's sector, else in
+           R0 with its own second half in R1 */
+        {
+            uint4 T[2][2];
+#pragma unroll
+            for (int it = 0; it < 2; it++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const uint8_t *p0 = nextp[it][q];
+                    const uint32_t nw = nwin[it][q];
+                    T[it][q] = *(const uint4 *)p0;
+                    R0[it][q] = make_uint4(0, 0, 0, 0);
+                    R1[it][q] = make_uint4(0, 0, 0, 0);
+                    if (par[it][q]) {
+                        if (1 < nw) R0[it][q] = *(const uint4 *)(p0 + 32);
+                        if (2 < nw) R1[it][q] = *(const uint4 *)(p0 + 64);
+                        nextp[it][q] = p0 + 96;
+                    } else {
+                        if (1 < nw) R1[it][q] = *(const uint4 *)(p0 + 32);
+                        nextp[it][q] = p0 + 64;
+                    }
+                }
+#pragma unroll
+            for (int it = 0; it < 2; it++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) stage(it, q, 0, T[it][q], true);
+        }
+
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        uint32_t st = 0, gc_cnt = 0, acgt_cnt = 0;
         unsigned long long found = 0;
 
-        for (uint32_t c = 0; c < nchunks; c++) {
-            uint32_t *t_seq = l_tiles + (c & 1) * 2 * TILE_WORDS, *t_qual = t_seq + TILE_WORDS;
-            /* ---- stage this lane's 16 bytes of chunk c ---- */
+        for (uint32_t c = 0; c < nch; c++) {
+            /* ---------------- STAGE window c + 1 ---------------- */
             {
-                uint4 v = (c & 1) ? pf_odd : pf_even;
-                const uint32_t p0 = c * CW + ld_piece * 16;
-                if (p0 < U) {
-                    if (ld_stream == 0) {
-                        v.x = cls2_of_dword(v.x); v.y = cls2_of_dword(v.y);
-                        v.z = cls2_of_dword(v.z); v.w = cls2_of_dword(v.w);
+#pragma unroll
+                for (int it = 0; it < 2; it++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        /* second half of its sector: it waited in R1 and the next sector is due */
+                        const bool second = ((par[it][q] + c + 1) & 1u) != 0;
+                        uint4 v;
+                        v.x = second ? R1[it][q].x : R0[it][q].x;
+                        v.y = second ? R1[it][q].y : R0[it][q].y;
+                        v.z = second ? R1[it][q].z : R0[it][q].z;
+                        v.w = second ? R1[it][q].w : R0[it][q].w;
+                        stage(it, q, c + 1, v, false);
+                        if (second) {
+                            const uint8_t *pn = nextp[it][q];
+                            if (c + 2 < nwin[it][q]) R0[it][q] = *(const uint4 *)pn;
+                            if (c + 3 < nwin[it][q]) R1[it][q] = *(const uint4 *)(pn + 32);
+                            nextp[it][q] = pn + 64;
+                        }
                     }
-                    const int nv = (int)min(16u, U - p0);
-                    if (nv < 16) {
-                        v.x = pad_tail(v.x, nv, pad4.x); v.y = pad_tail(v.y, nv - 4, pad4.x);
-                        v.z = pad_tail(v.z, nv - 8, pad4.x); v.w = pad_tail(v.w, nv - 12, pad4.x);
-                    }
-                }
-                uint32_t *t = ld_stream ? t_qual : t_seq;
-                const uint32_t d0 = ld_piece * 4;
-                t[tile_idx(ld_row, d0 + 0)] = v.x;
-                t[tile_idx(ld_row, d0 + 1)] = v.y;
-                t[tile_idx(ld_row, d0 + 2)] = v.z;
-                t[tile_idx(ld_row, d0 + 3)] = v.w;
-                if (c + 2 < nchunks) { /* refill the register that was just consumed */
-                    const uint4 nx = issue(c + 2);
-                    if (c & 1) pf_odd = nx; else pf_even = nx;
-                }
             }
-            /* workgroup barrier for the LDS tile only: __syncthreads() would also wait for
-               vmcnt(0) and drain the loads that were just issued for chunk c + 2 */
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 
-            const uint32_t nd = min(ROW_WORDS, (U - c * CW + 3) / 4);
-            if (wave == 0) {
-                /* the four interleaved chains of _qcmodule.c:2062-2097 */
-                for (uint32_t d = 0; d < nd; d++) {
-                    uint32_t qd = t_qual[tile_idx((uint32_t)lane, d)];
-                    qd = c * CW + d * 4 < Lmain ? qd : PAD4;
-                    const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
-                    const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
-                    acc0 += e0;
-                    acc1 += e1;
-                    acc2 += e2;
-                    acc3 += e3;
-                }
-            } else if (wave == 1) {
-                for (uint32_t d = 0; d < nd; d++) {
-                    const uint32_t sd = t_seq[tile_idx((uint32_t)lane, d)];
-                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
-                    acgt_cnt += __popc(~sd & 0x08080808u);
-                    if (AD) {
-                        uint32_t e[4];
+            /* ---------------- phase S: lane = read ---------------- */
+            const uint32_t c0 = c * CW;
+            const uint32_t nd = min(ROW_WORDS, (U - c0 + 3) / 4);
+            for (uint32_t d = 0; d < nd; d++) {
+                const uint32_t pos0 = c0 + d * 4;
+                const uint32_t ti = ring_idx((uint32_t)lane, 8 * c + d);
+                uint32_t sd = w_seq[ti];
+                if (pos0 + 4 > U) sd = pad_tail(sd, (int)(U - pos0), CLS2_PAD4); /* the dword at the end */
+                uint32_t qd = w_qual[ti];
+                qd = pos0 < Lmain ? qd : PAD4; /* the four chains stop four short of the end (:2068) */
+                const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
+                const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
+                acc0 += e0;
+                acc1 += e1;
+                acc2 += e2;
+                acc3 += e3;
+                gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                acgt_cnt += __popc(~sd & 0x08080808u);
+                if (AD) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
+                        e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
+                        st = e[j] & 0xFFF0u;
+                    }
+                    if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
+                        /* update_adapter_count_array, _qcmodule.c:2643-2672 */
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
-                            e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
-                            st = e[j] & 0xFFF0u;
-                        }
-                        if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
-                            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                if (!(e[j] & 1u)) continue;
-                                unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
-                                found |= hits;
-                                const uint32_t pos = c * CW + d * 4 + j;
-                                while (hits) {
-                                    const int a = __ffsll((long long)hits) - 1;
-                                    hits &= hits - 1;
-                                    const uint32_t start = pos - P.ad_len[a] + 1;
-                                    atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
-                                    atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
-                                }
+                            if (!(e[j] & 1u)) continue;
+                            unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                            found |= hits;
+                            const uint32_t pos = pos0 + j;
+                            while (hits) {
+                                const int a = __ffsll((long long)hits) - 1;
+                                hits &= hits - 1;
+                                const uint32_t start = pos - P.ad_len[a] + 1;
+                                atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                                atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
                             }
                         }
                     }
                 }
-            } else {
-                const uint32_t p = c * CW + pl;
-                if (p < U) {
-                    uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
+            }
+
+            /* ---------------- phase H: lane = position, two rows at a time ---------------- */
+            const uint32_t p = c0 + pl;
+            if (p < U) {
+                uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
+                const uint32_t mm = (8 * c + h_dw) & 15u;
 #pragma unroll
-                    for (uint32_t rp0 = 0; rp0 < 16; rp0 += 4) {
-                        uint32_t sw[4], qw[4];
+                for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                    uint32_t sw[4], qw[4];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) {
-                            const uint32_t rp = pair0 + rp0 + k;
-                            const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
-                            sw[k] = t_seq[ti];
-                            qw[k] = t_qual[ti];
-                        }
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t rp = rp0 + k;
+                        const uint32_t ti = (2 * rp + half) * RING_ROW_WORDS + (mm ^ (rp & 15u));
+                        sw[k] = w_seq[ti];
+                        qw[k] = w_qual[ti];
+                    }
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) {
-                            const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
-                            const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
-                            atomicAdd(&hb[cls * hs], 1u);
-                            atomicAdd(&hp[bin * hs], 1u);
-                        }
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
+                        const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
+                        atomicAdd(&hb[cls * hs], 1u);
+                        atomicAdd(&hp[bin * hs], 1u);
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
 
-        /* ---- per-read epilogue (wave 0), with wave 1's base counts ---- */
-        if (wave == 1) {
-            l_cnt[lane] = gc_cnt;
-            l_cnt[64 + lane] = acgt_cnt;
+        /* ---------------- per-read epilogue: lane = read ---------------- */
+        double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099 */
+        for (uint32_t pos = Lmain; pos < U; pos++) { /* :2100-2112 */
+            const uint32_t qb = P.buf[qoff + pos];
+            total += l_err[qb < 128 ? qb : 0];
         }
-        __syncthreads();
-        if (wave == 0) {
-            double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099 */
-            for (uint32_t pos = Lmain; pos < U; pos++) { /* :2100-2112 */
-                const uint32_t qb = P.buf[qoff + pos];
-                total += l_err[qb < 128 ? qb : 0];
-            }
-            P.metas[r].accumulated_error_rate = total; /* :2126 */
-            if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
-            const uint32_t gc = l_cnt[lane], acgt = l_cnt[64 + lane];
-            if (acgt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc * 100.0 / (double)acgt)], 1u);
-            const double avg = total / (double)U;
-            uint32_t lo = 0, hi = 93;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
-            }
-            atomicAdd(&l_ps[lo], 1u);
+        P.metas[r].accumulated_error_rate = total; /* :2126 */
+        if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+        if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+        const double avg = total / (double)U;
+        uint32_t lo = 0, hi = 93;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
         }
+        atomicAdd(&l_ps[lo], 1u);
     }
 
     /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
     __syncthreads();
     const uint32_t ean = min(P.ea_len, U);
-    for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
+    for (uint32_t i = tid; i < hs * BASE_COLS; i += RING_THREADS) {
         const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
         if (!v) continue;
         atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
         if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + c], (unsigned long long)v);
     }
-    for (uint32_t i = tid; i < hs * PHRED_COLS; i += WG_THREADS) {
+    for (uint32_t i = tid; i < hs * PHRED_COLS; i += RING_THREADS) {
         const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
         if (!v) continue;
         atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
         if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + c], (unsigned long long)v);
     }
-    for (uint32_t i = tid; i < 101; i += WG_THREADS)
+    for (uint32_t i = tid; i < 101; i += RING_THREADS)
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
-    for (uint32_t i = tid; i < 94; i += WG_THREADS)
+    for (uint32_t i = tid; i < 94; i += RING_THREADS)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
-size_t coop_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
+size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
 {
-    size_t b = COOP_FIXED_WORDS * 4 + 4 * TILE_WORDS * 4 + 128 * 8 + 128 * 4;
+    size_t b = FIXED_BYTES + (size_t)RING_WAVES * 2 * RING_TILE_WORDS * 4;
     b += (size_t)hist_stride(uniform_len) * (BASE_COLS + PHRED_COLS) * 4;
     if (ad) b += (size_t)dfa_states * 16;
     return b + 16;
@@ -1553,21 +1627,30 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             dfa_lds = states <= DFA_LDS_MAX_STATES;
         }
         if (!qc && !pt && !ad) break;
-        /* QCMetrics alone on uniform short reads runs one group per workgroup (k_coop, +22 %);
-           with the automaton in the pass its dependent table steps want a sequential chain
-           per wave, 16 per CU, and k_pass wins (302 vs 680 Gbases/s measured; SQ_COOP=1 forces
-           k_coop for experiments).  A trailing partial group goes through k_pass. */
-        const bool coop = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && !getenv("SQ_NO_COOP") &&
-                          (!ad || (dfa_lds && getenv("SQ_COOP")));
+        /* Uniform short reads: k_ring fetches every 64-byte sector once (1.07 x the
+           algorithmic bytes against 1.85 x for k_pass).  QCMetrics alone gains 17 % from it;
+           with the adapter automaton in the pass the sequential table walk is what binds,
+           not the fetch, and k_pass (smaller tiles, more LDS left) is 3 % ahead, so the
+           automaton keeps k_pass unless SQ_RING=1 (SQ_NO_RING=1: never k_ring).  A trailing
+           partial group goes through k_pass. */
         PassParams Pfull = P;
-        if (coop) {
+        const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states);
+        const bool ring = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && rlds <= 160 * 1024 &&
+                          !getenv("SQ_NO_RING") && (!ad || (dfa_lds && getenv("SQ_RING")));
+        if (ring) {
             PassParams C = P;
             C.n = (b->n / 64) * 64;
-            const size_t clds = coop_lds_bytes(P.uniform_len, ad, states);
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, (160 * 1024) / clds));
-            const int cgrid = (int)std::min<uint64_t>(C.n / 64, (uint64_t)ctx->num_cus * per_cu);
-            if (ad) hipLaunchKernelGGL((k_coop<true>), dim3(cgrid), dim3(WG_THREADS), clds, ctx->stream, C);
-            else hipLaunchKernelGGL((k_coop<false>), dim3(cgrid), dim3(WG_THREADS), clds, ctx->stream, C);
+            const int per_cu = rlds <= 80 * 1024 ? 2 : 1;
+            const uint64_t want = (C.n / 64 + RING_WAVES - 1) / RING_WAVES;
+            const int rgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus * per_cu));
+            static bool attr_set = false;
+            if (!attr_set) {
+                SQ_HIP(hipFuncSetAttribute((const void *)k_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                SQ_HIP(hipFuncSetAttribute((const void *)k_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            if (ad) hipLaunchKernelGGL((k_ring<true>), dim3(rgrid), dim3(RING_THREADS), rlds, ctx->stream, C);
+            else hipLaunchKernelGGL((k_ring<false>), dim3(rgrid), dim3(RING_THREADS), rlds, ctx->stream, C);
             SQ_HIP(hipGetLastError());
             if (C.n == b->n) continue;
             P.metas = b->d_metas + C.n;
@@ -1580,7 +1663,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         int grid = grid_for(ctx, b->n, wgs_per_cu);
         dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);
         SQ_HIP(hipGetLastError());
-        if (coop) P = Pfull;
+        if (ring) P = Pfull;
         if (qc && P.window) {
             const uint64_t rows = P.win_rows;
             hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 5 + 255) / 256, 4096)),

@@ -269,7 +269,9 @@ def test_nanopore_long_reads_all_modules():
 
 def test_two_million_reads_all_tables_equal_oracle():
     """bench-shaped input at a size the oracle still finishes in seconds: 2 M x 150 bp
-    generated in HBM, one fused launch (k_pass) and one QCMetrics-only launch (k_coop)"""
+    generated in HBM, one fused launch (k_pass), one QCMetrics-only launch (k_ring) and one
+    fused launch forced through k_ring (SQ_RING=1)"""
+    import os
     from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
     n = 2_000_000
     dev = synth.device_array(synth.ILLUMINA, 12345, n)
@@ -282,7 +284,17 @@ def test_two_million_reads_all_tables_equal_oracle():
     FusedPass(gq, ga).add_record_array(dev)
     errs = dev.accumulated_error_rates()
     gq2.add_record_array(dev)
-    for g in (gq, gq2):
+    gq3, ga3 = QCMetrics(), AdapterCounter(probes)
+    os.environ["SQ_RING"] = "1"
+    try:
+        FusedPass(gq3, ga3).add_record_array(dev)
+        gq3.flush()
+    finally:
+        del os.environ["SQ_RING"]
+    for (_, f, r), (_, fr, rr) in zip(ga3.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    for g in (gq, gq2, gq3):
         np.testing.assert_array_equal(u64(g.base_count_table()), rq.base_count_table())
         np.testing.assert_array_equal(u64(g.phred_count_table()), rq.phred_count_table())
         np.testing.assert_array_equal(u64(g.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
@@ -296,3 +308,47 @@ def test_two_million_reads_all_tables_equal_oracle():
         np.testing.assert_array_equal(u64(f), fr)
         np.testing.assert_array_equal(u64(r), rr)
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 50_000
+
+
+@pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
+def test_ring_kernel_every_alignment(U):
+    """k_ring cuts a read into 32-byte aligned windows and rotates them back in registers:
+    every length class and every start alignment (names of rotating length, so sequence
+    and quality starts walk through all residues mod 64), full groups plus a remainder,
+    with and without the automaton in the pass"""
+    import os
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(1000 + U)
+    n = 64 * 5 + 37
+    probes = ["ACGTACGTACGT"[:min(U, 12)], "GGGGG"[:min(U, 5)], "TTNAC"[:min(U, 5)]]
+    names, seqs, quals = [], [], []
+    for i in range(n):
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=U, p=[.24, .24, .24, .24, .04]).tobytes().decode()
+        if U >= 12 and i % 3 == 0:
+            at = int(rng.integers(0, U - 11))
+            s = s[:at] + "ACGTACGTACGT" + s[at + 12:]
+        names.append("r" * (1 + i % 67))
+        seqs.append(s)
+        quals.append((rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    for forced in (False, True):
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(), AdapterCounter(probes)
+        if forced:
+            os.environ["SQ_RING"] = "1"
+        try:
+            if forced:
+                FusedPass(gq, ga).add_record_array(arr)
+            else:
+                gq.add_record_array(arr)
+            gq.flush()
+        finally:
+            os.environ.pop("SQ_RING", None)
+        compare_qc(rq, gq, metas, arr)
+        if forced:
+            for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+                np.testing.assert_array_equal(u64(f), fr)
+                np.testing.assert_array_equal(u64(r), rr)
