@@ -36,6 +36,8 @@ extern "C" {
 #define SQ_ERR_TYPE (-4)          /* TypeError                                            */
 #define SQ_ERR_EOF (-5)           /* EOFError: incomplete record at the end of the file   */
 #define SQ_ERR_OVERFLOW (-6)      /* OverflowError                                        */
+#define SQ_ERR_RUNTIME (-7)       /* RuntimeError raised by the reference itself          */
+#define SQ_ERR_SYSTEM (-8)        /* the reference returns NULL without an exception set  */
 
 #define SQ_NUMBER_OF_NUCS 5       /* NUC_TABLE_SIZE   _qcmodule.c:1766 */
 #define SQ_NUMBER_OF_PHREDS 12    /* PHRED_TABLE_SIZE _qcmodule.c:1768 */
@@ -234,6 +236,36 @@ int64_t sq_insertsize_insert_sizes(sq_insertsize *z, uint64_t *out, size_t cap);
 /* adapters_read1/2 :5923-5944, slot order: bytes is [n][31] zero padded */
 int64_t sq_insertsize_adapters(sq_insertsize *z, int read2, uint8_t *bytes, uint8_t *lengths,
                                uint64_t *counts, size_t cap);
+
+/* ---- NanoStats, _qcmodule.c:4804-5430 ------------------------- */
+/* struct NanoInfo :4808-4815 */
+typedef struct sq_nanoinfo {
+    int64_t start_time;           /* unix UTC seconds */
+    float duration;
+    int32_t channel_id;
+    uint32_t length;
+    uint32_t pad_;
+    double cumulative_error_rate; /* FastqMeta.accumulated_error_rate of the read (:5314) */
+    uint64_t parent_id_hash;
+} sq_nanoinfo;
+typedef struct sq_nanostats sq_nanostats;
+sq_nanostats *sq_nanostats_new(sq_ctx *ctx);
+void sq_nanostats_free(sq_nanostats *s);
+/* add_record_array :5357; SQ_ERR_VALUE / SQ_ERR_RUNTIME / SQ_ERR_SYSTEM with the reference's
+ * message when a record's tags are malformed (records in front of it stay counted); a header
+ * without ch= / start_time= stops the module for good without an error (:5302-5312).
+ * Run it after the QCMetrics pass of the same batch: it reads accumulated_error_rate. */
+int sq_nanostats_add(sq_nanostats *s, const uint8_t *buf, size_t buf_len, const sq_meta *metas, size_t n);
+int sq_nanostats_add_batch(sq_nanostats *s, sq_batch *b);
+uint64_t sq_nanostats_number_of_reads(sq_nanostats *s);     /* members :5416-5428 */
+int64_t sq_nanostats_minimum_time(sq_nanostats *s);
+int64_t sq_nanostats_maximum_time(sq_nanostats *s);
+const char *sq_nanostats_skipped_reason(sq_nanostats *s);
+/* nano_info_iterator :5403: the NanoInfo of every counted read, in read order */
+int64_t sq_nanostats_infos(sq_nanostats *s, sq_nanoinfo *out, size_t cap);
+/* the "pi tag should have a valid uuid4 format" warnings (:5247) of the last add: the
+ * counted length of each */
+int64_t sq_nanostats_last_warnings(sq_nanostats *s, uint64_t *lengths, size_t cap);
 
 /* ---- multi-GPU: the order-dependent modules across shards ------ */
 /* One rank owns a contiguous range of the job's records.  What the reference makes

@@ -84,6 +84,13 @@ def _load() -> C.CDLL:
         "oq_isz_get_sizes": (None, [vp, vp]),
         "oq_isz_get_adapters": (sz, [vp, C.c_int, vp, vp, vp]),
         "oq_names_are_mates": (C.c_int, [u8p, sz, u8p, sz]),
+        "oq_nano_new": (vp, []), "oq_nano_free": (None, [vp]),
+        "oq_nano_add": (C.c_int, [vp, u8p, sz, vp, sz]),
+        "oq_nano_number_of_reads": (u64, [vp]), "oq_nano_skipped": (C.c_int, [vp]),
+        "oq_nano_skipped_record": (i64, [vp]), "oq_nano_min_time": (i64, [vp]),
+        "oq_nano_max_time": (i64, [vp]), "oq_nano_pi_warnings": (u64, [vp]),
+        "oq_nano_error_record": (i64, [vp]), "oq_nano_error_chars": (None, [vp, vp]),
+        "oq_nano_get": (None, [vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -121,6 +128,73 @@ def make_batch(names: Sequence[str], seqs: Sequence[str], quals: Sequence[str]
         parts.append(rec)
         pos += len(rec)
     return b"".join(parts), metas
+
+
+def make_view_batch(names: Sequence[str], seqs: Sequence[str], quals: Sequence[str],
+                    tags: Sequence[bytes]) -> Tuple[bytes, np.ndarray]:
+    """name|sequence|qualities|tags back to back: the layout FastqRecordArrayView builds
+    from FastqRecordView objects (_qcmodule.c:640-690) and BamParser produces."""
+    parts: List[bytes] = []
+    metas = np.zeros(len(names), dtype=META_DTYPE)
+    pos = 0
+    for i, (n, s, q, t) in enumerate(zip(names, seqs, quals, tags)):
+        nb, sb, qb = n.encode("ascii"), s.encode("ascii"), q.encode("ascii")
+        metas[i] = (pos, len(nb), len(nb), len(sb), len(nb) + len(sb), len(nb) + 2 * len(sb), len(t), 0.0)
+        parts += [nb, sb, qb, bytes(t)]
+        pos += len(nb) + 2 * len(sb) + len(t)
+    return b"".join(parts), metas
+
+
+NANOINFO_DTYPE = np.dtype([("start_time", "<i8"), ("duration", "<f4"), ("channel_id", "<i4"),
+                           ("length", "<u4"), ("pad", "<u4"), ("cumulative_error_rate", "<f8"),
+                           ("parent_id_hash", "<u8")])
+assert NANOINFO_DTYPE.itemsize == 40
+
+
+class NanoStatsError(Exception):
+    """code: 1 truncated tags, 2 invalid array type, 3 unknown tag type (ValueError in the
+    reference), 4 wrong typecode (RuntimeError), 5 ch tag that is not an integer"""
+
+    def __init__(self, code: int, record: int, chars: bytes):
+        super().__init__(f"NanoStats error {code} at record {record}: {chars!r}")
+        self.code, self.record, self.chars = code, record, chars
+
+
+class NanoStats:
+    """_qcmodule.c:4804-5430"""
+
+    def __init__(self):
+        self._h = LIB.oq_nano_new()
+
+    def __del__(self):
+        LIB.oq_nano_free(self._h)
+
+    def add(self, buf, metas: np.ndarray) -> None:
+        """metas carry accumulated_error_rate (QCMetrics ran before, :5314)"""
+        code = LIB.oq_nano_add(self._h, _ptr(buf), len(buf), metas.ctypes.data, len(metas))
+        if code:
+            chars = (C.c_uint8 * 3)()
+            LIB.oq_nano_error_chars(self._h, chars)
+            raise NanoStatsError(code, LIB.oq_nano_error_record(self._h), bytes(chars))
+
+    @property
+    def number_of_reads(self): return LIB.oq_nano_number_of_reads(self._h)
+    @property
+    def skipped(self) -> bool: return bool(LIB.oq_nano_skipped(self._h))
+    @property
+    def skipped_record(self) -> int: return LIB.oq_nano_skipped_record(self._h)
+    @property
+    def minimum_time(self): return LIB.oq_nano_min_time(self._h)
+    @property
+    def maximum_time(self): return LIB.oq_nano_max_time(self._h)
+    @property
+    def pi_warnings(self): return LIB.oq_nano_pi_warnings(self._h)
+
+    def nano_infos(self) -> np.ndarray:
+        out = np.zeros(self.number_of_reads, dtype=NANOINFO_DTYPE)
+        if len(out):
+            LIB.oq_nano_get(self._h, out.ctypes.data)
+        return out
 
 
 class ValueErrorWithIndex(ValueError):

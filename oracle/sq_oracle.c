@@ -1094,3 +1094,276 @@ oq_names_are_mates(const uint8_t *n1, size_t l1, const uint8_t *n2, size_t l2)
         id -= 1;
     return memcmp(n1, n2, id) == 0;
 }
+
+/* ================================ NanoStats ==================================
+ * _qcmodule.c:4804-5430.  One oq_nanoinfo per counted read. */
+typedef struct {
+    int64_t start_time;            /* struct NanoInfo :4808-4815 */
+    float duration;
+    int32_t channel_id;
+    uint32_t length;
+    uint32_t pad_;
+    double cumulative_error_rate;
+    uint64_t parent_id_hash;
+} oq_nanoinfo;
+
+/* error codes of oq_nano_add: which exception the reference raises */
+enum {
+    OQ_NANO_OK = 0,
+    OQ_NANO_TRUNCATED = 1,      /* ValueError "truncated tags" :5080,5092,5125,5138 */
+    OQ_NANO_ARRAY_TYPE = 2,     /* ValueError "Invalid type for array %c" :5118 */
+    OQ_NANO_UNKNOWN_TYPE = 3,   /* ValueError "Unknown tag type %c" :5133 */
+    OQ_NANO_WRONG_TYPECODE = 4, /* RuntimeError "Wrong tag type for '%s' expected '%c' got '%c'" :5193 */
+    OQ_NANO_CH_NOT_INT = 5,     /* -1 without an exception set (:5221): SystemError */
+};
+
+typedef struct {
+    int skipped;
+    int64_t skipped_record;     /* index (over all records given) of the unparsable header */
+    uint64_t number_of_reads, records_seen, cap;
+    oq_nanoinfo *infos;
+    int64_t min_time, max_time;
+    uint64_t pi_warnings;       /* UserWarning "pi tag should have a valid uuid4 format" :5247 */
+    int error_code;             /* of the record that stopped the last add */
+    int64_t error_record;
+    uint8_t error_chars[3];     /* tag id / typecodes for the message */
+} oq_nano;
+
+/* :159-180 */
+static int64_t
+oq_nano_decimal(const uint8_t *s, size_t n, const uint8_t *end)
+{
+    if (n < 1 || n > 18) return -1;
+    uint64_t r = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t c = s + i < end ? s[i] : 0; /* past the buffer reads as NUL here */
+        c -= '0';
+        if (c > 9) return -1;
+        r = r * 10 + c;
+    }
+    return (int64_t)r;
+}
+
+/* :247-262 */
+static int64_t
+oq_posix_gm_time(int64_t year, int64_t month, int64_t mday, int64_t hour, int64_t minute, int64_t second)
+{
+    static const int mday_to_yday[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
+    if (year < 1970 || month < 1 || month > 12) return -1;
+    year -= 1900;
+    int64_t yday = mday_to_yday[month - 1] + mday - 1;
+    return second + minute * 60 + hour * 3600 + yday * 86400 + (year - 70) * 31536000 +
+           ((year - 69) / 4) * 86400 - ((year - 1) / 100) * 86400 + ((year + 299) / 400) * 86400;
+}
+
+/* :271-322; `end` bounds the batch buffer (the reference reads on regardless) */
+static int64_t
+oq_time_string_to_timestamp(const uint8_t *s, const uint8_t *end)
+{
+#define OQ_AT(i) ((s + (i)) < end ? s[i] : 0)
+    int64_t year = oq_nano_decimal(s, 4, end), month = oq_nano_decimal(s + 5, 2, end);
+    int64_t day = oq_nano_decimal(s + 8, 2, end), hour = oq_nano_decimal(s + 11, 2, end);
+    int64_t minute = oq_nano_decimal(s + 14, 2, end), second = oq_nano_decimal(s + 17, 2, end);
+    if ((year | month | day | hour | minute | second) < 0 || OQ_AT(4) != '-' || OQ_AT(7) != '-' ||
+        OQ_AT(10) != 'T' || OQ_AT(13) != ':' || OQ_AT(16) != ':')
+        return -1;
+    size_t tz = 19;
+    if (OQ_AT(tz) == '.') {
+        size_t digits = 0;
+        while (OQ_AT(20 + digits) >= '0' && OQ_AT(20 + digits) <= '9') digits++;
+        tz += digits + 1;
+    }
+    switch (OQ_AT(tz)) {
+        case 'Z': break;
+        case '+':
+        case '-': {
+            int64_t oh = oq_nano_decimal(s + tz + 1, 2, end), om = oq_nano_decimal(s + tz + 4, 2, end);
+            if ((oh | om) < 0 || OQ_AT(tz + 3) != ':') return -1;
+            if (OQ_AT(tz) == '+') { hour += oh; minute += om; }
+            else { hour -= oh; minute -= om; }
+            break;
+        }
+        default: return -1;
+    }
+#undef OQ_AT
+    return oq_posix_gm_time(year, month, day, hour, minute, second);
+}
+
+/* NanoInfo_from_header :5005-5052 */
+static int
+oq_nano_from_header(const uint8_t *header, size_t n, const uint8_t *buf_end, oq_nanoinfo *info)
+{
+    const uint8_t *end = header + n;
+    const uint8_t *cursor = memchr(header, ' ', n);
+    if (!cursor) return -1;
+    cursor++;
+    int32_t channel = -1;
+    int64_t start = -1;
+    while (cursor < end) {
+        const uint8_t *name = cursor;
+        const uint8_t *eq = memchr(name, '=', end - name);
+        if (!eq) return -1;
+        size_t name_len = eq - name;
+        const uint8_t *value = eq + 1;
+        const uint8_t *value_end = memchr(value, ' ', end - value);
+        if (!value_end) value_end = end;
+        cursor = value_end + 1;
+        if (name_len == 2 && memcmp(name, "ch", 2) == 0)
+            channel = (int32_t)oq_nano_decimal(value, value_end - value, buf_end);
+        else if (name_len == 10 && memcmp(name, "start_time", 10) == 0)
+            start = oq_time_string_to_timestamp(value, buf_end);
+    }
+    if (channel == -1 || start == -1) return -1;
+    info->channel_id = channel;
+    info->start_time = start;
+    return 0;
+}
+
+/* tag_length :5077-5143; returns -1 and sets *err */
+static int64_t
+oq_tag_length(const uint8_t *tag, size_t max, int *err, uint8_t *err_char)
+{
+    if (max < 4) { *err = OQ_NANO_TRUNCATED; return -1; }
+    uint8_t type = tag[2];
+    const uint8_t *value = tag + 3;
+    size_t value_len;
+    int is_array = 0;
+    uint32_t count = 1;
+    if (type == 'B') {
+        is_array = 1;
+        value = tag + 8;
+        type = tag[3];
+        if (max < 8) { *err = OQ_NANO_TRUNCATED; return -1; }
+        memcpy(&count, tag + 4, 4);
+    }
+    switch (type) {
+        case 'A': case 'c': case 'C': value_len = 1; break;
+        case 's': case 'S': value_len = 2; break;
+        case 'I': case 'i': case 'f': value_len = 4; break;
+        case 'Z': case 'H': {
+            if (is_array) { *err = OQ_NANO_ARRAY_TYPE; *err_char = type; return -1; }
+            const uint8_t *z = memchr(value, 0, max - 3);
+            if (!z) { *err = OQ_NANO_TRUNCATED; return -1; }
+            value_len = (size_t)(z - value) + 1;
+            break;
+        }
+        default: *err = OQ_NANO_UNKNOWN_TYPE; *err_char = type; return -1;
+    }
+    size_t len = (size_t)(value - tag) + (size_t)count * value_len;
+    if (len > max) { *err = OQ_NANO_TRUNCATED; return -1; }
+    return (int64_t)len;
+}
+
+/* uuid4_hash :5155-5182 */
+static uint64_t
+oq_uuid4_hash(const uint8_t *u)
+{
+    if (u[8] != '-' || u[13] != '-' || u[14] != '4' || u[18] != '-' || u[23] != '-' || u[36] != 0) return 0;
+    uint64_t first = 0, last = 0;
+    for (int i = 0; i < 8; i++) { /* strtoull(uuid, &end, 16) must stop at position 8 */
+        uint8_t c = u[i];
+        int v = c >= '0' && c <= '9' ? c - '0' : (c | 0x20) >= 'a' && (c | 0x20) <= 'f' ? (c | 0x20) - 'a' + 10 : -1;
+        if (v < 0) return 0;
+        first = first * 16 + (uint64_t)v;
+    }
+    for (int i = 28; i < 36; i++) { /* strtoull(uuid + 28, ...) must run to the end */
+        uint8_t c = u[i];
+        int v = c >= '0' && c <= '9' ? c - '0' : (c | 0x20) >= 'a' && (c | 0x20) <= 'f' ? (c | 0x20) - 'a' + 10 : -1;
+        if (v < 0) return 0;
+        last = last * 16 + (uint64_t)v;
+    }
+    return (first << 32) | (last & 0xFFFFFFFFULL);
+}
+
+/* TagInfo_from_tags :5205-5259 */
+static int
+oq_nano_from_tags(oq_nano *s, const uint8_t *tags, size_t n, const uint8_t *buf_end, oq_nanoinfo *info)
+{
+    info->channel_id = -1;
+    info->duration = 0.0f;
+    info->start_time = 0;
+    info->parent_id_hash = 0;
+    while (n > 0) {
+        int err = 0;
+        uint8_t ch = 0;
+        int64_t len = oq_tag_length(tags, n, &err, &ch);
+        if (len < 0) { s->error_code = err; s->error_chars[0] = ch; return -1; }
+        uint8_t type = tags[2];
+        if (memcmp(tags, "ch", 2) == 0) {
+            int64_t v;
+            switch (type) { /* get_tag_int_value :5054-5075 */
+                case 'c': v = (int8_t)tags[3]; break;
+                case 'C': v = tags[3]; break;
+                case 's': { int16_t t; memcpy(&t, tags + 3, 2); v = t; break; }
+                case 'S': { uint16_t t; memcpy(&t, tags + 3, 2); v = t; break; }
+                case 'i': { int32_t t; memcpy(&t, tags + 3, 4); v = t; break; }
+                case 'I': { uint32_t t; memcpy(&t, tags + 3, 4); v = t; break; }
+                default: s->error_code = OQ_NANO_CH_NOT_INT; return -1;
+            }
+            info->channel_id = (int32_t)v;
+        } else if (memcmp(tags, "st", 2) == 0) {
+            if (type != 'Z') { s->error_code = OQ_NANO_WRONG_TYPECODE; memcpy(s->error_chars, "st", 2); s->error_chars[2] = type; return -1; }
+            info->start_time = oq_time_string_to_timestamp(tags + 3, buf_end);
+        } else if (memcmp(tags, "du", 2) == 0) {
+            if (type != 'f') { s->error_code = OQ_NANO_WRONG_TYPECODE; memcpy(s->error_chars, "du", 2); s->error_chars[2] = type; return -1; }
+            memcpy(&info->duration, tags + 3, 4);
+        } else if (memcmp(tags, "pi", 2) == 0) {
+            if (type != 'Z') { s->error_code = OQ_NANO_WRONG_TYPECODE; memcpy(s->error_chars, "pi", 2); s->error_chars[2] = type; return -1; }
+            if (len - 4 != 36) s->pi_warnings++;
+            else info->parent_id_hash = oq_uuid4_hash(tags + 3);
+        }
+        tags += len;
+        n -= (size_t)len;
+    }
+    return 0;
+}
+
+oq_nano *oq_nano_new(void) { return (oq_nano *)calloc(1, sizeof(oq_nano)); }
+void oq_nano_free(oq_nano *s) { if (s) { free(s->infos); free(s); } }
+
+/* NanoStats_add_meta :5269-5324 over a batch; returns 0 or the error code of the record
+ * that stopped it (records in front of it stay counted, :5367-5372) */
+int
+oq_nano_add(oq_nano *s, const uint8_t *buf, size_t buf_len, const oq_meta *metas, size_t n)
+{
+    s->error_code = 0;
+    for (size_t i = 0; i < n; i++, s->records_seen++) {
+        if (s->skipped) continue;
+        const oq_meta *m = &metas[i];
+        if (s->number_of_reads == s->cap) {
+            size_t nc = s->cap * 2 > 16 * 1024 ? s->cap * 2 : 16 * 1024;
+            s->infos = (oq_nanoinfo *)realloc(s->infos, nc * sizeof(oq_nanoinfo));
+            memset(s->infos + s->cap, 0, (nc - s->cap) * sizeof(oq_nanoinfo));
+            s->cap = nc;
+        }
+        oq_nanoinfo *info = &s->infos[s->number_of_reads];
+        info->length = m->sequence_length;
+        const uint8_t *name = buf + m->record_start;
+        if (m->tags_length) {
+            if (oq_nano_from_tags(s, name + m->tags_offset, m->tags_length, buf + buf_len, info) != 0) {
+                s->error_record = (int64_t)s->records_seen;
+                return s->error_code;
+            }
+        } else if (oq_nano_from_header(name, m->name_length, buf + buf_len, info) != 0) {
+            s->skipped = 1;
+            s->skipped_record = (int64_t)s->records_seen;
+            continue;
+        }
+        info->cumulative_error_rate = m->accumulated_error_rate;
+        int64_t t = info->start_time;
+        if (t > s->max_time) s->max_time = t;
+        if (s->min_time == 0 || t < s->min_time) s->min_time = t;
+        s->number_of_reads++;
+    }
+    return 0;
+}
+
+uint64_t oq_nano_number_of_reads(oq_nano *s) { return s->number_of_reads; }
+int oq_nano_skipped(oq_nano *s) { return s->skipped; }
+int64_t oq_nano_skipped_record(oq_nano *s) { return s->skipped_record; }
+int64_t oq_nano_min_time(oq_nano *s) { return s->min_time; }
+int64_t oq_nano_max_time(oq_nano *s) { return s->max_time; }
+uint64_t oq_nano_pi_warnings(oq_nano *s) { return s->pi_warnings; }
+int64_t oq_nano_error_record(oq_nano *s) { return s->error_record; }
+void oq_nano_error_chars(oq_nano *s, uint8_t *out) { memcpy(out, s->error_chars, 3); }
+void oq_nano_get(oq_nano *s, oq_nanoinfo *out) { memcpy(out, s->infos, s->number_of_reads * sizeof(oq_nanoinfo)); }

@@ -19,11 +19,13 @@ from ._qc import (A, C_ as C, G, N, T, DEFAULT_BASES_FROM_END, DEFAULT_BASES_FRO
                   INSERT_SIZE_MAX_ADAPTER_STORE_SIZE, MAX_SEQUENCE_SIZE, NUMBER_OF_NUCS,
                   NUMBER_OF_PHREDS, PHRED_MAX, TABLE_SIZE, AdapterCounter, DedupEstimator,
                   FastqParser, FastqRecordArrayView, FastqRecordView, FusedPass,
-                  InsertSizeMetrics, OverrepresentedSequences, PerTileQuality, QCMetrics)
+                  InsertSizeMetrics, NanoporeReadInfo, NanoStats, OverrepresentedSequences,
+                  PerTileQuality, QCMetrics)
 
 __all__ = [
     "A", "C", "G", "N", "T", "AdapterCounter", "DedupEstimator", "FastqParser",
     "FastqRecordArrayView", "FastqRecordView", "FusedPass", "InsertSizeMetrics",
+    "NanoStats", "NanoporeReadInfo",
     "OverrepresentedSequences", "PerTileQuality", "QCMetrics", "NUMBER_OF_NUCS",
     "NUMBER_OF_PHREDS", "PHRED_MAX", "TABLE_SIZE", "MAX_SEQUENCE_SIZE",
 ]

@@ -37,7 +37,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
-    text = re.sub(r"typedef struct sq_meta \{.*?\} sq_meta;", "", text, flags=re.S)
+    text = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", text, flags=re.S)
     text = re.sub(r"typedef [^;]*;", "", text)
     text = text.replace('extern "C" {', "")
     protos = {}
@@ -76,7 +76,7 @@ def last_error() -> str:
 
 
 _EXC = {-1: RuntimeError, -2: ValueError, -3: MemoryError, -4: TypeError, -5: EOFError,
-        -6: OverflowError}
+        -6: OverflowError, -7: RuntimeError, -8: SystemError}
 
 
 def check(rc):

@@ -936,3 +936,85 @@ class InsertSizeMetrics:
 
     def adapters_read2(self) -> List[Tuple[str, int]]:
         return self._adapters(1)
+
+
+NANOINFO_DTYPE = np.dtype([("start_time", "<i8"), ("duration", "<f4"), ("channel_id", "<i4"),
+                           ("length", "<u4"), ("pad", "<u4"), ("cumulative_error_rate", "<f8"),
+                           ("parent_id_hash", "<u8")])
+assert NANOINFO_DTYPE.itemsize == 40
+
+
+class NanoporeReadInfo:
+    """_qcmodule.c:4817-4872"""
+    __slots__ = ("start_time", "channel_id", "length", "cumulative_error_rate", "duration", "parent_id_hash")
+
+    def __init__(self, rec):
+        self.start_time = int(rec["start_time"])
+        self.channel_id = int(rec["channel_id"])
+        self.length = int(rec["length"])
+        self.cumulative_error_rate = float(rec["cumulative_error_rate"])
+        self.duration = float(rec["duration"])
+        self.parent_id_hash = int(rec["parent_id_hash"])
+
+
+class NanoStats:
+    """_qcmodule.c:4874-5430: per read start time, channel, duration, length,
+    summed error rate and parent id hash, from the BAM tags when the record has any, else
+    from the nanopore FASTQ header.  Reads FastqMeta.accumulated_error_rate where the
+    QCMetrics pass left it (HBM), so feed an array to QCMetrics first, as the reference's
+    driver does (__main__.py:279-306)."""
+
+    def __init__(self):
+        self._h = lib().sq_nanostats_new(context())
+        if not self._h:
+            raise MemoryError(_lib.last_error())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().sq_nanostats_free(self._h)
+        except Exception:
+            pass
+
+    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
+        arr = _require_array(record_array)
+        rc = lib().sq_nanostats_add_batch(self._h, arr._device().handle)
+        n = lib().sq_nanostats_last_warnings(self._h, None, 0)
+        if n:
+            lengths = np.zeros(n, dtype=np.uint64)
+            lib().sq_nanostats_last_warnings(self._h, lengths.ctypes.data, n)
+            for counted in lengths:  # :5247-5252
+                warnings.warn("pi tag should have a valid uuid4 format with 36 characters. "
+                              f"Counted {int(counted)}. Skipping tag.", UserWarning, stacklevel=2)
+        check(rc)
+
+    def add_read(self, read: FastqRecordView) -> None:
+        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+
+    @property
+    def number_of_reads(self) -> int:
+        return lib().sq_nanostats_number_of_reads(self._h)
+
+    @property
+    def minimum_time(self) -> int:
+        return lib().sq_nanostats_minimum_time(self._h)
+
+    @property
+    def maximum_time(self) -> int:
+        return lib().sq_nanostats_maximum_time(self._h)
+
+    @property
+    def skipped_reason(self) -> Optional[str]:
+        r = lib().sq_nanostats_skipped_reason(self._h)
+        return None if r is None else r.decode("ascii", "replace")
+
+    def nano_infos(self) -> np.ndarray:
+        """the NanoInfo structs of all counted reads (NANOINFO_DTYPE), one copy from HBM"""
+        n = self.number_of_reads
+        out = np.zeros(n, dtype=NANOINFO_DTYPE)
+        if n:
+            check(lib().sq_nanostats_infos(self._h, out.ctypes.data, n))
+        return out
+
+    def nano_info_iterator(self) -> Iterator[NanoporeReadInfo]:
+        return (NanoporeReadInfo(rec) for rec in self.nano_infos())

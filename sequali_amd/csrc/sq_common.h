@@ -108,6 +108,24 @@ int sq_grow_device(sq_ctx *ctx, T **ptr, size_t *cap, size_t want)
     return SQ_OK;
 }
 
+/* Python's repr() of an ASCII str, as %R prints it in _qcmodule.c:3144 */
+inline std::string sq_py_repr(const std::string &s)
+{
+    bool has_sq = s.find('\'') != std::string::npos, has_dq = s.find('"') != std::string::npos;
+    char quote = (has_sq && !has_dq) ? '"' : '\'';
+    std::string r(1, quote);
+    for (unsigned char c : s) {
+        if (c == (unsigned char)quote || c == '\\') { r += '\\'; r += (char)c; }
+        else if (c == '\t') r += "\\t";
+        else if (c == '\n') r += "\\n";
+        else if (c == '\r') r += "\\r";
+        else if (c < 0x20 || c == 0x7F) { char t[8]; snprintf(t, sizeof t, "\\x%02x", c); r += t; }
+        else r += (char)c;
+    }
+    r += quote;
+    return r;
+}
+
 /* device-side helpers -------------------------------------------------------- */
 #ifdef __HIPCC__
 /* NUCLEOTIDE_TO_INDEX, _qcmodule.c:1748-1763: A/a 0 C/c 1 G/g 2 T/t 3 else 4 */

@@ -1396,24 +1396,6 @@ SQ_EXPORT void sq_pertile_free(sq_pertile *p)
 
 namespace {
 
-/* Python's repr() of an ASCII str, as %R prints it in _qcmodule.c:3144 */
-std::string py_repr(const std::string &s)
-{
-    bool has_sq = s.find('\'') != std::string::npos, has_dq = s.find('"') != std::string::npos;
-    char quote = (has_sq && !has_dq) ? '"' : '\'';
-    std::string r(1, quote);
-    for (unsigned char c : s) {
-        if (c == (unsigned char)quote || c == '\\') { r += '\\'; r += (char)c; }
-        else if (c == '\t') r += "\\t";
-        else if (c == '\n') r += "\\n";
-        else if (c == '\r') r += "\\r";
-        else if (c < 0x20 || c == 0x7F) { char t[8]; snprintf(t, sizeof t, "\\x%02x", c); r += t; }
-        else r += (char)c;
-    }
-    r += quote;
-    return r;
-}
-
 int fetch_bytes(sq_batch *b, uint64_t off, uint64_t len, std::string &out)
 {
     out.resize(len);
@@ -1472,7 +1454,7 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
         rc = fetch_bytes(b, m.record_start, m.name_length, name);
         if (rc) return rc;
         p->skipped = true; /* :3137-3148 */
-        p->skipped_reason = "Can not parse header: " + py_repr(name);
+        p->skipped_reason = "Can not parse header: " + sq_py_repr(name);
     }
     p->number_of_reads += counted;
     /* max_length only moves for records that are counted (:3150) */

@@ -498,8 +498,139 @@ def parser():
         json.dump(errors, f, indent=0)
 
 
+def full_metas_of(arr) -> np.ndarray:
+    """FastqMeta structs (40 bytes) of a reference array with record_start made an offset"""
+    n = len(arr)
+    raw = bytearray((ctypes.c_char * (n * 40)).from_address(id(arr) + 32))
+    m = np.frombuffer(raw, dtype=np.dtype([("record_start", "<u8"), ("rest", "V24"), ("err", "<f8")]))
+    base = ctypes.cast(ctypes.c_char_p(arr.obj), ctypes.c_void_p).value
+    inside = (m["record_start"] >= base) & (m["record_start"] < base + max(len(arr.obj), 1))
+    if n and inside.all():
+        m["record_start"] -= np.uint64(base)
+    else:
+        # an array built from views keeps pointing at the views' own buffers (:672-684);
+        # its obj is the same records back to back: name|sequence|qualities|tags
+        f = np.frombuffer(bytes(raw), dtype=np.dtype([("p", "<u8"), ("nl", "<u4"), ("so", "<u4"), ("sl", "<u4"),
+                                                      ("qo", "<u4"), ("to", "<u4"), ("tl", "<u4"), ("e", "<f8")]))
+        sizes = f["nl"].astype(np.uint64) + 2 * f["sl"].astype(np.uint64) + f["tl"].astype(np.uint64)
+        m["record_start"] = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if n else m["record_start"]
+    return np.frombuffer(bytes(raw), dtype=np.uint8).reshape(n, 40)
+
+
+def nanostats():
+    """(5) NanoStats (_qcmodule.c:4804-5430) on the reference's nanopore data, on its BAM
+    file through the reference's BamParser (the arrays are stored, so the tags path is
+    pinned without a BAM parser on the other side) and on inline tag / header cases.
+    QCMetrics runs first, as in the driver (__main__.py:279-306), so that the metas carry
+    accumulated_error_rate.  -> nanostats_cases.npz"""
+    import struct
+    import warnings
+    cases = {}
+
+    def arrays_from_views(views, per_array=3):
+        return [_qc.FastqRecordArrayView(views[i:i + per_array]) for i in range(0, len(views), per_array)]
+
+    def z(b: bytes) -> bytes:
+        return b + b"\x00"
+
+    def tag(name: bytes, typ: bytes, payload: bytes) -> bytes:
+        return name + typ + payload
+
+    uuid = b"8D8AC610-566D-4EF0-9C22-186B2A5ED793"
+    good_tags = (tag(b"rn", b"C", struct.pack("<B", 10)) + tag(b"ch", b"S", struct.pack("<H", 444)) +
+                 tag(b"st", b"Z", z(b"2021-09-30T11:34:08Z")) + tag(b"RG", b"Z", z(b"SS_A1")) +
+                 tag(b"du", b"f", struct.pack("<f", 2.5)) + tag(b"pi", b"Z", z(uuid)))
+    V = _qc.FastqRecordView
+    hdr = "cb1dab45-aa4c-43fc-a91e-ad0ecc92f5c9 runid=c989 read=10 ch=%d start_time=%s flow_cell_id=PAI09842"
+    header_views = [
+        V(hdr % (444, "2021-09-30T11:34:08Z"), "ACGT", "AAAA"),
+        V(hdr % (1, "2019-01-26T18:52:46.123456+02:00"), "ACGTA", "AAAA5"),
+        V(hdr % (2048, "2024-02-29T23:59:59-09:30"), "A", "!"),
+        V(hdr % (12, "1970-01-01T00:00:00Z"), "", ""),
+        V("x ch=5 start_time=2021-09-30T11:34:08Z", "ACGT", "IIII"),
+        V("x start_time=2021-09-30T11:34:09Z ch=000000000000000018", "ACGT", "IIII"),
+        V("x ch=3 start_time=2038-01-19T03:14:08Z extra=a=b", "ACGT", "IIII"),
+        V("x ch=3 start_time=2100-03-01T00:00:00Z", "ACGT", "IIII"),
+    ]
+    cases["headers_ok"] = arrays_from_views(header_views)
+    for k, bad in enumerate(["noseparator", "x ch=5", "x start_time=2021-09-30T11:34:08Z", "x ch=5 novalue",
+                             "x ch=-1 start_time=2021-09-30T11:34:08Z", "x ch=5 start_time=2021-09-30 11:34:08Z",
+                             "x ch=5 start_time=1969-09-30T11:34:08Z", "x ch=5 start_time=2021-13-30T11:34:08Z",
+                             "x ch=5 start_time=2021-09-30T11:34:08", "x ch=5 start_time=2021-09-30T11:34:08+0200",
+                             "x ch=1234567890123456789 start_time=2021-09-30T11:34:08Z",
+                             "@SIM:1:FCX:1:1101:1:1 1:N:0:ATCCGA"]):
+        cases[f"header_bad_{k}"] = arrays_from_views(header_views[:4] + [V(bad, "ACGT", "IIII")] + header_views[4:])
+    tag_views = [
+        V("r1", "ACGT", "AAAA", good_tags),
+        V("r2", "ACGTAC", "AAAAAA", tag(b"ch", b"c", struct.pack("<b", -3)) + tag(b"st", b"Z", z(b"2022-05-06T07:08:09.5+01:00"))),
+        V("r3", "AC", "AA", tag(b"ch", b"I", struct.pack("<I", 70000)) + tag(b"du", b"f", struct.pack("<f", 0.125))),
+        V("r4", "ACG", "AAA", tag(b"ch", b"i", struct.pack("<i", 9)) + tag(b"st", b"Z", z(b"2022-05-06T07:08:10Z")) +
+          tag(b"XA", b"A", b"q") + tag(b"XB", b"B", b"s" + struct.pack("<I3h", 3, 1, 2, 3)) +
+          tag(b"XH", b"H", z(b"1AE301")) + tag(b"pi", b"Z", z(uuid.lower()))),
+        V("r5", "A", "A", tag(b"st", b"Z", z(b"garbage")) + tag(b"ch", b"s", struct.pack("<h", 77))),
+        V("r6", "ACGT", "AAAA", tag(b"pi", b"Z", z(b"8D8AC610-566D-3EF0-9C22-186B2A5ED793")) + tag(b"ch", b"C", b"\x05")),
+        V("r7", "ACGT", "AAAA", tag(b"pi", b"Z", z(b"8D8AC61G-566D-4EF0-9C22-186B2A5ED793")) + tag(b"ch", b"C", b"\x06")),
+        V("r8", "ACGT", "AAAA", tag(b"ch", b"C", b"\x07") + tag(b"st", b"Z", z(b"2023-01-01T00:00:00Z"))),
+    ]
+    cases["tags_ok"] = arrays_from_views(tag_views)
+    cases["tags_pi_short"] = arrays_from_views(tag_views[:2] + [V("w", "AC", "AA", tag(b"pi", b"Z", z(b"tooshort")) + tag(b"ch", b"C", b"\x01"))] + tag_views[2:])
+    bad_tags = [b"ch", tag(b"ch", b"S", b"\x01"), tag(b"st", b"Z", b"2021-09-30T11:34:08Z"),
+                tag(b"XB", b"B", b"Z" + struct.pack("<I", 1) + b"a\x00"), tag(b"XQ", b"Q", b"1234"),
+                tag(b"st", b"A", b"x"), tag(b"du", b"i", struct.pack("<i", 5)), tag(b"pi", b"i", struct.pack("<i", 5)),
+                tag(b"ch", b"f", struct.pack("<f", 1.0)), tag(b"ch", b"Z", z(b"12")),
+                tag(b"XB", b"B", b"i" + struct.pack("<I", 5) + b"\x00" * 8), tag(b"XB", b"B", b"c\x01")]
+    for k, t in enumerate(bad_tags):
+        cases[f"tags_bad_{k}"] = arrays_from_views(tag_views[:4] + [V("bad", "ACGT", "AAAA", t)] + tag_views[4:])
+    for name in ("100_nanopore_reads.fastq.gz", "nanopore_disparate_dates.fastq", "single_nanopore_metadata.fastq",
+                 "empty_nanopore_metadata.fastq", "100_illumina_adapters.fastq", "empty.fastq"):
+        cases["file_" + name.split(".")[0]] = arrays_of(read_file(name), 16 * 1024)
+    with open(os.path.join(REFDATA, "dorado_nanopore_100reads.bam"), "rb") as f:
+        bam = gzip.decompress(f.read()) if False else None
+    import zlib
+    with open(os.path.join(REFDATA, "dorado_nanopore_100reads.bam"), "rb") as f:
+        raw = f.read()
+    plain, pos = b"", 0
+    while pos < len(raw):  # BGZF blocks are gzip members
+        d = zlib.decompressobj(31)
+        plain += d.decompress(raw[pos:])
+        pos = len(raw) - len(d.unused_data)
+    cases["file_dorado_bam"] = list(_qc.BamParser(io.BytesIO(plain), 16 * 1024))
+
+    out, names = {}, []
+    for name, arrays in cases.items():
+        qcm, ns = _qc.QCMetrics(), _qc.NanoStats()
+        res = {}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            try:
+                for a in arrays:
+                    qcm.add_record_array(a)
+                    ns.add_record_array(a)
+            except BaseException as e:  # noqa: BLE001
+                res = {"error": type(e).__name__, "message": str(e)}
+        names.append(name)
+        out[name + "_n_arrays"] = np.int64(len(arrays))
+        for k, a in enumerate(arrays):
+            out[f"{name}_obj{k}"] = np.frombuffer(a.obj, np.uint8)
+            out[f"{name}_metas{k}"] = full_metas_of(a)
+        infos = list(ns.nano_info_iterator())
+        out[name + "_infos"] = np.array([(i.start_time, i.duration, i.channel_id, i.length, 0,
+                                          i.cumulative_error_rate, i.parent_id_hash) for i in infos],
+                                        dtype=[("start_time", "<i8"), ("duration", "<f4"), ("channel_id", "<i4"),
+                                               ("length", "<u4"), ("pad", "<u4"), ("cumulative_error_rate", "<f8"),
+                                               ("parent_id_hash", "<u8")])
+        out[name + "_scalars"] = np.array([ns.number_of_reads, ns.minimum_time, ns.maximum_time], np.int64)
+        out[name + "_result"] = np.array(json.dumps({"skipped_reason": ns.skipped_reason, **res,
+                                                      "warnings": [str(w.message) for w in caught]}))
+        print(name, len(infos), ns.skipped_reason, res, [str(w.message)[:40] for w in caught])
+    out["names"] = np.array(names)
+    save("nanostats_cases", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "synthetic":
+    if len(sys.argv) > 1 and sys.argv[1] == "nanostats":
+        nanostats()
+    elif len(sys.argv) > 1 and sys.argv[1] == "synthetic":
         synthetic()
     elif len(sys.argv) > 1 and sys.argv[1] == "parser":
         parser()

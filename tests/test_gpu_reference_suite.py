@@ -450,3 +450,45 @@ def test_c_abi_host_buffer_entry_points():
         np.testing.assert_array_equal(f, fr)
         np.testing.assert_array_equal(r, rr)
     lib.sq_adaptercounter_free(a)
+
+
+# ---- tests/test_nano_stats.py of the reference ----------------------------------------
+def test_nano_stats_from_header():
+    import datetime
+    from sequali_amd import FastqRecordView, NanoStats
+    view = FastqRecordView("cb1dab45-aa4c-43fc-a91e-ad0ecc92f5c9 "
+                           "runid=c989c681b782549923cb0a02c95f6ec9d2534335 "
+                           "read=10 ch=444 start_time=2021-09-30T11:34:08Z "
+                           "flow_cell_id=PAI09842 protocol_group_id=SS_210930_10xCDNA sample_id=SS_A1",
+                           "ACGT", "AAAA")
+    timestamp = datetime.datetime(2021, 9, 30, 11, 34, 8, tzinfo=datetime.timezone.utc).timestamp()
+    nanostats = NanoStats()
+    nanostats.add_read(view)
+    assert nanostats.minimum_time == timestamp and nanostats.maximum_time == timestamp
+    infos = list(nanostats.nano_info_iterator())
+    assert len(infos) == 1
+    info = infos[0]
+    assert info.start_time == timestamp and info.channel_id == 444 and info.length == 4
+    assert info.cumulative_error_rate == 4 * 10 ** (-(ord("A") - 33) / 10)
+    assert info.duration == 0.0
+
+
+def test_nano_stats_from_tags():
+    import datetime
+    import struct
+    from sequali_amd import FastqRecordView, NanoStats
+    timestamp_string, readgroup_string = b"2021-09-30T11:34:08Z\x00", b"SS_A1\x00"
+    parent_id = b"8D8AC610-566D-4EF0-9C22-186B2A5ED793\x00"
+    tags = struct.pack(f"<3sB3sH3s{len(timestamp_string)}s3s{len(readgroup_string)}s3sf3s{len(parent_id)}s",
+                       b"rnC", 10, b"chS", 444, b"stZ", timestamp_string, b"RGZ", readgroup_string,
+                       b"duf", 2.5, b"piZ", parent_id)
+    view = FastqRecordView("cb1dab45-aa4c-43fc-a91e-ad0ecc92f5c9", "ACGT", "AAAA", tags)
+    timestamp = datetime.datetime(2021, 9, 30, 11, 34, 8, tzinfo=datetime.timezone.utc).timestamp()
+    nanostats = NanoStats()
+    nanostats.add_read(view)
+    assert nanostats.minimum_time == timestamp and nanostats.maximum_time == timestamp
+    info, = list(nanostats.nano_info_iterator())
+    assert info.start_time == timestamp and info.channel_id == 444 and info.length == 4
+    assert info.cumulative_error_rate == 4 * 10 ** (-(ord("A") - 33) / 10)
+    assert info.duration == 2.5
+    assert info.parent_id_hash == int(parent_id[:8] + parent_id[-9:-1], 16)

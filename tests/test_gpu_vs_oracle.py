@@ -352,3 +352,49 @@ def test_ring_kernel_every_alignment(U):
             for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
                 np.testing.assert_array_equal(u64(f), fr)
                 np.testing.assert_array_equal(u64(r), rr)
+
+
+def test_nanostats_after_qcmetrics_on_device_batches():
+    """NanoStats reads accumulated_error_rate where QCMetrics left it in HBM: synthetic
+    nanopore reads generated on the device, two batches, nothing on the host in between"""
+    from sequali_amd import NanoStats, QCMetrics, synth
+    ref_q, ref_n = oracle.QCMetrics(), oracle.NanoStats()
+    got_q, got_n = QCMetrics(), NanoStats()
+    for first, n in ((0, 3000), (3000, 1500)):
+        buf, metas = synth.host_records(synth.NANOPORE, first, n)
+        ref_q.add(buf, metas)
+        ref_n.add(buf, metas)
+        dev = synth.device_array(synth.NANOPORE, first, n)
+        got_q.add_record_array(dev)
+        got_n.add_record_array(dev)
+    assert got_n.number_of_reads == ref_n.number_of_reads == 4500
+    assert got_n.skipped_reason is None and not ref_n.skipped
+    assert (got_n.minimum_time, got_n.maximum_time) == (ref_n.minimum_time, ref_n.maximum_time)
+    got, want = got_n.nano_infos(), ref_n.nano_infos()
+    for f in ("start_time", "channel_id", "length", "parent_id_hash"):
+        np.testing.assert_array_equal(got[f], want[f])
+    np.testing.assert_array_equal(got["cumulative_error_rate"].view(np.uint64),
+                                  want["cumulative_error_rate"].view(np.uint64))
+    assert float(want["cumulative_error_rate"].sum()) > 0
+
+
+def test_nanostats_minimum_time_restarts_after_a_zero_timestamp():
+    """records without an st tag have start_time 0, which resets minimum_time (:5319-5321)"""
+    import struct
+    from sequali_amd import FastqRecordArrayView, NanoStats
+    def st(ts):
+        return b"stZ" + ts + b"\x00"
+    ch = b"chC\x07"
+    tags = [ch + st(b"2021-09-30T11:34:08Z"), ch + st(b"2020-01-01T00:00:00Z"), ch,
+            ch + st(b"2022-02-02T02:02:02Z"), ch + st(b"2021-12-12T12:12:12Z"), ch,
+            ch + st(b"2023-03-03T03:03:03Z")]
+    names = [f"r{i}" for i in range(len(tags))]
+    buf, metas = oracle.make_view_batch(names, ["ACGT"] * len(tags), ["IIII"] * len(tags), tags)
+    for cut in (len(tags), 3, 5, 6):   # also with the zero as the last record of a batch
+        ref, got = oracle.NanoStats(), NanoStats()
+        for a, b in ((0, cut), (cut, len(tags))):
+            if b > a:
+                ref.add(buf, metas[a:b].copy())
+                got.add_record_array(FastqRecordArrayView._from_buffer(buf, metas[a:b].copy()))
+            assert (got.minimum_time, got.maximum_time) == (ref.minimum_time, ref.maximum_time)
+        assert got.number_of_reads == ref.number_of_reads == len(tags)
