@@ -112,6 +112,16 @@ sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len, v
  * or borrowed (device variant). */
 sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed);
 sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len, size_t *consumed);
+/* BAM input.  sq_bam_scan is the record walk of BamParser__next__
+ * (_qcmodule.c:1601-1681) on the host: offsets of the complete records of an uncompressed
+ * BAM record stream that are not secondary / supplementary (:1262,1611), the bytes they
+ * cover and how many were skipped; with offsets == NULL it only counts.
+ * sq_batch_from_bam decodes those records on the GPU into name | sequence | qualities |
+ * tags (4-bit bases -> ASCII :1264-1290, qualities + 33 :1350-1358, 0xff -> '!' :1642-1650,
+ * name without its NUL :1633). */
+int64_t sq_bam_scan(const uint8_t *bam, size_t len, uint64_t *offsets, size_t cap, size_t *consumed,
+                    uint64_t *skipped);
+sq_batch *sq_batch_from_bam(sq_ctx *ctx, const uint8_t *bam, size_t len, const uint64_t *offsets, size_t n);
 void sq_batch_free(sq_batch *b);
 uint64_t sq_batch_size(const sq_batch *b);
 uint64_t sq_batch_total_bases(const sq_batch *b);

@@ -84,6 +84,7 @@ def _load() -> C.CDLL:
         "oq_isz_get_sizes": (None, [vp, vp]),
         "oq_isz_get_adapters": (sz, [vp, C.c_int, vp, vp, vp]),
         "oq_names_are_mates": (C.c_int, [u8p, sz, u8p, sz]),
+        "oq_bam_decode": (i64, [u8p, sz, vp, vp, sz, vp, vp, vp]),
         "oq_nano_new": (vp, []), "oq_nano_free": (None, [vp]),
         "oq_nano_add": (C.c_int, [vp, u8p, sz, vp, sz]),
         "oq_nano_number_of_reads": (u64, [vp]), "oq_nano_skipped": (C.c_int, [vp]),
@@ -143,6 +144,19 @@ def make_view_batch(names: Sequence[str], seqs: Sequence[str], quals: Sequence[s
         parts += [nb, sb, qb, bytes(t)]
         pos += len(nb) + 2 * len(sb) + len(t)
     return b"".join(parts), metas
+
+
+def bam_decode(bam: bytes) -> Tuple[bytes, np.ndarray, int, int]:
+    """(decoded records name|sequence|qualities|tags, metas, bytes consumed, records skipped)
+    of the complete records at the start of an uncompressed BAM record stream
+    (BamParser__next__, _qcmodule.c:1601-1681)"""
+    consumed, skipped, out_len = C.c_size_t(0), C.c_uint64(0), C.c_size_t(0)
+    n = LIB.oq_bam_decode(_ptr(bam), len(bam), None, None, 0, C.byref(consumed), C.byref(skipped), C.byref(out_len))
+    out = np.zeros(out_len.value, dtype=np.uint8)
+    metas = np.zeros(n, dtype=META_DTYPE)
+    LIB.oq_bam_decode(_ptr(bam), len(bam), out.ctypes.data, metas.ctypes.data, n, C.byref(consumed),
+                      C.byref(skipped), C.byref(out_len))
+    return out.tobytes(), metas, consumed.value, skipped.value
 
 
 NANOINFO_DTYPE = np.dtype([("start_time", "<i8"), ("duration", "<f4"), ("channel_id", "<i4"),

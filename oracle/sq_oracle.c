@@ -1367,3 +1367,73 @@ uint64_t oq_nano_pi_warnings(oq_nano *s) { return s->pi_warnings; }
 int64_t oq_nano_error_record(oq_nano *s) { return s->error_record; }
 void oq_nano_error_chars(oq_nano *s, uint8_t *out) { memcpy(out, s->error_chars, 3); }
 void oq_nano_get(oq_nano *s, oq_nanoinfo *out) { memcpy(out, s->infos, s->number_of_reads * sizeof(oq_nanoinfo)); }
+
+/* ================================ BAM records ================================
+ * The record loop of BamParser__next__ (_qcmodule.c:1601-1681) over an uncompressed BAM
+ * stream positioned at the first record: which records are complete, which are skipped
+ * (secondary / supplementary, :1262,1611), and the decoded name|sequence|qualities|tags
+ * of the others (:1264-1290, :1350-1358, :1642-1650). */
+static uint32_t
+oq_le32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint16_t
+oq_le16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+/* Returns the number of records kept; *consumed = bytes of complete records (kept or
+ * skipped), *skipped = records left out.  out (may be NULL: sizes only) receives the
+ * decoded records back to back, metas their descriptors (record_start = offset in out). */
+int64_t
+oq_bam_decode(const uint8_t *bam, size_t len, uint8_t *out, oq_meta *metas, size_t cap,
+              size_t *consumed, uint64_t *skipped, size_t *out_len)
+{
+    const uint8_t *rec = bam, *end = bam + len;
+    size_t n = 0, at = 0;
+    uint64_t skip = 0;
+    for (;;) {
+        if (rec + 4 >= end) break; /* :1602 */
+        const uint32_t block_size = oq_le32(rec);
+        const uint8_t *rec_end = rec + 4 + block_size;
+        if (rec_end > end) break;
+        const uint16_t flag = oq_le16(rec + 18);
+        if (flag & (0x100 | 0x800)) { rec = rec_end; skip++; continue; }
+        if (n == cap && metas) break;
+        const uint8_t *name = rec + 36;
+        uint32_t name_len = rec[12];
+        const uint16_t n_cigar = oq_le16(rec + 16);
+        const uint32_t l_seq = oq_le32(rec + 20);
+        const uint8_t *seq = name + name_len + 4u * n_cigar;
+        const uint8_t *qual = seq + (l_seq + 1) / 2;
+        const uint8_t *tags = qual + l_seq;
+        const size_t tags_len = (size_t)(rec_end - tags);
+        if (name_len > 0) name_len -= 1; /* the terminating NUL, :1633 */
+        if (out) {
+            static const char *nuc = "=ACMGRSVTWYHKDBN";
+            uint8_t *o = out + at;
+            memcpy(o, name, name_len);
+            o += name_len;
+            for (uint32_t i = 0; i < l_seq; i++) o[i] = (uint8_t)nuc[(i & 1) ? (seq[i / 2] & 15) : (seq[i / 2] >> 4)];
+            o += l_seq;
+            if (l_seq && qual[0] == 0xff) memset(o, 33, l_seq);
+            else for (uint32_t i = 0; i < l_seq; i++) o[i] = (uint8_t)(qual[i] + 33);
+            o += l_seq;
+            memcpy(o, tags, tags_len);
+        }
+        if (metas) {
+            oq_meta *m = &metas[n];
+            m->record_start = at;
+            m->name_length = name_len;
+            m->sequence_offset = name_len;
+            m->sequence_length = l_seq;
+            m->qualities_offset = name_len + l_seq;
+            m->tags_offset = name_len + 2 * l_seq;
+            m->tags_length = (uint32_t)tags_len;
+            m->accumulated_error_rate = 0.0;
+        }
+        at += name_len + 2 * (size_t)l_seq + tags_len;
+        n++;
+        rec = rec_end;
+    }
+    if (consumed) *consumed = (size_t)(rec - bam);
+    if (skipped) *skipped = skip;
+    if (out_len) *out_len = at;
+    return (int64_t)n;
+}

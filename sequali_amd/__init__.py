@@ -17,13 +17,13 @@ from ._qc import (A, C_ as C, G, N, T, DEFAULT_BASES_FROM_END, DEFAULT_BASES_FRO
                   DEFAULT_FINGERPRINT_FRONT_SEQUENCE_OFFSET, DEFAULT_FRAGMENT_LENGTH,
                   DEFAULT_MAX_UNIQUE_FRAGMENTS, DEFAULT_UNIQUE_SAMPLE_EVERY,
                   INSERT_SIZE_MAX_ADAPTER_STORE_SIZE, MAX_SEQUENCE_SIZE, NUMBER_OF_NUCS,
-                  NUMBER_OF_PHREDS, PHRED_MAX, TABLE_SIZE, AdapterCounter, DedupEstimator,
+                  NUMBER_OF_PHREDS, PHRED_MAX, TABLE_SIZE, AdapterCounter, BamParser, DedupEstimator,
                   FastqParser, FastqRecordArrayView, FastqRecordView, FusedPass,
                   InsertSizeMetrics, NanoporeReadInfo, NanoStats, OverrepresentedSequences,
                   PerTileQuality, QCMetrics)
 
 __all__ = [
-    "A", "C", "G", "N", "T", "AdapterCounter", "DedupEstimator", "FastqParser",
+    "A", "C", "G", "N", "T", "AdapterCounter", "BamParser", "DedupEstimator", "FastqParser",
     "FastqRecordArrayView", "FastqRecordView", "FusedPass", "InsertSizeMetrics",
     "NanoStats", "NanoporeReadInfo",
     "OverrepresentedSequences", "PerTileQuality", "QCMetrics", "NUMBER_OF_NUCS",

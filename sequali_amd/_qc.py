@@ -248,13 +248,18 @@ class FastqRecordArrayView:
             i += n
         if i < 0 or i >= n:
             raise IndexError("array index out of range")
-        return FastqRecordView._from(self.obj, self._host_metas()[i:i + 1])
+        metas = self._host_metas()
+        return FastqRecordView._from(self.obj, metas[i:i + 1])
 
     def _host_metas(self) -> np.ndarray:
+        """the metas (and, for an array that was built in HBM, its bytes) on the host:
+        fetched once, when a record is first looked at"""
         if self._metas is None:
             if self.obj is None:
-                raise TypeError("this record array lives on the device only")
-            self._metas = self._batch.download_metas()  # split on the device: fetched once
+                buf, self._metas = self._batch.download()
+                self.obj = buf.tobytes()
+            else:
+                self._metas = self._batch.download_metas()  # split on the device
         return self._metas
 
     def is_mate(self, other) -> bool:
@@ -264,8 +269,8 @@ class FastqRecordArrayView:
         if len(self) != len(other):
             raise ValueError("other is not the same length as this record array view. "
                              f"This length: {len(self)}, other length: {len(other)}")
-        return bool(lib().sq_names_are_mates(_addr(self.obj), self._host_metas().ctypes.data,
-                                             _addr(other.obj), other._host_metas().ctypes.data,
+        m1, m2 = self._host_metas(), other._host_metas()
+        return bool(lib().sq_names_are_mates(_addr(self.obj), m1.ctypes.data, _addr(other.obj), m2.ctypes.data,
                                              len(self)))
 
     # -- device side ---------------------------------------------------------
@@ -431,6 +436,78 @@ class FastqParser:
         obj = bytes(buf)
         self._leftover = obj[consumed:]
         return FastqRecordArrayView._from_buffer(obj, metas)
+
+
+class BamParser:
+    """BamParser, _qcmodule.c:1362-1722: iterates record arrays over an *uncompressed* BAM
+    stream (the caller removes BGZF, as the reference's xopen does).  The record walk runs
+    on the host (sq_bam_scan), the decode on the GPU (sq_batch_from_bam); the
+    arrays live in HBM and come to the host only when a record is looked at.  Secondary and
+    supplementary alignments are left out (:1262)."""
+
+    def __init__(self, fileobj, initial_buffersize: int = 48 * 1024):
+        if initial_buffersize < 4:
+            raise ValueError(f"initial_buffersize must be at least 4, got {initial_buffersize}")
+        magic = fileobj.read(8)
+        if type(magic) is not bytes:
+            raise TypeError(f"file_obj {fileobj!r} is not a binary IO type, got {type(fileobj)!r}")
+        if len(magic) < 8:
+            raise EOFError("Truncated BAM file")
+        if magic[:4] != b"BAM\x01":
+            raise ValueError(f"fileobj: {fileobj!r}, is not a BAM file. No BAM magic, "
+                             f"instead found: {magic!r}")
+        l_text = int.from_bytes(magic[4:8], "little")
+        header = fileobj.read(l_text)
+        if len(header) != l_text:
+            raise EOFError("Truncated BAM file")
+        n_ref = fileobj.read(4)
+        if len(n_ref) != 4:
+            raise EOFError("Truncated BAM file")
+        for _ in range(int.from_bytes(n_ref, "little")):
+            l_name = fileobj.read(4)
+            if len(l_name) != 4:
+                raise EOFError("Truncated BAM file")
+            want = int.from_bytes(l_name, "little") + 4  # name and l_ref
+            if len(fileobj.read(want)) != want:
+                raise EOFError("Truncated BAM file")
+        self.header = header
+        self._file = fileobj
+        self._read_in_size = int(initial_buffersize)
+        self._leftover = b""
+
+    def __iter__(self) -> "BamParser":
+        return self
+
+    def __next__(self) -> FastqRecordArrayView:
+        """BamParser__next__ :1506-1703: the buffer grows until it holds one complete record"""
+        buf = bytearray(self._leftover)
+        while True:
+            if len(buf) >= 4:  # :1527-1531 enough for the record in front
+                want = max(int.from_bytes(buf[:4], "little"), self._read_in_size)
+            else:
+                want = self._read_in_size - len(buf)
+            chunk = bytearray(want)
+            got = self._file.readinto(chunk) or 0
+            if len(buf) + got == 0:
+                raise StopIteration  # :1564
+            if got == 0:  # :1569-1577
+                raise EOFError(f"Incomplete record at the end of file {bytes(buf)!r}")
+            buf += chunk[:got]
+            view = np.frombuffer(buf, dtype=np.uint8)
+            consumed, skipped = C.c_size_t(0), C.c_uint64(0)
+            n = check(lib().sq_bam_scan(view.ctypes.data, len(buf), None, 0, C.byref(consumed), C.byref(skipped)))
+            if n + skipped.value == 0:
+                del view
+                continue
+            offsets = np.zeros(max(n, 1), dtype=np.uint64)
+            check(lib().sq_bam_scan(view.ctypes.data, len(buf), offsets.ctypes.data, n, C.byref(consumed),
+                                    C.byref(skipped)))
+            h = lib().sq_batch_from_bam(context(), view.ctypes.data, consumed.value, offsets.ctypes.data, n)
+            del view
+            if not h:
+                raise MemoryError(_lib.last_error())
+            self._leftover = bytes(buf[consumed.value:])
+            return FastqRecordArrayView._from_device(_DeviceBatch(h))
 
 
 # ---------------------------------------------------------------------------

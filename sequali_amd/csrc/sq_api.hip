@@ -558,6 +558,184 @@ SQ_EXPORT sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, 
     return split_on_device(ctx, (uint8_t *)d_text, false, nullptr, len, consumed);
 }
 
+/* ---- BAM records ------------------------------------------------------
+ * The record walk of BamParser__next__ (_qcmodule.c:1601-1681) is a pointer chase through
+ * the block_size fields: it stays on the host and yields the offsets of the records to
+ * decode.  The decode is data parallel: sizes per record, exclusive scan, then one wave
+ * per record writes name | sequence | qualities | tags. */
+SQ_EXPORT int64_t sq_bam_scan(const uint8_t *bam, size_t len, uint64_t *offsets, size_t cap, size_t *consumed,
+                              uint64_t *skipped)
+{
+    const uint8_t *rec = bam, *end = bam + len;
+    int64_t n = 0;
+    uint64_t skip = 0;
+    for (;;) {
+        if (rec + 4 >= end) break; /* :1602 */
+        uint32_t block_size;
+        memcpy(&block_size, rec, 4);
+        const uint8_t *rec_end = rec + 4 + block_size;
+        if (rec_end > end) break;
+        if (block_size < 32) {
+            sq_set_error("BAM record of %u bytes is shorter than its fixed fields", block_size);
+            return SQ_ERR_VALUE;
+        }
+        uint16_t flag;
+        memcpy(&flag, rec + 18, 2);
+        if (flag & (0x100 | 0x800)) { /* BAM_FSECONDARY | BAM_FSUPPLEMENTARY, :1262,1611 */
+            rec = rec_end;
+            skip++;
+            continue;
+        }
+        if (offsets) {
+            if ((size_t)n == cap) break;
+            offsets[n] = (uint64_t)(rec - bam);
+        }
+        n++;
+        rec = rec_end;
+    }
+    if (consumed) *consumed = (size_t)(rec - bam);
+    if (skipped) *skipped = skip;
+    return n;
+}
+
+namespace {
+
+__device__ __forceinline__ uint32_t bam_le32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+struct BamFields {
+    uint32_t name_len, l_seq, tags_len;
+    uint64_t name, seq, qual, tags; /* offsets into the BAM bytes */
+};
+
+__device__ BamFields bam_fields(const uint8_t *bam, uint64_t off)
+{
+    const uint8_t *rec = bam + off;
+    BamFields f;
+    const uint32_t block_size = bam_le32(rec), l_read_name = rec[12];
+    const uint32_t n_cigar = (uint32_t)rec[16] | ((uint32_t)rec[17] << 8);
+    f.l_seq = bam_le32(rec + 20);
+    f.name = off + 36;
+    f.seq = f.name + l_read_name + 4ull * n_cigar;
+    f.qual = f.seq + (f.l_seq + 1) / 2;
+    f.tags = f.qual + f.l_seq;
+    f.tags_len = (uint32_t)(off + 4 + block_size - f.tags);
+    f.name_len = l_read_name ? l_read_name - 1 : 0; /* without the terminating NUL, :1633 */
+    return f;
+}
+
+__global__ void k_bam_sizes(const uint8_t *bam, const unsigned long long *offsets, uint64_t n,
+                            unsigned long long *sizes)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const BamFields f = bam_fields(bam, offsets[r]);
+        sizes[r] = (unsigned long long)f.name_len + 2ull * f.l_seq + f.tags_len;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sizes[n] = 0;
+}
+
+/* one wave per record; lanes take consecutive output bytes */
+__global__ void k_bam_decode(const uint8_t *bam, const unsigned long long *offsets,
+                             const unsigned long long *starts, uint64_t n, uint8_t *out, sq_meta *metas)
+{
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n; r += waves) {
+        const BamFields f = bam_fields(bam, offsets[r]);
+        uint8_t *o = out + starts[r];
+        for (uint32_t i = lane; i < f.name_len; i += 64) o[i] = bam[f.name + i];
+        o += f.name_len;
+        /* decode_bam_sequence :1264-1290: "=ACMGRSVTWYHKDBN"[nibble], high nibble first */
+        const unsigned long long lut_lo = 0x565352474D43413DULL, lut_hi = 0x4E42444B48595754ULL;
+        for (uint32_t i = lane; i < f.l_seq; i += 64) {
+            const uint32_t b = bam[f.seq + (i >> 1)];
+            const uint32_t code = (i & 1) ? (b & 15u) : (b >> 4);
+            o[i] = (uint8_t)(((code & 8u) ? lut_hi : lut_lo) >> (8 * (code & 7u)));
+        }
+        o += f.l_seq;
+        /* :1642-1650: missing qualities (0xff) become phred 0 */
+        const bool missing = f.l_seq && bam[f.qual] == 0xff;
+        for (uint32_t i = lane; i < f.l_seq; i += 64) o[i] = missing ? (uint8_t)33 : (uint8_t)(bam[f.qual + i] + 33);
+        o += f.l_seq;
+        for (uint32_t i = lane; i < f.tags_len; i += 64) o[i] = bam[f.tags + i];
+        if (lane == 0) {
+            sq_meta m;
+            m.record_start = starts[r];
+            m.name_length = f.name_len;
+            m.sequence_offset = f.name_len;
+            m.sequence_length = f.l_seq;
+            m.qualities_offset = f.name_len + f.l_seq;
+            m.tags_offset = f.name_len + 2 * f.l_seq;
+            m.tags_length = f.tags_len;
+            m.accumulated_error_rate = 0.0;
+            metas[r] = m;
+        }
+    }
+}
+
+} // namespace
+
+/* decoded batch of the BAM records at bam + offsets[i] (from sq_bam_scan); host pointers */
+SQ_EXPORT sq_batch *sq_batch_from_bam(sq_ctx *ctx, const uint8_t *bam, size_t len, const uint64_t *offsets, size_t n)
+{
+    sq_batch *b = new sq_batch();
+    b->ctx = ctx;
+    b->owns = true;
+    b->n = n;
+    uint8_t *d_bam = nullptr;
+    unsigned long long *d_off = nullptr, *d_sizes = nullptr, *d_starts = nullptr;
+    void *d_temp = nullptr;
+    auto fail = [&](const char *what) -> sq_batch * {
+        if (what) sq_set_error("%s", what);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *p : {(void *)d_bam, (void *)d_off, (void *)d_sizes, (void *)d_starts, d_temp})
+            if (p) (void)hipFree(p);
+        sq_batch_free(b);
+        return nullptr;
+    };
+    if (hipMalloc((void **)&b->d_metas, (n ? n : 1) * sizeof(sq_meta)) != hipSuccess) return fail("out of device memory");
+    if (n == 0) {
+        if (hipMalloc((void **)&b->d_buf, 64) != hipSuccess) return fail("out of device memory");
+        return b;
+    }
+    if (hipMalloc((void **)&d_bam, len + 64) != hipSuccess || hipMalloc((void **)&d_off, n * 8) != hipSuccess ||
+        hipMalloc((void **)&d_sizes, (n + 1) * 8) != hipSuccess || hipMalloc((void **)&d_starts, (n + 1) * 8) != hipSuccess)
+        return fail("out of device memory");
+    if (hipMemcpyAsync(d_bam, bam, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_off, offsets, n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail("copy to the device failed");
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_bam_sizes, dim3(blocks), dim3(256), 0, ctx->stream, d_bam, d_off, (uint64_t)n, d_sizes);
+    size_t temp_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_sizes, d_starts, (int)(n + 1), ctx->stream);
+    if (hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8) != hipSuccess) return fail("out of device memory");
+    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_sizes, d_starts, (int)(n + 1), ctx->stream);
+    (void)hipMemcpyAsync(&ctx->pinned[44], d_starts + n, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("BAM decode failed on the device");
+    b->buf_len = (size_t)ctx->pinned[44];
+    if (hipMalloc((void **)&b->d_buf, b->buf_len + 64) != hipSuccess) return fail("out of device memory");
+    const int wblocks = (int)std::min<uint64_t>((n + 3) / 4, 16384);
+    hipLaunchKernelGGL(k_bam_decode, dim3(wblocks), dim3(256), 0, ctx->stream, d_bam, d_off, d_starts, (uint64_t)n,
+                       b->d_buf, b->d_metas);
+    unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 5, 64);
+    if (!d_out) return fail("out of device memory");
+    (void)hipMemsetAsync(d_out, 0, 64, ctx->stream);
+    const int sb = (int)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, (size_t)n, d_out);
+    (void)hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("BAM decode failed on the device");
+    b->total_bases = ctx->pinned[0];
+    b->max_length = ctx->pinned[1];
+    b->max_name_length = ctx->pinned[2];
+    b->max_record_span = ctx->pinned[3];
+    b->min_length = ~ctx->pinned[4];
+    (void)hipFree(d_bam); (void)hipFree(d_off); (void)hipFree(d_sizes); (void)hipFree(d_starts); (void)hipFree(d_temp);
+    return b;
+}
+
 SQ_EXPORT void sq_batch_free(sq_batch *b)
 {
     if (!b) return;

@@ -627,8 +627,81 @@ def nanostats():
     save("nanostats_cases", **out)
 
 
+def bgzf_plain(name: str) -> bytes:
+    import zlib
+    with open(os.path.join(REFDATA, name), "rb") as f:
+        raw = f.read()
+    if not raw.startswith(b"\x1f\x8b"):
+        return raw
+    plain, pos = b"", 0
+    while pos < len(raw):  # BGZF blocks are gzip members
+        d = zlib.decompressobj(31)
+        plain += d.decompress(raw[pos:])
+        pos = len(raw) - len(d.unused_data)
+    return plain
+
+
+def bam():
+    """(6) what the reference's BamParser (_qcmodule.c:1386-1703) does with an uncompressed
+    BAM stream at a buffer size: header, the arrays it yields (record count, FastqMeta
+    structs, the used part of the decoded buffer) or the exception.  The BAM streams are
+    the reference's test files, BGZF removed.  -> bam_cases.npz, bam_errors.json"""
+    files = ["simple.unaligned.bam", "simple.raw.bam", "missing_quals.bam", "test_skip.bam",
+             "project.NIST_NIST7035_H7AP8ADXX_TAAGGCGA_1_NA12878.bwa.markDuplicates.bam",
+             "dorado_nanopore_100reads.bam", "secondary_alignment.bam"]
+    out, names = {}, []
+    for fname in files:
+        plain = bgzf_plain(fname)
+        key = fname[:-4].replace(".", "_")[:40]
+        out[key + "_bam"] = np.frombuffer(plain, np.uint8)
+        for bs in (4, 10, 40, 1000, 48 * 1024, 1 << 20):
+            if bs < 1000 and len(plain) > 100_000:
+                continue
+            parser = _qc.BamParser(io.BytesIO(plain), bs)
+            arrays = list(parser)
+            k = f"{key}_{bs}"
+            names.append(k)
+            out[k + "_header"] = np.frombuffer(parser.header, np.uint8)
+            out[k + "_sizes"] = np.array([len(a) for a in arrays], np.int64)
+            metas = [metas_of(a) for a in arrays]
+            out[k + "_metas"] = np.concatenate(metas) if metas else np.zeros((0, 7), np.int64)
+            used = []
+            for a, m in zip(arrays, metas):
+                end = int((m[:, 0] + m[:, 5] + m[:, 6]).max()) if len(m) else 0  # start + tags_offset + tags_length
+                used.append(np.frombuffer(a.obj[:end], np.uint8))
+            out[k + "_used"] = np.concatenate(used) if used else np.zeros(0, np.uint8)
+            out[k + "_used_lens"] = np.array([len(u) for u in used], np.int64)
+            print(k, [len(a) for a in arrays][:8], len(arrays))
+    out["names"] = np.array(names)
+    save("bam_cases", **out)
+
+    raw = bgzf_plain("simple.raw.bam")
+    record_with_header, header = raw[:115], raw[:54]
+    errors = []
+    cases = [record_with_header[:end] for end in range(0, len(record_with_header))]
+    cases += [b"@my header", raw[:200], raw + raw[54:115][:30]]
+    for data in cases:
+        for bs in (4, 48 * 1024):
+            try:
+                arrays = list(_qc.BamParser(io.BytesIO(data), bs))
+                res = {"sizes": [len(a) for a in arrays]}
+            except Exception as e:  # noqa: BLE001
+                res = {"error": type(e).__name__, "message": str(e)}
+            errors.append({"data": data.decode("latin-1"), "buffersize": bs, **res})
+    for bs in (0, 3):
+        try:
+            _qc.BamParser(io.BytesIO(raw), bs)
+        except Exception as e:  # noqa: BLE001
+            errors.append({"data": raw.decode("latin-1"), "buffersize": bs, "error": type(e).__name__, "message": str(e)})
+    with open(os.path.join(HERE, "bam_errors.json"), "wt") as f:
+        json.dump(errors, f, indent=0)
+    print(len(errors), "error cases;", sorted({e.get("error", "ok") for e in errors}))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "nanostats":
+    if len(sys.argv) > 1 and sys.argv[1] == "bam":
+        bam()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nanostats":
         nanostats()
     elif len(sys.argv) > 1 and sys.argv[1] == "synthetic":
         synthetic()
