@@ -147,6 +147,13 @@ __device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
     return (mask & 0x08080808u) | (~mask & lut);
 }
 
+/* &hist[row * stride] with a full-rate 24-bit multiply-add (v_mad_u32_u24): a plain 32-bit
+ * multiply is a quarter-rate instruction and there are two of these per base */
+__device__ __forceinline__ uint32_t *hist_row(uint32_t *base, uint32_t row, uint32_t stride_bytes)
+{
+    return (uint32_t *)((uint8_t *)base + __umul24(row, stride_bytes));
+}
+
 /* A wave walks its 64 reads in chunks of CW positions. */
 constexpr uint32_t CW = 32;               /* positions per chunk */
 constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
@@ -165,7 +172,7 @@ __device__ __forceinline__ uint32_t tile_idx(uint32_t row, uint32_t d)
 }
 
 template <bool QC, bool AD, bool PT, bool DFA_LDS>
-__global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
+__global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     /* ---- LDS carve-up (every region 16-byte aligned) ---- */
@@ -320,9 +327,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
             if (c0 + CW < maxL) prefetch(c0 + CW);
 
             /* ---------------- phase S: lane = read ---------------- */
-            if (QC || AD) {
-                const uint32_t nd = min(ROW_WORDS, (maxL - c0 + 3) / 4); /* dwords any read still has */
-                for (uint32_t d = 0; d < nd; d++) {
+            auto s_step = [&](uint32_t d) {
                     const uint32_t pos0 = c0 + d * 4;
                     const uint32_t ti = tile_idx((uint32_t)lane, d);
                     const uint32_t sd = w_seq[ti];
@@ -368,38 +373,57 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                             }
                         }
                     }
+            };
+            /* phase H of a full group of equally long reads, four row pairs: nothing depends on
+               the row but its two tile words (end-anchored tables are derived at the merge) */
+            const uint32_t p = c0 + pl;
+            const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
+            auto h_fast = [&](uint32_t rp0) {
+                uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
+                uint32_t sw[4], qw[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t rp = rp0 + k;
+                    const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                    sw[k] = w_seq[ti];
+                    qw[k] = w_qual[ti];
                 }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                    const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
+                    atomicAdd(hist_row(hb, cls, hs * 4), 1u);
+                    atomicAdd(hist_row(hp, bin, hs * 4), 1u);
+                }
+            };
+            const bool fast_group = QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n;
+            if (fast_group && c0 + CW <= P.uniform_len) {
+                /* a chunk that lies inside every read: the per-read chains of phase S (a table
+                   walk with one LDS round trip per base) and the histogram updates of phase H
+                   are independent, so they share one instruction stream and phase H fills the
+                   waits of phase S */
+#pragma unroll 1
+                for (uint32_t d = 0; d < ROW_WORDS; d++) {
+                    s_step(d);
+                    h_fast(4 * d);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            if (QC || AD) {
+                const uint32_t nd = min(ROW_WORDS, (maxL - c0 + 3) / 4); /* dwords any read still has */
+                for (uint32_t d = 0; d < nd; d++) s_step(d);
             }
 
             /* ---------------- phase H: lane = position, two rows at a time ---------------- */
             if (QC || PT) {
-                const uint32_t p = c0 + pl;
                 uint32_t *hb = l_hist_base + p;   /* + class * hs */
                 uint32_t *hp = l_hist_phred + p;
-                const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
-                if (QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n) {
-                    /* a full group whose reads all have P.uniform_len bases, every one inside the LDS
-                       histograms, and the end-anchored tables are derived at the merge:
-                       nothing in the loop depends on the row but its two tile words */
+                if (fast_group) {
                     if (p < P.uniform_len) {
 #pragma unroll
-                        for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
-                            uint32_t sw[4], qw[4];
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) {
-                                const uint32_t rp = rp0 + k;
-                                const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
-                                sw[k] = w_seq[ti];
-                                qw[k] = w_qual[ti];
-                            }
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) {
-                                const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
-                                const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
-                                atomicAdd(&hb[cls * hs], 1u);
-                                atomicAdd(&hp[bin * hs], 1u);
-                            }
-                        }
+                        for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) h_fast(rp0);
                     }
                 } else {
                     const bool in_lds = p < P.lds_len;
@@ -444,8 +468,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                                 const uint32_t bin = min(qb - 33u, 47u) >> 2;
                                 if (act) {
                                     if (in_lds) {
-                                        atomicAdd(&hb[cls * hs], 1u);
-                                        atomicAdd(&hp[bin * hs], 1u);
+                                        atomicAdd(hist_row(hb, cls, hs * 4), 1u);
+                                        atomicAdd(hist_row(hp, bin, hs * 4), 1u);
                                     } else if (P.window) {
                                         atomicAdd(&wb[min(cls, 4u) * CW], 1u);
                                         atomicAdd(&wb[(BASE_COLS + bin) * CW], 1u);
@@ -459,8 +483,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_pass(PassParams P)
                                         if (p >= Lr - ean) {
                                             const uint32_t e = P.ea_len - Lr + p;
                                             if (P.ea_in_lds) {
-                                                atomicAdd(&l_ea_base[cls * es + e], 1u);
-                                                atomicAdd(&l_ea_phred[bin * es + e], 1u);
+                                                atomicAdd(hist_row(l_ea_base + e, cls, es * 4), 1u);
+                                                atomicAdd(hist_row(l_ea_phred + e, bin, es * 4), 1u);
                                             } else {
                                                 atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
                                                 atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
@@ -844,10 +868,10 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
                     }
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
-                        const uint32_t cls = ((sw[k] >> h_sh) & 0xFF) >> 1;
-                        const uint32_t bin = min(((qw[k] >> h_sh) & 0xFF) - 33u, 47u) >> 2;
-                        atomicAdd(&hb[cls * hs], 1u);
-                        atomicAdd(&hp[bin * hs], 1u);
+                        const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                        const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
+                        atomicAdd(hist_row(hb, cls, hs * 4), 1u);
+                        atomicAdd(hist_row(hp, bin, hs * 4), 1u);
                     }
                 }
             }
