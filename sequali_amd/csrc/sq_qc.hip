@@ -327,52 +327,59 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
             if (c0 + CW < maxL) prefetch(c0 + CW);
 
             /* ---------------- phase S: lane = read ---------------- */
+            /* one dword (4 positions) of the per-read work; the automaton's four table entries
+               come back in e[] so that the caller can put other work in front of the (rare)
+               hit handling */
+            auto s_main = [&](uint32_t d, uint32_t e[4]) -> bool {
+                const uint32_t pos0 = c0 + d * 4;
+                const uint32_t ti = tile_idx((uint32_t)lane, d);
+                const uint32_t sd = w_seq[ti];
+                if (QC) {
+                    uint32_t qd = w_qual[ti];
+                    /* the reference's four chains stop four short of the end (:2068) */
+                    qd = pos0 < Lmain ? qd : PAD4;
+                    const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
+                    const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
+                    acc0 += e0;
+                    acc1 += e1;
+                    acc2 += e2;
+                    acc3 += e3;
+                    /* class codes are 0 2 4 6 (ACGT) 8 (other) 14 (padding): G/C have
+                       bit1 != bit2, non-ACGT have bit 3 (:1997-2049 counts) */
+                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                    acgt_cnt += __popc(~sd & 0x08080808u);
+                }
+                if (!AD) return false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
+                    if (DFA_LDS) e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
+                    else e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
+                    st = e[j] & 0xFFF0u;
+                }
+                return ((e[0] | e[1] | e[2] | e[3]) & 1u) != 0;
+            };
+            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+            auto s_hits = [&](uint32_t d, const uint32_t e[4]) {
+                const uint32_t pos0 = c0 + d * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!(e[j] & 1u)) continue;
+                    unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                    found |= hits;
+                    const uint32_t pos = pos0 + j;
+                    while (hits) {
+                        const int a = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        const uint32_t start = pos - P.ad_len[a] + 1;
+                        atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                        atomicAdd(&P.ad_rev[a * P.ad_cap + (L - 1 - start)], 1ULL);
+                    }
+                }
+            };
             auto s_step = [&](uint32_t d) {
-                    const uint32_t pos0 = c0 + d * 4;
-                    const uint32_t ti = tile_idx((uint32_t)lane, d);
-                    const uint32_t sd = w_seq[ti];
-                    if (QC) {
-                        uint32_t qd = w_qual[ti];
-                        /* the reference's four chains stop four short of the end (:2068) */
-                        qd = pos0 < Lmain ? qd : PAD4;
-                        const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
-                        const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
-                        acc0 += e0;
-                        acc1 += e1;
-                        acc2 += e2;
-                        acc3 += e3;
-                        /* class codes are 0 2 4 6 (ACGT) 8 (other) 14 (padding): G/C have
-                           bit1 != bit2, non-ACGT have bit 3 (:1997-2049 counts) */
-                        gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
-                        acgt_cnt += __popc(~sd & 0x08080808u);
-                    }
-                    if (AD) {
-                        uint32_t e[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
-                            if (DFA_LDS) e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
-                            else e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
-                            st = e[j] & 0xFFF0u;
-                        }
-                        if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
-                            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                if (!(e[j] & 1u)) continue;
-                                unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
-                                found |= hits;
-                                const uint32_t pos = pos0 + j;
-                                while (hits) {
-                                    const int a = __ffsll((long long)hits) - 1;
-                                    hits &= hits - 1;
-                                    const uint32_t start = pos - P.ad_len[a] + 1;
-                                    atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
-                                    atomicAdd(&P.ad_rev[a * P.ad_cap + (L - 1 - start)], 1ULL);
-                                }
-                            }
-                        }
-                    }
+                uint32_t e[4];
+                if (s_main(d, e)) s_hits(d, e);
             };
             /* phase H of a full group of equally long reads, four row pairs: nothing depends on
                the row but its two tile words (end-anchored tables are derived at the merge) */
@@ -404,8 +411,10 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                    waits of phase S */
 #pragma unroll 1
                 for (uint32_t d = 0; d < ROW_WORDS; d++) {
-                    s_step(d);
+                    uint32_t e[4];
+                    const bool hit = s_main(d, e);
                     h_fast(4 * d);
+                    if (hit) s_hits(d, e);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
