@@ -186,16 +186,19 @@ def main():
                 events.stop()
         _lib.synchronize()
         if use_dist:
-            # the job's one exchange step: sum the count tables of all ranks over RCCL
-            # (on copies, so that repeated steps keep accumulating the local counts)
-            from sequali_amd import dist as sqdist
-            tables = (sqdist.qcmetrics_tables(qc, device) if qc else []) + \
-                     (sqdist.adaptercounter_tables(ad, device) if ad else [])
+            # the job's one exchange step: sum the count tables of all ranks over RCCL, as ONE
+            # all-reduce over one flat buffer (on a copy, so that repeated steps keep
+            # accumulating the local counts); the aliases and the buffer are set up once
             if not scratch:
-                scratch.extend(torch.empty_like(t) for t in tables)
-            for dst, src in zip(scratch, tables):
-                dst.copy_(src)
-            sqdist.sum_tables(scratch)
+                from sequali_amd import dist as sqdist
+                tables = (sqdist.qcmetrics_tables(qc, device) if qc else []) + \
+                         (sqdist.adaptercounter_tables(ad, device) if ad else [])
+                tables = [t.reshape(-1) for t in tables if t.dtype == torch.int64]
+                flat = torch.empty(sum(t.numel() for t in tables), dtype=torch.int64, device=device)
+                scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables]))])
+            tables, flat, parts = scratch
+            torch._foreach_copy_(parts, tables)
+            dist.all_reduce(flat)
             torch.cuda.synchronize()
 
     def barrier():
