@@ -40,6 +40,7 @@ constexpr int WG_THREADS = 256;
 constexpr int WAVES = WG_THREADS / 64;
 constexpr uint32_t PAD4 = 0x80808080u;   /* quality tile: past the end of the read */
 constexpr uint32_t LDS_HIST_MAX = 512;  /* positions kept in LDS histograms */
+constexpr uint32_t STRIPE = 512;        /* positions per launch when reads are longer than that (256: more launches, slower) */
 constexpr uint32_t LDS_EA_MAX = 256;    /* end-anchor rows kept in LDS */
 constexpr uint32_t DFA_LDS_MAX_STATES = 1024; /* 16 KB of LDS */
 /* LDS histograms are class-major, [class][position] with the position stride rounded
@@ -53,6 +54,7 @@ constexpr uint32_t TILE_MAP_SIZE = 1u << 16;
 /* SCORE_TO_ERROR_RATE as bit patterns (score_to_error_rate.h:4-99) */
 __constant__ unsigned long long c_error_rate_bits[94] = {SQ_ERROR_RATE_BITS_LIST};
 
+struct sq_carry;
 struct PassParams {
     const uint8_t *buf;
     uint64_t buf_len;
@@ -60,12 +62,12 @@ struct PassParams {
     uint64_t n;
     uint64_t first_read_index; /* index of record 0 over everything the module saw */
     uint32_t lds_len;          /* positions covered by the LDS histograms */
-    uint32_t window;           /* != 0: positions >= lds_len go through a per-wave LDS window
-                                  that is merged into the u64 tables after every chunk */
+    /* stripes (reads longer than the LDS histograms): one launch covers positions
+       [pos_base, pos_end) of the reads that are longer than pos_base; what a read carries from
+       one stripe to the next (the f64 chains, the automaton, its base counts) lives in `carry` */
+    uint32_t pos_base, pos_end;
+    struct sq_carry *carry;    /* [records in processing order], NULL: one stripe holds every read */
     const uint32_t *order;     /* processing order of the records (NULL: as stored) */
-    unsigned long long *win_base, *win_phred; /* window regime: [n_copies][win_rows][5] / [12] */
-    uint32_t n_copies;         /* private copies of the two tables the windows merge into */
-    uint64_t win_rows;
     uint32_t blocked;          /* != 0: a wave takes a contiguous run of groups (tile-sorted order:
                                   concurrent waves then sit in different tiles) */
     /* QCMetrics */
@@ -159,7 +161,6 @@ constexpr uint32_t CW = 32;               /* positions per chunk */
 constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
 constexpr uint32_t TILE_WORDS = 64 * ROW_WORDS;
 constexpr uint32_t WAVE_WORDS = 2 * TILE_WORDS + 128 + 128 + 64;
-constexpr uint32_t WIN_WORDS = (BASE_COLS + PHRED_COLS) * CW; /* [class][CW positions] */
 constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
 
 /* tile address of dword d of row r: rows are ROW_WORDS = 8 dwords, the dword index
@@ -171,6 +172,13 @@ __device__ __forceinline__ uint32_t tile_idx(uint32_t row, uint32_t d)
     return row * ROW_WORDS + (d ^ ((row >> 2) & 7));
 }
 
+/* state of a read between two stripes */
+struct sq_carry {
+    double acc[4];
+    unsigned long long found;
+    uint32_t st, gc_cnt, acgt_cnt, pad_;
+};
+
 template <bool QC, bool AD, bool PT, bool DFA_LDS>
 __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
 {
@@ -181,9 +189,8 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
     uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
-    uint32_t *l_win = l_wave + WAVES * WAVE_WORDS;         /* per wave [CW][WIN_STRIDE] when P.window */
     const uint32_t hs = QC ? hist_stride(P.lds_len) : 0;   /* words per class row */
-    uint32_t *l_hist_base = l_win + (P.window ? WAVES * WIN_WORDS : 0); /* [5][hs] */
+    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [5][hs] */
     uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;               /* [12][hs] */
     uint32_t *l_ea_base = l_hist_phred + hs * PHRED_COLS;
     const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
@@ -216,8 +223,6 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     if (AD && DFA_LDS) {
         for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
     }
-    if (P.window)
-        for (uint32_t i = tid; i < WAVES * WIN_WORDS; i += WG_THREADS) l_win[i] = 0;
     __syncthreads();
 
     uint32_t *w_seq = l_wave + wave * WAVE_WORDS;
@@ -225,7 +230,6 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     unsigned long long *w_soff = (unsigned long long *)(w_qual + TILE_WORDS);
     unsigned long long *w_qoff = w_soff + 64;
     uint32_t *w_len = (uint32_t *)(w_qoff + 64);
-    uint32_t *w_win = l_win + wave * WIN_WORDS;
 
     const uint64_t ngroups = (P.n + 63) / 64;
     const bool ea_atomics = QC && !P.uniform_len;
@@ -240,10 +244,12 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     const uint64_t g_step = P.blocked ? 1 : n_waves;
     for (uint64_t g = g_begin; g < g_end; g += g_step) {
         const uint64_t slot_index = g * 64 + lane;
-        const bool valid = slot_index < P.n;
+        bool valid = slot_index < P.n;
         const uint64_t r = (valid && P.order) ? P.order[slot_index] : slot_index;
         sq_meta m;
         if (valid) m = P.metas[r];
+        /* in a later stripe only the reads that reach it take part */
+        if (valid && P.pos_base && m.sequence_length <= P.pos_base) valid = false;
         const uint32_t L = valid ? m.sequence_length : 0;
         const uint64_t soff = valid ? m.record_start + m.sequence_offset : 0;
         const uint64_t qoff = valid ? m.record_start + m.qualities_offset : 0;
@@ -257,6 +263,12 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         uint32_t st = 0;                 /* automaton state as the byte offset of its row */
         unsigned long long found = 0;    /* adapters already seen in this read */
         uint32_t gc_cnt = 0, acgt_cnt = 0;
+        if (P.pos_base && valid) {       /* pick up where the stripe in front left this read */
+            const sq_carry cy = P.carry[slot_index];
+            acc0 = cy.acc[0]; acc1 = cy.acc[1]; acc2 = cy.acc[2]; acc3 = cy.acc[3];
+            found = cy.found; st = cy.st; gc_cnt = cy.gc_cnt; acgt_cnt = cy.acgt_cnt;
+        }
+        const uint32_t stripe_end = min(maxL, P.pos_end);
         bool pt_on = false;
         int32_t pt_slot = -1;
         if (PT) {
@@ -284,9 +296,9 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 }
             }
         };
-        if (maxL > 0) prefetch(0);
+        if (stripe_end > P.pos_base) prefetch(P.pos_base);
 
-        for (uint32_t c0 = 0; c0 < maxL; c0 += CW) {
+        for (uint32_t c0 = P.pos_base; c0 < stripe_end; c0 += CW) {
             /* ---------------- STAGE: 2 lanes x 16 bytes per row ---------------- */
 #pragma unroll
             for (int it = 0; it < 2; it++) {
@@ -324,7 +336,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (c0 + CW < maxL) prefetch(c0 + CW);
+            if (c0 + CW < stripe_end) prefetch(c0 + CW);
 
             /* ---------------- phase S: lane = read ---------------- */
             /* one dword (4 positions) of the per-read work; the automaton's four table entries
@@ -421,22 +433,21 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 continue;
             }
             if (QC || AD) {
-                const uint32_t nd = min(ROW_WORDS, (maxL - c0 + 3) / 4); /* dwords any read still has */
+                const uint32_t nd = min(ROW_WORDS, (stripe_end - c0 + 3) / 4); /* dwords any read still has */
                 for (uint32_t d = 0; d < nd; d++) s_step(d);
             }
 
             /* ---------------- phase H: lane = position, two rows at a time ---------------- */
             if (QC || PT) {
-                uint32_t *hb = l_hist_base + p;   /* + class * hs */
-                uint32_t *hp = l_hist_phred + p;
+                uint32_t *hb = l_hist_base + (p - P.pos_base);   /* + class * hs */
+                uint32_t *hp = l_hist_phred + (p - P.pos_base);
                 if (fast_group) {
                     if (p < P.uniform_len) {
 #pragma unroll
                         for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) h_fast(rp0);
                     }
                 } else {
-                    const bool in_lds = p < P.lds_len;
-                    uint32_t *wb = w_win + pl;        /* + class * CW */
+                    const bool in_lds = p - P.pos_base < P.lds_len;
                     /* PerTileQuality: the records come sorted by tile (P.order), so a lane
                        keeps the running error sum of its position in a register and only
                        touches memory when the tile changes */
@@ -479,9 +490,6 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                                     if (in_lds) {
                                         atomicAdd(hist_row(hb, cls, hs * 4), 1u);
                                         atomicAdd(hist_row(hp, bin, hs * 4), 1u);
-                                    } else if (P.window) {
-                                        atomicAdd(&wb[min(cls, 4u) * CW], 1u);
-                                        atomicAdd(&wb[(BASE_COLS + bin) * CW], 1u);
                                     } else {
                                         atomicAdd(&P.qc_base[(uint64_t)p * 5 + min(cls, 4u)], 1ULL);
                                         atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], 1ULL);
@@ -520,24 +528,6 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                     }
                     if (PT && run_slot >= 0)
                         unsafeAtomicAdd(&P.pt_errors[(uint64_t)run_slot * P.pt_cap + p], run_sum);
-                    if (QC && P.window && c0 + CW > P.lds_len) {
-                        /* merge this chunk's window into the u64 tables and clear it */
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        for (uint32_t i = lane; i < WIN_WORDS; i += 64) {
-                            const uint32_t v = w_win[i];
-                            if (!v) continue;
-                            w_win[i] = 0;
-                            const uint32_t pos = c0 + i % CW, col = i / CW;
-                            /* thousands of waves walk the same positions at about the same time:
-                               spread them over private copies of the tables (summed afterwards) */
-                            const uint64_t copy = wave_id % P.n_copies;
-                            if (col < BASE_COLS)
-                                atomicAdd(&P.win_base[(copy * P.win_rows + pos) * 5 + col], (unsigned long long)v);
-                            else
-                                atomicAdd(&P.win_phred[(copy * P.win_rows + pos) * 12 + (col - BASE_COLS)], (unsigned long long)v);
-                        }
-                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -545,7 +535,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         }
 
         /* ---------------- per-read epilogue: lane = read ---------------- */
-        if (QC && valid) {
+        if (valid && L > P.pos_end) { /* the read goes on in the next stripe */
+            sq_carry cy;
+            cy.acc[0] = acc0; cy.acc[1] = acc1; cy.acc[2] = acc2; cy.acc[3] = acc3;
+            cy.found = found; cy.st = st; cy.gc_cnt = gc_cnt; cy.acgt_cnt = acgt_cnt; cy.pad_ = 0;
+            P.carry[slot_index] = cy;
+        }
+        if (QC && valid && L <= P.pos_end) {
             double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099, left to right */
             for (uint32_t pos = Lmain; pos < L; pos++) { /* :2100-2112 */
                 const uint32_t qb = P.buf[qoff + pos];
@@ -567,7 +563,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 atomicAdd(&l_ps[lo], 1u);
             }
         }
-        if (PT && pt_on && L > 0)
+        if (PT && pt_on && L > 0 && L <= P.pos_end)
             atomicAdd(&P.pt_len_counts[(uint64_t)pt_slot * P.pt_cap + (L - 1)], 1ULL);
     }
 
@@ -577,7 +573,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
             const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
             if (v) {
-                atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
+                atomicAdd(&P.qc_base[(uint64_t)(P.pos_base + pos) * 5 + c], (unsigned long long)v);
                 if (P.uniform_len) {
                     /* every read has the same length: the end-anchored table is a
                        window of the positional one (:1971-1972, 2034-2043) */
@@ -591,7 +587,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         for (uint32_t i = tid; i < hs * PHRED_COLS; i += WG_THREADS) {
             const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
             if (v) {
-                atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
+                atomicAdd(&P.qc_phred[(uint64_t)(P.pos_base + pos) * 12 + c], (unsigned long long)v);
                 if (P.uniform_len) {
                     const uint32_t ean = min(P.ea_len, P.uniform_len);
                     if (pos >= P.uniform_len - ean)
@@ -935,11 +931,9 @@ size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
     return b + 16;
 }
 
-size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states,
-                      bool window)
+size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states)
 {
     size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
-    if (window) b += (size_t)WAVES * WIN_WORDS * 4;
     if (qc) b += (size_t)(hist_stride(lds_len) + hist_stride(ea_rows)) * (BASE_COLS + PHRED_COLS) * 4;
     if (dfa_lds) b += (size_t)dfa_states * 16;
     return b + 16;
@@ -1114,16 +1108,19 @@ const uint32_t *sorted_order(sq_ctx *ctx, const sq_batch *b, const int32_t *slot
     return vals_out;
 }
 
-/* dst[i] += sum over copies of src[copy][i] */
-__global__ void k_sum_copies(unsigned long long *dst, const unsigned long long *src, uint64_t cells,
-                             uint32_t n_copies)
+/* records in `order` come longest first: counts[w] = how many are longer than w * stripe */
+__global__ void k_stripe_counts(const sq_meta *metas, const uint32_t *order, uint64_t n, uint32_t stripe,
+                                uint32_t n_stripes, unsigned long long *counts)
 {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cells;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        unsigned long long t = 0;
-        for (uint32_t c = 0; c < n_copies; c++) t += src[c * cells + i];
-        if (t) dst[i] += t;
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_stripes) return;
+    const uint64_t limit = (uint64_t)w * stripe;
+    uint64_t lo = 0, hi = n; /* first index whose read is not longer than limit */
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (metas[order[mid]].sequence_length > limit) lo = mid + 1; else hi = mid;
     }
+    counts[w] = lo;
 }
 
 int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
@@ -1586,15 +1583,18 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         uint64_t fb = p->first_bad == UINT64_MAX ? UINT64_MAX : p->first_bad - p->records_seen;
         P.pt_first_bad = fb == UINT64_MAX ? UINT64_MAX : fb + P.first_read_index;
     }
+    uint32_t stripes = 0; /* 0: one launch holds every read */
     if (m) {
         if (b->max_length <= LDS_HIST_MAX) {
             P.lds_len = (uint32_t)b->max_length; /* every position has its LDS counters */
             if (b->min_length == b->max_length && b->max_length > 0) P.uniform_len = P.lds_len;
         } else {
-            P.lds_len = 0;  /* long reads: a per-wave window of one chunk, merged chunk by chunk */
-            P.window = 1;
+            /* long reads: stripes of STRIPE positions, one launch each (see PassParams) */
+            P.lds_len = STRIPE;
+            stripes = (uint32_t)((b->max_length + STRIPE - 1) / STRIPE);
         }
     }
+    P.pos_end = UINT32_MAX;
     if (b->n >= 4096 && b->n < (1ull << 31)) {
         if (pt_active) {
             P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
@@ -1612,25 +1612,25 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         }
         P.ad_cap = a->cap;
     }
-    /* first automaton rides with the other modules; further groups get a pass of their own */
-    if (m && P.window) {
-        /* private copies of the positional tables for the window merges: as many as fit
-           in about 1 GB, at most 64 */
-        const uint64_t rows = b->max_length, cells = rows * 17;
-        uint32_t copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (1ull << 30) / (cells * 8)));
-        unsigned long long *priv = (unsigned long long *)sq_scratch(ctx, 5, (size_t)copies * cells * 8);
-        if (!priv) { sq_set_error("out of device memory for the long-read tables"); return SQ_ERR_MEMORY; }
-        SQ_HIP(hipMemsetAsync(priv, 0, (size_t)copies * cells * 8, ctx->stream));
-        P.win_base = priv;
-        P.win_phred = priv + (size_t)copies * rows * 5;
-        P.n_copies = copies;
-        P.win_rows = rows;
+    /* stripes: how many reads reach each of them, and the state they carry between launches */
+    std::vector<uint64_t> stripe_reads(std::max(stripes, 1u), b->n);
+    sq_carry *d_carry = nullptr;
+    if (stripes) {
+        d_carry = (sq_carry *)sq_scratch(ctx, 5, b->n * sizeof(sq_carry));
+        if (!d_carry) { sq_set_error("out of device memory for the long-read state"); return SQ_ERR_MEMORY; }
+        if (P.order && !P.blocked) { /* longest first: a stripe's reads are a prefix */
+            unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 4, stripes * 8);
+            if (!d_counts) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+            hipLaunchKernelGGL(k_stripe_counts, dim3((stripes + 255) / 256), dim3(256), 0, ctx->stream, b->d_metas,
+                               P.order, (uint64_t)b->n, STRIPE, stripes, d_counts);
+            SQ_HIP(hipMemcpyAsync(stripe_reads.data(), d_counts, stripes * 8, hipMemcpyDeviceToHost, ctx->stream));
+            SQ_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
+    /* first automaton rides with the other modules; further groups get a pass of their own */
     size_t ngroups = a ? a->groups.size() : 0;
-    const uint32_t window_regime = P.window;
     for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
         bool qc = m && gi == 0, pt = pt_active && gi == 0, ad = a != nullptr;
-        P.window = qc ? window_regime : 0;
         bool dfa_lds = false;
         uint32_t states = 0;
         if (ad) {
@@ -1672,20 +1672,28 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             P.first_read_index += C.n;
             P.n = b->n - C.n;
         }
-        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, qc && P.window);
+        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states);
         if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
-        int grid = grid_for(ctx, b->n, wgs_per_cu);
-        dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid, lds);
-        SQ_HIP(hipGetLastError());
-        if (ring) P = Pfull;
-        if (qc && P.window) {
-            const uint64_t rows = P.win_rows;
-            hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 5 + 255) / 256, 4096)),
-                               dim3(256), 0, ctx->stream, m->d_base, P.win_base, rows * 5, P.n_copies);
-            hipLaunchKernelGGL(k_sum_copies, dim3((unsigned)std::min<uint64_t>((rows * 12 + 255) / 256, 4096)),
-                               dim3(256), 0, ctx->stream, m->d_phred, P.win_phred, rows * 12, P.n_copies);
+        if (qc && stripes) {
+            const uint64_t n_all = P.n;
+            for (uint32_t w = 0; w < stripes && stripe_reads[w]; w++) {
+                P.pos_base = w * STRIPE;
+                P.pos_end = (w + 1) * STRIPE;
+                P.carry = d_carry;
+                P.n = std::min<uint64_t>(stripe_reads[w], n_all);
+                dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid_for(ctx, P.n, wgs_per_cu), lds);
+                SQ_HIP(hipGetLastError());
+            }
+            P.n = n_all;
+            P.pos_base = 0;
+            P.pos_end = UINT32_MAX;
+            P.carry = nullptr;
+        } else {
+            dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid_for(ctx, P.n, wgs_per_cu), lds);
+            SQ_HIP(hipGetLastError());
         }
+        if (ring) P = Pfull;
     }
     if (m) { m->number_of_reads += b->n; m->records_seen += b->n; }
     if (a) a->number_of_sequences += b->n;
