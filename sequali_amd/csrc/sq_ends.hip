@@ -449,6 +449,7 @@ struct IszTable {
 
 struct IszParams {
     const uint8_t *buf1, *buf2;
+    uint64_t len1; /* bytes of buf1 */
     const sq_meta *metas1, *metas2;
     uint64_t n;
     unsigned long long *insert_sizes; /* [cap] */
@@ -518,16 +519,26 @@ __global__ void k_insert_size(IszParams P)
         const uint32_t L1 = m1.sequence_length, L2 = m2.sequence_length;
         uint32_t result = 0;
         if (L1 >= 16 && L2 >= 16) {
+            /* the two needles: reverse complements of the first and of the last 16 bases of
+               read 2, from four 8-byte loads */
             uint64_t h_lo = 0, h_hi = 0, t_lo = 0, t_hi = 0;
-            for (int i = 0; i < 16; i++) {
-                /* needle byte (15 - i) = complement of R2 byte i */
-                const uint64_t hb = complement_or_zero(s2[i]);
-                const uint64_t tb = complement_or_zero(s2[L2 - 16 + i]);
-                const int pos = 15 - i;
-                if (pos < 8) { h_lo |= hb << (8 * pos); t_lo |= tb << (8 * pos); }
-                else { h_hi |= hb << (8 * (pos - 8)); t_hi |= tb << (8 * (pos - 8)); }
+            {
+                const uint64_t a0 = sq_load_u64_unaligned(s2), a1 = sq_load_u64_unaligned(s2 + 8);
+                const uint64_t z0 = sq_load_u64_unaligned(s2 + L2 - 16), z1 = sq_load_u64_unaligned(s2 + L2 - 8);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    /* needle byte (15 - i) = complement of R2 byte i */
+                    h_hi |= (uint64_t)complement_or_zero((uint8_t)(a0 >> (8 * i))) << (8 * (7 - i));
+                    h_lo |= (uint64_t)complement_or_zero((uint8_t)(a1 >> (8 * i))) << (8 * (7 - i));
+                    t_hi |= (uint64_t)complement_or_zero((uint8_t)(z0 >> (8 * i))) << (8 * (7 - i));
+                    t_lo |= (uint64_t)complement_or_zero((uint8_t)(z1 >> (8 * i))) << (8 * (7 - i));
+                }
             }
-            uint64_t lo = sq_load_u64_unaligned(s1), hi = sq_load_u64_unaligned(s1 + 8);
+            /* read 1 streams through a 16-byte window that moves one base at a time and is
+               refilled eight bytes at a time */
+            uint64_t lo = sq_load_u64_unaligned(s1), hi = sq_load_u64_unaligned(s1 + 8), nx = 0;
+            uint32_t avail = 0;
+            const uint8_t *end1 = P.buf1 + P.len1;
             const uint64_t UP = 0xDFDFDFDFDFDFDFDFULL;
             for (uint32_t i = 0; i + 16 <= L1; i++) {
                 const uint64_t ulo = lo & UP, uhi = hi & UP;
@@ -546,8 +557,20 @@ __global__ void k_insert_size(IszParams P)
                     if (d <= 1) { result = i + L2; break; }
                 }
                 if (i + 17 <= L1) { /* slide the 16-byte window by one base */
+                    if (avail == 0) {
+                        const uint8_t *src = s1 + i + 16;
+                        if (src + 8 <= end1) {
+                            nx = sq_load_u64_unaligned(src);
+                        } else {
+                            nx = 0;
+                            for (int b = 0; b < 8 && src + b < end1; b++) nx |= (uint64_t)src[b] << (8 * b);
+                        }
+                        avail = 8;
+                    }
                     lo = (lo >> 8) | (hi << 56);
-                    hi = (hi >> 8) | ((uint64_t)s1[i + 16] << 56);
+                    hi = (hi >> 8) | (nx << 56);
+                    nx >>= 8;
+                    avail--;
                 }
             }
         }
@@ -1704,6 +1727,7 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     if (rc) return rc;
     IszParams P{};
     P.buf1 = b1->d_buf; P.buf2 = b2->d_buf; P.metas1 = b1->d_metas; P.metas2 = b2->d_metas;
+    P.len1 = b1->buf_len;
     P.n = n; P.insert_sizes = z->d_sizes; P.max_insert = z->d_max;
     P.tab[0] = z->tab[0]; P.tab[1] = z->tab[1];
     P.rank_base = z->first_pair + z->total_reads;
