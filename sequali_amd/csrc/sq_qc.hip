@@ -998,12 +998,27 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
                               TileMap map, int32_t *slots, const unsigned long long *first_bad,
                               int *overflow)
 {
+    /* a flow cell has a few hundred tiles: a workgroup remembers the ones it has resolved in LDS
+       (write-once entries) instead of asking the L2 for the same hot lines 10 M times */
+    constexpr uint32_t CACHE = 1024;
+    __shared__ long long c_key[CACHE];
+    __shared__ int c_val[CACHE];
+    for (uint32_t i = threadIdx.x; i < CACHE; i += blockDim.x) { c_key[i] = TILE_EMPTY; c_val[i] = -1; }
+    __syncthreads();
     const unsigned long long stop = *first_bad;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
          r += (uint64_t)gridDim.x * blockDim.x) {
         const long long tile = tiles[r];
         int slot = -1;
         if (tile >= 0 && first_read_index + r < stop) {
+            const uint32_t ci = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 40) & (CACHE - 1);
+            if (__hip_atomic_load(&c_key[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tile) {
+                const int v = __hip_atomic_load(&c_val[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v >= 0) {
+                    slots[r] = v;
+                    continue;
+                }
+            }
             uint32_t idx = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 48) & (TILE_MAP_SIZE - 1);
             bool done = false;
             for (uint32_t probes = 0; !done && probes < 4 * TILE_MAP_SIZE; probes++) {
@@ -1031,6 +1046,9 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
                 }
             }
             if (!done) *overflow = 1;
+            else if (atomicCAS((unsigned long long *)&c_key[ci], (unsigned long long)TILE_EMPTY,
+                               (unsigned long long)tile) == (unsigned long long)TILE_EMPTY)
+                __hip_atomic_store(&c_val[ci], slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         slots[r] = slot;
     }
