@@ -1255,7 +1255,7 @@ int store_after_pair(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::v
  * estimator.  Only hashes that pass the mask in force at the start can matter; the mask
  * only ever gets stricter (H3). */
 int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned char *d_special, uint64_t n,
-               sq_batch *b1, sq_batch *b2)
+               sq_batch *b1, sq_batch *b2, uint64_t r_base = 0)
 {
     sq_ctx *ctx = d->ctx;
     DedupKeep keep{(1ULL << d->modulo_bits) - 1, d_hashes, d_special};
@@ -1289,7 +1289,7 @@ int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned c
             __builtin_prefetch(&d->count[slot]);
             __builtin_prefetch(&d->hash[slot]);
         }
-        const uint64_t r = idx[e];
+        const uint64_t r = r_base + idx[e];
         uint64_t h = hashes[e];
         if (special[e]) {
             std::vector<uint8_t> store;
@@ -1393,7 +1393,17 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
     if (d->deferred) {
         rc = dedup_defer(d, b1, b2, d_hashes, d_special, n);
     } else {
-        rc = dedup_tail(d, d_hashes, d_special, n, b1, b2);
+        /* in pieces: the mask only gets stricter, so every piece is filtered with the one in
+           force when it starts.  About max_stored << bits hashes go by before the next rebuild,
+           so that is the piece: a fresh estimator does not drag a whole batch through the host
+           at mask 0, a settled one takes the batch in one piece */
+        rc = SQ_OK;
+        for (uint64_t off = 0; off < n && rc == SQ_OK;) {
+            const uint64_t piece = std::min<uint64_t>(n - off, std::max<uint64_t>(d->max_stored, 1u << 16)
+                                                                   << std::min<uint64_t>(d->modulo_bits, 20));
+            rc = dedup_tail(d, d_hashes + off, d_special + off, piece, b1, b2, off);
+            off += piece;
+        }
         if (rc == SQ_OK && b2) { /* carry the store into the next batch (usually one step: the
                                     last pair rewrote all of it) */
             std::vector<uint8_t> store;
