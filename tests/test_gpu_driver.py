@@ -1,0 +1,133 @@
+"""The driver loop (sequali_amd.driver) on files: the reference's test data written
+to disk (plain, gzip, BGZF-less BAM) goes through `run` and every module's output equals
+what the oracle's modules give for the same records in the reference's order
+(__main__.py:279-306)."""
+import gzip
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import GOLDEN, golden, split_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+def u64(a):
+    return np.array(a, dtype=np.uint64)
+
+
+def oracle_single(text: bytes, probes):
+    buf, metas = split_fastq(text)
+    q, a, p, o, d, n = (oracle.QCMetrics(), oracle.AdapterCounter(probes), oracle.PerTileQuality(),
+                        oracle.OverrepresentedSequences(), oracle.DedupEstimator(front_sequence_offset=64,
+                                                                                 back_sequence_offset=0),
+                        oracle.NanoStats())
+    q.add(buf, metas)
+    a.add(buf, metas)
+    p.add(buf, metas)
+    o.add(buf, metas)
+    d.add(buf, metas)
+    n.add(buf, metas)
+    return q, a, p, o, d, n
+
+
+def check_qc(got, ref):
+    assert got.number_of_reads == ref.number_of_reads and got.max_length == ref.max_length
+    np.testing.assert_array_equal(u64(got.base_count_table()), ref.base_count_table())
+    np.testing.assert_array_equal(u64(got.phred_count_table()), ref.phred_count_table())
+    np.testing.assert_array_equal(u64(got.end_anchored_base_count_table()), ref.end_anchored_base_count_table())
+    np.testing.assert_array_equal(u64(got.gc_content()), ref.gc_content())
+    np.testing.assert_array_equal(u64(got.phred_scores()), ref.phred_scores())
+
+
+@pytest.mark.parametrize("name,tech,compress", [("ref_100_illumina_adapters", "illumina", False),
+                                                ("ref_100_illumina_adapters", "illumina", True),
+                                                ("ref_100_nanopore", "nanopore", True),
+                                                ("ref_simple", None, False)])
+def test_single_end_file(tmp_path, name, tech, compress):
+    import warnings
+    from sequali_amd import driver
+    text = golden(name)["fastq"].tobytes()
+    path = tmp_path / ("reads.fastq.gz" if compress else "reads.fastq")
+    path.write_bytes(gzip.compress(text) if compress else text)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = driver.run(str(path), buffersize=20_000)   # several record arrays
+    assert m["sequencing_technology"] == tech
+    probes = [a.sequence for a in driver.adapters_for(tech)]
+    assert len(probes) == {"illumina": 6, "nanopore": 14, None: 20}[tech]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        q, a, p, o, d, n = oracle_single(text, probes)
+    check_qc(m["metrics"], q)
+    for (s, f, r), (_, fr, rr) in zip(m["adapter_counter"].get_counts(), a.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    assert m["per_tile_quality"].number_of_reads == p.number_of_reads
+    assert (m["per_tile_quality"].skipped_reason is not None) == p.skipped
+    assert m["sequence_duplication"].sequence_counts() == o.sequence_counts()
+    np.testing.assert_array_equal(u64(m["dedup_estimator"].duplication_counts()), d.duplication_counts())
+    assert m["nanostats"].number_of_reads == n.number_of_reads
+    assert (m["nanostats"].skipped_reason is not None) == n.skipped
+    json.dumps(driver.raw_outputs(m))   # serialisable
+
+
+def test_paired_files_and_sync_errors(tmp_path):
+    from sequali_amd import driver
+    g = golden("ref_LTB_paired")
+    t1, t2 = g["fastq1"].tobytes(), g["fastq2"].tobytes()
+    p1, p2 = tmp_path / "r1.fastq.gz", tmp_path / "r2.fastq"
+    p1.write_bytes(gzip.compress(t1))
+    p2.write_bytes(t2)
+    m = driver.run(str(p1), str(p2), buffersize=50_000)
+    assert m["sequencing_technology"] == "illumina" and m["adapter_counter"] is None
+    b1, m1 = split_fastq(t1)
+    b2, m2 = split_fastq(t2)
+    q1, q2, z = oracle.QCMetrics(), oracle.QCMetrics(), oracle.InsertSizeMetrics()
+    d = oracle.DedupEstimator(front_sequence_offset=0, back_sequence_offset=0)
+    q1.add(b1, m1)
+    q2.add(b2, m2)
+    z.add_pair(b1, m1, b2, m2)
+    d.add_pair(b1, m1, b2, m2)
+    check_qc(m["metrics"], q1)
+    check_qc(m["metrics_reverse"], q2)
+    np.testing.assert_array_equal(u64(m["insert_size_metrics"].insert_sizes()), z.insert_sizes())
+    assert m["insert_size_metrics"].adapters_read1() == z.adapters_read1()
+    np.testing.assert_array_equal(u64(m["dedup_estimator"].duplication_counts()), d.duplication_counts())
+    # tests/test_integration.py of the reference: out of sync files and mismatching names
+    short = tmp_path / "short.fastq"
+    short.write_bytes(b"".join(t2.split(b"\n")[i] + b"\n" for i in range(4 * 10)))
+    with pytest.raises(RuntimeError, match="out of sync"):
+        driver.run(str(p1), str(short))
+    with pytest.raises(RuntimeError, match="out of sync"):
+        driver.run(str(short), str(p1))
+    renamed = tmp_path / "renamed.fastq"
+    lines = t2.split(b"\n")
+    lines[4 * 7] = b"@some_other_read/2"
+    renamed.write_bytes(b"\n".join(lines))
+    with pytest.raises(RuntimeError, match="Mismatching names found! .* some_other_read/2"):
+        driver.run(str(p1), str(renamed))
+
+
+def test_bam_file_and_cli(tmp_path):
+    from sequali_amd import driver
+    bam = np.load(os.path.join(GOLDEN, "bam_cases.npz"))["dorado_nanopore_100reads_bam"].tobytes()
+    path = tmp_path / "reads.bam"
+    path.write_bytes(gzip.compress(bam[:100_000]) + gzip.compress(bam[100_000:]))   # two gzip members, like BGZF
+    m = driver.run(str(path))
+    assert m["sequencing_technology"] == "nanopore"
+    assert m["nanostats"].number_of_reads == 100 and m["nanostats"].skipped_reason is None
+    assert len(m["adapters"]) == 14
+    out = tmp_path / "out.json"
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    subprocess.run([sys.executable, "-m", "sequali_amd", str(path), "--json", str(out)], check=True, env=env)
+    report = json.loads(out.read_text())
+    assert report["metrics"]["number_of_reads"] == 100
+    assert report["nanostats"]["number_of_reads"] == 100
+    assert report["adapter_counter"]["number_of_sequences"] == 100
