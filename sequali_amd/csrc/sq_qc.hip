@@ -611,6 +611,343 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     }
 }
 
+/* ---- long reads: k_read_sums + k_seg + k_adapter_first ---------------------------------
+ * A wave of k_pass walks 64 reads front to back, so a batch is as slow as its longest read
+ * (a 100 kb read is 3125 chunks of ~4 us).  Only two things are sequential per read: the f64
+ * error sum (exact order, :2062-2112) and the first-occurrence rule of AdapterCounter
+ * (:2657-2668).  So for long reads
+ *   k_read_sums     one lane per read streams the read once: the four f64 chains, the GC and
+ *                   ACGT counts, the per-read bins and accumulated_error_rate;
+ *   k_seg           everything per position, over SEGMENTS of SEG positions: a workgroup owns
+ *                   segment w of a block of reads (LDS histograms of SEG positions), all
+ *                   segments of all reads are in flight at once.  The automaton is restarted
+ *                   64 positions in front of the segment (a pattern is at most 64 long), a
+ *                   match belongs to the segment its last base lies in, and what a segment
+ *                   finds is only a candidate: atomicMin of the start per (read, adapter);
+ *   k_adapter_first turns the surviving first occurrences into the count tables.
+ * Records come longest first (P.order), so the reads that reach segment w are a prefix. */
+constexpr uint32_t SEG = 256;          /* positions per segment */
+constexpr uint32_t SEG_WARMUP = 64;    /* restart distance of the automaton: the longest pattern */
+
+struct SegParams {
+    const uint32_t *wg_table; /* per workgroup: segment, first group, number of groups */
+    const unsigned long long *seg_reads; /* [segments] reads longer than SEG * w */
+    unsigned int *first;      /* [records][n_adapters]: start of the first occurrence, ~0: none */
+    uint32_t n_adapters;
+};
+
+/* Four lanes per read (16 reads per wave): per step the quad loads 64 consecutive bytes of
+ * the read's sequence and of its qualities (whole sectors, where a lane-private stream would
+ * fetch 16-byte pieces), every lane turns its 16 qualities into error rates and puts them in
+ * LDS, and lane c of the quad then adds the ones at positions = c (mod 4), in position order,
+ * to chain c: the four interleaved f64 chains of the reference (:2062-2097), one per lane. */
+constexpr uint32_t SUMS_QUAD_STRIDE = 66; /* doubles per quad in LDS: 64 + padding against bank conflicts */
+
+__global__ void __launch_bounds__(256) k_read_sums(PassParams P)
+{
+    __shared__ double l_err[136], l_thr[96];
+    __shared__ uint32_t l_gc[104], l_ps[96];
+    __shared__ double l_e[4 * 16 * SUMS_QUAD_STRIDE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 136; i += 256) {
+        double e;
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
+        else if (i >= 128) e = 0.0;
+        else e = __longlong_as_double(0x7FF8000000000000LL);
+        l_err[i] = e;
+    }
+    for (int i = tid; i < 96; i += 256) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+    for (int i = tid; i < 104; i += 256) l_gc[i] = 0;
+    for (int i = tid; i < 96; i += 256) l_ps[i] = 0;
+    __syncthreads();
+    const uint32_t quad = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
+    double *qe = l_e + (wave * 16 + quad) * SUMS_QUAD_STRIDE;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
+    for (uint64_t first = wave_id * 16; first < P.n; first += n_waves * 16) {
+        const uint64_t slot = first + quad;
+        const bool valid = slot < P.n;
+        const uint64_t r = valid ? (P.order ? P.order[slot] : slot) : 0;
+        sq_meta m;
+        if (valid) m = P.metas[r];
+        const uint32_t L = valid ? m.sequence_length : 0;
+        const uint64_t soff = valid ? m.record_start + m.sequence_offset : 0;
+        const uint64_t qoff = valid ? m.record_start + m.qualities_offset : 0;
+        const uint32_t Lmain = L > 0 ? 4 * ((L - 1) / 4) : 0; /* :2062,2068 */
+        const uint32_t maxL = wave_max_u32(L);
+        double acc = 0.0;                   /* chain c of this read */
+        uint32_t gc_cnt = 0, acgt_cnt = 0;  /* this lane's share, :1997-2049 */
+        uint4 cs, cq, ns = make_uint4(0, 0, 0, 0), nq = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        auto load_piece = [&](uint32_t pos, uint4 &sv, uint4 &qv) {
+            sv = make_uint4(0, 0, 0, 0);
+            qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (pos < L) {
+                sv = load16(P.buf, soff + pos, P.buf_len);
+                qv = load16(P.buf, qoff + pos, P.buf_len);
+            }
+        };
+        load_piece(16 * c, cs, cq);
+        for (uint32_t base = 0; base < maxL; base += 64) {
+            const uint32_t p0 = base + 16 * c;
+            if (base + 64 < maxL) load_piece(p0 + 64, ns, nq);
+            const uint32_t qw[4] = {cq.x, cq.y, cq.z, cq.w}, sw[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t at = p0 + 4 * d;
+                /* positions behind Lmain (a multiple of four) add +0.0: the chains stop there */
+                const uint32_t w = at < Lmain ? qw[d] : PAD4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) /* position 16 c + 4 d + j of the step -> slot (4 d + j) * 4 + c */
+                    qe[(4 * d + j) * 4 + c] = l_err[min((w >> (8 * j)) & 0xFFu, 128u)];
+                if (at < L) {
+                    const uint32_t sd = pad_tail(cls2_of_dword(sw[d]), (int)(L - at), CLS2_PAD4);
+                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                    acgt_cnt += __popc(~sd & 0x08080808u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* chain c: positions c, c + 4, ..., c + 60 of the step = lane cc's value 4 mm + c */
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) acc += qe[(4 * mm + c) * 4 + cc];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cs = ns;
+            cq = nq;
+        }
+        /* the quad's four chains and counts */
+        const double a0 = __shfl(acc, (lane & ~3) + 0), a1 = __shfl(acc, (lane & ~3) + 1);
+        const double a2 = __shfl(acc, (lane & ~3) + 2), a3 = __shfl(acc, (lane & ~3) + 3);
+        gc_cnt += __shfl_xor(gc_cnt, 1); gc_cnt += __shfl_xor(gc_cnt, 2);
+        acgt_cnt += __shfl_xor(acgt_cnt, 1); acgt_cnt += __shfl_xor(acgt_cnt, 2);
+        if (valid && c == 0) {
+            double total = a0 + a1 + a2 + a3; /* :2098-2099, left to right */
+            for (uint32_t pos = Lmain; pos < L; pos++) { /* :2100-2112 */
+                const uint32_t qb = P.buf[qoff + pos];
+                total += l_err[qb < 128 ? qb : 0];
+            }
+            P.metas[r].accumulated_error_rate = total; /* :2126 */
+            if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+            if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+            if (L > 0) {
+                const double avg = total / (double)L;
+                uint32_t lo = 0, hi = 93;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+                }
+                atomicAdd(&l_ps[lo], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 101; i += 256)
+        if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
+    for (uint32_t i = tid; i < 94; i += 256)
+        if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+}
+
+template <bool AD>
+__global__ void __launch_bounds__(WG_THREADS, 4) k_seg(PassParams P, SegParams S)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t *l_wave = (uint32_t *)smem;                   /* per wave: seq tile, qual tile, offsets, lengths */
+    constexpr uint32_t hs = SEG;
+    uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [5][SEG] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12][SEG] */
+    uint32_t *l_ea_base = l_hist_phred + hs * PHRED_COLS;
+    const uint32_t ea_rows = P.ea_in_lds ? P.ea_len : 0, es = hist_stride(ea_rows);
+    uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
+    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + es * PHRED_COLS);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (uint32_t i = tid; i < (hs + es) * (BASE_COLS + PHRED_COLS); i += WG_THREADS) l_hist_base[i] = 0;
+    if (AD)
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+    __syncthreads();
+
+    uint32_t *w_seq = l_wave + wave * WAVE_WORDS, *w_qual = w_seq + TILE_WORDS;
+    unsigned long long *w_soff = (unsigned long long *)(w_qual + TILE_WORDS), *w_qoff = w_soff + 64;
+    uint32_t *w_len = (uint32_t *)(w_qoff + 64);
+    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2, row_base = half * ROW_WORDS;
+
+    const uint32_t seg = S.wg_table[3 * blockIdx.x], g_first = S.wg_table[3 * blockIdx.x + 1];
+    const uint32_t g_count = S.wg_table[3 * blockIdx.x + 2];
+    const uint32_t pos_base = seg * SEG, pos_stop = pos_base + SEG;
+    const uint64_t n_here = S.seg_reads[seg]; /* reads longer than pos_base: a prefix of the order */
+
+    for (uint32_t gi = wave; gi < g_count; gi += WAVES) {
+        const uint64_t slot_index = (uint64_t)(g_first + gi) * 64 + lane;
+        const bool valid = slot_index < n_here;
+        const uint64_t r = valid ? P.order[slot_index] : 0;
+        sq_meta m;
+        if (valid) m = P.metas[r];
+        const uint32_t L = valid ? m.sequence_length : 0;
+        w_soff[lane] = valid ? m.record_start + m.sequence_offset : 0;
+        w_qoff[lane] = valid ? m.record_start + m.qualities_offset : 0;
+        w_len[lane] = L;
+        const uint32_t stop = min(wave_max_u32(L), pos_stop);
+        uint32_t st = 0;
+        unsigned long long found = 0; /* adapters this segment has reported */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        uint4 pf_s[2], pf_q[2];
+        auto prefetch = [&](uint32_t c0) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const uint32_t row = it * 32 + ((uint32_t)lane >> 1), p0 = c0 + ((uint32_t)lane & 1) * 16;
+                pf_s[it] = make_uint4(0, 0, 0, 0);
+                pf_q[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (p0 < w_len[row]) {
+                    pf_s[it] = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                    if (c0 >= pos_base) pf_q[it] = load16(P.buf, w_qoff[row] + p0, P.buf_len);
+                }
+            }
+        };
+        /* the automaton starts SEG_WARMUP positions early (not in segment 0) */
+        const uint32_t c_begin = (AD && seg) ? pos_base - SEG_WARMUP : pos_base;
+        if (stop > c_begin) prefetch(c_begin);
+        for (uint32_t c0 = c_begin; c0 < stop; c0 += CW) {
+            const bool warm = c0 < pos_base;
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const uint32_t row = it * 32 + ((uint32_t)lane >> 1), piece = (uint32_t)lane & 1;
+                const uint32_t Lr = w_len[row], p0 = c0 + piece * 16;
+                uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4), qv = pf_q[it];
+                if (p0 < Lr) {
+                    const int nv = (int)min(16u, Lr - p0);
+                    sv.x = cls2_of_dword(pf_s[it].x); sv.y = cls2_of_dword(pf_s[it].y);
+                    sv.z = cls2_of_dword(pf_s[it].z); sv.w = cls2_of_dword(pf_s[it].w);
+                    if (nv < 16) {
+                        sv.x = pad_tail(sv.x, nv, CLS2_PAD4); sv.y = pad_tail(sv.y, nv - 4, CLS2_PAD4);
+                        sv.z = pad_tail(sv.z, nv - 8, CLS2_PAD4); sv.w = pad_tail(sv.w, nv - 12, CLS2_PAD4);
+                        qv.x = pad_tail(qv.x, nv, PAD4); qv.y = pad_tail(qv.y, nv - 4, PAD4);
+                        qv.z = pad_tail(qv.z, nv - 8, PAD4); qv.w = pad_tail(qv.w, nv - 12, PAD4);
+                    }
+                }
+                const uint32_t d0 = piece * 4;
+                w_seq[tile_idx(row, d0 + 0)] = sv.x; w_seq[tile_idx(row, d0 + 1)] = sv.y;
+                w_seq[tile_idx(row, d0 + 2)] = sv.z; w_seq[tile_idx(row, d0 + 3)] = sv.w;
+                w_qual[tile_idx(row, d0 + 0)] = qv.x; w_qual[tile_idx(row, d0 + 1)] = qv.y;
+                w_qual[tile_idx(row, d0 + 2)] = qv.z; w_qual[tile_idx(row, d0 + 3)] = qv.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c0 + CW < stop) prefetch(c0 + CW);
+
+            if (AD) { /* phase S: the automaton only */
+                const uint32_t nd = min(ROW_WORDS, (stop - c0 + 3) / 4);
+                for (uint32_t d = 0; d < nd; d++) {
+                    const uint32_t sd = w_seq[tile_idx((uint32_t)lane, d)];
+                    uint32_t e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | ((sd >> (8 * j)) & 0xFF)));
+                        st = e[j] & 0xFFF0u;
+                    }
+                    if (!warm && ((e[0] | e[1] | e[2] | e[3]) & 1u)) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (!(e[j] & 1u)) continue;
+                            unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                            found |= hits;
+                            const uint32_t pos = c0 + d * 4 + j;
+                            while (hits) {
+                                const int a = __ffsll((long long)hits) - 1;
+                                hits &= hits - 1;
+                                atomicMin(&S.first[r * S.n_adapters + a], pos - P.ad_len[a] + 1);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!warm) { /* phase H: lane = position, two rows at a time */
+                const uint32_t p = c0 + pl;
+                uint32_t *hb = l_hist_base + (p - pos_base), *hp = l_hist_phred + (p - pos_base);
+                for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                    uint32_t sw[4], qw[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t rp = rp0 + k;
+                        const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                        sw[k] = w_seq[ti];
+                        qw[k] = w_qual[ti];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t rp = rp0 + k;
+                        const uint32_t L_even = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp));
+                        const uint32_t L_odd = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)(2 * rp + 1));
+                        const uint32_t Lr = half ? L_odd : L_even;
+                        if (p >= Lr) continue;
+                        const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                        const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
+                        atomicAdd(hist_row(hb, cls, hs * 4), 1u);
+                        atomicAdd(hist_row(hp, bin, hs * 4), 1u);
+                        const uint32_t ean = min(P.ea_len, Lr); /* :1971-1972 */
+                        if (p >= Lr - ean) {
+                            const uint32_t e = P.ea_len - Lr + p;
+                            if (P.ea_in_lds) {
+                                atomicAdd(hist_row(l_ea_base + e, cls, es * 4), 1u);
+                                atomicAdd(hist_row(l_ea_phred + e, bin, es * 4), 1u);
+                            } else {
+                                atomicAdd(&P.qc_ea_base[(uint64_t)e * 5 + min(cls, 4u)], 1ULL);
+                                atomicAdd(&P.qc_ea_phred[(uint64_t)e * 12 + bin], 1ULL);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
+        const uint32_t v = l_hist_base[i];
+        if (v) atomicAdd(&P.qc_base[(uint64_t)(pos_base + i % hs) * 5 + i / hs], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < hs * PHRED_COLS; i += WG_THREADS) {
+        const uint32_t v = l_hist_phred[i];
+        if (v) atomicAdd(&P.qc_phred[(uint64_t)(pos_base + i % hs) * 12 + i / hs], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < es * BASE_COLS; i += WG_THREADS) {
+        const uint32_t v = l_ea_base[i];
+        if (v) atomicAdd(&P.qc_ea_base[(uint64_t)(i % es) * 5 + i / es], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < es * PHRED_COLS; i += WG_THREADS) {
+        const uint32_t v = l_ea_phred[i];
+        if (v) atomicAdd(&P.qc_ea_phred[(uint64_t)(i % es) * 12 + i / es], (unsigned long long)v);
+    }
+}
+
+/* update_adapter_count_array (:2643-2672) for the first occurrences k_seg left */
+__global__ void k_adapter_first(const unsigned int *first, const sq_meta *metas, uint64_t n, uint32_t n_adapters,
+                                const uint8_t *ad_len, unsigned long long *fwd, unsigned long long *rev,
+                                uint64_t cap)
+{
+    const uint64_t cells = n * n_adapters;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cells;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned int start = first[i];
+        if (start == ~0u) continue;
+        const uint64_t r = i / n_adapters;
+        const uint32_t a = (uint32_t)(i % n_adapters), L = metas[r].sequence_length;
+        atomicAdd(&fwd[a * cap + start], 1ULL);
+        atomicAdd(&rev[a * cap + (L - 1 - start)], 1ULL);
+    }
+}
+
+size_t seg_lds_bytes(uint32_t ea_rows, bool ad, uint32_t dfa_states)
+{
+    size_t b = (size_t)WAVES * WAVE_WORDS * 4 + (size_t)(SEG + hist_stride(ea_rows)) * (BASE_COLS + PHRED_COLS) * 4;
+    if (ad) b += (size_t)dfa_states * 16;
+    return b + 16;
+}
+
 /* ---- k_ring: the fused pass for uniform short reads, every 64-byte sector fetched once ----
  * k_pass fetches a read's 32-position chunk from wherever it lies: a 64-byte sector is
  * touched by two or three chunk loads some 10 us apart, has left the L2 in between and is
@@ -1630,18 +1967,27 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         }
         P.ad_cap = a->cap;
     }
-    /* stripes: how many reads reach each of them, and the state they carry between launches */
+    /* long reads.  Sorted longest first and without PerTileQuality: the segment kernels
+       (k_read_sums + k_seg + k_adapter_first).  Else stripes: one launch per 512 positions,
+       the per-read state carried from launch to launch. */
+    const bool segments = stripes && P.order && !P.blocked && !pt_active && !getenv("SQ_NO_SEGMENTS") &&
+                          (!a || a->groups[0].states <= DFA_LDS_MAX_STATES);
+    const uint32_t span = segments ? SEG : STRIPE;
+    if (stripes) stripes = (uint32_t)((b->max_length + span - 1) / span);
     std::vector<uint64_t> stripe_reads(std::max(stripes, 1u), b->n);
+    unsigned long long *d_stripe_reads = nullptr;
     sq_carry *d_carry = nullptr;
     if (stripes) {
-        d_carry = (sq_carry *)sq_scratch(ctx, 5, b->n * sizeof(sq_carry));
-        if (!d_carry) { sq_set_error("out of device memory for the long-read state"); return SQ_ERR_MEMORY; }
-        if (P.order && !P.blocked) { /* longest first: a stripe's reads are a prefix */
-            unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 4, stripes * 8);
-            if (!d_counts) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+        if (!segments) {
+            d_carry = (sq_carry *)sq_scratch(ctx, 5, b->n * sizeof(sq_carry));
+            if (!d_carry) { sq_set_error("out of device memory for the long-read state"); return SQ_ERR_MEMORY; }
+        }
+        if (P.order && !P.blocked) { /* longest first: the reads that reach a stripe are a prefix */
+            d_stripe_reads = (unsigned long long *)sq_scratch(ctx, 4, stripes * 8);
+            if (!d_stripe_reads) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
             hipLaunchKernelGGL(k_stripe_counts, dim3((stripes + 255) / 256), dim3(256), 0, ctx->stream, b->d_metas,
-                               P.order, (uint64_t)b->n, STRIPE, stripes, d_counts);
-            SQ_HIP(hipMemcpyAsync(stripe_reads.data(), d_counts, stripes * 8, hipMemcpyDeviceToHost, ctx->stream));
+                               P.order, (uint64_t)b->n, span, stripes, d_stripe_reads);
+            SQ_HIP(hipMemcpyAsync(stripe_reads.data(), d_stripe_reads, stripes * 8, hipMemcpyDeviceToHost, ctx->stream));
             SQ_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
@@ -1693,7 +2039,46 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states);
         if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
-        if (qc && stripes) {
+        if (qc && segments) {
+            /* (1) what is sequential per read */
+            hipLaunchKernelGGL(k_read_sums, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
+                               ctx->stream, P);
+            /* (2) every segment of every read: workgroups of up to 64 groups inside one segment */
+            std::vector<uint32_t> table;
+            for (uint32_t w = 0; w < stripes && stripe_reads[w]; w++) {
+                const uint64_t groups = (stripe_reads[w] + 63) / 64;
+                for (uint64_t g0 = 0; g0 < groups; g0 += 64) {
+                    table.push_back(w);
+                    table.push_back((uint32_t)g0);
+                    table.push_back((uint32_t)std::min<uint64_t>(64, groups - g0));
+                }
+            }
+            uint32_t *d_table = (uint32_t *)sq_scratch(ctx, 0, table.size() * 4 + 16);
+            if (!d_table) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+            SQ_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            SegParams S{};
+            S.wg_table = d_table;
+            S.seg_reads = d_stripe_reads;
+            const uint32_t n_ad = ad ? (uint32_t)a->groups[0].count : 0;
+            if (ad) {
+                S.n_adapters = n_ad;
+                S.first = (unsigned int *)sq_scratch(ctx, 5, b->n * n_ad * 4);
+                if (!S.first) { sq_set_error("out of device memory for the adapter candidates"); return SQ_ERR_MEMORY; }
+                SQ_HIP(hipMemsetAsync(S.first, 0xFF, b->n * n_ad * 4, ctx->stream));
+            }
+            const size_t slds = seg_lds_bytes(ea_rows, ad, states);
+            const unsigned sgrid = (unsigned)(table.size() / 3);
+            if (ad) hipLaunchKernelGGL((k_seg<true>), dim3(sgrid), dim3(WG_THREADS), slds, ctx->stream, P, S);
+            else hipLaunchKernelGGL((k_seg<false>), dim3(sgrid), dim3(WG_THREADS), slds, ctx->stream, P, S);
+            SQ_HIP(hipGetLastError());
+            /* (3) the first occurrence of every adapter in every read */
+            if (ad)
+                hipLaunchKernelGGL(k_adapter_first, dim3((unsigned)std::min<uint64_t>((b->n * n_ad + 255) / 256, 8192)),
+                                   dim3(256), 0, ctx->stream, S.first, b->d_metas, (uint64_t)b->n, n_ad, P.ad_len,
+                                   P.ad_fwd, P.ad_rev, P.ad_cap);
+            /* the host vector goes out of scope: the copy must have left it */
+            SQ_HIP(hipStreamSynchronize(ctx->stream));
+        } else if (qc && stripes) {
             const uint64_t n_all = P.n;
             for (uint32_t w = 0; w < stripes && stripe_reads[w]; w++) {
                 P.pos_base = w * STRIPE;

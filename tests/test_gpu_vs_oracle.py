@@ -398,3 +398,45 @@ def test_nanostats_minimum_time_restarts_after_a_zero_timestamp():
                 got.add_record_array(FastqRecordArrayView._from_buffer(buf, metas[a:b].copy()))
             assert (got.minimum_time, got.maximum_time) == (ref.minimum_time, ref.maximum_time)
         assert got.number_of_reads == ref.number_of_reads == len(tags)
+
+
+@pytest.mark.parametrize("which", [0, 2, 3])
+def test_long_reads_in_segments(which):
+    """>= 4096 reads longer than 512 bases take the segment kernels (k_read_sums, k_seg,
+    k_adapter_first): patterns planted across the 256-position segment borders (the automaton
+    is restarted 64 positions in front of a segment), repeated patterns (only the first
+    occurrence in a read counts, whichever segment sees it), up to 64 characters long,
+    more than 64 patterns (a second automaton in its own pass)"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(300 + which)
+    adapters = ADAPTER_SETS[which]
+    n = 4300
+    names, seqs, quals = [], [], []
+    for i in range(n):
+        L = int(rng.integers(0, 2600)) if i % 7 else int(rng.integers(0, 40))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[.245, .245, .245, .245, .02]).tobytes())
+        for _ in range(int(rng.integers(0, 4))):
+            word = adapters[int(rng.integers(0, len(adapters)))].encode()
+            if len(word) <= L:
+                border = 256 * int(rng.integers(0, L // 256 + 1))
+                at = min(max(border - int(rng.integers(0, len(word) + 2)), 0), L - len(word))
+                s[at:at + len(word)] = word
+        names.append(f"r{i}")
+        seqs.append(s.decode())
+        quals.append((rng.integers(0, 94, size=L) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(adapters)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq, ga = QCMetrics(), AdapterCounter(adapters)
+    FusedPass(gq, ga).add_record_array(arr)
+    compare_qc(rq, gq, metas, arr)
+    for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 500
+    gq2 = QCMetrics()   # QCMetrics alone: k_seg without the automaton
+    arr2 = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq2.add_record_array(arr2)
+    compare_qc(rq, gq2, metas, arr2)
