@@ -43,7 +43,7 @@ def timed(label, arr, ad):
 
 
 for ad in (True, False):
-    os.environ["SQ_NO_COOP"] = "1"
+    os.environ["SQ_NO_RING"] = "1"   # k_pass for both, to see the effect of the alignment alone
     print("QC+AD" if ad else "QC only (k_pass)")
     timed("L=160 nl=32 rec=352: all windows 32B aligned", layout(32, 160), ad)
     timed("L=160 nl=33 rec=353: rotating alignment", layout(33, 160), ad)
