@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sequali_amd import DedupEstimator, _lib, synth
 n = 25_000_000
 r1 = synth.device_array(synth.ILLUMINA, 0, n)

@@ -90,16 +90,26 @@ __host__ __device__ inline uint64_t murmur3_x64_64(Get get, uint64_t len, uint64
 
 /* sequence_to_canonical_kmer, _qcmodule.c:3657-3694.  >= 0: k-mer; -1: a byte
  * outside ACGTN; -2: N present */
-__device__ long long canonical_kmer(const uint8_t *s, uint32_t k)
+__device__ long long canonical_kmer(const uint8_t *s, uint32_t k, const uint8_t *buf_end)
 {
     uint64_t kmer = 0;
     bool has_n = false, has_other = false;
-    for (uint32_t i = 0; i < k; i++) {
-        const unsigned c = s[i], cls = sq_base_class(c);
-        if (cls == 4) {
-            if ((c | 0x20u) == 'n') has_n = true; else has_other = true;
+    for (uint32_t i0 = 0; i0 < k; i0 += 8) { /* eight bases per load */
+        uint64_t w;
+        if (s + i0 + 8 <= buf_end) {
+            w = sq_load_u64_unaligned(s + i0);
+        } else {
+            w = 0;
+            for (uint32_t b = 0; b < 8 && s + i0 + b < buf_end; b++) w |= (uint64_t)s[i0 + b] << (8 * b);
         }
-        kmer = (kmer << 2) | (cls & 3);
+        const uint32_t nb = min(8u, k - i0);
+        for (uint32_t b = 0; b < nb; b++) {
+            const unsigned c = (unsigned)(w >> (8 * b)) & 0xFFu, cls = sq_base_class(c);
+            if (cls == 4) {
+                if ((c | 0x20u) == 'n') has_n = true; else has_other = true;
+            }
+            kmer = (kmer << 2) | (cls & 3);
+        }
     }
     if (has_other) return -1;
     if (has_n) return -2;
@@ -119,6 +129,7 @@ constexpr unsigned long long RANK_NONE = ~0ULL;
 
 struct OvrParams {
     const uint8_t *buf;
+    uint64_t buf_len;
     const sq_meta *metas;
     uint64_t n;               /* records in the batch */
     uint64_t first_sample;    /* record index of the first sampled record */
@@ -199,7 +210,7 @@ __global__ void k_overrep(OvrParams P)
         unsigned long long valid = 0;
         for (long long f = 0; f < total; f++) {
             const long long at = f < n_start ? f * k : L - n_end * k + (f - n_start) * k;
-            const long long km = canonical_kmer(seq + at, (uint32_t)k);
+            const long long km = canonical_kmer(seq + at, (uint32_t)k, P.buf + P.buf_len);
             if (km < 0) {
                 if (km == -1) warn = true;
                 continue;
@@ -222,7 +233,9 @@ __global__ void k_overrep(OvrParams P)
             atomicMax(P.warn_last, (long long)(P.record_base + r));
         }
     }
-    if (local_frags) atomicAdd(P.total_fragments, local_frags);
+    /* one atomic per wave, not per lane: they all go to the same address */
+    for (int off = 32; off > 0; off >>= 1) local_frags += __shfl_xor(local_frags, off);
+    if ((threadIdx.x & 63) == 0 && local_frags) atomicAdd(P.total_fragments, local_frags);
 }
 
 /* crossing batch, before the launch: keys already in the table rank in front of everything */
@@ -814,7 +827,7 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
     const bool need_big = big_size > 32;
 
     OvrParams P{};
-    P.buf = b->d_buf; P.metas = b->d_metas; P.n = n;
+    P.buf = b->d_buf; P.buf_len = b->buf_len; P.metas = b->d_metas; P.n = n;
     P.first_sample = first; P.record_base = record_base;
     P.k = (uint32_t)k; P.sample_every = (uint32_t)o->sample_every;
     P.frags_start = o->frags_start; P.frags_end = o->frags_end;
@@ -874,29 +887,29 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
             /* H2: the table keeps the first max_unique distinct hashes in (sampled read,
                staging slot) order; drop the new keys that rank behind the cut */
             const uint64_t n_new = n_after - o->n_unique_host, keep = o->max_unique - o->n_unique_host;
-            unsigned long long *d_rank = nullptr, *d_slot = nullptr, *d_n = nullptr;
-            SQ_HIP(hipMalloc((void **)&d_rank, n_new * 8));
-            SQ_HIP(hipMalloc((void **)&d_slot, n_new * 8));
+            unsigned long long *d_buf = nullptr, *d_n = nullptr;
+            SQ_HIP(hipMalloc((void **)&d_buf, 4 * n_new * 8));
             SQ_HIP(hipMalloc((void **)&d_n, 8));
             SQ_HIP(hipMemsetAsync(d_n, 0, 8, ctx->stream));
+            unsigned long long *d_rank = d_buf, *d_slot = d_buf + n_new, *d_rank2 = d_buf + 2 * n_new,
+                               *d_slot2 = d_buf + 3 * n_new;
             hipLaunchKernelGGL(k_ovr_collect_new, dim3(blocks_for(o->table_size)), dim3(256), 0,
                                ctx->stream, o->d_ranks, o->table_size, d_rank, d_slot, d_n);
-            std::vector<unsigned long long> ranks(n_new), slots(n_new);
-            SQ_HIP(hipMemcpyAsync(ranks.data(), d_rank, n_new * 8, hipMemcpyDeviceToHost, ctx->stream));
-            SQ_HIP(hipMemcpyAsync(slots.data(), d_slot, n_new * 8, hipMemcpyDeviceToHost, ctx->stream));
-            SQ_HIP(hipStreamSynchronize(ctx->stream));
-            std::vector<uint64_t> order(n_new);
-            for (uint64_t i = 0; i < n_new; i++) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return ranks[x] < ranks[y]; });
-            std::vector<unsigned long long> dead;
-            for (uint64_t i = keep; i < n_new; i++) dead.push_back(slots[order[i]]);
-            SQ_HIP(hipMemcpyAsync(d_slot, dead.data(), dead.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_ovr_kill, dim3(blocks_for(dead.size())), dim3(256), 0, ctx->stream,
-                               o->d_counts, d_slot, (uint64_t)dead.size());
+            /* by rank, on the device: the keys behind the first `keep` lose their counts */
+            size_t temp_bytes = 0;
+            void *d_temp = nullptr;
+            SQ_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_rank, d_rank2, d_slot, d_slot2, (int)n_new, 0,
+                                                      64, ctx->stream));
+            SQ_HIP(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8));
+            SQ_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_rank, d_rank2, d_slot, d_slot2, (int)n_new, 0,
+                                                      64, ctx->stream));
+            if (n_new > keep)
+                hipLaunchKernelGGL(k_ovr_kill, dim3(blocks_for(n_new - keep)), dim3(256), 0, ctx->stream,
+                                   o->d_counts, d_slot2 + keep, (uint64_t)(n_new - keep));
             unsigned long long capped = o->max_unique;
             SQ_HIP(hipMemcpyAsync(o->d_scalars, &capped, 8, hipMemcpyHostToDevice, ctx->stream));
             SQ_HIP(hipStreamSynchronize(ctx->stream));
-            (void)hipFree(d_rank); (void)hipFree(d_slot); (void)hipFree(d_n);
+            (void)hipFree(d_temp); (void)hipFree(d_buf); (void)hipFree(d_n);
             o->n_unique_host = o->max_unique;
         } else {
             o->n_unique_host = n_after;
