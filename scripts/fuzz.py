@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Randomised differential run: HIP modules against the oracle on random batches, random
+module parameters and random batch splits.  python scripts/fuzz.py [iterations] [seed]"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle  # noqa: E402
+from sequali_amd import (AdapterCounter, DedupEstimator, FastqRecordArrayView, FusedPass, InsertSizeMetrics,  # noqa: E402
+                         NanoStats, OverrepresentedSequences, PerTileQuality, QCMetrics)
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+
+
+def u64(a):
+    return np.array(a, dtype=np.uint64)
+
+
+def make(rng, n, max_len, uniform, illumina, adapters):
+    names, seqs, quals = [], [], []
+    U = int(rng.integers(1, max_len + 1))
+    pool = []
+    for i in range(n):
+        L = U if uniform else int(rng.integers(0, max_len + 1))
+        if pool and rng.random() < 0.25:
+            s = pool[int(rng.integers(0, len(pool)))]
+            s = (s * (L // max(len(s), 1) + 1))[:L]
+        else:
+            s = rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), size=L,
+                           p=[.22, .22, .22, .22, .02, .025, .025, .025, .025]).tobytes().decode()
+            if len(pool) < 50:
+                pool.append(s)
+        if adapters and rng.random() < 0.3:
+            w = adapters[int(rng.integers(0, len(adapters)))]
+            if len(w) <= L:
+                at = int(rng.integers(0, L - len(w) + 1))
+                s = s[:at] + w + s[at + len(w):]
+        q = (rng.integers(0, 94, size=L) + 33).astype(np.uint8).tobytes().decode()
+        tile = int(rng.choice([1101, 1102, 2205, 7, 99239]))
+        names.append(f"M:1:F:{i % 4}:{tile}:{i}:{L} 1:N:0:X" if illumina else f"read{i} ch={i % 512} start_time=2021-09-30T11:34:{i % 60:02d}Z")
+        seqs.append(s)
+        quals.append(q)
+    return oracle.make_batch(names, seqs, quals)
+
+
+ADS = [["AGATCGGAAGAG", "CTGTCTCTTATA", "GGGGGGGGGGGG"], ["ACG", "NN", "GTAC", "TTTTTTTT"], ["ACGT" * 16, "A" * 40]]
+failures = 0
+for it in range(iters):
+    rng = np.random.default_rng(seed0 * 1000 + it)
+    n = int(rng.choice([1, 63, 64, 65, 500, 3000, 4500, 6000]))
+    max_len = int(rng.choice([5, 40, 151, 300, 700, 2500]))
+    if n * max_len > 16_000_000:
+        n = 16_000_000 // max_len
+    uniform, illumina = bool(rng.random() < 0.4), bool(rng.random() < 0.7)
+    adapters = ADS[int(rng.integers(0, len(ADS)))]
+    cuts = sorted({0, n, *(int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3))))})
+    b1, m1 = make(rng, n, max_len, uniform, illumina, adapters)
+    b2, m2 = make(rng, n, max_len, uniform, illumina, adapters)
+    okw = dict(max_unique_fragments=int(rng.choice([50, 700, 5_000_000])), sample_every=int(rng.choice([1, 3, 8])),
+               fragment_length=int(rng.choice([5, 21, 31])))
+    dkw = dict(max_stored_fingerprints=int(rng.choice([100, 300, 1_000_000])),
+               front_sequence_offset=int(rng.choice([0, 8, 64])), back_sequence_offset=int(rng.choice([0, 8])))
+    zcap = int(rng.choice([3, 50, 10000]))
+    ea = int(rng.choice([0, 7, 100, 300]))
+    ref = dict(q=oracle.QCMetrics(ea), a=oracle.AdapterCounter(adapters), p=oracle.PerTileQuality(),
+               o=oracle.OverrepresentedSequences(**okw), d=oracle.DedupEstimator(**dkw), dp=oracle.DedupEstimator(**dkw),
+               z=oracle.InsertSizeMetrics(zcap), n=oracle.NanoStats())
+    got = dict(q=QCMetrics(ea), a=AdapterCounter(adapters), p=PerTileQuality(), o=OverrepresentedSequences(**okw),
+               d=DedupEstimator(**dkw), dp=DedupEstimator(**dkw), z=InsertSizeMetrics(zcap), n=NanoStats())
+    fused = FusedPass(got["q"], got["a"], got["p"]) if rng.random() < 0.5 else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            x1, x2 = m1[lo:hi].copy(), m2[lo:hi].copy()
+            ref["q"].add(b1, x1); ref["a"].add(b1, x1); ref["p"].add(b1, x1); ref["o"].add(b1, x1)
+            ref["d"].add(b1, x1); ref["dp"].add_pair(b1, x1, b2, x2); ref["z"].add_pair(b1, x1, b2, x2); ref["n"].add(b1, x1)
+            a1 = FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy())
+            a2 = FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy())
+            if fused:
+                fused.add_record_array(a1)
+            else:
+                got["q"].add_record_array(a1); got["a"].add_record_array(a1); got["p"].add_record_array(a1)
+            got["o"].add_record_array(a1); got["d"].add_record_array(a1); got["dp"].add_record_array_pair(a1, a2)
+            got["z"].add_record_array_pair(a1, a2); got["n"].add_record_array(a1)
+    try:
+        g, r = got["q"], ref["q"]
+        assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length)
+        for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                     "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+            assert np.array_equal(u64(getattr(g, name)()), getattr(r, name)()), name
+        for (_, f, rv), (_, fr, rr) in zip(got["a"].get_counts(), ref["a"].get_counts()):
+            assert np.array_equal(u64(f), fr) and np.array_equal(u64(rv), rr), "adapter"
+        assert got["p"].number_of_reads == ref["p"].number_of_reads
+        for (t, e, c), (tr, er, cr) in zip(got["p"].get_tile_counts(), ref["p"].get_tile_counts()):
+            assert t == tr and np.array_equal(u64(c), cr) and np.allclose(np.array(e), er, rtol=1e-6), "pertile"
+        assert got["o"].sequence_counts() == ref["o"].sequence_counts(), "overrep"
+        assert got["o"].total_fragments == ref["o"].total_fragments
+        for k in ("d", "dp"):
+            assert got[k]._modulo_bits == ref[k]._modulo_bits
+            assert np.array_equal(u64(got[k].duplication_counts()), ref[k].duplication_counts()), k
+        assert np.array_equal(u64(got["z"].insert_sizes()), ref["z"].insert_sizes())
+        assert got["z"].adapters_read1() == ref["z"].adapters_read1() and got["z"].adapters_read2() == ref["z"].adapters_read2()
+        assert got["n"].number_of_reads == ref["n"].number_of_reads
+        gi, ri = got["n"].nano_infos(), ref["n"].nano_infos()
+        assert np.array_equal(gi["cumulative_error_rate"].view(np.uint64), ri["cumulative_error_rate"].view(np.uint64))
+        assert np.array_equal(gi["start_time"], ri["start_time"])
+        print(f"[{it}] ok  n={n} max_len={max_len} uniform={uniform} cuts={cuts} fused={bool(fused)}", flush=True)
+    except AssertionError as e:
+        failures += 1
+        print(f"[{it}] FAIL {e!r} n={n} max_len={max_len} uniform={uniform} illumina={illumina} cuts={cuts} "
+              f"okw={okw} dkw={dkw} zcap={zcap} ea={ea} fused={bool(fused)} adapters={adapters}", flush=True)
+print("failures:", failures)
+sys.exit(1 if failures else 0)
