@@ -182,7 +182,22 @@ __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long
         maxspan = c > maxspan ? c : maxspan;
         minlen_inv = d > minlen_inv ? d : minlen_inv;
     }
+    /* one set of global atomics per workgroup (they all go to the same five addresses) */
+    __shared__ unsigned long long part[5][16];
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
+        part[0][wave] = bases; part[1][wave] = maxlen; part[2][wave] = maxname;
+        part[3][wave] = maxspan; part[4][wave] = minlen_inv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nwaves; w++) {
+            bases += part[0][w];
+            maxlen = part[1][w] > maxlen ? part[1][w] : maxlen;
+            maxname = part[2][w] > maxname ? part[2][w] : maxname;
+            maxspan = part[3][w] > maxspan ? part[3][w] : maxspan;
+            minlen_inv = part[4][w] > minlen_inv ? part[4][w] : minlen_inv;
+        }
         atomicAdd(&out[0], bases);
         atomicMax(&out[1], maxlen);
         atomicMax(&out[2], maxname);

@@ -86,6 +86,44 @@ __host__ __device__ inline uint64_t murmur3_x64_64(Get get, uint64_t len, uint64
     return h2;
 }
 
+/* the same hash over at most 32 bytes held in four words (little endian, zero padded) */
+__host__ __device__ inline uint64_t murmur3_x64_64_w4(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3,
+                                                      uint64_t len, uint64_t seed)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    uint64_t t1 = w0, t2 = w1; /* the words the tail starts at */
+    if (len >= 16) {
+        uint64_t k1 = w0, k2 = w1;
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        t1 = w2; t2 = w3;
+    }
+    if (len >= 32) { /* two whole blocks: no tail */
+        uint64_t k1 = w2, k2 = w3;
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint64_t rem = len & 15;
+    if (rem > 8) {
+        uint64_t k2 = t2 & (rem >= 16 ? ~0ULL : ((1ULL << (8 * (rem - 8))) - 1));
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (rem > 0) {
+        uint64_t k1 = rem >= 8 ? t1 : (t1 & ((1ULL << (8 * rem)) - 1));
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h2;
+}
+
 /* ================================ OverrepresentedSequences ======================== */
 
 /* sequence_to_canonical_kmer, _qcmodule.c:3657-3694.  >= 0: k-mer; -1: a byte
@@ -151,7 +189,8 @@ struct OvrParams {
 };
 
 /* Sequence_duplication_insert_hash, _qcmodule.c:3542-3568, concurrent form */
-__device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned long long rank)
+__device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned long long rank,
+                           unsigned long long &new_keys)
 {
     uint64_t i = h & P.table_mask;
     for (;;) {
@@ -160,7 +199,7 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
             if (P.mode == OVR_FULL) return; /* table is closed: new keys are dropped (:3553) */
             cur = atomicCAS(&P.hashes[i], 0ULL, h);
             if (cur == 0) {
-                atomicAdd(P.n_unique, 1ULL);
+                new_keys++; /* added to P.n_unique once per wave */
                 cur = h;
             }
         }
@@ -183,7 +222,7 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
 /* OverrepresentedSequences_add_meta, _qcmodule.c:3829-3942: one lane per sampled record */
 __global__ void k_overrep(OvrParams P)
 {
-    unsigned long long local_frags = 0;
+    unsigned long long local_frags = 0, new_keys = 0;
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < P.n_samples;
          s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = P.first_sample + (P.sample_base + s) * P.sample_every;
@@ -226,7 +265,7 @@ __global__ void k_overrep(OvrParams P)
             }
         }
         for (uint64_t i = 0; i < size; i++) /* flushed in slot order (:3925-3930) */
-            if (stage[i]) ovr_insert(P, stage[i], ((P.rank_base + s) << 24) | i);
+            if (stage[i]) ovr_insert(P, stage[i], ((P.rank_base + s) << 24) | i, new_keys);
         local_frags += valid;
         if (warn) {
             atomicAdd(P.warn_count, 1ULL);
@@ -234,8 +273,14 @@ __global__ void k_overrep(OvrParams P)
         }
     }
     /* one atomic per wave, not per lane: they all go to the same address */
-    for (int off = 32; off > 0; off >>= 1) local_frags += __shfl_xor(local_frags, off);
-    if ((threadIdx.x & 63) == 0 && local_frags) atomicAdd(P.total_fragments, local_frags);
+    for (int off = 32; off > 0; off >>= 1) {
+        local_frags += __shfl_xor(local_frags, off);
+        new_keys += __shfl_xor(new_keys, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (local_frags) atomicAdd(P.total_fragments, local_frags);
+        if (new_keys) atomicAdd(P.n_unique, new_keys);
+    }
 }
 
 /* crossing batch, before the launch: keys already in the table rank in front of everything */
@@ -462,7 +507,7 @@ struct IszTable {
 
 struct IszParams {
     const uint8_t *buf1, *buf2;
-    uint64_t len1; /* bytes of buf1 */
+    uint64_t len1, len2; /* bytes of buf1 / buf2 */
     const sq_meta *metas1, *metas2;
     uint64_t n;
     unsigned long long *insert_sizes; /* [cap] */
@@ -473,15 +518,36 @@ struct IszParams {
     int closed;                       /* the first-come cap was reached in an earlier batch */
 };
 
-__device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t len,
-                                  unsigned long long rank, int closed)
+/* the remainder a[0..len) (<= 31 bytes) as the 32-byte key {length, bytes} and its hash */
+__device__ unsigned long long isz_key_of(const uint8_t *a, uint32_t len, const uint8_t *buf_end,
+                                         unsigned long long key[4])
 {
-    unsigned long long key[4] = {0, 0, 0, 0};
-    key[0] = len;
-    for (uint32_t i = 0; i < len; i++) key[(i + 1) >> 3] |= (unsigned long long)a[i] << (8 * ((i + 1) & 7));
-    unsigned long long h = murmur3_x64_64([&](uint64_t i) { return a[i]; }, len, 0);
-    if (h == 0) h = 1; /* 0 marks a free slot */
-    atomicAdd(T.n_events, 1ULL);
+    unsigned long long r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t *src = a + 8 * k;
+        unsigned long long w = 0;
+        if (8u * k < len) {
+            if (src + 8 <= buf_end) w = sq_load_u64_unaligned(src);
+            else
+                for (int b = 0; b < 8 && src + b < buf_end; b++) w |= (unsigned long long)src[b] << (8 * b);
+            const uint32_t left = len - 8u * k;
+            if (left < 8) w &= (1ULL << (8 * left)) - 1;
+        }
+        r[k] = w;
+    }
+    key[0] = len | (r[0] << 8);
+    key[1] = (r[0] >> 56) | (r[1] << 8);
+    key[2] = (r[1] >> 56) | (r[2] << 8);
+    key[3] = (r[2] >> 56) | (r[3] << 8);
+    const unsigned long long h = murmur3_x64_64_w4(r[0], r[1], r[2], r[3], len, 0);
+    return h ? h : 1; /* 0 marks a free slot */
+}
+
+/* `count` occurrences of a key, the earliest of them at `rank`, into the device table */
+__device__ void isz_table_add(const IszTable &T, const unsigned long long key[4], unsigned long long h,
+                              unsigned long long count, unsigned long long rank, int closed)
+{
     uint64_t idx = h & T.mask;
     bool mine = false;
     for (uint64_t spins = 0; spins < (1ull << 22); spins++) {
@@ -505,7 +571,7 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
             if (!mine)
                 for (int k = 0; k < 4; k++) same &= T.key[idx * 4 + k] == key[k];
             if (same) {
-                atomicAdd(&T.count[idx], 1ULL);
+                atomicAdd(&T.count[idx], count);
                 atomicMin(&T.rank[idx], rank);
                 return;
             }
@@ -515,26 +581,91 @@ __device__ void isz_count_adapter(const IszTable &T, const uint8_t *a, uint32_t 
     *T.overflow = 1;
 }
 
+/* Adapter remainders repeat: most reads that run into the adapter leave the same 31 bytes.
+ * A workgroup therefore counts them in a small LDS table first (write-once entries: hash,
+ * key, count, earliest rank) and brings each entry to the device table once, instead of
+ * hammering one device address with two atomics per read. */
+constexpr uint32_t ISZ_CACHE = 32;
+struct IszCache {
+    unsigned long long hash[2][ISZ_CACHE], rank[2][ISZ_CACHE], key[2][ISZ_CACHE][4];
+    unsigned int count[2][ISZ_CACHE], ready[2][ISZ_CACHE];
+};
+
+__device__ void isz_count_adapter(const IszTable &T, IszCache &C, int which, const uint8_t *a, uint32_t len,
+                                  unsigned long long rank, int closed, const uint8_t *buf_end)
+{
+    unsigned long long key[4];
+    const unsigned long long h = isz_key_of(a, len, buf_end, key);
+    const uint32_t e = (uint32_t)(h >> 20) & (ISZ_CACHE - 1);
+    unsigned long long cur = atomicCAS(&C.hash[which][e], 0ULL, h);
+    if (cur == 0) { /* this lane opens the entry */
+        for (int k = 0; k < 4; k++) C.key[which][e][k] = key[k];
+        __hip_atomic_store(&C.ready[which][e], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cur = h;
+    }
+    if (cur == h && __hip_atomic_load(&C.ready[which][e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        bool same = true;
+        for (int k = 0; k < 4; k++) same &= C.key[which][e][k] == key[k];
+        if (same) {
+            atomicAdd(&C.count[which][e], 1u);
+            atomicMin(&C.rank[which][e], rank);
+            return;
+        }
+    }
+    isz_table_add(T, key, h, 1, rank, closed); /* entry taken by another key (or not published yet) */
+}
+
+/* bytes of v that are not zero */
+__device__ __forceinline__ uint32_t isz_nonzero_bytes(uint32_t v)
+{
+    return (uint32_t)__popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
+}
+
+__device__ __forceinline__ uint32_t isz_wave_max(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 /* calculate_insert_size, _qcmodule.c:5667-5707, and the bookkeeping of
  * InsertSizeMetrics_add_sequence_pair_ptr :5709-5744 */
 __global__ void k_insert_size(IszParams P)
 {
     /* most pairs report the same few sizes (0 = no overlap found): count per workgroup first */
     extern __shared__ unsigned int l_sizes[];
+    __shared__ unsigned int l_events[2]; /* number_of_adapters_read1/2 of this workgroup */
+    __shared__ unsigned int l_max;       /* its largest insert size */
+    __shared__ IszCache cache;
     for (uint32_t i = threadIdx.x; i < P.lds_sizes; i += blockDim.x) l_sizes[i] = 0;
+    if (threadIdx.x < 2) l_events[threadIdx.x] = 0;
+    if (threadIdx.x == 2) l_max = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * ISZ_CACHE; i += blockDim.x) {
+        cache.hash[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+        cache.rank[i / ISZ_CACHE][i % ISZ_CACHE] = ~0ULL;
+        cache.count[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+        cache.ready[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+    }
     __syncthreads();
     unsigned long long local_max = 0;
-    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n;
-         r += (uint64_t)gridDim.x * blockDim.x) {
-        const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
+    /* whole waves stay in the loop (the scan below runs in lock step): a lane behind the last
+       pair has two empty reads */
+    for (uint64_t r0 = blockIdx.x * (uint64_t)blockDim.x + (threadIdx.x & ~63u); r0 < P.n;
+         r0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = r0 + (threadIdx.x & 63u);
+        const bool valid = r < P.n;
+        sq_meta m1 = {}, m2 = {};
+        if (valid) { m1 = P.metas1[r]; m2 = P.metas2[r]; }
         const uint8_t *s1 = P.buf1 + m1.record_start + m1.sequence_offset;
         const uint8_t *s2 = P.buf2 + m2.record_start + m2.sequence_offset;
         const uint32_t L1 = m1.sequence_length, L2 = m2.sequence_length;
         uint32_t result = 0;
+        uint64_t h_lo = 0, h_hi = 0, t_lo = 0, t_hi = 0;
         if (L1 >= 16 && L2 >= 16) {
             /* the two needles: reverse complements of the first and of the last 16 bases of
                read 2, from four 8-byte loads */
-            uint64_t h_lo = 0, h_hi = 0, t_lo = 0, t_hi = 0;
             {
                 const uint64_t a0 = sq_load_u64_unaligned(s2), a1 = sq_load_u64_unaligned(s2 + 8);
                 const uint64_t z0 = sq_load_u64_unaligned(s2 + L2 - 16), z1 = sq_load_u64_unaligned(s2 + L2 - 8);
@@ -547,61 +678,96 @@ __global__ void k_insert_size(IszParams P)
                     t_lo |= (uint64_t)complement_or_zero((uint8_t)(z1 >> (8 * i))) << (8 * (7 - i));
                 }
             }
-            /* read 1 streams through a 16-byte window that moves one base at a time and is
-               refilled eight bytes at a time */
-            uint64_t lo = sq_load_u64_unaligned(s1), hi = sq_load_u64_unaligned(s1 + 8), nx = 0;
-            uint32_t avail = 0;
+        }
+        /* read 1 streams through a 16-byte window that moves one base at a time and is refilled
+           eight bytes at a time.  The loop runs in lock step for the wave (its trip count and the
+           refill steps are scalar), a lane only branches when one of its four 8-byte compares
+           hits (:5695), which is rare */
+        {
+            const bool scan = L1 >= 16 && L2 >= 16;
+            const uint32_t last = scan ? L1 - 16 : 0;            /* last window start of this lane */
+            const uint32_t wave_last = isz_wave_max(scan ? last + 1 : 0); /* windows the wave looks at */
+            /* the window as four dwords and the refill as two: a slide is six v_alignbyte_b32
+               (64-bit shifts and compares are quarter-rate instructions) */
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n0 = 0, n1 = 0;
+            if (scan) {
+                const uint64_t lo = sq_load_u64_unaligned(s1), hi = sq_load_u64_unaligned(s1 + 8);
+                w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32); w2 = (uint32_t)hi; w3 = (uint32_t)(hi >> 32);
+            }
             const uint8_t *end1 = P.buf1 + P.len1;
-            const uint64_t UP = 0xDFDFDFDFDFDFDFDFULL;
-            for (uint32_t i = 0; i + 16 <= L1; i++) {
-                const uint64_t ulo = lo & UP, uhi = hi & UP;
-                if (ulo == h_lo || uhi == h_hi) { /* :5695 then exact Hamming on raw bytes */
-                    const uint64_t x = lo ^ h_lo, y = hi ^ h_hi;
-                    int d = 0;
-                    for (int b = 0; b < 8; b++) d += ((x >> (8 * b)) & 0xFF) != 0;
-                    for (int b = 0; b < 8; b++) d += ((y >> (8 * b)) & 0xFF) != 0;
-                    if (d <= 1) { result = i + 16; break; }
-                }
-                if (ulo == t_lo || uhi == t_hi) {
-                    const uint64_t x = lo ^ t_lo, y = hi ^ t_hi;
-                    int d = 0;
-                    for (int b = 0; b < 8; b++) d += ((x >> (8 * b)) & 0xFF) != 0;
-                    for (int b = 0; b < 8; b++) d += ((y >> (8 * b)) & 0xFF) != 0;
-                    if (d <= 1) { result = i + L2; break; }
-                }
-                if (i + 17 <= L1) { /* slide the 16-byte window by one base */
-                    if (avail == 0) {
+            const uint32_t UP4 = 0xDFDFDFDFu;
+            const uint32_t hl = (uint32_t)h_lo, hh = (uint32_t)h_hi, tl = (uint32_t)t_lo, th = (uint32_t)t_hi;
+            bool done = !scan;
+            for (uint32_t i = 0; i < wave_last; i++) {
+                if ((i & 7u) == 0) { /* bytes [i + 16, i + 24) of read 1 */
+                    if ((i & 63u) == 0 && i && __all(done || i > last)) break;
+                    uint64_t nx = 0;
+                    if (scan && i + 16 < L1) {
                         const uint8_t *src = s1 + i + 16;
-                        if (src + 8 <= end1) {
-                            nx = sq_load_u64_unaligned(src);
-                        } else {
-                            nx = 0;
+                        if (src + 8 <= end1) nx = sq_load_u64_unaligned(src);
+                        else
                             for (int b = 0; b < 8 && src + b < end1; b++) nx |= (uint64_t)src[b] << (8 * b);
-                        }
-                        avail = 8;
                     }
-                    lo = (lo >> 8) | (hi << 56);
-                    hi = (hi >> 8) | (nx << 56);
-                    nx >>= 8;
-                    avail--;
+                    n0 = (uint32_t)nx;
+                    n1 = (uint32_t)(nx >> 32);
                 }
+                /* a window can only match a needle half (:5695) if the half's low dword matches */
+                const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
+                const bool maybe = (u0 == hl) | (u2 == hh) | (u0 == tl) | (u2 == th);
+                if (maybe && !done && i <= last) {
+                    const uint32_t u1 = w1 & UP4, u3 = w3 & UP4;
+                    /* :5695-5704: a half matches case-insensitively, then at most one raw byte
+                       of the 16 may differ */
+                    if ((u0 == hl && u1 == (uint32_t)(h_lo >> 32)) || (u2 == hh && u3 == (uint32_t)(h_hi >> 32))) {
+                        const uint32_t d = isz_nonzero_bytes(w0 ^ hl) + isz_nonzero_bytes(w1 ^ (uint32_t)(h_lo >> 32)) +
+                                           isz_nonzero_bytes(w2 ^ hh) + isz_nonzero_bytes(w3 ^ (uint32_t)(h_hi >> 32));
+                        if (d <= 1) { result = i + 16; done = true; }
+                    }
+                    if (!done && ((u0 == tl && u1 == (uint32_t)(t_lo >> 32)) || (u2 == th && u3 == (uint32_t)(t_hi >> 32)))) {
+                        const uint32_t d = isz_nonzero_bytes(w0 ^ tl) + isz_nonzero_bytes(w1 ^ (uint32_t)(t_lo >> 32)) +
+                                           isz_nonzero_bytes(w2 ^ th) + isz_nonzero_bytes(w3 ^ (uint32_t)(t_hi >> 32));
+                        if (d <= 1) { result = i + L2; done = true; }
+                    }
+                }
+                w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); /* slide the window by one base */
+                w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+                w2 = __builtin_amdgcn_alignbyte(w3, w2, 1);
+                w3 = __builtin_amdgcn_alignbyte(n0, w3, 1);
+                n0 = __builtin_amdgcn_alignbyte(n1, n0, 1);
+                n1 >>= 8;
             }
         }
+        if (!valid) continue;
         if (result < P.lds_sizes) atomicAdd(&l_sizes[result], 1u);
         else atomicAdd(&P.insert_sizes[result], 1ULL);
         if (result) {
             if (result > local_max) local_max = result;
             const unsigned long long rank = 2 * (P.rank_base + r);
-            if (L1 > result) /* :5729-5735 */
-                isz_count_adapter(P.tab[0], s1 + result, min(L1 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank, P.closed);
-            if (L2 > result) /* :5736-5742 */
-                isz_count_adapter(P.tab[1], s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE), rank + 1, P.closed);
+            if (L1 > result) { /* :5729-5735 */
+                atomicAdd(&l_events[0], 1u);
+                isz_count_adapter(P.tab[0], cache, 0, s1 + result, min(L1 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE),
+                                  rank, P.closed, P.buf1 + P.len1);
+            }
+            if (L2 > result) { /* :5736-5742 */
+                atomicAdd(&l_events[1], 1u);
+                isz_count_adapter(P.tab[1], cache, 1, s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE),
+                                  rank + 1, P.closed, P.buf2 + P.len2);
+            }
         }
     }
-    if (local_max) atomicMax(P.max_insert, local_max);
+    /* one global atomic per workgroup: half a million threads on one address take milliseconds */
+    if (local_max) atomicMax(&l_max, (unsigned int)local_max);
     __syncthreads();
+    if (threadIdx.x == 0 && l_max) atomicMax(P.max_insert, (unsigned long long)l_max);
+    if (threadIdx.x < 2 * ISZ_CACHE) { /* the workgroup's remainders, each once */
+        const uint32_t w = threadIdx.x / ISZ_CACHE, e = threadIdx.x % ISZ_CACHE;
+        if (cache.hash[w][e] && cache.count[w][e])
+            isz_table_add(P.tab[w], cache.key[w][e], cache.hash[w][e], cache.count[w][e], cache.rank[w][e], P.closed);
+    }
     for (uint32_t i = threadIdx.x; i < P.lds_sizes; i += blockDim.x)
         if (l_sizes[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_sizes[i]);
+    if (threadIdx.x < 2 && l_events[threadIdx.x])
+        atomicAdd(P.tab[threadIdx.x].n_events, (unsigned long long)l_events[threadIdx.x]);
 }
 
 /* used slots of an adapter table, unordered */
@@ -1751,6 +1917,7 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     IszParams P{};
     P.buf1 = b1->d_buf; P.buf2 = b2->d_buf; P.metas1 = b1->d_metas; P.metas2 = b2->d_metas;
     P.len1 = b1->buf_len;
+    P.len2 = b2->buf_len;
     P.n = n; P.insert_sizes = z->d_sizes; P.max_insert = z->d_max;
     P.tab[0] = z->tab[0]; P.tab[1] = z->tab[1];
     P.rank_base = z->first_pair + z->total_reads;

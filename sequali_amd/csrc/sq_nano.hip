@@ -258,6 +258,16 @@ __global__ void k_nano_scan1(const sq_nanoinfo *infos, const uint32_t *status, u
         mn = t < mn ? t : mn;
         if (t == 0) lz = r + 1;
     }
+    /* per wave first: every thread would hit the same four addresses */
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long omx = __shfl_xor(mx, off), omn = __shfl_xor(mn, off);
+        const unsigned long long olz = __shfl_xor(lz, off);
+        mx = omx > mx ? omx : mx;
+        mn = omn < mn ? omn : mn;
+        lz = olz > lz ? olz : lz;
+        w += __shfl_xor(w, off);
+    }
+    if ((threadIdx.x & 63) != 0) return;
     if (mx != INT64_MIN) atomicMax(max_time, mx);
     if (mn != INT64_MAX) atomicMin(all_min, mn);
     if (lz) atomicMax(last_zero, lz);
@@ -273,7 +283,11 @@ __global__ void k_nano_scan2(const sq_nanoinfo *infos, uint64_t from, uint64_t n
         const long long t = infos[r].start_time;
         mn = t < mn ? t : mn;
     }
-    if (mn != INT64_MAX) atomicMin(min_time, mn);
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(mn, off);
+        mn = o < mn ? o : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && mn != INT64_MAX) atomicMin(min_time, mn);
 }
 
 int nano_blocks(uint64_t n)
