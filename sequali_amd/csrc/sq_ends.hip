@@ -190,7 +190,7 @@ struct OvrParams {
 
 /* Sequence_duplication_insert_hash, _qcmodule.c:3542-3568, concurrent form */
 __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned long long rank,
-                           unsigned long long &new_keys)
+                           unsigned long long &new_keys, unsigned int count = 1)
 {
     uint64_t i = h & P.table_mask;
     for (;;) {
@@ -207,9 +207,9 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
             if (P.mode == OVR_FULL) {
                 /* entries removed by the cap keep their key with a zero count */
                 if (__hip_atomic_load(&P.counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                    atomicAdd(&P.counts[i], 1u);
+                    atomicAdd(&P.counts[i], count);
             } else {
-                atomicAdd(&P.counts[i], 1u);
+                atomicAdd(&P.counts[i], count);
                 /* keys from earlier launches carry rank 0 and stay there */
                 if (P.mode >= OVR_CROSSING) atomicMin(&P.ranks[i], rank + 1);
             }
@@ -220,8 +220,17 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
 }
 
 /* OverrepresentedSequences_add_meta, _qcmodule.c:3829-3942: one lane per sampled record */
+/* Overrepresented fragments are, by definition, the same hash over and over (poly-G tails,
+ * adapters): a workgroup counts fragments in a small LDS table first (write-once entries:
+ * hash, count, earliest rank) and brings each entry to the device table once. */
+constexpr uint32_t OVR_CACHE = 128;
+
 __global__ void k_overrep(OvrParams P)
 {
+    __shared__ unsigned long long c_hash[OVR_CACHE], c_rank[OVR_CACHE];
+    __shared__ unsigned int c_count[OVR_CACHE];
+    for (uint32_t i = threadIdx.x; i < OVR_CACHE; i += blockDim.x) { c_hash[i] = 0; c_rank[i] = ~0ULL; c_count[i] = 0; }
+    __syncthreads();
     unsigned long long local_frags = 0, new_keys = 0;
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < P.n_samples;
          s += (uint64_t)gridDim.x * blockDim.x) {
@@ -264,14 +273,28 @@ __global__ void k_overrep(OvrParams P)
                 i = (i + 1) & (size - 1);
             }
         }
-        for (uint64_t i = 0; i < size; i++) /* flushed in slot order (:3925-3930) */
-            if (stage[i]) ovr_insert(P, stage[i], ((P.rank_base + s) << 24) | i, new_keys);
+        for (uint64_t i = 0; i < size; i++) { /* flushed in slot order (:3925-3930) */
+            const unsigned long long h = stage[i];
+            if (!h) continue;
+            const unsigned long long rank = ((P.rank_base + s) << 24) | i;
+            const uint32_t e = (uint32_t)(h >> 24) & (OVR_CACHE - 1);
+            const unsigned long long cur = atomicCAS(&c_hash[e], 0ULL, h);
+            if (cur == 0 || cur == h) {
+                atomicAdd(&c_count[e], 1u);
+                atomicMin(&c_rank[e], rank);
+            } else {
+                ovr_insert(P, h, rank, new_keys);
+            }
+        }
         local_frags += valid;
         if (warn) {
             atomicAdd(P.warn_count, 1ULL);
             atomicMax(P.warn_last, (long long)(P.record_base + r));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < OVR_CACHE && c_hash[threadIdx.x])
+        ovr_insert(P, c_hash[threadIdx.x], c_rank[threadIdx.x], new_keys, c_count[threadIdx.x]);
     /* one atomic per wave, not per lane: they all go to the same address */
     for (int off = 32; off > 0; off >>= 1) {
         local_frags += __shfl_xor(local_frags, off);
