@@ -84,6 +84,8 @@ struct PassParams {
     const uint8_t *ad_len;    /* [n_adapters] */
     unsigned long long *ad_fwd, *ad_rev; /* [n_adapters][ad_cap] */
     uint64_t ad_cap;
+    uint32_t ad_lds;          /* != 0: number of adapters whose hits a workgroup counts in LDS first
+                                 (batches of one read length: the reverse table is derived at the merge) */
     /* PerTileQuality */
     const int32_t *pt_slot;   /* per record, from k_tile_prepass */
     unsigned long long *pt_len_counts;
@@ -197,6 +199,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     const uint32_t es = hist_stride(ea_rows);
     uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
     uint16_t *l_dfa = (uint16_t *)(l_ea_phred + es * PHRED_COLS);
+    uint32_t *l_adf = (uint32_t *)(l_dfa + ((AD && DFA_LDS) ? P.dfa_states * 8 : 0)); /* [ad_lds][hs] */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -222,6 +225,8 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     }
     if (AD && DFA_LDS) {
         for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+        if (QC)
+            for (uint32_t i = tid; i < P.ad_lds * hs; i += WG_THREADS) l_adf[i] = 0;
     }
     __syncthreads();
 
@@ -384,8 +389,12 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                         const int a = __ffsll((long long)hits) - 1;
                         hits &= hits - 1;
                         const uint32_t start = pos - P.ad_len[a] + 1;
-                        atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
-                        atomicAdd(&P.ad_rev[a * P.ad_cap + (L - 1 - start)], 1ULL);
+                        if (QC && AD && DFA_LDS && P.ad_lds) {
+                            atomicAdd(&l_adf[a * hs + start], 1u);
+                        } else {
+                            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                            atomicAdd(&P.ad_rev[a * P.ad_cap + (L - 1 - start)], 1ULL);
+                        }
                     }
                 }
             };
@@ -568,6 +577,16 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     }
 
     /* ---------------- merge the workgroup's histograms ---------------- */
+    if (QC && AD && DFA_LDS && P.ad_lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < P.ad_lds * hs; i += WG_THREADS) {
+            const uint32_t v = l_adf[i];
+            if (!v) continue;
+            const uint32_t a = i / hs, start = i % hs;
+            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
+            atomicAdd(&P.ad_rev[a * P.ad_cap + (P.uniform_len - 1 - start)], (unsigned long long)v);
+        }
+    }
     if (QC) {
         __syncthreads();
         for (uint32_t i = tid; i < hs * BASE_COLS; i += WG_THREADS) {
@@ -1268,11 +1287,12 @@ size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
     return b + 16;
 }
 
-size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states)
+size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states,
+                      uint32_t ad_lds = 0)
 {
     size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
     if (qc) b += (size_t)(hist_stride(lds_len) + hist_stride(ea_rows)) * (BASE_COLS + PHRED_COLS) * 4;
-    if (dfa_lds) b += (size_t)dfa_states * 16;
+    if (dfa_lds) b += (size_t)dfa_states * 16 + (size_t)ad_lds * hist_stride(lds_len) * 4;
     return b + 16;
 }
 
@@ -2004,6 +2024,11 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             P.ad_rev = a->d_rev + g.first * a->cap;
             states = g.states;
             dfa_lds = states <= DFA_LDS_MAX_STATES;
+            /* one read length: hits are counted per workgroup in LDS (a handful of adapters x
+               positions) and reach the device tables once, reverse positions derived there */
+            P.ad_lds = 0;
+            if (qc && !pt && dfa_lds && P.uniform_len && g.count * hist_stride(P.lds_len) * 4 <= 8192)
+                P.ad_lds = (uint32_t)g.count;
         }
         if (!qc && !pt && !ad) break;
         /* Uniform short reads: k_ring fetches every 64-byte sector once (1.07 x the
@@ -2036,7 +2061,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             P.first_read_index += C.n;
             P.n = b->n - C.n;
         }
-        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states);
+        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, ad ? P.ad_lds : 0);
         if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         if (qc && segments) {
