@@ -13,9 +13,8 @@ pin it against).
 """
 from __future__ import annotations
 
-import gzip
 import io
-import string
+import re
 import zlib
 from typing import Dict, List, NamedTuple, Optional
 
@@ -69,46 +68,45 @@ def adapters_for(sequencing_technology: Optional[str]) -> List[Adapter]:
             a.sequencing_technology in (sequencing_technology, "all")]
 
 
+_UUID_NAME = re.compile(r"[0-9a-fA-F]{8}(-[0-9a-fA-F]{4}){3}-[0-9a-fA-F]{12}\Z")
+
+
 def fastq_header_is_illumina(header: str) -> bool:
-    """util.py:187-210"""
-    parts = header.split(maxsplit=1)
-    if not parts:
+    """Same verdict as util.py:187-210: `<instrument>:<run>:<flowcell>:<lane>:<tile>:<x>:<y>`
+    (six colons in the read name) and, when a comment follows, `<read>:<Y|N>:<control>:<sample>`."""
+    tokens = header.split(maxsplit=1)
+    if not tokens:
         return False
-    metadata = parts[1] if len(parts) == 2 else None
-    if metadata:
-        if metadata.count(":") != 3:
+    name = tokens[0]
+    comment = tokens[1] if len(tokens) > 1 else ""
+    if comment:
+        fields = comment.split(":")
+        if len(fields) != 4 or fields[1] not in ("Y", "N"):
             return False
-        if metadata.split(":")[1] not in ("Y", "N"):
-            return False
-    return parts[0].count(":") == 6
+    return name.count(":") == 6
 
 
 def fastq_header_is_nanopore(header: str) -> bool:
-    """util.py:213-235"""
-    fields = header.split()
-    if not fields:
+    """Same verdict as util.py:213-235: a UUID read name followed by key=value fields among
+    which one starts with `ch` and one with `st` (guppy FASTQ, or uBAM converted to FASTQ)."""
+    tokens = header.split()
+    if not tokens or not _UUID_NAME.match(tokens[0]):
         return False
-    name, metadata = fields[0], fields[1:]
-    if name.count("-") != 4:
-        return False
-    parts = name.split("-")
-    hexdigits = set(string.hexdigits)
-    return (all(set(p).issubset(hexdigits) for p in parts) and
-            all(len(p) == n for p, n in zip(parts, (8, 4, 4, 4, 12))) and
-            any(m.startswith("ch") for m in metadata) and any(m.startswith("st") for m in metadata))
+    keys = tokens[1:]
+    return any(k[:2] == "ch" for k in keys) and any(k[:2] == "st" for k in keys)
 
 
 def technology_from_bam_header(header: bytes) -> Optional[str]:
-    """util.py:238-253"""
+    """Same verdict as util.py:238-253: the platform (PL) of the first read group that names
+    ONT or Illumina."""
+    platforms = {"ONT": "nanopore", "Illumina": "illumina"}
     for line in header.decode("utf-8").splitlines():
-        if line.startswith("@RG"):
-            for field in line.split("\t")[1:]:
-                tag, value = field.split(":", maxsplit=1)
-                if tag == "PL":
-                    if value == "ONT":
-                        return "nanopore"
-                    if value == "Illumina":
-                        return "illumina"
+        if not line.startswith("@RG"):
+            continue
+        for field in line.split("\t")[1:]:
+            tag, value = field.split(":", maxsplit=1)
+            if tag == "PL" and value in platforms:
+                return platforms[value]
     return None
 
 
@@ -185,11 +183,12 @@ class NGSFile:
 
 
 def sequence_names_match(name1: str, name2: str) -> bool:
-    """util.py:256-268"""
-    id1, id2 = name1.split(maxsplit=1)[0], name2.split(maxsplit=1)[0]
-    if (id1[-1], id2[-1]) in (("1", "2"), ("2", "1")):  # the /1 or /2 at the end of paired reads
-        id1, id2 = id1[:-1], id2[:-1]
-    return id1 == id2
+    """Same verdict as util.py:256-268: the read ids (up to the first blank) are equal, a
+    trailing 1 / 2 mate digit aside."""
+    ids = [n.split(maxsplit=1)[0] for n in (name1, name2)]
+    if {ids[0][-1], ids[1][-1]} == {"1", "2"}:
+        ids = [i[:-1] for i in ids]
+    return ids[0] == ids[1]
 
 
 def run(input_path: str, input_reverse: Optional[str] = None, *,
