@@ -80,6 +80,7 @@ struct PassParams {
     /* AdapterCounter */
     const uint16_t *dfa;      /* [states][8] */
     uint32_t dfa_states;
+    uint32_t dfa_accept;      /* states >= this one are the ones some adapter ends in */
     const unsigned long long *dfa_out; /* [states] adapters ending in that state */
     const uint8_t *ad_len;    /* [n_adapters] */
     unsigned long long *ad_fwd, *ad_rev; /* [n_adapters][ad_cap] */
@@ -174,6 +175,58 @@ __device__ __forceinline__ uint32_t tile_idx(uint32_t row, uint32_t d)
     return row * ROW_WORDS + (d ^ ((row >> 2) & 7));
 }
 
+/* k_pass keeps a wave's two tiles interleaved in blocks of 8 rows (256 B of sequence classes,
+ * then the 256 B of qualities of the same rows): the quality word of a tile word is always
+ * 64 words further on, which one ds_read2_b32 reaches, and rows 8d .. 8d+7 (what one step of
+ * the fused loop touches in phase H) are block d.  Banks are those of tile_idx. */
+constexpr uint32_t QUAL_WORDS = 64;       /* w_qual = w_seq + QUAL_WORDS */
+__device__ __forceinline__ uint32_t ptile_idx(uint32_t row, uint32_t d)
+{
+    return (row >> 3) * 128 + (row & 7) * ROW_WORDS + (d ^ ((row >> 2) & 7));
+}
+/* phase H: dword h_dw of row 2 * rp + half */
+__device__ __forceinline__ uint32_t ptile_idx_h(uint32_t rp, uint32_t half, uint32_t h_dw)
+{
+    return (rp >> 2) * 128 + (2 * (rp & 3) + half) * ROW_WORDS + (h_dw ^ ((rp >> 1) & 7));
+}
+
+/* LDS through 32-bit addresses: the fused loop computes them with one instruction each */
+#define SQ_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(SQ_LDS const uint8_t *)p; }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(SQ_LDS const uint32_t *)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(SQ_LDS const uint16_t *)(uintptr_t)a; }
+__device__ __forceinline__ double lds_f64(uint32_t a) { return *(SQ_LDS const double *)(uintptr_t)a; }
+/* a | byte J of w, and byte J of w << 3, in one instruction each (SDWA operand selects) */
+template <int J> __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w)
+{
+    uint32_t r;
+    if (J == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+template <int J> __device__ __forceinline__ uint32_t shl3_byte(uint32_t w)
+{
+    uint32_t r;
+    if (J == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(3u), "v"(w));
+    return r;
+}
+__device__ __forceinline__ void lds_inc(uint32_t a)
+{
+    __hip_atomic_fetch_add((SQ_LDS uint32_t *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* (x ^ s) + b */
+__device__ __forceinline__ uint32_t xor_add(uint32_t x, uint32_t s, uint32_t b)
+{
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(b));
+    return r;
+}
+
 /* state of a read between two stripes */
 struct sq_carry {
     double acc[4];
@@ -190,7 +243,10 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     double *l_thr = l_err + 136;                           /* [96] */
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
-    uint32_t *l_wave = l_ps + 96;                          /* per wave: seq tile, qual tile, offsets, lengths */
+    /* the automaton sits in front of everything of variable size: its rows are addressed by
+       16-bit LDS addresses (table entries are the address of the next row) */
+    uint16_t *l_dfa = (uint16_t *)(l_ps + 96);
+    uint32_t *l_wave = (uint32_t *)(l_dfa + ((AD && DFA_LDS) ? P.dfa_states * 8 : 0)); /* per wave: tiles, offsets, lengths */
     const uint32_t hs = QC ? hist_stride(P.lds_len) : 0;   /* words per class row */
     uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [5][hs] */
     uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;               /* [12][hs] */
@@ -198,10 +254,12 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     const uint32_t ea_rows = (QC && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
     const uint32_t es = hist_stride(ea_rows);
     uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
-    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + es * PHRED_COLS);
-    uint32_t *l_adf = (uint32_t *)(l_dfa + ((AD && DFA_LDS) ? P.dfa_states * 8 : 0)); /* [ad_lds][hs] */
+    uint32_t *l_adf = l_ea_phred + es * PHRED_COLS;       /* [ad_lds][hs] */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    /* the fused loop turns a quality byte into the address of its error rate with one shift:
+       the kernel has no static LDS, so the dynamic block (and l_err) starts at address 0 */
+    if (lds_addr(l_err) != 0) __builtin_trap();
 
     /* ---- fill tables ---- */
     for (int i = tid; i < 136; i += WG_THREADS) {
@@ -223,16 +281,22 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         uint32_t nh = (hs + es) * (BASE_COLS + PHRED_COLS);
         for (uint32_t i = tid; i < nh; i += WG_THREADS) l_hist_base[i] = 0;
     }
+    /* in LDS a table entry is the LDS address of the next row; a row some adapter ends in lies
+       at or behind dfa_hit (build_dfa numbers those states last) */
+    const uint32_t dfa_root = (AD && DFA_LDS) ? lds_addr(l_dfa) : 0;
+    const uint32_t dfa_hit = dfa_root + P.dfa_accept * 16;
     if (AD && DFA_LDS) {
-        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS)
+            l_dfa[i] = (uint16_t)((P.dfa[i] & 0xFFF0u) + dfa_root);
         if (QC)
             for (uint32_t i = tid; i < P.ad_lds * hs; i += WG_THREADS) l_adf[i] = 0;
     }
     __syncthreads();
 
     uint32_t *w_seq = l_wave + wave * WAVE_WORDS;
-    uint32_t *w_qual = w_seq + TILE_WORDS;
-    unsigned long long *w_soff = (unsigned long long *)(w_qual + TILE_WORDS);
+    uint32_t *w_qual = w_seq + QUAL_WORDS;
+    const uint32_t s_row = lds_addr(w_seq) + ((uint32_t)lane >> 3) * 512 + ((uint32_t)lane & 7) * 32;
+    unsigned long long *w_soff = (unsigned long long *)(w_seq + 2 * TILE_WORDS);
     unsigned long long *w_qoff = w_soff + 64;
     uint32_t *w_len = (uint32_t *)(w_qoff + 64);
 
@@ -241,6 +305,9 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     /* phase H: lanes 0-31 take an even row, lanes 32-63 the odd row after it */
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
+    /* byte-address parts of the fused loop (ptile_idx / ptile_idx_h split into what is fixed per
+       lane and what changes per step) */
+    const uint32_t s_sw4 = 4 * (((uint32_t)lane >> 2) & 7), h_u4 = 32 * half + 4 * h_dw;
 
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES, wave_id = (uint64_t)blockIdx.x * WAVES + wave;
     const uint64_t per_wave = (ngroups + n_waves - 1) / n_waves;
@@ -265,13 +332,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         const uint32_t Lmain = L > 0 ? 4 * ((L - 1) / 4) : 0; /* _qcmodule.c:2062,2068 */
 
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        uint32_t st = 0;                 /* automaton state as the byte offset of its row */
+        uint32_t st = dfa_root;          /* automaton state: where its row starts (LDS address or byte offset) */
         unsigned long long found = 0;    /* adapters already seen in this read */
         uint32_t gc_cnt = 0, acgt_cnt = 0;
         if (P.pos_base && valid) {       /* pick up where the stripe in front left this read */
             const sq_carry cy = P.carry[slot_index];
             acc0 = cy.acc[0]; acc1 = cy.acc[1]; acc2 = cy.acc[2]; acc3 = cy.acc[3];
-            found = cy.found; st = cy.st; gc_cnt = cy.gc_cnt; acgt_cnt = cy.acgt_cnt;
+            found = cy.found; st = cy.st + dfa_root; gc_cnt = cy.gc_cnt; acgt_cnt = cy.acgt_cnt;
         }
         const uint32_t stripe_end = min(maxL, P.pos_end);
         bool pt_on = false;
@@ -327,16 +394,16 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 }
                 const uint32_t d0 = piece * 4;
                 if (QC || AD) {
-                    w_seq[tile_idx(row, d0 + 0)] = sv.x;
-                    w_seq[tile_idx(row, d0 + 1)] = sv.y;
-                    w_seq[tile_idx(row, d0 + 2)] = sv.z;
-                    w_seq[tile_idx(row, d0 + 3)] = sv.w;
+                    w_seq[ptile_idx(row, d0 + 0)] = sv.x;
+                    w_seq[ptile_idx(row, d0 + 1)] = sv.y;
+                    w_seq[ptile_idx(row, d0 + 2)] = sv.z;
+                    w_seq[ptile_idx(row, d0 + 3)] = sv.w;
                 }
                 if (QC || PT) {
-                    w_qual[tile_idx(row, d0 + 0)] = qv.x;
-                    w_qual[tile_idx(row, d0 + 1)] = qv.y;
-                    w_qual[tile_idx(row, d0 + 2)] = qv.z;
-                    w_qual[tile_idx(row, d0 + 3)] = qv.w;
+                    w_qual[ptile_idx(row, d0 + 0)] = qv.x;
+                    w_qual[ptile_idx(row, d0 + 1)] = qv.y;
+                    w_qual[ptile_idx(row, d0 + 2)] = qv.z;
+                    w_qual[ptile_idx(row, d0 + 3)] = qv.w;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -349,7 +416,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                hit handling */
             auto s_main = [&](uint32_t d, uint32_t e[4]) -> bool {
                 const uint32_t pos0 = c0 + d * 4;
-                const uint32_t ti = tile_idx((uint32_t)lane, d);
+                const uint32_t ti = ptile_idx((uint32_t)lane, d);
                 const uint32_t sd = w_seq[ti];
                 if (QC) {
                     uint32_t qd = w_qual[ti];
@@ -367,11 +434,18 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                     acgt_cnt += __popc(~sd & 0x08080808u);
                 }
                 if (!AD) return false;
+                if (DFA_LDS) { /* one VALU + one LDS read per base */
+                    e[0] = lds_u16(or_byte<0>(st, sd));
+                    e[1] = lds_u16(or_byte<1>(e[0], sd));
+                    e[2] = lds_u16(or_byte<2>(e[1], sd));
+                    e[3] = lds_u16(or_byte<3>(e[2], sd));
+                    st = e[3];
+                    return max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
-                    if (DFA_LDS) e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
-                    else e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
+                    e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | cls2));
                     st = e[j] & 0xFFF0u;
                 }
                 return ((e[0] | e[1] | e[2] | e[3]) & 1u) != 0;
@@ -381,8 +455,8 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 const uint32_t pos0 = c0 + d * 4;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (!(e[j] & 1u)) continue;
-                    unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                    if (DFA_LDS ? e[j] < dfa_hit : !(e[j] & 1u)) continue;
+                    unsigned long long hits = P.dfa_out[(e[j] - dfa_root) >> 4] & ~found;
                     found |= hits;
                     const uint32_t pos = pos0 + j;
                     while (hits) {
@@ -405,14 +479,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
             /* phase H of a full group of equally long reads, four row pairs: nothing depends on
                the row but its two tile words (end-anchored tables are derived at the merge) */
             const uint32_t p = c0 + pl;
-            const uint32_t row_base = half * ROW_WORDS; /* odd row of the pair for lanes 32-63 */
             auto h_fast = [&](uint32_t rp0) {
                 uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
                 uint32_t sw[4], qw[4];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t rp = rp0 + k;
-                    const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                    const uint32_t ti = ptile_idx_h(rp, half, h_dw);
                     sw[k] = w_seq[ti];
                     qw[k] = w_qual[ti];
                 }
@@ -425,16 +498,61 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 }
             };
             const bool fast_group = QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n;
-            if (fast_group && c0 + CW <= P.uniform_len) {
-                /* a chunk that lies inside every read: the per-read chains of phase S (a table
-                   walk with one LDS round trip per base) and the histogram updates of phase H
-                   are independent, so they share one instruction stream and phase H fills the
-                   waits of phase S */
+            /* a chunk inside every read, and inside what the four chains cover (:2068) */
+            if (fast_group && c0 + CW <= P.uniform_len && c0 + CW - 4 < 4 * ((P.uniform_len - 1) / 4)) {
+                /* The per-read chains of phase S (a table walk with one LDS round trip per base)
+                   and the histogram updates of phase H are independent, so they share one
+                   instruction stream and phase H fills the waits of phase S.  Step d takes
+                   dword d of every row (S) and the rows of block d (H); LDS addresses are
+                   computed by hand, one v_xad_u32 each: (swizzle ^ step) + base. */
+                uint32_t hv = lds_addr(w_seq);
+                const uint32_t hbp = lds_addr(l_hist_base + p), hpp = lds_addr(l_hist_phred + p);
 #pragma unroll 1
                 for (uint32_t d = 0; d < ROW_WORDS; d++) {
+                    const uint32_t sa = xor_add(s_sw4, 4 * d, s_row);
+                    const uint32_t sd = lds_u32(sa), qd = lds_u32(sa + 4 * QUAL_WORDS);
+                    /* l_err is at LDS address 0 (checked at the top): byte << 3 is the address */
+                    const double e0 = lds_f64(shl3_byte<0>(qd)), e1 = lds_f64(shl3_byte<1>(qd));
+                    const double e2 = lds_f64(shl3_byte<2>(qd)), e3 = lds_f64(shl3_byte<3>(qd));
+                    acc0 += e0;
+                    acc1 += e1;
+                    acc2 += e2;
+                    acc3 += e3;
+                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                    acgt_cnt += __popc(~sd & 0x08080808u);
                     uint32_t e[4];
-                    const bool hit = s_main(d, e);
-                    h_fast(4 * d);
+                    bool hit = false;
+                    if (AD && DFA_LDS) {
+                        e[0] = lds_u16(or_byte<0>(st, sd));
+                        e[1] = lds_u16(or_byte<1>(e[0], sd));
+                        e[2] = lds_u16(or_byte<2>(e[1], sd));
+                        e[3] = lds_u16(or_byte<3>(e[2], sd));
+                        st = e[3];
+                        hit = max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit;
+                    } else if (AD) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            e[j] = *(const uint16_t *)((const uint8_t *)P.dfa + (st | ((sd >> (8 * j)) & 0xFF)));
+                            st = e[j] & 0xFFF0u;
+                        }
+                        hit = ((e[0] | e[1] | e[2] | e[3]) & 1u) != 0;
+                    }
+                    /* phase H: rows 8 d .. 8 d + 7 = block d, two rows per step */
+                    const uint32_t sx = (8 * d) & 28;
+                    const uint32_t ha = xor_add(h_u4, sx, hv), hb = xor_add(h_u4, sx | 4, hv);
+                    hv += 8 * ROW_WORDS * 4 * 2;
+                    uint32_t sw[4], qw[4];
+                    sw[0] = lds_u32(ha);       qw[0] = lds_u32(ha + 256);
+                    sw[1] = lds_u32(ha + 64);  qw[1] = lds_u32(ha + 64 + 256);
+                    sw[2] = lds_u32(hb + 128); qw[2] = lds_u32(hb + 128 + 256);
+                    sw[3] = lds_u32(hb + 192); qw[3] = lds_u32(hb + 192 + 256);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                        const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
+                        lds_inc(hbp + __umul24(cls, hs * 4));
+                        lds_inc(hpp + __umul24(bin, hs * 4));
+                    }
                     if (hit) s_hits(d, e);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -479,7 +597,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) {
                             const uint32_t rp = rp0 + k;
-                            const uint32_t ti = 2 * rp * ROW_WORDS + row_base + (h_dw ^ ((rp >> 1) & 7));
+                            const uint32_t ti = ptile_idx_h(rp, half, h_dw);
                             sw[k] = QC ? w_seq[ti] : 0;
                             qw[k] = w_qual[ti];
                         }
@@ -547,7 +665,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
         if (valid && L > P.pos_end) { /* the read goes on in the next stripe */
             sq_carry cy;
             cy.acc[0] = acc0; cy.acc[1] = acc1; cy.acc[2] = acc2; cy.acc[3] = acc3;
-            cy.found = found; cy.st = st; cy.gc_cnt = gc_cnt; cy.acgt_cnt = acgt_cnt; cy.pad_ = 0;
+            cy.found = found; cy.st = st - dfa_root; cy.gc_cnt = gc_cnt; cy.acgt_cnt = acgt_cnt; cy.pad_ = 0;
             P.carry[slot_index] = cy;
         }
         if (QC && valid && L <= P.pos_end) {
@@ -990,10 +1108,18 @@ constexpr int RING_THREADS = 512, RING_WAVES = RING_THREADS / 64;
 constexpr uint32_t RING_ROW_WORDS = 16, RING_TILE_WORDS = 64 * RING_ROW_WORDS;
 
 /* ring address of position dword m of a row: the row's 16 dwords are XOR-ed with bits of
- * the row so that "lane = row, same dword" (phase S) hits 32 different banks */
+ * the row so that "lane = row, same dword" (phase S) hits 32 different banks.  The two streams
+ * are interleaved in pairs of rows (128 B of classes, then the 128 B of qualities of the same
+ * two rows), so that the quality word is RING_QUAL_WORDS behind the class word (one
+ * ds_read2_b32) and row pair rp of phase H starts at 256 rp */
+constexpr uint32_t RING_QUAL_WORDS = 2 * RING_ROW_WORDS;
+__device__ __forceinline__ uint32_t ring_row(uint32_t row)
+{
+    return (row >> 1) * 4 * RING_ROW_WORDS + (row & 1u) * RING_ROW_WORDS;
+}
 __device__ __forceinline__ uint32_t ring_idx(uint32_t row, uint32_t m)
 {
-    return row * RING_ROW_WORDS + ((m & 15u) ^ ((row >> 1) & 15u));
+    return ring_row(row) + ((m & 15u) ^ ((row >> 1) & 15u));
 }
 
 /* value of the neighbouring lane (lane ^ 1) */
@@ -1010,13 +1136,16 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
     double *l_thr = l_err + 136;                           /* [96] */
     uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
     uint32_t *l_ps = l_gc + 104;                           /* [96] */
-    uint32_t *l_ring = l_ps + 96;                          /* [waves][seq, qual][RING_TILE_WORDS] */
+    uint16_t *l_dfa = (uint16_t *)(l_ps + 96);             /* in front: rows are addressed with 16 bits */
+    uint32_t *l_ring = (uint32_t *)(l_dfa + (AD ? P.dfa_states * 8 : 0)); /* [waves][2 * RING_TILE_WORDS] */
     const uint32_t U = P.uniform_len, hs = hist_stride(U);
     uint32_t *l_hist_base = l_ring + RING_WAVES * 2 * RING_TILE_WORDS; /* [5][hs] */
     uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;             /* [12][hs] */
-    uint16_t *l_dfa = (uint16_t *)(l_hist_phred + hs * PHRED_COLS);
+    uint32_t *l_adf = l_hist_phred + hs * PHRED_COLS;     /* [ad_lds][hs] adapter hits of this workgroup */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (lds_addr(l_err) != 0) __builtin_trap(); /* see k_pass: byte << 3 is the address of its error rate */
+    const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + P.dfa_accept * 16;
     for (int i = tid; i < 136; i += RING_THREADS) {
         double e;
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
@@ -1028,11 +1157,14 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
     for (int i = tid; i < 104; i += RING_THREADS) l_gc[i] = 0;
     for (int i = tid; i < 96; i += RING_THREADS) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += RING_THREADS) l_hist_base[i] = 0;
-    if (AD)
-        for (uint32_t i = tid; i < P.dfa_states * 8; i += RING_THREADS) l_dfa[i] = P.dfa[i];
+    if (AD) { /* entries become the LDS address of the next row, hits are the rows from dfa_hit on */
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += RING_THREADS)
+            l_dfa[i] = (uint16_t)((P.dfa[i] & 0xFFF0u) + dfa_root);
+        for (uint32_t i = tid; i < P.ad_lds * hs; i += RING_THREADS) l_adf[i] = 0;
+    }
     __syncthreads();
 
-    uint32_t *w_seq = l_ring + wave * 2 * RING_TILE_WORDS, *w_qual = w_seq + RING_TILE_WORDS;
+    uint32_t *w_seq = l_ring + wave * 2 * RING_TILE_WORDS, *w_qual = w_seq + RING_QUAL_WORDS;
     const uint32_t nch = (U + CW - 1) / CW;
     const uint32_t Lmain = 4 * ((U - 1) / 4);
     const uint64_t ngroups = P.n / 64;
@@ -1040,6 +1172,10 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
     /* phase H: lanes 0-31 an even row, lanes 32-63 the odd row after it */
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
+    /* byte addresses of the fused loop: what is fixed per lane */
+    const uint32_t s_row = lds_addr(w_seq) + ((uint32_t)lane >> 1) * 256 + ((uint32_t)lane & 1) * 64;
+    const uint32_t s_sw4 = 4 * (((uint32_t)lane >> 1) & 15);
+    const uint32_t h_row = lds_addr(w_seq) + 64 * half;
     /* loader: rows st_row and st_row + 32, bytes [16 k, 16 k + 16) of every window */
     const uint32_t st_row = (uint32_t)lane >> 1, k16 = ((uint32_t)lane & 1) * 16;
 
@@ -1057,8 +1193,8 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
            (32-byte aligned), so these loads need no bounds checks; bytes that are not
            the read's never reach a result. */
         const uint8_t *nextp[2][2];
-        uint32_t nwin[2][2], sb_[2][2], par[2][2];
-        int mbase[2][2]; /* position dword of y[0] for window 0 */
+        uint32_t s6[2][2]; /* address & 63: s = s6 & 31, sector half of window 0 = s6 >> 5 (kept packed:
+                              registers are what limits this kernel) */
         uint4 R0[2][2], R1[2][2];
         uint32_t last3[2][2];
 #pragma unroll
@@ -1071,10 +1207,7 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
                 const uint64_t addr = bufaddr + off[q];
                 const uint32_t s = (uint32_t)addr & 31u;
                 nextp[it][q] = (const uint8_t *)(uintptr_t)(addr - s + k16);
-                nwin[it][q] = (s + U + 31u) >> 5;
-                sb_[it][q] = s & 3u;
-                par[it][q] = (uint32_t)(addr >> 5) & 1u;
-                mbase[it][q] = (int)(k16 >> 2) - 1 - (int)(s >> 2);
+                s6[it][q] = (uint32_t)addr & 63u;
                 last3[it][q] = 0;
             }
         }
@@ -1083,7 +1216,7 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
            bases, so what lies behind the read's end needs no masking here: phase S pads the
            one dword that straddles the end and nothing reads further */
         auto stage = [&](int it, int q, uint32_t j, uint4 v, bool head) {
-            const uint32_t sb = sb_[it][q];
+            const uint32_t sb = s6[it][q] & 3u;
             if (q == 0) {
                 v.x = cls2_of_dword(v.x); v.y = cls2_of_dword(v.y);
                 v.z = cls2_of_dword(v.z); v.w = cls2_of_dword(v.w);
@@ -1099,8 +1232,9 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
             y[2] = __builtin_amdgcn_alignbyte(v.z, v.y, sb);
             y[3] = __builtin_amdgcn_alignbyte(v.w, v.z, sb);
             /* y[i] = positions 4 m .. 4 m + 3 with m = m0 + i */
-            const int m0 = (int)(8 * j) + mbase[it][q];
-            uint32_t *trow = (q ? w_qual : w_seq) + ((uint32_t)it * 32 + st_row) * RING_ROW_WORDS;
+            /* position dword of y[0]: window 0 starts s bytes in front of the read */
+            const int m0 = (int)(8 * j) + (int)(k16 >> 2) - 1 - (int)((s6[it][q] & 31u) >> 2);
+            uint32_t *trow = (q ? w_qual : w_seq) + ring_row((uint32_t)it * 32 + st_row);
             const uint32_t swz = (((uint32_t)it * 32 + st_row) >> 1) & 15u;
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -1117,11 +1251,12 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const uint8_t *p0 = nextp[it][q];
-                    const uint32_t nw = nwin[it][q];
+                    const uint32_t nw = ((s6[it][q] & 31u) + U + 31u) >> 5; /* windows with bytes of the read */
+                    const uint32_t par = s6[it][q] >> 5;
                     T[it][q] = *(const uint4 *)p0;
                     R0[it][q] = make_uint4(0, 0, 0, 0);
                     R1[it][q] = make_uint4(0, 0, 0, 0);
-                    if (par[it][q]) {
+                    if (par) {
                         if (1 < nw) R0[it][q] = *(const uint4 *)(p0 + 32);
                         if (2 < nw) R1[it][q] = *(const uint4 *)(p0 + 64);
                         nextp[it][q] = p0 + 96;
@@ -1137,7 +1272,7 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
         }
 
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        uint32_t st = 0, gc_cnt = 0, acgt_cnt = 0;
+        uint32_t st = dfa_root, gc_cnt = 0, acgt_cnt = 0;
         unsigned long long found = 0;
 
         for (uint32_t c = 0; c < nch; c++) {
@@ -1148,7 +1283,8 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
                         /* second half of its sector: it waited in R1 and the next sector is due */
-                        const bool second = ((par[it][q] + c + 1) & 1u) != 0;
+                        const bool second = (((s6[it][q] >> 5) + c + 1) & 1u) != 0;
+                        const uint32_t nw = ((s6[it][q] & 31u) + U + 31u) >> 5;
                         uint4 v;
                         v.x = second ? R1[it][q].x : R0[it][q].x;
                         v.y = second ? R1[it][q].y : R0[it][q].y;
@@ -1157,8 +1293,8 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
                         stage(it, q, c + 1, v, false);
                         if (second) {
                             const uint8_t *pn = nextp[it][q];
-                            if (c + 2 < nwin[it][q]) R0[it][q] = *(const uint4 *)pn;
-                            if (c + 3 < nwin[it][q]) R1[it][q] = *(const uint4 *)(pn + 32);
+                            if (c + 2 < nw) R0[it][q] = *(const uint4 *)pn;
+                            if (c + 3 < nw) R1[it][q] = *(const uint4 *)(pn + 32);
                             nextp[it][q] = pn + 64;
                         }
                     }
@@ -1166,18 +1302,47 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            /* ---------------- phase S: lane = read ---------------- */
             const uint32_t c0 = c * CW;
+            const uint32_t p = c0 + pl;
+            const uint32_t mm = (8 * c + h_dw) & 15u;
+            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+            auto hits_of = [&](uint32_t pos0, const uint32_t e[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (e[j] < dfa_hit) continue;
+                    unsigned long long hits = P.dfa_out[(e[j] - dfa_root) >> 4] & ~found;
+                    found |= hits;
+                    const uint32_t pos = pos0 + j;
+                    while (hits) {
+                        const int a = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        const uint32_t start = pos - P.ad_len[a] + 1;
+                        if (P.ad_lds) {
+                            atomicAdd(&l_adf[a * hs + start], 1u);
+                        } else {
+                            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                            atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
+                        }
+                    }
+                }
+            };
+            /* ---------------- phase S: lane = read ----------------
+               LDS addresses by hand as in k_pass, one v_xad_u32 each.  Dwords from d_plain on
+               need care: the four chains stop four short of the end (:2068) and the dword that
+               straddles the end of the read is padded */
             const uint32_t nd = min(ROW_WORDS, (U - c0 + 3) / 4);
+            const uint32_t d_plain = Lmain > c0 ? min(ROW_WORDS, (Lmain - c0) / 4) : 0;
+#pragma unroll 1
             for (uint32_t d = 0; d < nd; d++) {
-                const uint32_t pos0 = c0 + d * 4;
-                const uint32_t ti = ring_idx((uint32_t)lane, 8 * c + d);
-                uint32_t sd = w_seq[ti];
-                if (pos0 + 4 > U) sd = pad_tail(sd, (int)(U - pos0), CLS2_PAD4); /* the dword at the end */
-                uint32_t qd = w_qual[ti];
-                qd = pos0 < Lmain ? qd : PAD4; /* the four chains stop four short of the end (:2068) */
-                const double e0 = l_err[qd & 0xFF], e1 = l_err[(qd >> 8) & 0xFF];
-                const double e2 = l_err[(qd >> 16) & 0xFF], e3 = l_err[qd >> 24];
+                const uint32_t sa = xor_add(s_sw4, 4 * ((8 * c + d) & 15u), s_row);
+                uint32_t sd = lds_u32(sa), qd = lds_u32(sa + 4 * RING_QUAL_WORDS);
+                if (d >= d_plain) {
+                    const uint32_t pos0 = c0 + d * 4;
+                    if (pos0 + 4 > U) sd = pad_tail(sd, (int)(U - pos0), CLS2_PAD4);
+                    if (pos0 >= Lmain) qd = PAD4;
+                }
+                const double e0 = lds_f64(shl3_byte<0>(qd)), e1 = lds_f64(shl3_byte<1>(qd));
+                const double e2 = lds_f64(shl3_byte<2>(qd)), e3 = lds_f64(shl3_byte<3>(qd));
                 acc0 += e0;
                 acc1 += e1;
                 acc2 += e2;
@@ -1186,53 +1351,38 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
                 acgt_cnt += __popc(~sd & 0x08080808u);
                 if (AD) {
                     uint32_t e[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t cls2 = (sd >> (8 * j)) & 0xFF;
-                        e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | cls2));
-                        st = e[j] & 0xFFF0u;
-                    }
-                    if ((e[0] | e[1] | e[2] | e[3]) & 1u) {
-                        /* update_adapter_count_array, _qcmodule.c:2643-2672 */
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (!(e[j] & 1u)) continue;
-                            unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
-                            found |= hits;
-                            const uint32_t pos = pos0 + j;
-                            while (hits) {
-                                const int a = __ffsll((long long)hits) - 1;
-                                hits &= hits - 1;
-                                const uint32_t start = pos - P.ad_len[a] + 1;
-                                atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
-                                atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
-                            }
-                        }
-                    }
+                    e[0] = lds_u16(or_byte<0>(st, sd));
+                    e[1] = lds_u16(or_byte<1>(e[0], sd));
+                    e[2] = lds_u16(or_byte<2>(e[1], sd));
+                    e[3] = lds_u16(or_byte<3>(e[2], sd));
+                    st = e[3];
+                    if (max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit) hits_of(c0 + 4 * d, e);
                 }
             }
 
-            /* ---------------- phase H: lane = position, two rows at a time ---------------- */
-            const uint32_t p = c0 + pl;
+            /* ---------------- phase H: lane = position, two rows at a time ----------------
+               step d: row pairs rp = 4 d + k at 256 rp + 64 half + 4 (mm ^ (rp & 15)) */
             if (p < U) {
-                uint32_t *hb = l_hist_base + p, *hp = l_hist_phred + p;
-                const uint32_t mm = (8 * c + h_dw) & 15u;
-#pragma unroll
-                for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                const uint32_t hbp = lds_addr(l_hist_base + p), hpp = lds_addr(l_hist_phred + p);
+                const uint32_t mm4 = 4 * mm;
+                uint32_t hv = h_row;
+#pragma unroll 1
+                for (uint32_t d = 0; d < 8; d++) {
+                    const uint32_t sx = (16 * d) & 60;
                     uint32_t sw[4], qw[4];
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
-                        const uint32_t rp = rp0 + k;
-                        const uint32_t ti = (2 * rp + half) * RING_ROW_WORDS + (mm ^ (rp & 15u));
-                        sw[k] = w_seq[ti];
-                        qw[k] = w_qual[ti];
+                        const uint32_t ha = xor_add(mm4, sx | (4 * k), hv);
+                        sw[k] = lds_u32(ha + 256 * k);
+                        qw[k] = lds_u32(ha + 256 * k + 4 * RING_QUAL_WORDS);
                     }
+                    hv += 4 * 256;
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
                         const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
                         const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
-                        atomicAdd(hist_row(hb, cls, hs * 4), 1u);
-                        atomicAdd(hist_row(hp, bin, hs * 4), 1u);
+                        lds_inc(hbp + __umul24(cls, hs * 4));
+                        lds_inc(hpp + __umul24(bin, hs * 4));
                     }
                 }
             }
@@ -1260,6 +1410,14 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
 
     /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
     __syncthreads();
+    if (AD)
+        for (uint32_t i = tid; i < P.ad_lds * hs; i += RING_THREADS) {
+            const uint32_t v = l_adf[i];
+            if (!v) continue;
+            const uint32_t a = i / hs, start = i % hs;
+            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
+            atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
+        }
     const uint32_t ean = min(P.ea_len, U);
     for (uint32_t i = tid; i < hs * BASE_COLS; i += RING_THREADS) {
         const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
@@ -1279,11 +1437,423 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
-size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states)
+#ifdef SQ_PROBE
+/* memory-pattern probe (experiments only): a wave visits its 64 reads BPR bytes per row and
+   stream at a time, one visit of loads in flight ahead of the one being consumed; FLAT: the
+   same bytes as one linear stream */
+template <int BPR>
+__global__ void __launch_bounds__(256, 4) k_probe(PassParams P, unsigned long long *sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int LPR = BPR / 16, RPI = 64 / LPR, ITS = 64 / RPI;
+    const uint32_t U = P.uniform_len;
+    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
+    uint32_t acc = 0;
+    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
+        const sq_meta m = P.metas[g * 64 + lane];
+        const unsigned long long soff = m.record_start + m.sequence_offset, qoff = m.record_start + m.qualities_offset;
+        unsigned long long so[ITS], qo[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+            const int row = it * RPI + lane / LPR;
+            so[it] = __shfl(soff, row) + (lane % LPR) * 16;
+            qo[it] = __shfl(qoff, row) + (lane % LPR) * 16;
+        }
+        uint4 a[ITS], b[ITS], a2[ITS], b2[ITS];
+        auto fetch = [&](uint32_t v, uint4 (&x)[ITS], uint4 (&y)[ITS]) {
+#pragma unroll
+            for (int it = 0; it < ITS; it++) {
+                x[it] = make_uint4(0, 0, 0, 0); y[it] = x[it];
+                if (v * BPR + (lane % LPR) * 16 < U) {
+                    x[it] = *(const uint4 *)(P.buf + so[it] + v * BPR);
+                    y[it] = *(const uint4 *)(P.buf + qo[it] + v * BPR);
+                }
+            }
+        };
+        const uint32_t nv = (U + BPR - 1) / BPR;
+        fetch(0, a, b);
+        for (uint32_t v = 0; v < nv; v++) {
+            if (v + 1 < nv) fetch(v + 1, a2, b2);
+#pragma unroll
+            for (int it = 0; it < ITS; it++) acc ^= a[it].x ^ a[it].y ^ a[it].z ^ a[it].w ^ b[it].x ^ b[it].y ^ b[it].z ^ b[it].w;
+#pragma unroll
+            for (int it = 0; it < ITS; it++) { a[it] = a2[it]; b[it] = b2[it]; }
+        }
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+/* lane = row: every lane streams its own read, BPV bytes per stream and visit */
+template <int BPV>
+__global__ void __launch_bounds__(256, 4) k_probe_row(PassParams P, unsigned long long *sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int K = BPV / 16;
+    const uint32_t U = P.uniform_len;
+    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
+    uint32_t acc = 0;
+    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
+        const sq_meta m = P.metas[g * 64 + lane];
+        const uint8_t *sp = P.buf + m.record_start + m.sequence_offset, *qp = P.buf + m.record_start + m.qualities_offset;
+        uint4 a[K], b[K], a2[K], b2[K];
+        auto fetch = [&](uint32_t v, uint4 (&x)[K], uint4 (&y)[K]) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                x[k] = make_uint4(0, 0, 0, 0); y[k] = x[k];
+                if (v * BPV + k * 16 < U) {
+                    x[k] = *(const uint4 *)(sp + v * BPV + k * 16);
+                    y[k] = *(const uint4 *)(qp + v * BPV + k * 16);
+                }
+            }
+        };
+        const uint32_t nv = (U + BPV - 1) / BPV;
+        fetch(0, a, b);
+        for (uint32_t v = 0; v < nv; v++) {
+            if (v + 1 < nv) fetch(v + 1, a2, b2);
+#pragma unroll
+            for (int k = 0; k < K; k++) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w ^ b[k].x ^ b[k].y ^ b[k].z ^ b[k].w;
+#pragma unroll
+            for (int k = 0; k < K; k++) { a[k] = a2[k]; b[k] = b2[k]; }
+        }
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+__global__ void __launch_bounds__(256, 4) k_probe_flat(const uint4 *buf, uint64_t n16, unsigned long long *sink)
+{
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = buf[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+/* flat stream in wave-private contiguous spans of 64 records (what a wave of a row-streaming
+   kernel would read) */
+__global__ void __launch_bounds__(256, 4) k_probe_span(PassParams P, unsigned long long *sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
+    uint32_t acc = 0;
+    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
+        const unsigned long long first = P.metas[g * 64].record_start;
+        const sq_meta ml = P.metas[g * 64 + 63];
+        const unsigned long long end = ml.record_start + ml.qualities_offset + ml.sequence_length;
+        const unsigned long long a0 = first & ~15ull;
+        for (unsigned long long o = a0 + (unsigned long long)lane * 16; o < end; o += 4 * 1024) {
+            uint4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x[k] = make_uint4(0, 0, 0, 0);
+                if (o + k * 1024 < end) x[k] = *(const uint4 *)(P.buf + o + k * 1024);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
+        }
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+#endif
+
+/* ---- k_wide: batches of one read length, 64 bytes per row and visit ----
+ * What bounds the fused pass on short reads is how the memory system takes the gather: a wave
+ * that visits its 64 rows 32 bytes at a time (k_pass, k_ring) moves 8.7 GB of records in
+ * 3.7 ms whatever it computes; 64 bytes per row and visit, four lanes side by side on one row,
+ * take 2.3 ms (a linear stream: 1.4 ms).  So this kernel walks the reads in
+ * chunks of 64 positions: tile rows are 64 bytes (the geometry of k_ring's rings, without the
+ * rotation: loads start at positions, not at sectors), a chunk is staged by four lanes per
+ * row, phase S takes 16 dwords per row and chunk and phase H two halves of 32 positions.
+ * 8 KB of tiles per wave: one workgroup of 16 waves per CU shares one set of LDS histograms
+ * (150 KB in all).  Row offsets live in registers (no LDS left for them). */
+constexpr int WIDE_THREADS = 1024, WIDE_WAVES = WIDE_THREADS / 64;
+constexpr uint32_t WIDE_CW = 64;
+
+size_t wide_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states, uint32_t ad_lds)
+{
+    size_t b = FIXED_BYTES + (size_t)WIDE_WAVES * 2 * RING_TILE_WORDS * 4;
+    b += (size_t)hist_stride(uniform_len) * (BASE_COLS + PHRED_COLS) * 4;
+    if (ad) b += (size_t)dfa_states * 16 + (size_t)ad_lds * hist_stride(uniform_len) * 4;
+    return b + 16;
+}
+
+template <bool AD>
+__global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    double *l_err = (double *)smem;                        /* [136] by raw quality byte, 128 = padding */
+    double *l_thr = l_err + 136;                           /* [96] */
+    uint32_t *l_gc = (uint32_t *)(l_thr + 96);             /* [104] */
+    uint32_t *l_ps = l_gc + 104;                           /* [96] */
+    uint16_t *l_dfa = (uint16_t *)(l_ps + 96);             /* rows addressed with 16 bits */
+    uint32_t *l_tiles = (uint32_t *)(l_dfa + (AD ? P.dfa_states * 8 : 0));
+    const uint32_t U = P.uniform_len, hs = hist_stride(U);
+    uint32_t *l_hist_base = l_tiles + WIDE_WAVES * 2 * RING_TILE_WORDS; /* [5][hs] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS;               /* [12][hs] */
+    uint32_t *l_adf = l_hist_phred + hs * PHRED_COLS;                    /* [ad_lds][hs] */
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (lds_addr(l_err) != 0) __builtin_trap(); /* see k_pass: byte << 3 is the address of its error rate */
+    const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + P.dfa_accept * 16;
+    for (int i = tid; i < 136; i += WIDE_THREADS) {
+        double e;
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
+        else if (i >= 128) e = 0.0;
+        else e = __longlong_as_double(0x7FF8000000000000LL);
+        l_err[i] = e;
+    }
+    for (int i = tid; i < 96; i += WIDE_THREADS) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+    for (int i = tid; i < 104; i += WIDE_THREADS) l_gc[i] = 0;
+    for (int i = tid; i < 96; i += WIDE_THREADS) l_ps[i] = 0;
+    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += WIDE_THREADS) l_hist_base[i] = 0;
+    if (AD) {
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WIDE_THREADS)
+            l_dfa[i] = (uint16_t)((P.dfa[i] & 0xFFF0u) + dfa_root);
+        for (uint32_t i = tid; i < P.ad_lds * hs; i += WIDE_THREADS) l_adf[i] = 0;
+    }
+    __syncthreads();
+
+    uint32_t *w_seq = l_tiles + wave * 2 * RING_TILE_WORDS, *w_qual = w_seq + RING_QUAL_WORDS;
+    const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
+    /* byte addresses of the fused loop: what is fixed per lane (ring_idx split up) */
+    const uint32_t s_row = lds_addr(w_seq) + ((uint32_t)lane >> 1) * 256 + ((uint32_t)lane & 1) * 64;
+    const uint32_t s_sw4 = 4 * (((uint32_t)lane >> 1) & 15);
+    const uint32_t h_row = lds_addr(w_seq) + 64 * half;
+    const uint32_t Lmain = 4 * ((U - 1) / 4); /* _qcmodule.c:2062,2068 */
+    /* loader: rows it * 16 + (lane >> 2), bytes [16 piece, 16 piece + 16) of the chunk */
+    const uint32_t l_row = (uint32_t)lane >> 2, piece16 = ((uint32_t)lane & 3) * 16;
+
+    const uint64_t ngroups = P.n / 64;
+    const uint64_t n_waves = (uint64_t)gridDim.x * WIDE_WAVES, wave_id = (uint64_t)blockIdx.x * WIDE_WAVES + wave;
+    const uint32_t c_last = WIDE_CW * ((U - 1) / WIDE_CW);   /* the chunk that holds the end of the reads */
+
+    /* One pipeline over all (group, chunk) steps of the wave: the loads of the step after the
+       current one are always in flight, across group boundaries too (the first chunk of the next
+       group is fetched while the last chunk of this one is counted; its record offsets were
+       fetched a group earlier). */
+    uint64_t g = wave_id;
+    const uint8_t *sp[4], *qp[4]; /* where this lane's 16 bytes of the four rows it loads start */
+    uint4 pf_s[4], pf_q[4];
+    auto rows_of = [&](unsigned long long soff, unsigned long long qoff) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = it * 16 + (int)l_row;
+            sp[it] = P.buf + (unsigned long long)__shfl(soff, row) + piece16;
+            qp[it] = P.buf + (unsigned long long)__shfl(qoff, row) + piece16;
+        }
+    };
+    auto fetch = [&](uint32_t c0) {
+        const bool on = c0 + piece16 < U;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            pf_s[it] = make_uint4(0, 0, 0, 0);
+            pf_q[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (on) { /* the buffer is the library's own: 64 readable bytes behind its end */
+                pf_s[it] = *(const uint4 *)(sp[it] + c0);
+                pf_q[it] = *(const uint4 *)(qp[it] + c0);
+            }
+        }
+    };
+    unsigned long long soff_n = 0, qoff_n = 0; /* sequence / qualities of this lane's read in the next group */
+    if (g < ngroups) {
+        const sq_meta m = P.metas[g * 64 + lane];
+        rows_of(m.record_start + m.sequence_offset, m.record_start + m.qualities_offset);
+        fetch(0);
+    }
+    while (g < ngroups) {
+        const uint64_t r = g * 64 + lane;
+        const bool has_next = g + n_waves < ngroups;
+        if (has_next) {
+            const sq_meta m = P.metas[r + n_waves * 64];
+            soff_n = m.record_start + m.sequence_offset;
+            qoff_n = m.record_start + m.qualities_offset;
+        }
+
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        uint32_t st = dfa_root, gc_cnt = 0, acgt_cnt = 0;
+        unsigned long long found = 0;
+
+        for (uint32_t c0 = 0; c0 < U; c0 += WIDE_CW) {
+            /* ---------------- STAGE: 4 lanes x 16 bytes per row ---------------- */
+            {
+                const uint32_t p0 = c0 + piece16;
+                const int nv = p0 < U ? (int)min(16u, U - p0) : 0;
+                const uint32_t m0 = piece16 >> 2;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const uint32_t row = (uint32_t)it * 16 + l_row;
+                    uint4 sv, qv = pf_q[it];
+                    sv.x = cls2_of_dword(pf_s[it].x); sv.y = cls2_of_dword(pf_s[it].y);
+                    sv.z = cls2_of_dword(pf_s[it].z); sv.w = cls2_of_dword(pf_s[it].w);
+                    if (nv < 16) { /* the chunk at the end of the reads */
+                        sv.x = pad_tail(sv.x, nv, CLS2_PAD4); sv.y = pad_tail(sv.y, nv - 4, CLS2_PAD4);
+                        sv.z = pad_tail(sv.z, nv - 8, CLS2_PAD4); sv.w = pad_tail(sv.w, nv - 12, CLS2_PAD4);
+                        qv.x = pad_tail(qv.x, nv, PAD4); qv.y = pad_tail(qv.y, nv - 4, PAD4);
+                        qv.z = pad_tail(qv.z, nv - 8, PAD4); qv.w = pad_tail(qv.w, nv - 12, PAD4);
+                    }
+                    uint32_t *ts = w_seq + ring_row(row), *tq = w_qual + ring_row(row);
+                    const uint32_t swz = (row >> 1) & 15u;
+                    ts[(m0 + 0) ^ swz] = sv.x; ts[(m0 + 1) ^ swz] = sv.y;
+                    ts[(m0 + 2) ^ swz] = sv.z; ts[(m0 + 3) ^ swz] = sv.w;
+                    tq[(m0 + 0) ^ swz] = qv.x; tq[(m0 + 1) ^ swz] = qv.y;
+                    tq[(m0 + 2) ^ swz] = qv.z; tq[(m0 + 3) ^ swz] = qv.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c0 + WIDE_CW < U) {
+                fetch(c0 + WIDE_CW);
+            } else if (has_next) {
+                rows_of(soff_n, qoff_n);
+                fetch(0);
+            }
+            /* update_adapter_count_array, _qcmodule.c:2643-2672 */
+            auto hits_of = [&](uint32_t pos0, const uint32_t e[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (e[j] < dfa_hit) continue;
+                    unsigned long long hits = P.dfa_out[(e[j] - dfa_root) >> 4] & ~found;
+                    found |= hits;
+                    const uint32_t pos = pos0 + j;
+                    while (hits) {
+                        const int a = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        const uint32_t start = pos - P.ad_len[a] + 1;
+                        if (P.ad_lds) {
+                            atomicAdd(&l_adf[a * hs + start], 1u);
+                        } else {
+                            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
+                            atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], 1ULL);
+                        }
+                    }
+                }
+            };
+            /* Phases S (lane = read: the chains) and H (lane = position: the histograms) share
+               one instruction stream, H fills the waits of S.  A chunk is two halves of 32
+               positions; step d of half hc: dword 8 hc + d of every row (S), row pairs 4 d ..
+               4 d + 3 at the positions of that half (H).  Nothing is asked per step: what lies
+               behind the end of the reads is padding that counts for nothing (class 7 walks the
+               automaton back to its root, its quality adds +0.0, and in the histograms it falls
+               into columns >= U, which the merge skips); only the four chains need a word: they
+               stop four short of the end (:2068), dwords from d_plain on are taken as padding */
+            const uint32_t d_plain = Lmain > c0 ? min(2 * ROW_WORDS, (Lmain - c0) / 4) : 0;
+#pragma unroll 1
+            for (uint32_t hc = 0; hc < 2; hc++) {
+                if (c0 + 32 * hc >= U) break;
+                const uint32_t p = c0 + 32 * hc + pl; /* < hist_stride(U) */
+                uint32_t hv = h_row;
+                const uint32_t hbp = lds_addr(l_hist_base + p), hpp = lds_addr(l_hist_phred + p);
+                const uint32_t mm4 = 4 * (h_dw + 8 * hc);
+#pragma unroll 1
+                for (uint32_t d = 0; d < ROW_WORDS; d++) {
+                    const uint32_t ds = 8 * hc + d;
+                    const uint32_t sa = xor_add(s_sw4, 4 * ds, s_row);
+                    const uint32_t sd = lds_u32(sa);
+                    uint32_t qd = lds_u32(sa + 4 * RING_QUAL_WORDS);
+                    qd = ds < d_plain ? qd : PAD4;
+                    const double e0 = lds_f64(shl3_byte<0>(qd)), e1 = lds_f64(shl3_byte<1>(qd));
+                    const double e2 = lds_f64(shl3_byte<2>(qd)), e3 = lds_f64(shl3_byte<3>(qd));
+                    acc0 += e0;
+                    acc1 += e1;
+                    acc2 += e2;
+                    acc3 += e3;
+                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                    acgt_cnt += __popc(~sd & 0x08080808u);
+                    uint32_t e[4];
+                    bool hit = false;
+                    if (AD) {
+                        e[0] = lds_u16(or_byte<0>(st, sd));
+                        e[1] = lds_u16(or_byte<1>(e[0], sd));
+                        e[2] = lds_u16(or_byte<2>(e[1], sd));
+                        e[3] = lds_u16(or_byte<3>(e[2], sd));
+                        st = e[3];
+                        hit = max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit;
+                    }
+                    /* row pair rp = 4 d + k: 256 rp + 64 half + 4 (mm ^ (rp & 15)) */
+                    const uint32_t sx = (16 * d) & 60;
+                    uint32_t sw[4], qw[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t ha = xor_add(mm4, sx | (4 * k), hv);
+                        sw[k] = lds_u32(ha + 256 * k);
+                        qw[k] = lds_u32(ha + 256 * k + 4 * RING_QUAL_WORDS);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                        const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
+                        lds_inc(hbp + __umul24(cls, hs * 4));
+                        lds_inc(hpp + __umul24(bin, hs * 4));
+                    }
+                    hv += 4 * 256;
+                    if (AD && hit) hits_of(c0 + 4 * ds, e);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        /* ---------------- per-read epilogue: lane = read ---------------- */
+        double total = acc0 + acc1 + acc2 + acc3; /* :2098-2099 */
+        {   /* :2100-2112: the 1-4 qualities behind the chains lie in one dword of the tile the last
+               chunk left; what is past the end of the read is padding and adds +0.0 */
+            const uint32_t qt = w_qual[ring_idx((uint32_t)lane, (Lmain - c_last) >> 2)];
+            total += l_err[qt & 0xFF];
+            total += l_err[(qt >> 8) & 0xFF];
+            total += l_err[(qt >> 16) & 0xFF];
+            total += l_err[qt >> 24];
+        }
+        P.metas[r].accumulated_error_rate = total; /* :2126 */
+        if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+        if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+        const double avg = total / (double)U;
+        uint32_t lo = 0, hi = 93;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+        }
+        atomicAdd(&l_ps[lo], 1u);
+        /* the next STAGE overwrites the tile this epilogue read */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        g += n_waves;
+    }
+
+    /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
+    __syncthreads();
+    if (AD)
+        for (uint32_t i = tid; i < P.ad_lds * hs; i += WIDE_THREADS) {
+            const uint32_t v = l_adf[i];
+            if (!v) continue;
+            const uint32_t a = i / hs, start = i % hs;
+            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
+            atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
+        }
+    const uint32_t ean = min(P.ea_len, U);
+    for (uint32_t i = tid; i < hs * BASE_COLS; i += WIDE_THREADS) {
+        const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
+        if (!v || pos >= U) continue; /* columns behind U collected the padding */
+        atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
+        if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + c], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < hs * PHRED_COLS; i += WIDE_THREADS) {
+        const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
+        if (!v || pos >= U) continue;
+        atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
+        if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + c], (unsigned long long)v);
+    }
+    for (uint32_t i = tid; i < 101; i += WIDE_THREADS)
+        if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
+    for (uint32_t i = tid; i < 94; i += WIDE_THREADS)
+        if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+}
+
+size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states, uint32_t ad_lds = 0)
 {
     size_t b = FIXED_BYTES + (size_t)RING_WAVES * 2 * RING_TILE_WORDS * 4;
     b += (size_t)hist_stride(uniform_len) * (BASE_COLS + PHRED_COLS) * 4;
-    if (ad) b += (size_t)dfa_states * 16;
+    if (ad) b += (size_t)dfa_states * 16 + (size_t)ad_lds * hist_stride(uniform_len) * 4;
     return b + 16;
 }
 
@@ -1534,6 +2104,7 @@ struct sq_adaptercounter {
     struct Group {
         size_t first, count;
         uint32_t states;
+        uint32_t accept_first;   /* states >= this one are hits */
         uint16_t *d_dfa = nullptr;
         unsigned long long *d_out = nullptr;
         uint8_t *d_len = nullptr;
@@ -1615,7 +2186,8 @@ namespace {
  * many adapters there are.  Row = 8 u16: next-row byte offset | 1 when some
  * adapter ends in the target state; class 5 (padding) returns to the root. */
 int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
-              std::vector<uint16_t> &dfa, std::vector<unsigned long long> &out, uint32_t *n_states)
+              std::vector<uint16_t> &dfa, std::vector<unsigned long long> &out, uint32_t *n_states,
+              uint32_t *n_accept_first)
 {
     struct Node { int next[5]; int fail; unsigned long long out; };
     std::vector<Node> t(1);
@@ -1659,14 +2231,21 @@ int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
             else { t[v].fail = t[t[u].fail].next[c]; queue.push_back(v); }
         }
     }
-    /* outputs of a node are final only after its fail chain is: BFS order guarantees it */
+    /* outputs of a node are final only after its fail chain is: BFS order guarantees it.
+       States some adapter ends in are numbered last, so that "is it a hit" can also be asked
+       of a row's position (k_pass) instead of the flag bit */
+    std::vector<int> number(t.size());
+    int next_number = 0;
+    for (size_t s = 0; s < t.size(); s++) if (!t[s].out) number[s] = next_number++;
+    *n_accept_first = (uint32_t)next_number;
+    for (size_t s = 0; s < t.size(); s++) if (t[s].out) number[s] = next_number++;
     dfa.assign(t.size() * 8, 0);
     out.assign(t.size(), 0);
     for (size_t s = 0; s < t.size(); s++) {
-        out[s] = t[s].out;
+        out[number[s]] = t[s].out;
         for (int c = 0; c < 5; c++) {
             int v = t[s].next[c];
-            dfa[s * 8 + c] = (uint16_t)((v << 4) | (t[v].out ? 1 : 0));
+            dfa[number[s] * 8 + c] = (uint16_t)((number[v] << 4) | (t[v].out ? 1 : 0));
         }
     }
     *n_states = (uint32_t)t.size();
@@ -1704,7 +2283,7 @@ SQ_EXPORT sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *cons
         g.count = count;
         std::vector<uint16_t> dfa;
         std::vector<unsigned long long> out;
-        if (build_dfa(a->adapters, first, count, dfa, out, &g.states) != 0) {
+        if (build_dfa(a->adapters, first, count, dfa, out, &g.states, &g.accept_first) != 0) {
             sq_set_error("adapter automaton too large");
             delete a;
             return nullptr;
@@ -2011,6 +2590,21 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             SQ_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
+#ifdef SQ_PROBE
+    if (const char *pm = getenv("SQ_PROBE_MODE")) {
+        unsigned long long *sink = (unsigned long long *)sq_scratch(ctx, 0, 64);
+        const int mode = atoi(pm), grid = ctx->num_cus * 4;
+        if (mode == 32) hipLaunchKernelGGL((k_probe<32>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        else if (mode == 64) hipLaunchKernelGGL((k_probe<64>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        else if (mode == 128) hipLaunchKernelGGL((k_probe<128>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        else if (mode == 33) hipLaunchKernelGGL((k_probe_row<32>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        else if (mode == 65) hipLaunchKernelGGL((k_probe_row<64>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        else if (mode == 1) hipLaunchKernelGGL(k_probe_flat, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)P.buf, (uint64_t)(b->buf_len / 16), sink);
+        else hipLaunchKernelGGL(k_probe_span, dim3(grid), dim3(256), 0, ctx->stream, P, sink);
+        SQ_HIP(hipGetLastError());
+        return SQ_OK;
+    }
+#endif
     /* first automaton rides with the other modules; further groups get a pass of their own */
     size_t ngroups = a ? a->groups.size() : 0;
     for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
@@ -2019,7 +2613,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         uint32_t states = 0;
         if (ad) {
             auto &g = a->groups[gi];
-            P.dfa = g.d_dfa; P.dfa_states = g.states; P.dfa_out = g.d_out; P.ad_len = g.d_len;
+            P.dfa = g.d_dfa; P.dfa_states = g.states; P.dfa_accept = g.accept_first; P.dfa_out = g.d_out; P.ad_len = g.d_len;
             P.ad_fwd = a->d_fwd + g.first * a->cap;
             P.ad_rev = a->d_rev + g.first * a->cap;
             states = g.states;
@@ -2031,16 +2625,41 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
                 P.ad_lds = (uint32_t)g.count;
         }
         if (!qc && !pt && !ad) break;
-        /* Uniform short reads: k_ring fetches every 64-byte sector once (1.07 x the
-           algorithmic bytes against 1.85 x for k_pass).  QCMetrics alone gains 17 % from it;
-           with the adapter automaton in the pass the sequential table walk is what binds,
-           not the fetch, and k_pass (smaller tiles, more LDS left) is 3 % ahead, so the
-           automaton keeps k_pass unless SQ_RING=1 (SQ_NO_RING=1: never k_ring).  A trailing
-           partial group goes through k_pass. */
+        /* Batches of one read length (<= 512) in stored order skip k_pass's general machinery; a
+           trailing partial group of fewer than 64 records goes through k_pass.
+           - QCMetrics + AdapterCounter: k_wide (64 bytes per row and visit).  Its 16-byte loads may
+             run past the last record, so the buffer must be the library's own (64 bytes of slack);
+             wrapped device memory keeps k_pass.  SQ_NO_WIDE=1: k_pass; SQ_WIDE=1: also QCMetrics alone.
+           - QCMetrics alone: k_ring (every 64-byte sector fetched once), 8 % ahead of k_wide there.
+             SQ_NO_RING=1: k_pass; SQ_RING=1: also with the automaton. */
         PassParams Pfull = P;
-        const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states);
-        const bool ring = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && rlds <= 160 * 1024 &&
-                          !getenv("SQ_NO_RING") && (!ad || (dfa_lds && getenv("SQ_RING")));
+        const bool uniform_fast = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && (!ad || dfa_lds);
+        const char *wide_env = getenv("SQ_WIDE");
+        const size_t wlds = wide_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
+        const bool wide = uniform_fast && b->owns && wlds <= 160 * 1024 && !getenv("SQ_NO_WIDE") &&
+                          (ad ? !getenv("SQ_RING") : (wide_env && atoi(wide_env)));
+        const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
+        const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !getenv("SQ_NO_RING") &&
+                          (!ad || getenv("SQ_RING"));
+        if (wide) {
+            PassParams C = P;
+            C.n = (b->n / 64) * 64;
+            static bool wattr = false;
+            if (!wattr) {
+                SQ_HIP(hipFuncSetAttribute((const void *)k_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                SQ_HIP(hipFuncSetAttribute((const void *)k_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                wattr = true;
+            }
+            const uint64_t want = (C.n / 64 + WIDE_WAVES - 1) / WIDE_WAVES;
+            const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus));
+            if (ad) hipLaunchKernelGGL((k_wide<true>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
+            else hipLaunchKernelGGL((k_wide<false>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
+            SQ_HIP(hipGetLastError());
+            if (C.n == b->n) continue;
+            P.metas = b->d_metas + C.n;
+            P.first_read_index += C.n;
+            P.n = b->n - C.n;
+        }
         if (ring) {
             PassParams C = P;
             C.n = (b->n / 64) * 64;
@@ -2121,7 +2740,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             dispatch_pass(ctx, P, qc, ad, pt, dfa_lds, grid_for(ctx, P.n, wgs_per_cu), lds);
             SQ_HIP(hipGetLastError());
         }
-        if (ring) P = Pfull;
+        if (ring || wide) P = Pfull;
     }
     if (m) { m->number_of_reads += b->n; m->records_seen += b->n; }
     if (a) a->number_of_sequences += b->n;

@@ -267,11 +267,24 @@ def test_nanopore_long_reads_all_modules():
         np.testing.assert_array_equal(u64(r), rr)
 
 
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_two_million_reads_all_tables_equal_oracle():
     """bench-shaped input at a size the oracle still finishes in seconds: 2 M x 150 bp
-    generated in HBM, one fused launch (k_pass), one QCMetrics-only launch (k_ring) and one
-    fused launch forced through k_ring (SQ_RING=1)"""
-    import os
+    generated in HBM through every kernel that takes such a batch: the fused launch (k_wide),
+    the same forced through k_pass and through k_ring, and QCMetrics alone (k_ring)"""
     from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
     n = 2_000_000
     dev = synth.device_array(synth.ILLUMINA, 12345, n)
@@ -284,17 +297,16 @@ def test_two_million_reads_all_tables_equal_oracle():
     FusedPass(gq, ga).add_record_array(dev)
     errs = dev.accumulated_error_rates()
     gq2.add_record_array(dev)
-    gq3, ga3 = QCMetrics(), AdapterCounter(probes)
-    os.environ["SQ_RING"] = "1"
-    try:
-        FusedPass(gq3, ga3).add_record_array(dev)
-        gq3.flush()
-    finally:
-        del os.environ["SQ_RING"]
-    for (_, f, r), (_, fr, rr) in zip(ga3.get_counts(), ra.get_counts()):
-        np.testing.assert_array_equal(u64(f), fr)
-        np.testing.assert_array_equal(u64(r), rr)
-    for g in (gq, gq2, gq3):
+    forced = []
+    for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}):
+        q, a = QCMetrics(), AdapterCounter(probes)
+        _with_env(env, lambda: (FusedPass(q, a).add_record_array(dev), q.flush()))
+        forced.append((q, a))
+    for g in (ga, forced[0][1], forced[1][1]):
+        for (_, f, r), (_, fr, rr) in zip(g.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(f), fr)
+            np.testing.assert_array_equal(u64(r), rr)
+    for g in (gq, gq2, forced[0][0], forced[1][0]):
         np.testing.assert_array_equal(u64(g.base_count_table()), rq.base_count_table())
         np.testing.assert_array_equal(u64(g.phred_count_table()), rq.phred_count_table())
         np.testing.assert_array_equal(u64(g.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
@@ -304,19 +316,17 @@ def test_two_million_reads_all_tables_equal_oracle():
     np.testing.assert_array_equal(errs.view(np.uint64), metas["accumulated_error_rate"].view(np.uint64))
     np.testing.assert_array_equal(dev.accumulated_error_rates().view(np.uint64),
                                   metas["accumulated_error_rate"].view(np.uint64))
-    for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
-        np.testing.assert_array_equal(u64(f), fr)
-        np.testing.assert_array_equal(u64(r), rr)
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 50_000
 
 
 @pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
-def test_ring_kernel_every_alignment(U):
-    """k_ring cuts a read into 32-byte aligned windows and rotates them back in registers:
-    every length class and every start alignment (names of rotating length, so sequence
-    and quality starts walk through all residues mod 64), full groups plus a remainder,
-    with and without the automaton in the pass"""
-    import os
+def test_uniform_length_kernels_every_alignment(U):
+    """Batches of one read length have three kernels.  k_ring cuts a read into 32-byte aligned
+    windows and rotates them back in registers, k_wide stages 64 positions at a time with four
+    lanes per row and lets padding absorb the end of the reads, k_pass is the general one: every
+    length class and every start alignment (names of rotating length, so sequence and quality
+    starts walk through all residues mod 64), full groups plus a remainder, with and without
+    the automaton in the pass (one probe holds an N: padding must not look like it)"""
     from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
     rng = np.random.default_rng(1000 + U)
     n = 64 * 5 + 37
@@ -327,6 +337,8 @@ def test_ring_kernel_every_alignment(U):
         if U >= 12 and i % 3 == 0:
             at = int(rng.integers(0, U - 11))
             s = s[:at] + "ACGTACGTACGT" + s[at + 12:]
+        if U >= 5 and i % 7 == 0:
+            s = s[:U - 4] + "TTNA"  # the N probe one base short of matching at the very end
         names.append("r" * (1 + i % 67))
         seqs.append(s)
         quals.append((rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode())
@@ -334,21 +346,25 @@ def test_ring_kernel_every_alignment(U):
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for forced in (False, True):
+    cases = [(False, {}),                                        # QCMetrics alone: k_ring
+             (False, {"SQ_WIDE": "1"}),                          # QCMetrics alone: k_wide
+             (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
+             (True, {}),                                         # + AdapterCounter: k_wide
+             (True, {"SQ_RING": "1"}),                           # k_ring
+             (True, {"SQ_NO_WIDE": "1"})]                        # k_pass
+    for with_adapters, env in cases:
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(probes)
-        if forced:
-            os.environ["SQ_RING"] = "1"
-        try:
-            if forced:
+
+        def run():
+            if with_adapters:
                 FusedPass(gq, ga).add_record_array(arr)
             else:
                 gq.add_record_array(arr)
             gq.flush()
-        finally:
-            os.environ.pop("SQ_RING", None)
+        _with_env(env, run)
         compare_qc(rq, gq, metas, arr)
-        if forced:
+        if with_adapters:
             for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
                 np.testing.assert_array_equal(u64(f), fr)
                 np.testing.assert_array_equal(u64(r), rr)
