@@ -96,6 +96,19 @@ class HipEvents:
         return out
 
 
+def dominant_kernel(kind, mods):
+    """the kernel sq_fused_add_batch launches for the synthetic batch of this run"""
+    if kind != "illumina":
+        return "k_seg (long reads: k_read_sums + k_seg + k_adapter_first)"
+    if "pertile" in mods:
+        return "k_pass (fused per-base pass, tile-sorted order)"
+    if "adapter" in mods and "qc" in mods:
+        return "k_wide<AD> (fused per-base pass, one read length)"
+    if "qc" in mods:
+        return "k_ring (QCMetrics, one read length)"
+    return "k_pass (fused per-base pass)"
+
+
 def cpu_baseline(sample_reads: int, passes: int = 1):
     """One QC thread (the reference's second thread only decompresses,
     __main__.py:189-192) over the first `sample_reads` records of the workload."""
@@ -274,7 +287,7 @@ def main():
                        "modules": sorted(mods), "sharding": f"records x{world}, RCCL all-reduce of count tables"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "k_pass<QC,AD> (fused per-base pass)",
+                         "kernel": dominant_kernel(args.kind, mods),
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launch_ms)},
             "checks": checks,
