@@ -147,9 +147,10 @@ __device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
     const uint32_t lut = __builtin_amdgcn_perm(0x04080806u, 0x02080008u, idx);
     const uint32_t want = __builtin_amdgcn_perm(0x47000054u, 0x43004100u, idx);
     const uint32_t d = (w & 0xDFDFDFDFu) ^ want;
-    const uint32_t ne = ((d + 0x7F7F7F7Fu) & 0x80808080u) >> 7; /* 1 where it is not that letter */
-    const uint32_t mask = (ne << 8) - ne;                        /* 0xFF per such byte */
-    return (mask & 0x08080808u) | (~mask & lut);
+    const uint32_t ne4 = ((d + 0x7F7F7F7Fu) & 0x80808080u) >> 5; /* 4 where it is not that letter */
+    /* a third v_perm picks, byte by byte, the class (selectors 4-7: bytes of lut) or 8 (selectors
+       0-3: bytes of the constant) */
+    return __builtin_amdgcn_perm(lut, 0x08080808u, 0x07060504u - ne4);
 }
 
 /* &hist[row * stride] with a full-rate 24-bit multiply-add (v_mad_u32_u24): a plain 32-bit
