@@ -886,23 +886,26 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
+constexpr int SEG_DEPTH = 2; /* chunks of loads in flight per wave (3: -2 %, 4 costs a wave per SIMD: -15 %) */
 template <bool AD>
-__global__ void __launch_bounds__(WG_THREADS, 4) k_seg(PassParams P, SegParams S)
+__global__ void __launch_bounds__(WG_THREADS, 3) k_seg(PassParams P, SegParams S)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t *l_wave = (uint32_t *)smem;                   /* per wave: seq tile, qual tile, offsets, lengths */
+    uint16_t *l_dfa = (uint16_t *)smem;                    /* in front: rows are addressed with 16 bits (see k_pass) */
+    uint32_t *l_wave = (uint32_t *)(l_dfa + (AD ? P.dfa_states * 8 : 0)); /* per wave: tiles, offsets, lengths */
     constexpr uint32_t hs = SEG;
     uint32_t *l_hist_base = l_wave + WAVES * WAVE_WORDS;   /* [5][SEG] */
     uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12][SEG] */
     uint32_t *l_ea_base = l_hist_phred + hs * PHRED_COLS;
     const uint32_t ea_rows = P.ea_in_lds ? P.ea_len : 0, es = hist_stride(ea_rows);
     uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
-    uint16_t *l_dfa = (uint16_t *)(l_ea_phred + es * PHRED_COLS);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (uint32_t i = tid; i < (hs + es) * (BASE_COLS + PHRED_COLS); i += WG_THREADS) l_hist_base[i] = 0;
+    const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + P.dfa_accept * 16;
     if (AD)
-        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS) l_dfa[i] = P.dfa[i];
+        for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS)
+            l_dfa[i] = (uint16_t)((P.dfa[i] & 0xFFF0u) + dfa_root);
     __syncthreads();
 
     uint32_t *w_seq = l_wave + wave * WAVE_WORDS, *w_qual = w_seq + TILE_WORDS;
@@ -927,38 +930,42 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_seg(PassParams P, SegParams S
         w_qoff[lane] = valid ? m.record_start + m.qualities_offset : 0;
         w_len[lane] = L;
         const uint32_t stop = min(wave_max_u32(L), pos_stop);
-        uint32_t st = 0;
+        uint32_t st = dfa_root;
         unsigned long long found = 0; /* adapters this segment has reported */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        uint4 pf_s[2], pf_q[2];
-        auto prefetch = [&](uint32_t c0) {
+        /* LDS leaves this kernel three waves per SIMD (168 VGPRs): the loads run SEG_DEPTH chunks
+           ahead of the counting */
+        uint4 pf_s[SEG_DEPTH][2], pf_q[SEG_DEPTH][2];
+        auto fetch = [&](uint32_t c0, uint4 (&fs)[2], uint4 (&fq)[2]) {
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const uint32_t row = it * 32 + ((uint32_t)lane >> 1), p0 = c0 + ((uint32_t)lane & 1) * 16;
-                pf_s[it] = make_uint4(0, 0, 0, 0);
-                pf_q[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                fs[it] = make_uint4(0, 0, 0, 0);
+                fq[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
                 if (p0 < w_len[row]) {
-                    pf_s[it] = load16(P.buf, w_soff[row] + p0, P.buf_len);
-                    if (c0 >= pos_base) pf_q[it] = load16(P.buf, w_qoff[row] + p0, P.buf_len);
+                    fs[it] = load16(P.buf, w_soff[row] + p0, P.buf_len);
+                    if (c0 >= pos_base) fq[it] = load16(P.buf, w_qoff[row] + p0, P.buf_len);
                 }
             }
         };
         /* the automaton starts SEG_WARMUP positions early (not in segment 0) */
         const uint32_t c_begin = (AD && seg) ? pos_base - SEG_WARMUP : pos_base;
-        if (stop > c_begin) prefetch(c_begin);
+#pragma unroll
+        for (int k = 0; k < SEG_DEPTH; k++)
+            if (c_begin + k * CW < stop) fetch(c_begin + k * CW, pf_s[k], pf_q[k]);
         for (uint32_t c0 = c_begin; c0 < stop; c0 += CW) {
             const bool warm = c0 < pos_base;
 #pragma unroll
             for (int it = 0; it < 2; it++) {
                 const uint32_t row = it * 32 + ((uint32_t)lane >> 1), piece = (uint32_t)lane & 1;
                 const uint32_t Lr = w_len[row], p0 = c0 + piece * 16;
-                uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4), qv = pf_q[it];
+                uint4 sv = make_uint4(CLS2_PAD4, CLS2_PAD4, CLS2_PAD4, CLS2_PAD4), qv = pf_q[0][it];
                 if (p0 < Lr) {
                     const int nv = (int)min(16u, Lr - p0);
-                    sv.x = cls2_of_dword(pf_s[it].x); sv.y = cls2_of_dword(pf_s[it].y);
-                    sv.z = cls2_of_dword(pf_s[it].z); sv.w = cls2_of_dword(pf_s[it].w);
+                    sv.x = cls2_of_dword(pf_s[0][it].x); sv.y = cls2_of_dword(pf_s[0][it].y);
+                    sv.z = cls2_of_dword(pf_s[0][it].z); sv.w = cls2_of_dword(pf_s[0][it].w);
                     if (nv < 16) {
                         sv.x = pad_tail(sv.x, nv, CLS2_PAD4); sv.y = pad_tail(sv.y, nv - 4, CLS2_PAD4);
                         sv.z = pad_tail(sv.z, nv - 8, CLS2_PAD4); sv.w = pad_tail(sv.w, nv - 12, CLS2_PAD4);
@@ -974,23 +981,27 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_seg(PassParams P, SegParams S
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (c0 + CW < stop) prefetch(c0 + CW);
+#pragma unroll
+            for (int k = 0; k + 1 < SEG_DEPTH; k++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) { pf_s[k][it] = pf_s[k + 1][it]; pf_q[k][it] = pf_q[k + 1][it]; }
+            if (c0 + SEG_DEPTH * CW < stop) fetch(c0 + SEG_DEPTH * CW, pf_s[SEG_DEPTH - 1], pf_q[SEG_DEPTH - 1]);
 
             if (AD) { /* phase S: the automaton only */
                 const uint32_t nd = min(ROW_WORDS, (stop - c0 + 3) / 4);
                 for (uint32_t d = 0; d < nd; d++) {
                     const uint32_t sd = w_seq[tile_idx((uint32_t)lane, d)];
                     uint32_t e[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        e[j] = *(const uint16_t *)((const uint8_t *)l_dfa + (st | ((sd >> (8 * j)) & 0xFF)));
-                        st = e[j] & 0xFFF0u;
-                    }
-                    if (!warm && ((e[0] | e[1] | e[2] | e[3]) & 1u)) {
+                    e[0] = lds_u16(or_byte<0>(st, sd));
+                    e[1] = lds_u16(or_byte<1>(e[0], sd));
+                    e[2] = lds_u16(or_byte<2>(e[1], sd));
+                    e[3] = lds_u16(or_byte<3>(e[2], sd));
+                    st = e[3];
+                    if (!warm && max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            if (!(e[j] & 1u)) continue;
-                            unsigned long long hits = P.dfa_out[e[j] >> 4] & ~found;
+                            if (e[j] < dfa_hit) continue;
+                            unsigned long long hits = P.dfa_out[(e[j] - dfa_root) >> 4] & ~found;
                             found |= hits;
                             const uint32_t pos = c0 + d * 4 + j;
                             while (hits) {
