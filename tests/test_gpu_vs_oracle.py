@@ -370,6 +370,42 @@ def test_uniform_length_kernels_every_alignment(U):
                 np.testing.assert_array_equal(u64(r), rr)
 
 
+def test_uniform_length_many_adapters_counted_in_device_tables():
+    """with more adapters than the per-workgroup LDS hit table takes (8 KB), k_wide counts hits
+    straight into the device tables; 150 bp and 250 bp (the longest k_wide's LDS still fits)"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(77)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    probes = [rng.choice(letters, size=int(rng.integers(6, 20))).tobytes().decode() for _ in range(20)]
+    for U in (150, 250):
+        n = 64 * 9 + 5
+        names, seqs, quals = [], [], []
+        for i in range(n):
+            s = rng.choice(letters, size=U).tobytes().decode()
+            for _ in range(int(rng.integers(0, 3))):
+                w = probes[int(rng.integers(0, len(probes)))]
+                at = int(rng.integers(0, U - len(w) + 1))
+                s = s[:at] + w + s[at + len(w):]
+            names.append(f"q{i}")
+            seqs.append(s)
+            quals.append((rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode())
+        buf, metas = oracle.make_batch(names, seqs, quals)
+        rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+        rq.add(buf, metas)
+        ra.add(buf, metas)
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(), AdapterCounter(probes)
+        FusedPass(gq, ga).add_record_array(arr)
+        gq.flush()
+        compare_qc(rq, gq, metas, arr)
+        total = 0
+        for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(f), fr)
+            np.testing.assert_array_equal(u64(r), rr)
+            total += int(fr.sum())
+        assert total > n // 2
+
+
 def test_nanostats_after_qcmetrics_on_device_batches():
     """NanoStats reads accumulated_error_rate where QCMetrics left it in HBM: synthetic
     nanopore reads generated on the device, two batches, nothing on the host in between"""
