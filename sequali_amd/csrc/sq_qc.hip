@@ -220,6 +220,23 @@ __device__ __forceinline__ void lds_inc(uint32_t a)
 {
     __hip_atomic_fetch_add((SQ_LDS uint32_t *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+/* phred bins of two quality bytes at once (packed 16-bit math): byte `sel`-selected of qa in
+ * the low half, of qb in the high half; min(q - 33, 47) >> 2 like the scalar form */
+typedef unsigned short sq_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bins_of_two(uint32_t qa, uint32_t qb, uint32_t sel)
+{
+    sq_us2 v = __builtin_bit_cast(sq_us2, __builtin_amdgcn_perm(qb, qa, sel));
+    v = __builtin_elementwise_min(v - (unsigned short)33, (sq_us2)(unsigned short)47) >> (unsigned short)2;
+    return __builtin_bit_cast(uint32_t, v);
+}
+/* base + (low / high half of packed) * stride: v_mad_u32_u16, the half picked by op_sel */
+template <int HI> __device__ __forceinline__ uint32_t mad_half(uint32_t packed, uint32_t stride, uint32_t base)
+{
+    uint32_t r;
+    if (HI) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(stride), "v"(base));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(stride), "v"(base));
+    return r;
+}
 /* (x ^ s) + b */
 __device__ __forceinline__ uint32_t xor_add(uint32_t x, uint32_t s, uint32_t b)
 {
@@ -1628,6 +1645,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
     uint32_t *w_seq = l_tiles + wave * 2 * RING_TILE_WORDS, *w_qual = w_seq + RING_QUAL_WORDS;
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     const uint32_t h_sh = 8 * (pl & 3), h_dw = pl >> 2;
+    /* v_perm selector of bins_of_two: this lane's byte of the first word into the low half, of
+       the second word into the high half, zeros (0x0c) above them */
+    const uint32_t q_sel = 0x0c000c00u | (pl & 3) | ((4 + (pl & 3)) << 16);
     /* byte addresses of the fused loop: what is fixed per lane (ring_idx split up) */
     const uint32_t s_row = lds_addr(w_seq) + ((uint32_t)lane >> 1) * 256 + ((uint32_t)lane & 1) * 64;
     const uint32_t s_sw4 = 4 * (((uint32_t)lane >> 1) & 15);
@@ -1792,11 +1812,12 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
                         qw[k] = lds_u32(ha + 256 * k + 4 * RING_QUAL_WORDS);
                     }
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) {
-                        const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
-                        const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
-                        lds_inc(hbp + __umul24(cls, hs * 4));
-                        lds_inc(hpp + __umul24(bin, hs * 4));
+                    for (uint32_t k = 0; k < 4; k += 2) {
+                        const uint32_t bins = bins_of_two(qw[k], qw[k + 1], q_sel);
+                        lds_inc(hbp + __umul24(__builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3), hs * 4));
+                        lds_inc(mad_half<0>(bins, hs * 4, hpp));
+                        lds_inc(hbp + __umul24(__builtin_amdgcn_ubfe(sw[k + 1], h_sh + 1, 3), hs * 4));
+                        lds_inc(mad_half<1>(bins, hs * 4, hpp));
                     }
                     hv += 4 * 256;
                     if (AD && hit) hits_of(c0 + 4 * ds, e);
