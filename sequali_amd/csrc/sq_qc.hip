@@ -1667,6 +1667,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
     uint64_t g = wave_id;
     const uint8_t *sp[4], *qp[4]; /* where this lane's 16 bytes of the four rows it loads start */
     uint4 pf_s[4], pf_q[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) pf_s[it] = pf_q[it] = make_uint4(0, 0, 0, 0);
     auto rows_of = [&](unsigned long long soff, unsigned long long qoff) {
 #pragma unroll
         for (int it = 0; it < 4; it++) {
@@ -1676,12 +1678,12 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
         }
     };
     auto fetch = [&](uint32_t c0) {
-        const bool on = c0 + piece16 < U;
+        /* a piece behind the end of the reads is not loaded: STAGE turns whatever the registers
+           still hold into padding.  The buffer is the library's own: 64 readable bytes behind
+           its end */
+        if (c0 + piece16 < U) {
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            pf_s[it] = make_uint4(0, 0, 0, 0);
-            pf_q[it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
-            if (on) { /* the buffer is the library's own: 64 readable bytes behind its end */
+            for (int it = 0; it < 4; it++) {
                 pf_s[it] = *(const uint4 *)(sp[it] + c0);
                 pf_q[it] = *(const uint4 *)(qp[it] + c0);
             }
