@@ -175,6 +175,8 @@ def main():
 
     mods = set(args.modules.split(","))
     kind = synth.NANOPORE if args.kind == "nanopore" else synth.ILLUMINA
+    if args.kind == "illumina" and os.environ.get("SQ_BENCH_BY_TILE"):  # the order a sequencer writes
+        kind = synth.ILLUMINA_BY_TILE
     probes = synth.NANOPORE_PROBES if args.kind == "nanopore" else synth.ILLUMINA_PROBES
     qc = QCMetrics() if "qc" in mods else None
     ad = AdapterCounter(list(probes)) if "adapter" in mods else None

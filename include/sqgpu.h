@@ -346,6 +346,7 @@ int sq_adaptercounter_set_totals(sq_adaptercounter *a, uint64_t number_of_sequen
 #define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */
 #define SQ_SYNTH_ILLUMINA_R2 1    /* the mate of read i              */
 #define SQ_SYNTH_NANOPORE 2       /* variable length, ~10 kb          */
+#define SQ_SYNTH_ILLUMINA_BY_TILE 3 /* kind 0 with the reads ordered by tile */
 /* Size in bytes of records [first, first+n) and the generators themselves.
  * Host version writes FASTQ text + metas into caller memory; device version
  * allocates a batch in HBM and fills it with a kernel. */

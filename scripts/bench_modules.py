@@ -49,5 +49,11 @@ def config3():
 
 
 timed("config 3: (QCMetrics+PerTileQuality) x2 + InsertSizeMetrics", config3, 2 * bases)
+# the same reads in the order a sequencer writes them (tile by tile): no sort, no gather
+rt = synth.device_array(synth.ILLUMINA_BY_TILE, 0, n)
+pt2 = PerTileQuality()
+timed("PerTileQuality, reads ordered by tile", lambda: pt2.add_record_array(rt), bases)
+ft = FusedPass(QCMetrics(), None, PerTileQuality())
+timed("QCMetrics+PerTileQuality, reads ordered by tile", lambda: ft.add_record_array(rt) or ft.qc_metrics._pending.clear(), bases)
 print("dedup modulo bits", dd._modulo_bits, "tracked", dd.tracked_sequences,
       "| overrep unique", ov.collected_unique_fragments, "| insert sizes", sum(isz.insert_sizes()[1:]))

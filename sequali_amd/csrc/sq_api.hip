@@ -812,7 +812,7 @@ __host__ __device__ static inline void synth_write_record(int kind, uint64_t see
     if (lane == 0) {
         dst[0] = '@';
         if (kind == SQ_SYNTH_NANOPORE) sqs_nanopore_name(seed, i, dst + 1);
-        else sqs_illumina_name(seed, i, mate, dst + 1);
+        else sqs_illumina_name(seed, i, mate, dst + 1, kind == SQ_SYNTH_ILLUMINA_BY_TILE);
         dst[1 + nl] = '\n';
         dst[2 + nl + L] = '\n';
         dst[3 + nl + L] = '+';

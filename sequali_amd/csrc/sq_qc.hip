@@ -273,6 +273,9 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     const uint32_t es = hist_stride(ea_rows);
     uint32_t *l_ea_phred = l_ea_base + es * BASE_COLS;
     uint32_t *l_adf = l_ea_phred + es * PHRED_COLS;       /* [ad_lds][hs] */
+    /* PerTileQuality: per wave, the error-rate sums of the tile its groups are in, [position] */
+    const uint32_t pts = PT ? hist_stride(P.lds_len) : 0;
+    double *l_pt = (double *)(l_adf + (((AD && DFA_LDS && QC) ? P.ad_lds * hs : 0) + 1) / 2 * 2);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     /* the fused loop turns a quality byte into the address of its error rate with one shift:
@@ -303,6 +306,8 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
        at or behind dfa_hit (build_dfa numbers those states last) */
     const uint32_t dfa_root = (AD && DFA_LDS) ? lds_addr(l_dfa) : 0;
     const uint32_t dfa_hit = dfa_root + P.dfa_accept * 16;
+    if (PT)
+        for (uint32_t i = tid; i < WAVES * pts; i += WG_THREADS) l_pt[i] = 0.0;
     if (AD && DFA_LDS) {
         for (uint32_t i = tid; i < P.dfa_states * 8; i += WG_THREADS)
             l_dfa[i] = (uint16_t)((P.dfa[i] & 0xFFF0u) + dfa_root);
@@ -332,6 +337,26 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
     const uint64_t g_begin = P.blocked ? wave_id * per_wave : wave_id;
     const uint64_t g_end = P.blocked ? min(ngroups, g_begin + per_wave) : ngroups;
     const uint64_t g_step = P.blocked ? 1 : n_waves;
+    /* device atomics on a tile's row come from every wave that is in that tile, from all XCDs:
+       a wave keeps the sums of its current tile in LDS and hands them over when its groups move
+       on to another tile */
+    double *w_pt = l_pt + wave * pts;
+    int32_t pt_acc_slot = -1;
+    uint32_t pt_acc_reads = 0; /* reads of that tile the wave has seen (all of length uniform_len) */
+    auto pt_flush = [&]() {
+        if (pt_acc_slot < 0) return;
+        if (lane == 0 && pt_acc_reads)
+            atomicAdd(&P.pt_len_counts[(uint64_t)pt_acc_slot * P.pt_cap + (P.uniform_len - 1)],
+                      (unsigned long long)pt_acc_reads);
+        pt_acc_reads = 0;
+        for (uint32_t i = lane; i < pts; i += 64) {
+            const double v = w_pt[i];
+            if (v != 0.0) {
+                unsafeAtomicAdd(&P.pt_errors[(uint64_t)pt_acc_slot * P.pt_cap + i], v);
+                w_pt[i] = 0.0;
+            }
+        }
+    };
     for (uint64_t g = g_begin; g < g_end; g += g_step) {
         const uint64_t slot_index = g * 64 + lane;
         bool valid = slot_index < P.n;
@@ -365,6 +390,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
             pt_slot = valid ? P.pt_slot[r] : -1;
             pt_on = valid && pt_slot >= 0 && (P.first_read_index + r) < P.pt_first_bad;
             if (!pt_on) pt_slot = -1;
+        }
+        /* every read of the group counts for the same tile (wave-uniform slot) */
+        const int32_t pt_group_slot = PT ? __builtin_amdgcn_readfirstlane(pt_slot) : -1;
+        const bool pt_one_tile = PT && pt_group_slot >= 0 && __all(pt_on && pt_slot == pt_group_slot);
+        if (PT && pt_one_tile && pt_group_slot != pt_acc_slot) {
+            pt_flush();
+            pt_acc_slot = pt_group_slot;
         }
         /* the staging lanes of other rows read w_soff / w_qoff / w_len */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -516,8 +548,10 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 }
             };
             const bool fast_group = QC && !PT && P.uniform_len && (g + 1) * 64 <= P.n;
+            const bool pt_group = PT && P.uniform_len && P.uniform_len <= P.lds_len && !P.pos_base && (g + 1) * 64 <= P.n && pt_one_tile;
             /* a chunk inside every read, and inside what the four chains cover (:2068) */
-            if (fast_group && c0 + CW <= P.uniform_len && c0 + CW - 4 < 4 * ((P.uniform_len - 1) / 4)) {
+            if ((fast_group || (QC && pt_group)) && c0 + CW <= P.uniform_len &&
+                c0 + CW - 4 < 4 * ((P.uniform_len - 1) / 4)) {
                 /* The per-read chains of phase S (a table walk with one LDS round trip per base)
                    and the histogram updates of phase H are independent, so they share one
                    instruction stream and phase H fills the waits of phase S.  Step d takes
@@ -525,6 +559,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                    computed by hand, one v_xad_u32 each: (swizzle ^ step) + base. */
                 uint32_t hv = lds_addr(w_seq);
                 const uint32_t hbp = lds_addr(l_hist_base + p), hpp = lds_addr(l_hist_phred + p);
+                double pt_run = 0.0; /* PerTileQuality, a group of one tile: this position's error rates */
 #pragma unroll 1
                 for (uint32_t d = 0; d < ROW_WORDS; d++) {
                     const uint32_t sa = xor_add(s_sw4, 4 * d, s_row);
@@ -570,9 +605,11 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                         const uint32_t bin = min(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) - 33u, 47u) >> 2;
                         lds_inc(hbp + __umul24(cls, hs * 4));
                         lds_inc(hpp + __umul24(bin, hs * 4));
+                        if (PT) pt_run += lds_f64(__builtin_amdgcn_ubfe(qw[k], h_sh, 8) << 3);
                     }
                     if (hit) s_hits(d, e);
                 }
+                if (PT) unsafeAtomicAdd(&w_pt[p], pt_run); /* two lanes per position: even rows, odd rows */
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 continue;
@@ -590,6 +627,36 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                     if (p < P.uniform_len) {
 #pragma unroll
                         for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) h_fast(rp0);
+                    }
+                } else if (PT && pt_group) {
+                    /* PerTileQuality on a full group of equally long reads of ONE tile (what the
+                       tile-sorted order makes of nearly every group): no row asks anything, a
+                       lane sums the error rates of its position over the 64 reads in a register
+                       and adds them to the tile's row once */
+                    if (p < P.uniform_len) {
+                        double run = 0.0;
+#pragma unroll 2
+                        for (uint32_t rp0 = 0; rp0 < 32; rp0 += 4) {
+                            uint32_t sw[4], qw[4];
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t ti = ptile_idx_h(rp0 + k, half, h_dw);
+                                sw[k] = QC ? w_seq[ti] : 0;
+                                qw[k] = w_qual[ti];
+                            }
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t qb = __builtin_amdgcn_ubfe(qw[k], h_sh, 8);
+                                if (QC) {
+                                    const uint32_t cls = __builtin_amdgcn_ubfe(sw[k], h_sh + 1, 3);
+                                    const uint32_t bin = min(qb - 33u, 47u) >> 2;
+                                    atomicAdd(hist_row(hb, cls, hs * 4), 1u);
+                                    atomicAdd(hist_row(hp, bin, hs * 4), 1u);
+                                }
+                                run += l_err[qb < 128 ? qb : 0];
+                            }
+                        }
+                        unsafeAtomicAdd(&w_pt[p], run);
                     }
                 } else {
                     const bool in_lds = p - P.pos_base < P.lds_len;
@@ -708,10 +775,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_pass(PassParams P)
                 atomicAdd(&l_ps[lo], 1u);
             }
         }
-        if (PT && pt_on && L > 0 && L <= P.pos_end)
+        if (PT && pt_one_tile && P.uniform_len && !P.pos_base && P.pos_end >= P.uniform_len && pt_acc_slot == pt_group_slot)
+            pt_acc_reads += 64; /* one device atomic per tile and wave instead of one per read on one address */
+        else if (PT && pt_on && L > 0 && L <= P.pos_end)
             atomicAdd(&P.pt_len_counts[(uint64_t)pt_slot * P.pt_cap + (L - 1)], 1ULL);
     }
 
+    if (PT) pt_flush();
     /* ---------------- merge the workgroup's histograms ---------------- */
     if (QC && AD && DFA_LDS && P.ad_lds) {
         __syncthreads();
@@ -1893,11 +1963,12 @@ size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states, uint32
 }
 
 size_t pass_lds_bytes(bool qc, uint32_t lds_len, uint32_t ea_rows, bool dfa_lds, uint32_t dfa_states,
-                      uint32_t ad_lds = 0)
+                      uint32_t ad_lds = 0, uint32_t pt_len = 0)
 {
     size_t b = FIXED_BYTES + (size_t)WAVES * WAVE_WORDS * 4;
     if (qc) b += (size_t)(hist_stride(lds_len) + hist_stride(ea_rows)) * (BASE_COLS + PHRED_COLS) * 4;
     if (dfa_lds) b += (size_t)dfa_states * 16 + (size_t)ad_lds * hist_stride(lds_len) * 4;
+    if (pt_len) b += (size_t)WAVES * hist_stride(pt_len) * 8 + 8;
     return b + 16;
 }
 
@@ -1968,9 +2039,11 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
     for (uint32_t i = threadIdx.x; i < CACHE; i += blockDim.x) { c_key[i] = TILE_EMPTY; c_val[i] = -1; }
     __syncthreads();
     const unsigned long long stop = *first_bad;
+    uint32_t changes = 0; /* neighbours in stored order with different tiles: overflow[1] */
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
          r += (uint64_t)gridDim.x * blockDim.x) {
         const long long tile = tiles[r];
+        if (r > 0 && tiles[r - 1] != tile) changes++;
         int slot = -1;
         if (tile >= 0 && first_read_index + r < stop) {
             const uint32_t ci = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 40) & (CACHE - 1);
@@ -2014,6 +2087,8 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
         }
         slots[r] = slot;
     }
+    for (int off = 32; off > 0; off >>= 1) changes += __shfl_xor(changes, off);
+    if ((threadIdx.x & 63) == 0 && changes) atomicAdd((unsigned int *)&overflow[1], changes);
 }
 
 /* ---- phred_scores thresholds ----------------------------------------------------
@@ -2149,6 +2224,7 @@ struct sq_adaptercounter {
 
 struct sq_pertile {
     sq_ctx *ctx;
+    uint32_t tile_changes = 0; /* of the batch in hand: neighbours in stored order with different tiles */
     bool skipped = false;
     std::string skipped_reason;
     uint64_t number_of_reads = 0, max_length = 0, records_seen = 0;
@@ -2392,12 +2468,12 @@ SQ_EXPORT sq_pertile *sq_pertile_new(sq_ctx *ctx)
     SQ_HIP_NULL(hipMalloc((void **)&p->map.vals, TILE_MAP_SIZE * 4));
     SQ_HIP_NULL(hipMalloc((void **)&p->map.n_slots, 4));
     SQ_HIP_NULL(hipMalloc((void **)&p->d_first_bad, 8));
-    SQ_HIP_NULL(hipMalloc((void **)&p->d_overflow, 4));
+    SQ_HIP_NULL(hipMalloc((void **)&p->d_overflow, 8)); /* [0] map overflow, [1] tile changes of the batch */
     SQ_HIP_NULL(hipMemsetAsync(p->map.keys, 0xFF, TILE_MAP_SIZE * 8, ctx->stream));
     SQ_HIP_NULL(hipMemsetAsync(p->map.vals, 0xFF, TILE_MAP_SIZE * 4, ctx->stream));
     SQ_HIP_NULL(hipMemsetAsync(p->map.n_slots, 0, 4, ctx->stream));
     SQ_HIP_NULL(hipMemsetAsync(p->d_first_bad, 0xFF, 8, ctx->stream));
-    SQ_HIP_NULL(hipMemsetAsync(p->d_overflow, 0, 4, ctx->stream));
+    SQ_HIP_NULL(hipMemsetAsync(p->d_overflow, 0, 8, ctx->stream));
     SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
     return p;
 }
@@ -2448,6 +2524,7 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
         p->slots_cap = b->n;
     }
     int blocks = (int)std::min<uint64_t>((b->n + 255) / 256, 8192);
+    SQ_HIP(hipMemsetAsync(p->d_overflow + 1, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, b->d_metas,
                        (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
     hipLaunchKernelGGL(k_tile_assign, dim3(blocks), dim3(256), 0, ctx->stream, p->d_tiles,
@@ -2455,10 +2532,11 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
                        p->d_overflow);
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[1], p->map.n_slots, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[2], p->d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[2], p->d_overflow, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     p->first_bad = ctx->pinned[0];
     p->n_slots = (int)(uint32_t)ctx->pinned[1];
+    p->tile_changes = (uint32_t)(ctx->pinned[2] >> 32);
     if ((uint32_t)ctx->pinned[2]) {
         sq_set_error("PerTileQuality: more than %u distinct tile ids", TILE_MAP_SIZE / 2);
         return SQ_ERR_MEMORY;
@@ -2573,6 +2651,8 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
         P.pt_first_bad = fb == UINT64_MAX ? UINT64_MAX : fb + P.first_read_index;
     }
     uint32_t stripes = 0; /* 0: one launch holds every read */
+    if (!m && pt_active && b->max_length <= LDS_HIST_MAX && b->min_length == b->max_length && b->max_length > 0)
+        P.lds_len = P.uniform_len = (uint32_t)b->max_length; /* PerTileQuality alone: its one-tile groups */
     if (m) {
         if (b->max_length <= LDS_HIST_MAX) {
             P.lds_len = (uint32_t)b->max_length; /* every position has its LDS counters */
@@ -2586,8 +2666,13 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
     P.pos_end = UINT32_MAX;
     if (b->n >= 4096 && b->n < (1ull << 31)) {
         if (pt_active) {
-            P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
-            P.blocked = P.order != nullptr;
+            /* A sequencer writes its reads tile by tile: such a batch is walked as stored (a wave
+               takes a contiguous run of groups, and nearly every group is of one tile).  Only a
+               batch whose tiles are mixed (on average fewer than 256 reads between two changes)
+               is walked in tile-sorted order, which costs the sort and makes every load a gather */
+            if (getenv("SQ_PT_SORT") || ((uint64_t)p->tile_changes * 256 > b->n && !getenv("SQ_PT_STORED")))
+                P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
+            P.blocked = 1;
         }
         else if ((m || a) && b->max_length > 2 * b->min_length + 64)
             P.order = sorted_order(ctx, b, nullptr, (uint32_t)b->max_length);
@@ -2715,7 +2800,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
             P.first_read_index += C.n;
             P.n = b->n - C.n;
         }
-        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, ad ? P.ad_lds : 0);
+        size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, ad ? P.ad_lds : 0, pt ? P.lds_len : 0);
         if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         if (qc && segments) {

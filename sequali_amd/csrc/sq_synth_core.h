@@ -7,7 +7,8 @@
  * the HIP kernel (sq_synth_device) produce identical bytes and records can be
  * generated in any order / on any rank.
  *
- * Illumina (kind 0 = R1 / single end, kind 1 = R2 of the same pair):
+ * Illumina (kind 0 = R1 / single end, kind 1 = R2 of the same pair, kind 3 = kind 0 with the
+ * reads ordered by tile, 65536 in a row, as a sequencer writes them):
  *   pair i has a fragment F_i: length ~ N(300,60) clipped to [40,600] for 92 %
  *   of the pairs, uniform [40,150) for 8 % (adapter read-through); 10 % of the
  *   pairs re-use the fragment of an earlier pair (duplicates); bases uniform
@@ -139,12 +140,13 @@ SQ_HD void sqs_put_dec(uint8_t *dst, uint64_t v, int width)
 }
 
 /* header of pair i, mate 0/1: exactly SQ_SYNTH_ILLUMINA_NAME bytes */
-SQ_HD void sqs_illumina_name(uint64_t seed, uint64_t i, int mate, uint8_t *dst)
+SQ_HD void sqs_illumina_name(uint64_t seed, uint64_t i, int mate, uint8_t *dst, int by_tile = 0)
 {
     const char *pre = "SIM:1:FCX:";
     const char *post = ":N:0:ATCCGA";
     uint64_t r = sqs_rand(seed, SQS_HEAD, i, 0);
-    uint32_t t = (uint32_t)((r >> 8) % 96);
+    /* by_tile: the order a sequencer writes, 65536 reads of a tile in a row */
+    uint32_t t = by_tile ? (uint32_t)((i >> 16) % 96) : (uint32_t)((r >> 8) % 96);
     uint32_t tile = (t / 48 + 1) * 1000 + ((t / 24) % 2 + 1) * 100 + (t % 24) + 1;
     for (int k = 0; k < 10; k++) dst[k] = (uint8_t)pre[k];
     dst[10] = (uint8_t)('1' + (r & 3));

@@ -11,7 +11,7 @@ from ._lib import check, context, lib
 from ._qc import META_DTYPE, FastqRecordArrayView, _DeviceBatch
 
 DEFAULT_SEED = 20250912
-ILLUMINA, ILLUMINA_R2, NANOPORE = 0, 1, 2
+ILLUMINA, ILLUMINA_R2, NANOPORE, ILLUMINA_BY_TILE = 0, 1, 2, 3
 
 ILLUMINA_PROBES = ("AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA",
                    "GGGGGGGGGGGG", "AAAAAAAAAAAA")  # adapters/adapter_list.tsv:8-15

@@ -134,6 +134,32 @@ def test_pertile_ragged():
         np.testing.assert_array_equal(u64(c), cr)
 
 
+def test_pertile_reads_ordered_by_tile_are_walked_as_stored():
+    """a batch whose tiles come in long runs (what a sequencer writes) skips the tile sort:
+    stored order, one-tile groups counted without asking per row; 100 k device-generated
+    reads in runs of 65536 (two tiles, the change in the middle of a group) and the same batch
+    forced through the sorted walk give the oracle's tables"""
+    from sequali_amd import FusedPass, PerTileQuality, QCMetrics, synth
+    n = 100_000
+    dev = synth.device_array(synth.ILLUMINA_BY_TILE, 0, n)
+    buf, metas = dev._batch.download()
+    rp, rq = oracle.PerTileQuality(), oracle.QCMetrics()
+    rp.add(buf, metas)
+    rq.add(buf, metas)
+    want = {t: (e, c) for t, e, c in rp.get_tile_counts()}
+    assert len(want) == 2
+    for env in ({}, {"SQ_PT_SORT": "1"}):
+        gq, gp = QCMetrics(), PerTileQuality()
+        _with_env(env, lambda: (FusedPass(gq, None, gp).add_record_array(dev), gq.flush()))
+        got = {t: (e, c) for t, e, c in gp.get_tile_counts()}
+        assert set(got) == set(want)
+        for t in want:
+            np.testing.assert_array_equal(u64(got[t][1]), want[t][1])
+            np.testing.assert_allclose(np.array(got[t][0]), want[t][0], rtol=1e-6, atol=0)
+        np.testing.assert_array_equal(u64(gq.phred_count_table()), rq.phred_count_table())
+        np.testing.assert_array_equal(u64(gq.base_count_table()), rq.base_count_table())
+
+
 def test_overrep_vs_oracle_with_cap_crossing():
     from sequali_amd import OverrepresentedSequences
     rng = np.random.default_rng(41)
