@@ -92,6 +92,30 @@ def test_qc_invalid_phred_raises():
         m.base_count_table()
 
 
+@pytest.mark.parametrize("U,bad_read,bad_pos", [(150, 70, 149), (150, 3, 0), (100, 191, 64), (70, 130, 67)])
+def test_invalid_phred_in_a_batch_of_one_length(U, bad_read, bad_pos):
+    """the deferred ValueError also comes out of the kernels that take batches of one read
+    length (k_ring for QCMetrics alone, k_wide with the adapters): the bad byte in the chains,
+    behind them (the 1-4 trailing qualities) or in the first chunk"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(U + bad_read)
+    n = 64 * 3 + 10
+    names = [f"r{i}" for i in range(n)]
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=U).tobytes().decode() for _ in range(n)]
+    quals = ["I" * U for _ in range(n)]
+    quals[bad_read] = quals[bad_read][:bad_pos] + " " + quals[bad_read][bad_pos + 1:]
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    for with_adapters in (False, True):
+        m, a = QCMetrics(), AdapterCounter(["ACGTACGTAC"])
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        if with_adapters:
+            FusedPass(m, a).add_record_array(arr)
+        else:
+            m.add_record_array(arr)
+        with pytest.raises(ValueError, match="Not a valid phred character:  "):
+            m.base_count_table()
+
+
 ADAPTER_SETS = [
     ["AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA", "GGGGGGGGGGGG", "AAAAAAAAAAAA"],
     ["ACG", "CGT", "A", "NN", "GTAC", "TTTTTTTT"],
