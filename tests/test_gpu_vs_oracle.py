@@ -427,7 +427,9 @@ def test_uniform_length_many_adapters_counted_in_device_tables():
     rng = np.random.default_rng(77)
     letters = np.frombuffer(b"ACGT", np.uint8)
     probes = [rng.choice(letters, size=int(rng.integers(6, 20))).tobytes().decode() for _ in range(20)]
-    for U in (150, 250):
+    for U in (150, 250, 151):
+        if U == 151:  # more than 64 adapters: two automatons, the second one gets a pass of its own
+            probes = probes + [rng.choice(letters, size=int(rng.integers(5, 12))).tobytes().decode() for _ in range(50)]
         n = 64 * 9 + 5
         names, seqs, quals = [], [], []
         for i in range(n):
