@@ -12,6 +12,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <thread>
 #include <cmath>
 
 #include "sq_common.h"
@@ -865,29 +866,28 @@ int blocks_for(uint64_t n, int cap = 16384)
     return (int)(b ? b : 1);
 }
 
-/* indices [0,n) for which pred holds, in order, on the device; count on the host */
+/* indices [0,n) for which pred holds, in order, on the device; count on the host.  The result
+ * lives in the context's scratch (valid until the next call): a hipMalloc / hipFree pair per
+ * array and batch costs more than the selection */
 template <typename Pred>
 int ordered_select(sq_ctx *ctx, uint64_t n, Pred pred, unsigned long long **d_out, uint64_t *count)
 {
-    unsigned long long *d_in = nullptr, *d_sel = nullptr, *d_num = nullptr;
-    void *d_temp = nullptr;
     size_t temp_bytes = 0;
     *d_out = nullptr;
     *count = 0;
     if (n == 0) return SQ_OK;
-    SQ_HIP(hipMalloc((void **)&d_in, n * 8));
-    SQ_HIP(hipMalloc((void **)&d_sel, n * 8));
-    SQ_HIP(hipMalloc((void **)&d_num, 8));
+    unsigned long long *d_in = (unsigned long long *)sq_scratch(ctx, 6, n * 8);
+    unsigned long long *d_sel = (unsigned long long *)sq_scratch(ctx, 7, n * 8);
+    unsigned long long *d_num = (unsigned long long *)sq_scratch(ctx, 8, 8);
+    if (!d_in || !d_sel || !d_num) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
     hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_in, n);
     SQ_HIP(hipcub::DeviceSelect::If(nullptr, temp_bytes, d_in, d_sel, d_num, (int)n, pred, ctx->stream));
-    SQ_HIP(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8));
+    void *d_temp = sq_scratch(ctx, 9, temp_bytes ? temp_bytes : 8);
+    if (!d_temp) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
     SQ_HIP(hipcub::DeviceSelect::If(d_temp, temp_bytes, d_in, d_sel, d_num, (int)n, pred, ctx->stream));
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[16], d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     *count = ctx->pinned[16];
-    (void)hipFree(d_temp);
-    (void)hipFree(d_in);
-    (void)hipFree(d_num);
     *d_out = d_sel;
     return SQ_OK;
 }
@@ -1302,6 +1302,10 @@ struct sq_dedup {
     std::vector<uint64_t> hash;
     std::vector<uint32_t> count;
     std::vector<uint8_t> store; /* the fingerprint buffer the reference reuses */
+    /* host side of a piece of survivors (dedup_tail): grow-only */
+    std::vector<unsigned long long> h_idx, h_hashes;
+    std::vector<unsigned char> h_special, h_state;
+    unsigned parallel_skip = 0; /* pieces that skip the parallel attempt after one was taken back */
     /* deferred mode (a shard of a multi-GPU job): add_* only hashes; the hashes
        stay in HBM until sq_dedup_resolve() runs the insertion tail over them, after the
        state of the shard in front has been imported */
@@ -1465,26 +1469,102 @@ int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned c
     uint64_t n_keep = 0;
     int rc = ordered_select(ctx, n, keep, &d_idx, &n_keep);
     if (rc) return rc;
-    std::vector<unsigned long long> idx(n_keep), hashes(n_keep);
-    std::vector<unsigned char> special(n_keep, 0);
-    if (n_keep) {
-        unsigned long long *d_kh = nullptr;
-        unsigned char *d_ks = nullptr;
-        SQ_HIP(hipMalloc((void **)&d_kh, n_keep * 8));
-        SQ_HIP(hipMalloc((void **)&d_ks, n_keep));
+    if (n_keep == 0) return SQ_OK;
+    /* host copies live in the estimator and only grow (a fresh 10 MB vector per batch is a
+       millisecond of page faults) */
+    std::vector<unsigned long long> &idx = d->h_idx, &hashes = d->h_hashes;
+    std::vector<unsigned char> &special = d->h_special;
+    if (idx.size() < n_keep) { idx.resize(n_keep); hashes.resize(n_keep); special.resize(n_keep); d->h_state.resize(n_keep); }
+    {
+        unsigned long long *d_kh = (unsigned long long *)sq_scratch(ctx, 10, n_keep * 8);
+        unsigned char *d_ks = (unsigned char *)sq_scratch(ctx, 11, n_keep);
+        if (!d_kh || !d_ks) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
         hipLaunchKernelGGL(k_dedup_gather, dim3(blocks_for(n_keep)), dim3(256), 0, ctx->stream, d_idx,
                            n_keep, d_hashes, d_special, d_kh, d_ks);
         SQ_HIP(hipMemcpyAsync(idx.data(), d_idx, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
         SQ_HIP(hipMemcpyAsync(hashes.data(), d_kh, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (d_special)
             SQ_HIP(hipMemcpyAsync(special.data(), d_ks, n_keep, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            memset(special.data(), 0, n_keep);
         SQ_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_kh);
-        (void)hipFree(d_ks);
     }
-    (void)hipFree(d_idx);
     const uint64_t fp_len = d->front_len + d->back_len;
+    /* Most of a settled estimator's survivors are already in the table.  Counting those is
+       order-free as long as no rebuild can fall into this piece: lookups do not change the
+       table, an entry never moves between rebuilds, and a rebuild needs stored >= max_stored
+       when a hash arrives, which the inserts of this piece cannot reach if there are few
+       enough of them.  So host threads look every survivor up in the table as it stands and
+       count the ones they find at once (atomic adds); if stored + (survivors not found) stays
+       below max_stored that was right, and only the others walk through the sequential
+       insert, in order (the first of several equal new hashes inserts, the rest find it).
+       Otherwise the counts are taken back and the whole piece takes the sequential loop,
+       hash by hash.  A piece that had to be taken back makes the next few skip the attempt
+       (a young estimator meets mostly new hashes). */
+    uint8_t *state = d->h_state.data(); /* 1: counted in parallel */
+    memset(state, 0, n_keep);
+    const unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (d->parallel_skip) d->parallel_skip--;
+    else if (n_keep >= 32768 && n_threads > 1 && !getenv("SQ_DEDUP_SEQUENTIAL")) {
+        const uint64_t bits = d->modulo_bits, mask = d->table_size - 1;
+        const uint64_t per = (n_keep + n_threads - 1) / n_threads;
+        std::vector<uint64_t> missing(n_threads, 0);
+        auto in_parallel = [&](auto &&fn) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_threads; t++)
+                pool.emplace_back([&, t]() { fn(t, t * per, std::min<uint64_t>(n_keep, (t + 1) * per)); });
+            for (auto &th : pool) th.join();
+        };
+        in_parallel([&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint64_t miss = 0;
+            for (uint64_t e = lo; e < hi; e++) {
+                if (e + 8 < hi) {
+                    const uint64_t sn = (hashes[e + 8] >> bits) & mask;
+                    __builtin_prefetch(&d->count[sn]);
+                    __builtin_prefetch(&d->hash[sn]);
+                }
+                bool found = false;
+                if (!special[e]) {
+                    const uint64_t h = hashes[e];
+                    for (uint64_t i = (h >> bits) & mask;; i = (i + 1) & mask) {
+                        /* counts only grow here and never from 0: a slot that is empty stays empty */
+                        if (__atomic_load_n(&d->count[i], __ATOMIC_RELAXED) == 0) break;
+                        if (d->hash[i] == h) {
+                            __atomic_fetch_add(&d->count[i], 1u, __ATOMIC_RELAXED);
+                            found = true;
+                            break;
+                        }
+                    }
+                }
+                state[e] = found;
+                miss += !found;
+            }
+            missing[t] = miss;
+        });
+        uint64_t not_found = 0;
+        for (uint64_t m : missing) not_found += m;
+        if (d->stored + not_found >= d->max_stored) { /* a rebuild may fall into this piece: take it back */
+            in_parallel([&](unsigned, uint64_t lo, uint64_t hi) {
+                const uint64_t bits2 = d->modulo_bits, mask2 = d->table_size - 1;
+                for (uint64_t e = lo; e < hi; e++) {
+                    if (!state[e]) continue;
+                    const uint64_t h = hashes[e];
+                    for (uint64_t i = (h >> bits2) & mask2;; i = (i + 1) & mask2)
+                        if (d->hash[i] == h && __atomic_load_n(&d->count[i], __ATOMIC_RELAXED) != 0) {
+                            __atomic_fetch_sub(&d->count[i], 1u, __ATOMIC_RELAXED);
+                            break;
+                        }
+                    state[e] = 0;
+                }
+            });
+            d->parallel_skip = 4;
+            if (getenv("SQ_DEDUP_DEBUG")) fprintf(stderr, "dedup piece: %llu kept, %llu new, taken back\n", (unsigned long long)n_keep, (unsigned long long)not_found);
+        } else if (getenv("SQ_DEDUP_DEBUG")) {
+            fprintf(stderr, "dedup piece: %llu kept, %llu new, counted by threads\n", (unsigned long long)n_keep, (unsigned long long)not_found);
+        }
+    }
     for (uint64_t e = 0; e < n_keep; e++) {
+        if (state[e]) continue;
         if (e + 12 < n_keep) { /* the slot a hash lands in is known ahead: hide the table's cache misses */
             const uint64_t hn = hashes[e + 12];
             const uint64_t slot = (hn >> d->modulo_bits) & (d->table_size - 1);
@@ -1534,7 +1614,6 @@ int dedup_defer(sq_dedup *d, sq_batch *b1, sq_batch *b2, const unsigned long lon
         if (rc) return rc;
         std::vector<unsigned long long> idx(n_special);
         if (n_special) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_special * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(d_idx);
         std::vector<uint8_t> cur = d->store, known = d->store_known, w;
         uint64_t prev = UINT64_MAX;
         for (uint64_t e = 0; e < n_special; e++) {
@@ -1578,10 +1657,9 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
     sq_ctx *ctx = d->ctx;
     const uint64_t n = b1->n;
     if (n == 0) return SQ_OK;
-    unsigned long long *d_hashes = nullptr;
-    unsigned char *d_special = nullptr;
-    SQ_HIP(hipMalloc((void **)&d_hashes, n * 8));
-    SQ_HIP(hipMalloc((void **)&d_special, n));
+    unsigned long long *d_hashes = (unsigned long long *)sq_scratch(ctx, 12, n * 8);
+    unsigned char *d_special = (unsigned char *)sq_scratch(ctx, 13, n);
+    if (!d_hashes || !d_special) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
     DedupParams P{};
     P.buf1 = b1->d_buf; P.metas1 = b1->d_metas;
     P.buf2 = b2 ? b2->d_buf : nullptr; P.metas2 = b2 ? b2->d_metas : nullptr;
@@ -1614,7 +1692,6 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
         }
     }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_hashes); (void)hipFree(d_special);
     return rc;
 }
 

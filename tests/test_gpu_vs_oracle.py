@@ -229,6 +229,29 @@ def test_dedup_vs_oracle_rebuilds():
     np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
 
 
+def test_dedup_survivors_counted_by_host_threads():
+    """pieces of >= 32768 survivors are looked up and counted by host threads when no rebuild
+    can fall into them, and taken back and re-run hash by hash when one can: device-generated
+    batches that overlap by half (found and new hashes mixed), a table small enough to be
+    rebuilt several times, the same run forced through the sequential tail, and the oracle"""
+    from sequali_amd import DedupEstimator, synth
+    kw = dict(max_stored_fingerprints=150_000, front_sequence_offset=0, back_sequence_offset=0)
+    # 140 k new hashes fit (nothing to take back), the next batch finds 40 k of them and brings
+    # 100 k new ones: counted, then taken back because the table would fill; then larger batches
+    spans = [(0, 140_000), (100_000, 140_000), (0, 300_000), (150_000, 300_000), (0, 300_000)]
+    batches = [synth.device_array(synth.ILLUMINA, first, n) for first, n in spans]
+    ref = oracle.DedupEstimator(**kw)
+    for b in batches:
+        buf, metas = b._batch.download()
+        ref.add(buf, metas)
+    for env in ({}, {"SQ_DEDUP_SEQUENTIAL": "1"}):
+        got = DedupEstimator(**kw)
+        _with_env(env, lambda: [got.add_record_array(b) for b in batches])
+        assert got._modulo_bits == ref._modulo_bits >= 1
+        assert got.tracked_sequences == ref.tracked_sequences
+        np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
+
+
 def test_dedup_pairs_with_short_reads_stale_bytes():
     """pairs shorter than the fingerprint reuse bytes of the previous fingerprint (:4512)"""
     from sequali_amd import DedupEstimator
