@@ -2585,7 +2585,9 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
     SQ_HIP(hipMemsetAsync(p->d_overflow + 1, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, (uint64_t)b->buf_len,
                        b->d_metas, (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
-    hipLaunchKernelGGL(k_tile_assign, dim3(blocks), dim3(256), 0, ctx->stream, p->d_tiles,
+    /* a workgroup sets up a 12 KB LDS cache of resolved tiles first: fewer, longer-lived ones */
+    const int ablocks = (int)std::min<uint64_t>((b->n + 255) / 256, (uint64_t)ctx->num_cus * 4);
+    hipLaunchKernelGGL(k_tile_assign, dim3(ablocks), dim3(256), 0, ctx->stream, p->d_tiles,
                        (uint64_t)b->n, p->records_seen, p->map, p->d_slots, p->d_first_bad,
                        p->d_overflow);
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
