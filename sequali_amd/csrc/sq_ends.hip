@@ -1060,7 +1060,7 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         P.sample_base = done;
         P.rank_base = o->shard ? samples_before + done : done;
         P.n_samples = chunk;
-        hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk)), dim3(256), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, P); /* a workgroup counts hot fragments in LDS first: fewer, longer-lived ones */
         SQ_HIP(hipGetLastError());
         if (need_big) {
             SQ_HIP(hipStreamSynchronize(ctx->stream));
