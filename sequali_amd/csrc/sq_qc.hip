@@ -2671,7 +2671,23 @@ void dispatch_pass(sq_ctx *ctx, const PassParams &P, bool qc, bool ad, bool pt, 
 
 } // namespace
 
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p);
+
 SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
+{
+    /* QCMetrics + AdapterCounter + PerTileQuality on a batch of one read length: k_wide for the
+       first two and a PerTileQuality pass of its own (qualities only) read the batch twice and
+       still beat the one k_pass that carries all three (3.5 against 3.7 ms per 10 M reads) */
+    if (m && a && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
+        b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !getenv("SQ_NO_WIDE") && !getenv("SQ_RING") &&
+        !getenv("SQ_NO_SPLIT")) {
+        int rc = fused_add_batch(b, m, a, nullptr);
+        return rc ? rc : fused_add_batch(b, nullptr, nullptr, p);
+    }
+    return fused_add_batch(b, m, a, p);
+}
+
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
 {
     sq_ctx *ctx = b->ctx;
     bool pt_active = false;
