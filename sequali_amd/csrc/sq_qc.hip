@@ -1954,6 +1954,152 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
+/* ---- k_ptq: PerTileQuality alone on a batch of one read length ----
+ * The pass needs the qualities only: per tile and position the sum of the error rates
+ * (`:3196-3212`) and per tile the count of reads per length.  Like k_wide it visits 64 bytes per
+ * row at a time (four lanes side by side on a row); the tile needs no swizzle (a row is staged
+ * with one ds_write_b128 per lane, and the 64 lanes of the counting phase read 16 consecutive
+ * dwords of one row, four lanes per dword).  Lane p owns position c0 + p of the chunk and sums
+ * the error rates of the 64 rows in a register; a wave keeps the sums of the tile its groups are
+ * in (and the number of reads it has seen of it) in LDS and hands them over when the tile
+ * changes.  A group whose reads are not all of one tile (the seam between two tiles) adds row by
+ * row to the device tables.  Full groups only; the walk follows P.order when the host sorted by
+ * tile, with a contiguous run of groups per wave either way. */
+constexpr int PTQ_THREADS = 512, PTQ_WAVES = PTQ_THREADS / 64, PTQ_DEPTH = 3;
+
+size_t ptq_lds_bytes(uint32_t uniform_len)
+{
+    return 136 * 8 + (size_t)PTQ_WAVES * (64 * 64 + hist_stride(uniform_len) * 8) + 16;
+}
+
+__global__ void __launch_bounds__(PTQ_THREADS, 2) k_ptq(PassParams P)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    double *l_err = (double *)smem;                                  /* [136] by raw quality byte, 128 = padding */
+    const uint32_t U = P.uniform_len, pts = hist_stride(U);
+    double *l_pt = l_err + 136;                                      /* [waves][pts] */
+    uint32_t *l_tiles = (uint32_t *)(l_pt + PTQ_WAVES * pts);        /* [waves][64 rows][16 dwords] */
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 136; i += PTQ_THREADS) {
+        double e;
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
+        else if (i >= 128) e = 0.0;
+        else e = __longlong_as_double(0x7FF8000000000000LL);
+        l_err[i] = e;
+    }
+    for (uint32_t i = tid; i < PTQ_WAVES * pts; i += PTQ_THREADS) l_pt[i] = 0.0;
+    __syncthreads();
+    double *w_pt = l_pt + wave * pts;
+    uint32_t *w_tile = l_tiles + wave * 64 * 16;
+    const uint32_t l_row = (uint32_t)lane >> 2, piece16 = ((uint32_t)lane & 3) * 16;
+
+    int32_t acc_slot = -1;
+    uint32_t acc_reads = 0;
+    auto flush = [&]() {
+        if (acc_slot < 0) return;
+        if (lane == 0 && acc_reads)
+            atomicAdd(&P.pt_len_counts[(uint64_t)acc_slot * P.pt_cap + (U - 1)], (unsigned long long)acc_reads);
+        acc_reads = 0;
+        for (uint32_t i = lane; i < pts; i += 64) {
+            const double v = w_pt[i];
+            if (v != 0.0) {
+                unsafeAtomicAdd(&P.pt_errors[(uint64_t)acc_slot * P.pt_cap + i], v);
+                w_pt[i] = 0.0;
+            }
+        }
+    };
+
+    const uint64_t ngroups = P.n / 64;
+    const uint64_t n_waves = (uint64_t)gridDim.x * PTQ_WAVES, wave_id = (uint64_t)blockIdx.x * PTQ_WAVES + wave;
+    /* tile-sorted walk: a contiguous run of groups per wave (few tiles per wave).  Stored order
+       (the batch came ordered by tile): neighbouring waves take neighbouring groups, all waves
+       move through the batch together (one tile at a time, and no two waves a large power-of-two
+       stride apart in memory) */
+    const uint64_t per_wave = (ngroups + n_waves - 1) / n_waves;
+    const uint64_t g_begin = P.order ? wave_id * per_wave : wave_id;
+    const uint64_t g_end = P.order ? min(ngroups, (wave_id + 1) * per_wave) : ngroups;
+    const uint64_t g_step = P.order ? 1 : n_waves;
+    for (uint64_t g = g_begin; g < g_end; g += g_step) {
+        const uint64_t slot_index = g * 64 + lane;
+        const uint64_t r = P.order ? P.order[slot_index] : slot_index;
+        const sq_meta m = P.metas[r];
+        const unsigned long long qoff = m.record_start + m.qualities_offset;
+        int32_t slot = P.pt_slot[r];
+        if (slot < 0 || P.first_read_index + r >= P.pt_first_bad) slot = -1;
+        const int32_t g_slot = __builtin_amdgcn_readfirstlane(slot);
+        const bool one_tile = g_slot >= 0 && __all(slot == g_slot);
+        if (one_tile && g_slot != acc_slot) {
+            flush();
+            acc_slot = g_slot;
+        }
+        const uint8_t *qp[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++)
+            qp[it] = P.buf + (unsigned long long)__shfl(qoff, it * 16 + (int)l_row) + piece16;
+        /* registers are plentiful here (one stream, no chains): three chunks of loads in flight */
+        uint4 pf[PTQ_DEPTH][4];
+#pragma unroll
+        for (int k = 0; k < PTQ_DEPTH; k++)
+#pragma unroll
+            for (int it = 0; it < 4; it++) pf[k][it] = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        auto fetch = [&](uint32_t c0, uint4 (&f)[4]) { /* the buffer is the library's own: 64 readable bytes behind its end */
+            if (c0 + piece16 < U) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) f[it] = *(const uint4 *)(qp[it] + c0);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < PTQ_DEPTH; k++) fetch(k * WIDE_CW, pf[k]);
+        for (uint32_t c0 = 0; c0 < U; c0 += WIDE_CW) {
+            {
+                const uint32_t p0 = c0 + piece16;
+                const int nv = p0 < U ? (int)min(16u, U - p0) : 0;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    uint4 qv = pf[0][it];
+                    if (nv < 16) {
+                        qv.x = pad_tail(qv.x, nv, PAD4); qv.y = pad_tail(qv.y, nv - 4, PAD4);
+                        qv.z = pad_tail(qv.z, nv - 8, PAD4); qv.w = pad_tail(qv.w, nv - 12, PAD4);
+                    }
+                    *(uint4 *)(w_tile + ((uint32_t)it * 16 + l_row) * 16 + (piece16 >> 2)) = qv;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k + 1 < PTQ_DEPTH; k++)
+#pragma unroll
+                for (int it = 0; it < 4; it++) pf[k][it] = pf[k + 1][it];
+            fetch(c0 + PTQ_DEPTH * WIDE_CW, pf[PTQ_DEPTH - 1]);
+            const uint32_t p = c0 + (uint32_t)lane;
+            if (p < U) {
+                const uint32_t dw = (uint32_t)lane >> 2, sh = 8 * ((uint32_t)lane & 3);
+                if (one_tile) {
+                    double run = 0.0;
+#pragma unroll 8
+                    for (uint32_t row = 0; row < 64; row++) {
+                        const uint32_t qb = (w_tile[row * 16 + dw] >> sh) & 0xFF;
+                        run += l_err[qb < 136 ? qb : 0];
+                    }
+                    w_pt[p] += run; /* this lane is the only one of the wave at position p */
+                } else {
+                    for (uint32_t row = 0; row < 64; row++) {
+                        const int32_t s_row = __builtin_amdgcn_readlane(slot, (int)row);
+                        if (s_row < 0) continue;
+                        const uint32_t qb = (w_tile[row * 16 + dw] >> sh) & 0xFF;
+                        unsafeAtomicAdd(&P.pt_errors[(uint64_t)s_row * P.pt_cap + p], l_err[qb < 136 ? qb : 0]);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (one_tile) acc_reads += 64;
+        else if (slot >= 0) atomicAdd(&P.pt_len_counts[(uint64_t)slot * P.pt_cap + (U - 1)], 1ULL);
+    }
+    flush();
+}
+
 size_t ring_lds_bytes(uint32_t uniform_len, bool ad, uint32_t dfa_states, uint32_t ad_lds = 0)
 {
     size_t b = FIXED_BYTES + (size_t)RING_WAVES * 2 * RING_TILE_WORDS * 4;
@@ -2098,20 +2244,32 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
     __syncthreads();
     const unsigned long long stop = *first_bad;
     uint32_t changes = 0; /* neighbours in stored order with different tiles: overflow[1] */
-    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n;
-         r += (uint64_t)gridDim.x * blockDim.x) {
+    /* a workgroup takes a contiguous stretch of the batch: reads ordered by tile then ask it for
+       one or two tiles, which it resolves once */
+    const uint64_t per_wg = ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    const uint64_t r_end = min(n, (blockIdx.x + 1) * per_wg);
+    for (uint64_t r = blockIdx.x * per_wg + threadIdx.x; r < r_end; r += blockDim.x) {
         const long long tile = tiles[r];
         if (r > 0 && tiles[r - 1] != tile) changes++;
         int slot = -1;
-        if (tile >= 0 && first_read_index + r < stop) {
+        /* reads ordered by tile: the 64 records of a wave ask for one tile, and with a stride of
+           gridDim x 256 records between a workgroup's rounds it is a tile the workgroup has not
+           resolved yet more often than not: one lane asks for all */
+        const bool mine = tile >= 0 && first_read_index + r < stop;
+        const long long tile0 = __shfl(tile, __ffsll((long long)__ballot(1)) - 1);
+        const bool shared = __all(mine && tile == tile0);
+        const int leader = __ffsll((long long)__ballot(1)) - 1;
+        if (mine && (!shared || (int)(threadIdx.x & 63) == leader)) {
             const uint32_t ci = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 40) & (CACHE - 1);
+            bool cached = false;
             if (__hip_atomic_load(&c_key[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tile) {
                 const int v = __hip_atomic_load(&c_val[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (v >= 0) {
-                    slots[r] = v;
-                    continue;
+                    slot = v;
+                    cached = true;
                 }
             }
+            if (!cached) {
             uint32_t idx = (uint32_t)(((unsigned long long)tile * 0x9E3779B97F4A7C15ULL) >> 48) & (TILE_MAP_SIZE - 1);
             bool done = false;
             for (uint32_t probes = 0; !done && probes < 4 * TILE_MAP_SIZE; probes++) {
@@ -2142,7 +2300,9 @@ __global__ void k_tile_assign(const long long *tiles, uint64_t n, uint64_t first
             else if (atomicCAS((unsigned long long *)&c_key[ci], (unsigned long long)TILE_EMPTY,
                                (unsigned long long)tile) == (unsigned long long)TILE_EMPTY)
                 __hip_atomic_store(&c_val[ci], slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        if (shared) slot = __shfl(slot, leader);
         slots[r] = slot;
     }
     for (int off = 32; off > 0; off >>= 1) changes += __shfl_xor(changes, off);
@@ -2748,7 +2908,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                is walked in tile-sorted order, which costs the sort and makes every load a gather */
             if (getenv("SQ_PT_SORT") || ((uint64_t)p->tile_changes * 256 > b->n && !getenv("SQ_PT_STORED")))
                 P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
-            P.blocked = 1;
+            P.blocked = P.order != nullptr; /* stored order: waves move through the batch together */
         }
         else if ((m || a) && b->max_length > 2 * b->min_length + 64)
             P.order = sorted_order(ctx, b, nullptr, (uint32_t)b->max_length);
@@ -2801,9 +2961,37 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         return SQ_OK;
     }
 #endif
+    /* PerTileQuality alone on a batch of one read length: k_ptq for the full groups, k_pass for
+       a trailing partial one (SQ_NO_PTQ=1: k_pass for all) */
+    bool ptq_done = false;
+    if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !getenv("SQ_NO_PTQ") &&
+        ptq_lds_bytes(P.uniform_len) <= 80 * 1024) {
+        PassParams C = P;
+        C.n = (b->n / 64) * 64;
+        static bool pattr = false;
+        if (!pattr) {
+            SQ_HIP(hipFuncSetAttribute((const void *)k_ptq, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            pattr = true;
+        }
+        const uint64_t want = (C.n / 64 + PTQ_WAVES - 1) / PTQ_WAVES;
+        const int pgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus * 2));
+        hipLaunchKernelGGL(k_ptq, dim3(pgrid), dim3(PTQ_THREADS), ptq_lds_bytes(P.uniform_len), ctx->stream, C);
+        SQ_HIP(hipGetLastError());
+        if (C.n == b->n) {
+            ptq_done = true;
+        } else if (P.order) {      /* the walk goes on behind the full groups */
+            P.order += C.n;
+            P.n = b->n - C.n;
+        } else {
+            P.metas += C.n;
+            P.pt_slot += C.n;
+            P.first_read_index += C.n;
+            P.n = b->n - C.n;
+        }
+    }
     /* first automaton rides with the other modules; further groups get a pass of their own */
     size_t ngroups = a ? a->groups.size() : 0;
-    for (size_t gi = 0; gi == 0 || gi < ngroups; gi++) {
+    for (size_t gi = 0; !ptq_done && (gi == 0 || gi < ngroups); gi++) {
         bool qc = m && gi == 0, pt = pt_active && gi == 0, ad = a != nullptr;
         bool dfa_lds = false;
         uint32_t states = 0;
