@@ -729,18 +729,24 @@ __global__ void k_insert_size(IszParams P)
             const uint32_t UP4 = 0xDFDFDFDFu;
             const uint32_t hl = (uint32_t)h_lo, hh = (uint32_t)h_hi, tl = (uint32_t)t_lo, th = (uint32_t)t_hi;
             bool done = !scan;
+            /* the refill is fetched a round (eight bases) before the window reaches it */
+            auto refill = [&](uint32_t at) -> uint64_t { /* bytes [at, at + 8) of read 1 */
+                uint64_t nx = 0;
+                if (scan && at < L1) {
+                    const uint8_t *src = s1 + at;
+                    if (src + 8 <= end1) nx = sq_load_u64_unaligned(src);
+                    else
+                        for (int b = 0; b < 8 && src + b < end1; b++) nx |= (uint64_t)src[b] << (8 * b);
+                }
+                return nx;
+            };
+            uint64_t ahead = refill(16);
             for (uint32_t i = 0; i < wave_last; i++) {
                 if ((i & 7u) == 0) { /* bytes [i + 16, i + 24) of read 1 */
                     if ((i & 63u) == 0 && i && __all(done || i > last)) break;
-                    uint64_t nx = 0;
-                    if (scan && i + 16 < L1) {
-                        const uint8_t *src = s1 + i + 16;
-                        if (src + 8 <= end1) nx = sq_load_u64_unaligned(src);
-                        else
-                            for (int b = 0; b < 8 && src + b < end1; b++) nx |= (uint64_t)src[b] << (8 * b);
-                    }
-                    n0 = (uint32_t)nx;
-                    n1 = (uint32_t)(nx >> 32);
+                    n0 = (uint32_t)ahead;
+                    n1 = (uint32_t)(ahead >> 32);
+                    ahead = refill(i + 24);
                 }
                 /* a window can only match a needle half (:5695) if the half's low dword matches */
                 const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
