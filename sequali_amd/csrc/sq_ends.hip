@@ -717,7 +717,9 @@ __global__ void k_insert_size(IszParams P)
         {
             const bool scan = L1 >= 16 && L2 >= 16;
             const uint32_t last = scan ? L1 - 16 : 0;            /* last window start of this lane */
-            const uint32_t wave_last = isz_wave_max(scan ? last + 1 : 0); /* windows the wave looks at */
+            /* windows the wave looks at; in a scalar register, so that the loop, its refill rounds
+               and its early exit are scalar control flow */
+            const uint32_t wave_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)isz_wave_max(scan ? last + 1 : 0));
             /* the window as four dwords and the refill as two: a slide is six v_alignbyte_b32
                (64-bit shifts and compares are quarter-rate instructions) */
             uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n0 = 0, n1 = 0;
