@@ -1,0 +1,225 @@
+/* sq_pass.h -- what the kernels of the per-base pass share (sq_qc.hip, sq_span.hip): the launch
+ * parameters, LDS histogram geometry, class codes of a dword of bases, LDS addressing helpers. */
+#ifndef SQ_PASS_H
+#define SQ_PASS_H
+
+#include "sq_common.h"
+#include "sq_error_table.h"
+
+/* parameters of one launch of the per-base pass (global scope: sq_span.hip takes them from sq_qc.hip) */
+struct sq_carry;
+struct PassParams {
+    const uint8_t *buf;
+    uint64_t buf_len;
+    sq_meta *metas;
+    uint64_t n;
+    uint64_t first_read_index; /* index of record 0 over everything the module saw */
+    uint32_t lds_len;          /* positions covered by the LDS histograms */
+    /* stripes (reads longer than the LDS histograms): one launch covers positions
+       [pos_base, pos_end) of the reads that are longer than pos_base; what a read carries from
+       one stripe to the next (the f64 chains, the automaton, its base counts) lives in `carry` */
+    uint32_t pos_base, pos_end;
+    struct sq_carry *carry;    /* [records in processing order], NULL: one stripe holds every read */
+    const uint32_t *order;     /* processing order of the records (NULL: as stored) */
+    uint32_t blocked;          /* != 0: a wave takes a contiguous run of groups (tile-sorted order:
+                                  concurrent waves then sit in different tiles) */
+    /* QCMetrics */
+    unsigned long long *qc_base, *qc_phred, *qc_ea_base, *qc_ea_phred, *qc_gc, *qc_ps;
+    uint32_t ea_len;
+    uint32_t ea_in_lds;
+    uint32_t uniform_len;     /* != 0: every record of the batch has this length (<= lds_len) */
+    const double *thresholds; /* [94], see phred_thresholds() */
+    unsigned long long *qc_first_bad;
+    /* AdapterCounter */
+    const uint16_t *dfa;      /* [states][8] */
+    uint32_t dfa_states;
+    uint32_t dfa_accept;      /* states >= this one are the ones some adapter ends in */
+    const unsigned long long *dfa_out; /* [states] adapters ending in that state */
+    const uint8_t *ad_len;    /* [n_adapters] */
+    unsigned long long *ad_fwd, *ad_rev; /* [n_adapters][ad_cap] */
+    uint64_t ad_cap;
+    uint32_t ad_lds;          /* != 0: number of adapters whose hits a workgroup counts in LDS first
+                                 (batches of one read length: the reverse table is derived at the merge) */
+    uint32_t ad_maxlen;       /* longest adapter of this automaton */
+    /* PerTileQuality */
+    const int32_t *pt_slot;   /* per record, from k_tile_prepass */
+    unsigned long long *pt_len_counts;
+    double *pt_errors;
+    uint64_t pt_cap;          /* row length of the two tables */
+    uint64_t pt_first_bad;    /* records >= this are ignored */
+};
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int WAVES = WG_THREADS / 64;
+constexpr uint32_t PAD4 = 0x80808080u;   /* quality tile: past the end of the read */
+constexpr uint32_t LDS_HIST_MAX = 512;  /* positions kept in LDS histograms */
+constexpr uint32_t STRIPE = 512;        /* positions per launch when reads are longer than that (256: more launches, slower) */
+constexpr uint32_t LDS_EA_MAX = 256;    /* end-anchor rows kept in LDS */
+constexpr uint32_t DFA_LDS_MAX_STATES = 1024; /* 16 KB of LDS */
+/* LDS histograms are class-major, [class][position] with the position stride rounded
+ * up to 32 words: the lanes of one atomic instruction hold consecutive positions, so
+ * whatever their classes they fall into 32 different banks */
+constexpr uint32_t BASE_COLS = 5, PHRED_COLS = 12;
+__host__ __device__ inline uint32_t hist_stride(uint32_t rows) { return (rows + 31u) & ~31u; }
+constexpr int64_t TILE_EMPTY = -1;
+constexpr uint32_t TILE_MAP_SIZE = 1u << 16;
+
+/* SCORE_TO_ERROR_RATE as bit patterns (score_to_error_rate.h:4-99) */
+__constant__ unsigned long long c_error_rate_bits[94] = {SQ_ERROR_RATE_BITS_LIST};
+
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+/* 16 bytes from an arbitrary byte address; falls back to byte loads when the
+ * 16-byte window would leave the buffer */
+__device__ __forceinline__ uint4 load16(const uint8_t *buf, uint64_t off, uint64_t buf_len)
+{
+    uint4 v;
+    if (off + 16 <= buf_len) {
+        __builtin_memcpy(&v, buf + off, 16);
+    } else {
+        uint32_t w[4] = {PAD4, PAD4, PAD4, PAD4};
+        for (int k = 0; k < 16; k++) {
+            if (off + k < buf_len) {
+                uint32_t sh = 8 * (k & 3);
+                w[k >> 2] = (w[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)buf[off + k] << sh);
+            }
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+/* keep the first `nvalid` (0..4) bytes of w, the rest become `pad` */
+__device__ __forceinline__ uint32_t pad_tail(uint32_t w, int nvalid, uint32_t pad)
+{
+    if (nvalid >= 4) return w;
+    if (nvalid <= 0) return pad;
+    uint32_t keep = (1u << (8 * nvalid)) - 1u;
+    return (w & keep) | (pad & ~keep);
+}
+
+/* Four sequence bytes -> four class codes, doubled (A 0, C 2, G 4, T 6, other 8),
+ * without a table in memory.  The low three bits of A/C/G/T (either case) are
+ * 1/3/7/4 (the observation the reference cites from fastp, _qcmodule.c:1731-1739)
+ * and index two 8-byte LUTs held in registers (v_perm_b32): the class and the
+ * upper-case letter that class requires.  A byte whose upper-cased value is not
+ * that letter is class 4 like in NUCLEOTIDE_TO_INDEX (:1748-1763).  Bytes must be
+ * 7-bit ASCII (the parser guarantees it, :1055). */
+constexpr uint32_t CLS2_PAD4 = 0x0E0E0E0Eu; /* class 7 = past the end of the read */
+__device__ __forceinline__ uint32_t cls2_of_dword(uint32_t w)
+{
+    const uint32_t idx = w & 0x07070707u;
+    const uint32_t lut = __builtin_amdgcn_perm(0x04080806u, 0x02080008u, idx);
+    const uint32_t want = __builtin_amdgcn_perm(0x47000054u, 0x43004100u, idx);
+    const uint32_t d = (w & 0xDFDFDFDFu) ^ want;
+    const uint32_t ne4 = ((d + 0x7F7F7F7Fu) & 0x80808080u) >> 5; /* 4 where it is not that letter */
+    /* a third v_perm picks, byte by byte, the class (selectors 4-7: bytes of lut) or 8 (selectors
+       0-3: bytes of the constant) */
+    return __builtin_amdgcn_perm(lut, 0x08080808u, 0x07060504u - ne4);
+}
+
+/* &hist[row * stride] with a full-rate 24-bit multiply-add (v_mad_u32_u24): a plain 32-bit
+ * multiply is a quarter-rate instruction and there are two of these per base */
+__device__ __forceinline__ uint32_t *hist_row(uint32_t *base, uint32_t row, uint32_t stride_bytes)
+{
+    return (uint32_t *)((uint8_t *)base + __umul24(row, stride_bytes));
+}
+
+/* A wave walks its 64 reads in chunks of CW positions. */
+constexpr uint32_t CW = 32;               /* positions per chunk */
+constexpr uint32_t ROW_WORDS = CW / 4;    /* dwords per read and chunk in a tile */
+constexpr uint32_t TILE_WORDS = 64 * ROW_WORDS;
+constexpr uint32_t WAVE_WORDS = 2 * TILE_WORDS + 128 + 128 + 64;
+constexpr uint32_t FIXED_BYTES = 136 * 8 + 96 * 8 + 104 * 4 + 96 * 4;
+
+/* tile address of dword d of row r: rows are ROW_WORDS = 8 dwords, the dword index
+ * is XOR-ed with bits of the row so that "lane = row, same dword" (phase S),
+ * "lane = position, one or two rows" (phase H) and the staging writes all spread
+ * over the 32 banks */
+__device__ __forceinline__ uint32_t tile_idx(uint32_t row, uint32_t d)
+{
+    return row * ROW_WORDS + (d ^ ((row >> 2) & 7));
+}
+
+/* k_pass keeps a wave's two tiles interleaved in blocks of 8 rows (256 B of sequence classes,
+ * then the 256 B of qualities of the same rows): the quality word of a tile word is always
+ * 64 words further on, which one ds_read2_b32 reaches, and rows 8d .. 8d+7 (what one step of
+ * the fused loop touches in phase H) are block d.  Banks are those of tile_idx. */
+constexpr uint32_t QUAL_WORDS = 64;       /* w_qual = w_seq + QUAL_WORDS */
+__device__ __forceinline__ uint32_t ptile_idx(uint32_t row, uint32_t d)
+{
+    return (row >> 3) * 128 + (row & 7) * ROW_WORDS + (d ^ ((row >> 2) & 7));
+}
+/* phase H: dword h_dw of row 2 * rp + half */
+__device__ __forceinline__ uint32_t ptile_idx_h(uint32_t rp, uint32_t half, uint32_t h_dw)
+{
+    return (rp >> 2) * 128 + (2 * (rp & 3) + half) * ROW_WORDS + (h_dw ^ ((rp >> 1) & 7));
+}
+
+/* LDS through 32-bit addresses: the fused loop computes them with one instruction each */
+#define SQ_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(SQ_LDS const uint8_t *)p; }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(SQ_LDS const uint32_t *)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(SQ_LDS const uint16_t *)(uintptr_t)a; }
+__device__ __forceinline__ double lds_f64(uint32_t a) { return *(SQ_LDS const double *)(uintptr_t)a; }
+/* a | byte J of w, and byte J of w << 3, in one instruction each (SDWA operand selects) */
+template <int J> __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w)
+{
+    uint32_t r;
+    if (J == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(w));
+    if (J == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+template <int J> __device__ __forceinline__ uint32_t shl3_byte(uint32_t w)
+{
+    uint32_t r;
+    if (J == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(3u), "v"(w));
+    if (J == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(3u), "v"(w));
+    return r;
+}
+__device__ __forceinline__ void lds_inc(uint32_t a)
+{
+    __hip_atomic_fetch_add((SQ_LDS uint32_t *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* phred bins of two quality bytes at once (packed 16-bit math): byte `sel`-selected of qa in
+ * the low half, of qb in the high half; min(q - 33, 47) >> 2 like the scalar form */
+typedef unsigned short sq_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bins_of_two(uint32_t qa, uint32_t qb, uint32_t sel)
+{
+    sq_us2 v = __builtin_bit_cast(sq_us2, __builtin_amdgcn_perm(qb, qa, sel));
+    v = __builtin_elementwise_min(v - (unsigned short)33, (sq_us2)(unsigned short)47) >> (unsigned short)2;
+    return __builtin_bit_cast(uint32_t, v);
+}
+/* base + (low / high half of packed) * stride: v_mad_u32_u16, the half picked by op_sel */
+template <int HI> __device__ __forceinline__ uint32_t mad_half(uint32_t packed, uint32_t stride, uint32_t base)
+{
+    uint32_t r;
+    if (HI) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(stride), "v"(base));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(stride), "v"(base));
+    return r;
+}
+/* (x ^ s) + b */
+__device__ __forceinline__ uint32_t xor_add(uint32_t x, uint32_t s, uint32_t b)
+{
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(b));
+    return r;
+}
+
+} // namespace
+
+#endif

@@ -1,0 +1,43 @@
+/* sq_span.h -- LDS layout of k_span (sq_span.hip), shared by the kernel and its launcher */
+#ifndef SQ_SPAN_H
+#define SQ_SPAN_H
+
+#include <cstddef>
+#include <cstdint>
+
+constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
+constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
+
+struct SpanLds {
+    uint32_t thr, gc, ps, dfa, out, adlen, hist, first, rows, slots;
+    size_t total;
+};
+
+/* nw: 32-position windows per read; U: read length; states / n_ad / ad_lds: the automaton, its
+ * adapters, how many of them are counted in LDS (0 without AdapterCounter); waves per workgroup */
+__host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t states, uint32_t n_ad,
+                                                   uint32_t ad_lds, int waves)
+{
+    SpanLds L;
+    const uint32_t hs = (U + 31u) & ~31u;
+    uint32_t o = 136 * 8;               /* error rates by quality byte, at LDS address 0 */
+    L.thr = o; o += 96 * 8;
+    L.gc = o; o += 104 * 4;
+    L.ps = o; o += 96 * 4;
+    L.dfa = o; o += states * 32;         /* 32-byte rows (o is a multiple of 32 here) */
+    L.out = o; o += states * 8;
+    L.adlen = o; o += states ? 64 : 0;
+    L.hist = o; o += hs * (5 + 12) * 4 + ad_lds * hs * 4;
+    L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
+    L.rows = o; o += (uint32_t)waves * 32 * 4;
+    o = (o + 15u) & ~15u;
+    L.slots = o;
+    L.total = (size_t)o + (size_t)waves * 2 * 16 * 64 * (size_t)nw;
+    return L;
+}
+
+struct sq_ctx;
+struct PassParams;
+int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint64_t *done);
+
+#endif
