@@ -2824,7 +2824,13 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         bool span_done = false;
         if (uniform_fast && b->owns && getenv("SQ_SPAN") && !getenv("SQ_RING") && !wide_env) {
             uint64_t covered = 0;
+#ifdef SQ_SPAN_PROBE
+            if (const char *pm = getenv("SQ_SPAN_PROBE")) P.blocked = (uint32_t)atoi(pm);
+#endif
             int rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
+#ifdef SQ_SPAN_PROBE
+            P.blocked = 0;
+#endif
             if (rc) return rc;
             if (covered == b->n) continue;
             if (covered) {

@@ -7,9 +7,11 @@
 
 constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
 constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
+constexpr uint32_t SPAN_BIN_OFF = 136 * 8;
+constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
 
 struct SpanLds {
-    uint32_t thr, gc, ps, dfa, out, adlen, hist, first, rows, slots;
+    uint32_t thr, gc, ps, dfa, out, adlen, hist, first, rows, dma, meta, slots;
     size_t total;
 };
 
@@ -21,6 +23,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     SpanLds L;
     const uint32_t hs = (U + 31u) & ~31u;
     uint32_t o = 136 * 8;               /* error rates by quality byte, at LDS address 0 */
+    o += 256 * 2;                        /* SPAN_BIN_OFF: phred histogram row by quality byte */
     L.thr = o; o += 96 * 8;
     L.gc = o; o += 104 * 4;
     L.ps = o; o += 96 * 4;
@@ -30,9 +33,11 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.hist = o; o += hs * (5 + 12) * 4 + ad_lds * hs * 4;
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
     L.rows = o; o += (uint32_t)waves * 32 * 4;
+    L.dma = o; o += ((16u * (4 * (uint32_t)nw + 1) + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
+    L.meta = o; o += (uint32_t)waves * 2 * SPAN_META_BYTES;
     L.slots = o;
-    L.total = (size_t)o + (size_t)waves * 2 * 16 * 64 * (size_t)nw;
+    L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * (4 * (size_t)nw + 1); /* two slots of 16 rows of 4 nw + 1 pieces */
     return L;
 }
 

@@ -33,6 +33,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "sq_pass.h"
 #include "sq_span.h"
@@ -87,6 +88,57 @@ __device__ __forceinline__ void dma16(const uint8_t *g, uint32_t lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
+
+/* LDS reads the compiler neither counts nor waits for: the rounds of phase S keep a dozen of them
+ * in flight behind the automaton's dependent reads and wait by hand (lgkmcnt, LDS answers in
+ * order; the counter has four bits).  A value is used only behind a wait_* that names it. */
+template <int OFF> __device__ __forceinline__ uint32_t rd_u8(uint32_t a)
+{
+    uint32_t r;
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+    return r;
+}
+template <int OFF> __device__ __forceinline__ uint32_t rd_u16(uint32_t a)
+{
+    uint32_t r;
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+    return r;
+}
+template <int OFF> __device__ __forceinline__ uint32_t rd_b32(uint32_t a)
+{
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ double rd_f64(uint32_t a)
+{
+    double r;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+template <int OFF> __device__ __forceinline__ void inc_u32(uint32_t a, uint32_t one)
+{
+    asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"(a), "v"(one), "i"(OFF) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_1(uint32_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_2(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_4d(double &a, double &b, double &c, double &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <int CTRL> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
@@ -102,15 +154,28 @@ template <int CTRL> __device__ __forceinline__ double quad_bcast_f64(double v)
  * 168 registers per lane instead of 128 */
 constexpr int span_max_waves(int nw) { return nw <= 3 ? 16 : 12; }
 
+#ifdef SQ_SPAN_PROBE
+__device__ unsigned long long g_span_stamps[4]; /* cycles summed over waves: top wait, DMA issue, counting; spans */
+#define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+#endif
 template <int NW, bool AD>
 __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, uint32_t n_ad)
 {
-    constexpr uint32_t SB = 32 * NW, ROWB = 64 * NW, SLOT = SPAN_R * ROWB, Q4 = 2 * NW;
+#ifdef SQ_SPAN_PROBE
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0;
+#endif
+    /* Row r of a slot: sequence at r * ROWB, qualities at r * ROWB + SB.  A row is an odd number
+       of 16-byte pieces (the last one is never loaded) and a lane's quarter an odd number of
+       dwords, so that the 32 lanes of an LDS instruction of phase S (8 rows x 4 quarters) fall
+       into 32 different banks */
+    constexpr uint32_t SB = 32 * NW, PR = 4 * NW + 1, ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
+    constexpr uint32_t DW = 8 * NW, Q4 = 2 * NW + 1, ND = (SPAN_R * PR + 63) / 64;
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t U = P.uniform_len, hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
     const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W);
     double *l_err = (double *)smem;                        /* [136] by raw quality byte */
+    uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
     uint32_t *l_gc = (uint32_t *)(smem + L.gc);            /* [104] */
     uint32_t *l_ps = (uint32_t *)(smem + L.ps);            /* [96] */
@@ -133,16 +198,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         else e = __longlong_as_double(0x7FF8000000000000LL);
         l_err[i] = e;
     }
+    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((min((uint32_t)i - 33u, 47u) >> 2) * hs * 4);
     for (int i = tid; i < 96; i += T) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += T) l_hist_base[i] = 0;
     if (AD) {
         for (uint32_t i = tid; i < P.dfa_states * 16; i += T) {
-            const uint32_t s = i >> 4, k = i & 15;
+            const uint32_t st = i >> 4, k = i & 15;
             /* byte offset 6 c holds the row behind class c; everything else (30: padding) the root */
             uint32_t next = dfa_root;
-            if (k % 3 == 0 && k < 15) next = dfa_root + ((uint32_t)(P.dfa[s * 8 + k / 3] >> 4) << 5);
+            if (k % 3 == 0 && k < 15) next = dfa_root + ((uint32_t)(P.dfa[st * 8 + k / 3] >> 4) << 5);
             l_dfa[i] = (uint16_t)next;
         }
         for (uint32_t i = tid; i < P.dfa_states; i += T) l_out[i] = P.dfa_out[i];
@@ -153,44 +219,53 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     __syncthreads();
 
     const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
-    /* DMA: piece i = 64 k + lane of a slot is 16 bytes of row i / (4 NW), stream and offset by
-       the rest; where that row's stream starts (relative to the span's first record) is read
-       from l_rows */
-    uint32_t dma_tbl[NW], dma_off[NW];
+    /* DMA: piece i = 64 k + lane of a slot is 16 bytes of row i / PR: of its sequence (the first
+       2 NW pieces), of its qualities (the next 2 NW), or the unused last one; where a row's
+       streams start (relative to the span's first record) is read from l_rows */
+    /* per piece (l_dma[k][lane]): byte offset into l_rows | offset inside the stream << 8 | loaded at all << 31 */
+    uint32_t *l_dma = (uint32_t *)(smem + L.dma);
+    if (wave == 0) {
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const uint32_t i = 64 * k + lane, row = i / (4 * NW), pir = i % (4 * NW), stream = pir >= 2 * NW;
-        dma_tbl[k] = lds_addr(l_rows) + row * 8 + stream * 4;
-        dma_off[k] = (pir - stream * 2 * NW) * 16;
+        for (int k = 0; k < (int)ND; k++) {
+            const uint32_t i = 64 * k + lane, row = i / PR, pir = i % PR, stream = pir >= 2 * NW;
+            const bool on = i < SPAN_R * PR && pir < 4 * NW;
+            l_dma[64 * k + lane] = on ? (row * 8 + stream * 4) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u : 0;
+        }
     }
+    __syncthreads();
     const uint64_t nspans = P.n / SPAN_R;
     const uint64_t stride = (uint64_t)gridDim.x * W;
     uint64_t s = (uint64_t)blockIdx.x * W + wave;
 
-    unsigned long long m_rs = 0; /* metas of the span to be fetched next: record start, offsets */
-    uint32_t m_so = 0, m_qo = 0;
-    auto load_meta = [&](uint64_t sp) {
-        const sq_meta *m = P.metas + sp * SPAN_R + q;
-        m_rs = m->record_start;
-        m_so = m->sequence_offset;
-        m_qo = m->qualities_offset;
+    /* The 640 bytes of a span's metas come through LDS too (one more DMA of 40 lanes, two buffers
+       per wave): the loop below holds no load hipcc counts, or its waits for one (vmcnt counts in
+       order) would wait for the DMA issued in front of it.  Meta buffer k goes with slot k. */
+    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 2 * SPAN_META_BYTES;
+    auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
+        if (lane < (int)(SPAN_META_BYTES / 16))
+            dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
     };
-    auto issue = [&](uint32_t slot_addr) {
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr) {
+        const uint32_t ma = maddr + 40 * q;
+        const unsigned long long m_rs = *(SQ_LDS const unsigned long long *)(uintptr_t)ma; /* record_start */
+        const uint32_t m_so = lds_u32(ma + 12), m_qo = lds_u32(ma + 20);             /* sequence_offset, qualities_offset */
         const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m_rs >> 32)) << 32) |
                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m_rs);
         const uint32_t rel = (uint32_t)(m_rs - base);
         if (c == 0) { l_rows[2 * q] = rel + m_so; l_rows[2 * q + 1] = rel + m_qo; }
         const uint8_t *g0 = P.buf + base;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const int32_t r = (int32_t)lds_u32(dma_tbl[k]);
-            dma16(g0 + (long long)r + dma_off[k], __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
+        for (int k = 0; k < (int)ND; k++) {
+            const uint32_t pk = l_dma[64 * k + lane];
+            const int32_t r = (int32_t)lds_u32(lds_addr(l_rows) + (pk & 0xFFu));
+            if ((int32_t)pk < 0)
+                dma16(g0 + (long long)r + ((pk >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
         }
     };
 
     const uint32_t Lmain = 4 * ((U - 1) / 4), nsteps = Lmain / 4; /* _qcmodule.c:2062,2068 */
     const uint32_t W4 = AD ? (P.ad_maxlen + 2) / 4 : 0;            /* dwords holding >= maxlen - 1 positions */
-    const uint32_t npad = SB - U;
+    const uint32_t npad = SB - U;                                  /* padding positions of a row */
     const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     uint32_t cnt[NW];
 #pragma unroll
@@ -213,75 +288,227 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 
     int cur = 0;
     if (s < nspans) {
-        load_meta(s);
-        issue(slot_base);
-        if (s + stride < nspans) load_meta(s + stride);
+        issue_meta(s, meta_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(slot_base, meta_base);
+        if (s + stride < nspans) issue_meta(s + stride, meta_base + SPAN_META_BYTES);
     }
     while (s < nspans) {
-        /* the span in slot `cur` has landed (and the metas of the one after it have arrived) */
+        /* the span in slot `cur` has landed, and so have the metas of the one after it */
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t0);
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t1);
+#endif
         if (s + stride < nspans) {
-            issue(slot_base + (cur ^ 1) * SLOT);
-            if (s + 2 * stride < nspans) load_meta(s + 2 * stride);
+#ifdef SQ_SPAN_PROBE
+            if (!(P.blocked & 1))
+#endif
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
+            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * SPAN_META_BYTES);
         }
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t2);
+        if (P.blocked & 2) { cur ^= 1; s += stride; a_wait += t1 - t0; a_issue += t2 - t1; a_spans++; continue; }
+#endif
         const uint32_t sa = slot_base + cur * SLOT;
         const uint64_t r = s * SPAN_R + q;
         const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + SB;
 
-        /* ---------------- phase S: four lanes per read ---------------- */
-        uint32_t st = dfa_root, gacc = 0, nacc = 0;
-        bool any_hit = false;
-        const uint32_t seg = seq_row + 4 * Q4 * c; /* this lane's quarter: dwords [Q4 c, Q4 (c + 1)) */
-        if (AD) {
-#pragma unroll 1
-            for (uint32_t t = 0; t < W4; t++) { /* the stretch in front of the quarter: state only */
-                uint32_t cl = cls6_of_dword(lds_u32(seg - 4 * W4 + 4 * t));
-                cl = Q4 * c + t < W4 ? CLS6_PAD4 : cl; /* nothing in front of the read */
-                st = lds_u16(or_byte<0>(st, cl));
-                st = lds_u16(or_byte<1>(st, cl));
-                st = lds_u16(or_byte<2>(st, cl));
-                st = lds_u16(or_byte<3>(st, cl));
-            }
-        }
+        /* ---------------- phase S: four lanes per read ----------------
+           (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
+           x 4 lanes of an instruction in 32 banks), writes the codes back in place (phase H and the
+           automaton read them) and counts G/C and non-ACGT bases */
+        uint32_t gacc = 0, nacc = 0;
+        {
+            const uint32_t cb = seq_row + 4 * c;
+            uint32_t Uv = U, cv = c; /* opaque: hipcc would keep the padding masks of all 2 NW dwords in registers across spans */
+            asm volatile("" : "+s"(Uv), "+v"(cv));
+            uint32_t raw[2 * NW];
 #pragma unroll
-        for (uint32_t t = 0; t < Q4; t++) {
-            uint32_t cl = cls6_of_dword(lds_u32(seg + 4 * t));
-            if (4 * (3 * Q4 + t) + 4 > U) { /* a dword that reaches behind the reads in the last quarter */
-                const uint32_t p0 = 4 * (Q4 * c + t);
-                cl = pad_tail(cl, p0 < U ? (int)min(4u, U - p0) : 0, CLS6_PAD4);
-            }
-            lds_store_u32(seg + 4 * t, cl);
-            gacc += cl & 0x04040404u;                 /* C, G and padding */
-            nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
-            if (AD) {
-                uint32_t e[4];
-                e[0] = lds_u16(or_byte<0>(st, cl));
-                e[1] = lds_u16(or_byte<1>(e[0], cl));
-                e[2] = lds_u16(or_byte<2>(e[1], cl));
-                e[3] = lds_u16(or_byte<3>(e[2], cl));
-                st = e[3];
-                if (max(max(e[0], e[1]), max(e[2], e[3])) >= dfa_hit) {
-                    any_hit = true;
+            for (int t = 0; t < 2 * NW; t++) raw[t] = lds_u32(cb + 16 * t);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (e[j] < dfa_hit) continue;
-                        unsigned long long hits = l_out[(e[j] - dfa_root) >> 5];
-                        const uint32_t pos = 4 * (Q4 * c + t) + j; /* where the match ends */
-                        while (hits) {
-                            const int a = __ffsll((long long)hits) - 1;
-                            hits &= hits - 1;
-                            lds_min(lds_addr(l_first + q * n_ad + a), pos);
-                        }
-                    }
+            for (int t = 0; t < 2 * NW; t++) {
+                uint32_t cl = cls6_of_dword(raw[t]);
+                if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
+                    const uint32_t p0 = 16 * t + 4 * cv;
+                    cl = pad_tail(cl, p0 < Uv ? (int)min(4u, Uv - p0) : 0, CLS6_PAD4);
                 }
+                lds_store_u32(cb + 16 * t, cl);
+                gacc += cl & 0x04040404u;                 /* C, G and padding */
+                nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
             }
         }
-        /* the four chains, :2062-2097 */
+        /* (2) the automaton: W4 rounds over the dwords in front of the lane's quarter (state only),
+           then the Q4 dwords of the quarter.  Its four table reads per dword depend on each other;
+           everything else that is left to do for the span has no such chain and is spread over the
+           Q4 rounds, hand scheduled into the waits: four steps of the lane's f64 chain per round
+           (positions c, c + 4, ...) and phase H (lane = position, two rows x 32 positions per
+           instruction), HI (window, row pair) items per round.  What a round consumes was loaded
+           in the round before it (class dword, the bytes of its phase H items, the quality bytes of
+           its chain steps); the loads are asm the compiler does not wait for (rd_*, wait_*). */
+        uint32_t st = dfa_root;
+        bool any_hit = false;
         double acc = 0.0;
         {
-            const uint32_t qa = qual_row + c;
-#pragma unroll 4
-            for (uint32_t k = 0; k < nsteps; k++) acc += lds_f64(lds_u8(qa + 4 * k) << 3);
+            int32_t dwi = (int32_t)(Q4 * c) - (int32_t)W4;      /* dword of the row the next round looks at */
+            asm volatile("" : "+v"(dwi));                        /* opaque: no per-round masks kept across spans */
+            uint32_t addr = seq_row + 4u * (uint32_t)dwi;
+            const uint32_t qp = qual_row + c;
+            const uint32_t bs = sa + h * ROWB + pl;
+            const uint32_t hpp = lds_addr(l_hist_phred + pl);
+            constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = 4;
+            static_assert(HI * (int)Q4 >= ITEMS, "phase H does not fit the rounds");
+            constexpr int KR = (int)Q4 < 2 * (NW - 1) ? (int)Q4 : 2 * (NW - 1); /* rounds that carry chain steps whatever U is */
+            /* a lane's first match of the span is kept in `rec` (row of the automaton | end position
+               << 12 | 1 << 31) and looked at behind the rounds; a second one in the same lane sends
+               the wave through the rounds again, one dword at a time (walk_again) */
+            uint32_t rec = 0;
+            bool multi = false;
+            wait_lgkm<0>();
+            /* what round 0 of the quarter consumes */
+            uint32_t cb[HI], qb[HI], qc[4];
+            static_for<0, HI>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                cb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF)>(bs);
+                qb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF) + (int)SB>(bs);
+            });
+            qc[0] = rd_u8<0>(qp); qc[1] = rd_u8<4>(qp); qc[2] = rd_u8<8>(qp); qc[3] = rd_u8<12>(qp);
+            uint32_t cl = AD ? rd_b32<0>(addr) : 0;
+            if (AD) {
+#pragma unroll 1
+                for (uint32_t i = 0; i < W4; i++) {
+                    uint32_t cln = rd_b32<4>(addr);
+                    wait_1<1>(cl);
+                    cl = (uint32_t)dwi < DW ? cl : CLS6_PAD4;   /* nothing in front of the read */
+                    uint32_t e = rd_u16<0>(or_byte<0>(st, cl));
+                    wait_1<0>(e);
+                    e = rd_u16<0>(or_byte<1>(e, cl));
+                    wait_1<0>(e);
+                    e = rd_u16<0>(or_byte<2>(e, cl));
+                    wait_1<0>(e);
+                    e = rd_u16<0>(or_byte<3>(e, cl));
+                    wait_2<0>(e, cln);
+                    st = e;
+                    cl = cln;
+                    addr += 4;
+                    dwi++;
+                }
+            }
+            wait_4<0>(cb[0], cb[1], cb[2], cb[3]);
+            wait_4<0>(qb[0], qb[1], qb[2], qb[3]);
+            wait_4<0>(qc[0], qc[1], qc[2], qc[3]);
+            wait_1<0>(cl);
+            const uint32_t one = 1, st0 = st; /* st0: the state in front of the quarter */
+            static_for<0, (int)Q4>([&](auto rc) {
+                constexpr int rr = decltype(rc)::value;
+                constexpr bool chain = rr < KR;
+                /* LDS operations of this round, for the hand-counted waits (at most 15 can be named) */
+                constexpr int n_l = ITEMS - rr * HI < 0 ? 0 : ITEMS - rr * HI < HI ? ITEMS - rr * HI : HI; /* items of this round */
+                constexpr int n_nx = ITEMS - (rr + 1) * HI < 0 ? 0 : ITEMS - (rr + 1) * HI < HI ? ITEMS - (rr + 1) * HI : HI;
+                constexpr int n_d = chain ? 4 : 0, n_cln = AD && rr + 1 < (int)Q4 ? 1 : 0, n_qc = rr + 1 < KR ? 4 : 0;
+                constexpr int n_pf = n_cln + 2 * n_nx + n_qc;     /* loads for the next round */
+                constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
+                /* the furthest lane's dword of this round lies behind the row's sequence: padding */
+                if (AD && 3 * (int)Q4 + rr >= (int)DW) cl = (uint32_t)dwi < DW ? cl : CLS6_PAD4;
+                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                if (AD) e0 = rd_u16<0>(or_byte<0>(st, cl));
+                /* rows of the phred histogram of this round's items, error rates of its chain steps */
+                uint32_t l[HI] = {0, 0, 0, 0};
+                static_for<0, HI>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(qb[m] << 1);
+                });
+                double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+                if constexpr (chain) { d0 = rd_f64(qc[0] << 3); d1 = rd_f64(qc[1] << 3); d2 = rd_f64(qc[2] << 3); d3 = rd_f64(qc[3] << 3); }
+                /* base counts of this round's items: one shift-add per base into the window's register */
+                static_for<0, HI>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    if constexpr (m < n_l) cnt[(rr * HI + m) / HALF] = one_shl_add(cb[m], cnt[(rr * HI + m) / HALF]);
+                });
+                /* what the next round consumes */
+                uint32_t cln = 0;
+                if constexpr (n_cln) cln = rd_b32<4>(addr);
+                static_for<0, HI>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, it = (rr + 1) * HI + m;
+                    if constexpr (m < n_nx) {
+                        cb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF)>(bs);
+                        qb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF) + (int)SB>(bs);
+                    }
+                });
+                if constexpr (n_qc) {
+                    qc[0] = rd_u8<16 * (rr + 1)>(qp); qc[1] = rd_u8<16 * (rr + 1) + 4>(qp);
+                    qc[2] = rd_u8<16 * (rr + 1) + 8>(qp); qc[3] = rd_u8<16 * (rr + 1) + 12>(qp);
+                }
+                if (AD) { wait_1<cap(n_l + n_d + n_pf)>(e0); e1 = rd_u16<0>(or_byte<1>(e0, cl)); }
+                if constexpr (n_l) {
+                    wait_4<cap(n_d + n_pf + (AD ? 1 : 0))>(l[0], l[1], l[2], l[3]);
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        if constexpr (m < n_l) inc_u32<128 * ((rr * HI + m) / HALF)>(hpp + l[m], one);
+                    });
+                }
+                /* behind this wait only the atomics are in flight: e1, the error rates and the loads
+                   for the next round have arrived */
+                if (AD) { wait_1<n_l>(e1); e2 = rd_u16<0>(or_byte<2>(e1, cl)); }
+                if constexpr (chain) {
+                    wait_4d<AD ? n_l + 1 : cap(n_pf + n_l)>(d0, d1, d2, d3);
+                    acc += d0; acc += d1; acc += d2; acc += d3;
+                }
+                if (AD) { wait_1<0>(e2); e3 = rd_u16<0>(or_byte<3>(e2, cl)); }
+                if constexpr (n_nx) {
+                    wait_4<AD ? 1 : n_l>(cb[0], cb[1], cb[2], cb[3]);
+                    wait_4<AD ? 1 : n_l>(qb[0], qb[1], qb[2], qb[3]);
+                }
+                if constexpr (n_qc) wait_4<AD ? 1 : n_l>(qc[0], qc[1], qc[2], qc[3]);
+                if (AD) {
+                    wait_2<0>(e3, cln);
+                    st = e3;
+                    if (max(max(e0, e1), max(e2, e3)) >= dfa_hit) {
+                        const uint32_t nh = (e0 >= dfa_hit) + (e1 >= dfa_hit) + (e2 >= dfa_hit) + (e3 >= dfa_hit);
+                        const uint32_t j = e0 >= dfa_hit ? 0 : e1 >= dfa_hit ? 1 : e2 >= dfa_hit ? 2 : 3;
+                        const uint32_t ej = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
+                        if (rec || nh > 1) multi = true;
+                        else rec = 0x80000000u | ((4 * (uint32_t)dwi + j) << 12) | ((ej - dfa_root) >> 5);
+                    }
+                    cl = cln;
+                    addr += 4;
+                    dwi++;
+                }
+            });
+            wait_lgkm<0>();
+            if (AD && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
+                any_hit = true;
+                auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton */
+                    unsigned long long hits = l_out[row];
+                    while (hits) {
+                        const int a = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        lds_min(lds_addr(l_first + q * n_ad + a), pos);
+                    }
+                };
+                if (__builtin_amdgcn_ballot_w64(multi)) {
+                    uint32_t s2 = st0;
+#pragma unroll 1
+                    for (uint32_t t = 0; t < Q4; t++) {
+                        const uint32_t dw = Q4 * c + t;
+                        uint32_t cl2 = lds_u32(seq_row + 4 * dw);
+                        cl2 = dw < DW ? cl2 : CLS6_PAD4;
+#pragma unroll 1
+                        for (uint32_t j = 0; j < 4; j++) {
+                            s2 = lds_u16(s2 | ((cl2 >> (8 * j)) & 0xFFu));
+                            if (s2 >= dfa_hit) matches((s2 - dfa_root) >> 5, 4 * dw + j);
+                        }
+                    }
+                } else if (rec) {
+                    matches(rec & 0xFFFu, (rec >> 12) & 0xFFFu);
+                }
+            }
+            /* the chain steps the rounds did not carry */
+#pragma unroll 1
+            for (uint32_t k = 4 * KR; k < nsteps; k++) acc += lds_f64(lds_u8(qp + 4 * k) << 3);
         }
         double total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
         for (uint32_t p = Lmain; p < U; p++) total += lds_f64(lds_u8(qual_row + p) << 3); /* :2100-2112 */
@@ -290,7 +517,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
         if (c == 0) {
             const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
-            P.metas[r].accumulated_error_rate = total; /* :2126 */
+            {   /* :2126; a store hipcc does not count either */
+                double *dst = &P.metas[r].accumulated_error_rate;
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(total) : "memory");
+            }
             if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
             if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
             const double avg = total / (double)U;
@@ -316,28 +546,20 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             }
         }
 
-        /* ---------------- phase H: lane = position, two rows per instruction ---------------- */
-        {
-            const uint32_t bs = sa + h * ROWB + pl;
-            const uint32_t hpp = lds_addr(l_hist_phred + pl);
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                if (32u * w + pl < U) {
-#pragma unroll
-                    for (int j = 0; j < (int)SPAN_R / 2; j++) {
-                        const uint32_t cb = lds_u8(bs + 2 * j * ROWB + 32 * w);
-                        const uint32_t qb = lds_u8(bs + 2 * j * ROWB + 32 * w + SB);
-                        cnt[w] = one_shl_add(cb, cnt[w]);
-                        const uint32_t bin = min(qb - 33u, 47u) >> 2; /* :1767-1784 */
-                        lds_inc(hpp + 128 * w + __umul24(bin, hs * 4));
-                    }
-                }
-            }
-        }
         if (++since_flush == 7) { flush_counts(); since_flush = 0; }
         cur ^= 1;
         s += stride;
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t3);
+        a_wait += t1 - t0; a_issue += t2 - t1; a_comp += t3 - t2; a_spans++;
+#endif
     }
+#ifdef SQ_SPAN_PROBE
+    if (lane == 0) {
+        atomicAdd(&g_span_stamps[0], a_wait); atomicAdd(&g_span_stamps[1], a_issue);
+        atomicAdd(&g_span_stamps[2], a_comp); atomicAdd(&g_span_stamps[3], a_spans);
+    }
+#endif
     flush_counts();
 
     /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
@@ -396,8 +618,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || P.ad_maxlen > 64)) return SQ_OK;
     int nw = (int)((U + 31) / 32);
-    while (nw <= SPAN_NW_MAX && nw != 2 && nw != 5 && nw != 8) nw++;
-    if (nw > SPAN_NW_MAX) return SQ_OK;
+    if (nw > SPAN_NW_MAX || (ad && nw > 5)) return SQ_OK; /* the automaton's rounds spill registers from 161 positions on: k_wide */
     /* as many waves as LDS takes, at most 16 */
     int waves = span_max_waves(nw);
     while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total > 160 * 1024) waves--;
@@ -410,11 +631,27 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
     int rc;
     switch (nw) {
+        case 1: rc = launch_nw<1>(ctx, C, ad, n_ad, waves, lds, grid); break;
         case 2: rc = launch_nw<2>(ctx, C, ad, n_ad, waves, lds, grid); break;
+        case 3: rc = launch_nw<3>(ctx, C, ad, n_ad, waves, lds, grid); break;
+        case 4: rc = launch_nw<4>(ctx, C, ad, n_ad, waves, lds, grid); break;
         case 5: rc = launch_nw<5>(ctx, C, ad, n_ad, waves, lds, grid); break;
+        case 6: rc = launch_nw<6>(ctx, C, ad, n_ad, waves, lds, grid); break;
+        case 7: rc = launch_nw<7>(ctx, C, ad, n_ad, waves, lds, grid); break;
         default: rc = launch_nw<8>(ctx, C, ad, n_ad, waves, lds, grid); break;
     }
     if (rc) return rc;
+#ifdef SQ_SPAN_PROBE
+    if (getenv("SQ_SPAN_STAMPS")) {
+        unsigned long long h[4];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
+        fprintf(stderr, "k_span stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans)\n",
+                (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3]);
+        unsigned long long z[4] = {0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
+    }
+#endif
     *done = C.n;
     return SQ_OK;
 }

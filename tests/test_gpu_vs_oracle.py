@@ -371,15 +371,15 @@ def test_two_million_reads_all_tables_equal_oracle():
     errs = dev.accumulated_error_rates()
     gq2.add_record_array(dev)
     forced = []
-    for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}):
+    for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}, {"SQ_SPAN": "1"}):
         q, a = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(q, a).add_record_array(dev), q.flush()))
         forced.append((q, a))
-    for g in (ga, forced[0][1], forced[1][1]):
+    for g in (ga,) + tuple(f[1] for f in forced):
         for (_, f, r), (_, fr, rr) in zip(g.get_counts(), ra.get_counts()):
             np.testing.assert_array_equal(u64(f), fr)
             np.testing.assert_array_equal(u64(r), rr)
-    for g in (gq, gq2, forced[0][0], forced[1][0]):
+    for g in (gq, gq2) + tuple(f[0] for f in forced):
         np.testing.assert_array_equal(u64(g.base_count_table()), rq.base_count_table())
         np.testing.assert_array_equal(u64(g.phred_count_table()), rq.phred_count_table())
         np.testing.assert_array_equal(u64(g.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
@@ -424,7 +424,9 @@ def test_uniform_length_kernels_every_alignment(U):
              (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
              (True, {}),                                         # + AdapterCounter: k_wide
              (True, {"SQ_RING": "1"}),                           # k_ring
-             (True, {"SQ_NO_WIDE": "1"})]                        # k_pass
+             (True, {"SQ_NO_WIDE": "1"}),                        # k_pass
+             (False, {"SQ_SPAN": "1"}),                          # QCMetrics alone: k_span (records through LDS by LDS-DMA)
+             (True, {"SQ_SPAN": "1"})]                           # k_span with the automaton (k_wide from 161 positions on)
     for with_adapters, env in cases:
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(probes)
