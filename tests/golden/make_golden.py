@@ -189,9 +189,20 @@ def save(name: str, **arrays):
     print("wrote", name, {k: getattr(v, "shape", None) for k, v in list(arrays.items())[:4]}, "...")
 
 
-def single_end_case(name: str, text: bytes, probes, **extra):
+def text_entry(key: str, text: bytes, gen=None) -> dict:
+    """The input text of a fixture: the bytes, or -- for slices of the build's own counter-based
+    generator -- (kind, first, n, seed) and the SHA-256 of the bytes the reference was run on
+    (tests/helpers.py golden_text regenerates and checks them)."""
+    if gen is None:
+        return {key: np.frombuffer(text, np.uint8)}
+    import hashlib
+    return {key + "_gen": np.array(gen, dtype=np.int64),
+            key + "_sha256": np.frombuffer(hashlib.sha256(text).digest(), np.uint8)}
+
+
+def single_end_case(name: str, text: bytes, probes, gen=None, **extra):
     arrays = arrays_of(text)
-    out = {"fastq": np.frombuffer(text, np.uint8)}
+    out = text_entry("fastq", text, gen)
     out.update(qc_outputs(arrays))
     out.update(adapter_outputs(arrays, probes))
     out.update(pertile_outputs(arrays))
@@ -402,10 +413,11 @@ def synthetic():
     generator; run after `python -c 'import __graft_entry__ as g; g.build()'`)."""
     from sequali_amd import synth
     text = synth.illumina_fastq(0, 20000, seed=synth.DEFAULT_SEED)
-    single_end_case("synth_illumina_20k", text, ILLUMINA_PROBES)
+    single_end_case("synth_illumina_20k", text, ILLUMINA_PROBES, gen=(synth.ILLUMINA, 0, 20000, synth.DEFAULT_SEED))
     t1, t2 = synth.illumina_paired_fastq(0, 20000, seed=synth.DEFAULT_SEED)
     a1, a2 = paired_arrays(t1, t2)
-    out = {"fastq1": np.frombuffer(t1, np.uint8), "fastq2": np.frombuffer(t2, np.uint8)}
+    out = text_entry("fastq1", t1, (synth.ILLUMINA, 0, 20000, synth.DEFAULT_SEED))
+    out.update(text_entry("fastq2", t2, (synth.ILLUMINA_R2, 0, 20000, synth.DEFAULT_SEED)))
     out.update(qc_outputs(a1, prefix="qc1_"))
     out.update(qc_outputs(a2, prefix="qc2_"))
     out.update(pertile_outputs(a1, prefix="pt1_"))
@@ -417,7 +429,7 @@ def synthetic():
     out.update(insert_outputs(a1, a2, prefix="iscap_", max_adapters=16))
     save("synth_illumina_paired_20k", **out)
     text = synth.nanopore_fastq(0, 300, seed=synth.DEFAULT_SEED)
-    single_end_case("synth_nanopore_300", text, NANOPORE_PROBES)
+    single_end_case("synth_nanopore_300", text, NANOPORE_PROBES, gen=(synth.NANOPORE, 0, 300, synth.DEFAULT_SEED))
 
 
 def metas_of(arr) -> np.ndarray:

@@ -19,7 +19,25 @@ def golden(name: str):
 
 
 def golden_names(pattern: str) -> List[str]:
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+    if not names:   # a parametrisation that silently expands to nothing tests nothing
+        raise FileNotFoundError(f"no golden fixture matches {pattern!r} in {GOLDEN}")
+    return names
+
+
+def golden_text(g, key: str) -> bytes:
+    """Input text of a fixture.  The synth_* fixtures keep (kind, first, n, seed) of the build's
+    counter-based generator and the SHA-256 of the bytes the reference was run on instead of the
+    bytes: regenerate (host generator of libsqgpu.so, no GPU needed) and check."""
+    if key in g.files:
+        return g[key].tobytes()
+    import hashlib
+    from sequali_amd import synth
+    kind, first, n, seed = (int(x) for x in g[key + "_gen"])
+    text = synth.host_records(kind, first, n, seed)[0]
+    if hashlib.sha256(text).digest() != g[key + "_sha256"].tobytes():
+        raise AssertionError(f"the synthetic generator no longer produces the bytes fixture {key} was captured on")
+    return text
 
 
 def golden_json(name: str):

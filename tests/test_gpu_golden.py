@@ -6,7 +6,7 @@ import warnings
 import numpy as np
 import pytest
 
-from tests.helpers import golden, golden_json, golden_names, kwargs_of
+from tests.helpers import golden, golden_json, golden_names, golden_text, kwargs_of
 
 pytestmark = pytest.mark.gpu
 
@@ -124,7 +124,7 @@ def check_insert(g, arrays1, arrays2, prefix="is_"):
 @pytest.mark.parametrize("name", golden_names("ref_[!L]*") + golden_names("synth_*[!d]_[0-9]*"))
 def test_single_end_files(name):
     g = golden(name)
-    arrays = arrays_of(g["fastq"].tobytes())
+    arrays = arrays_of(golden_text(g, "fastq"))
     check_qc(g, arrays)
     check_adapter(g, arrays)
     check_pertile(g, arrays)
@@ -139,7 +139,7 @@ def test_single_end_files_fused(name):
     """the three per-base modules in one pass give the same tables"""
     from sequali_amd import AdapterCounter, FusedPass, PerTileQuality, QCMetrics
     g = golden(name)
-    arrays = arrays_of(g["fastq"].tobytes(), 64 * 1024)
+    arrays = arrays_of(golden_text(g, "fastq"), 64 * 1024)
     m, c, p = QCMetrics(), AdapterCounter([str(x) for x in g["ad_probes"]]), PerTileQuality()
     fused = FusedPass(m, c, p)
     for a in arrays:
@@ -165,7 +165,7 @@ def test_single_end_files_fused(name):
 @pytest.mark.parametrize("name", ["ref_LTB_paired"] + golden_names("synth_*paired*"))
 def test_paired_files(name):
     g = golden(name)
-    a1, a2 = paired_arrays(g["fastq1"].tobytes(), g["fastq2"].tobytes())
+    a1, a2 = paired_arrays(golden_text(g, "fastq1"), golden_text(g, "fastq2"))
     if "is_mate" in g:
         assert [x.is_mate(y) for x, y in zip(a1, a2)] == [bool(v) for v in g["is_mate"]]
     check_qc(g, a1, prefix="qc1_")
@@ -186,7 +186,7 @@ def test_paired_files(name):
 @pytest.mark.parametrize("name", golden_names("inline_qc_[0-9]*"))
 def test_inline_qc(name):
     g = golden(name)
-    check_qc(g, arrays_of(g["fastq"].tobytes()))
+    check_qc(g, arrays_of(golden_text(g, "fastq")))
 
 
 def test_inline_qc_long_quality():
@@ -224,43 +224,43 @@ def test_h1_uniform_quality_grid():
 @pytest.mark.parametrize("name", golden_names("inline_adapter_*"))
 def test_inline_adapter(name):
     g = golden(name)
-    check_adapter(g, arrays_of(g["fastq"].tobytes()))
+    check_adapter(g, arrays_of(golden_text(g, "fastq")))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_pertile_*"))
 def test_inline_pertile(name):
     g = golden(name)
-    check_pertile(g, arrays_of(g["fastq"].tobytes()))
+    check_pertile(g, arrays_of(golden_text(g, "fastq")))
     # and with the records spread over several small arrays
-    check_pertile(g, arrays_of(g["fastq"].tobytes(), 300))
+    check_pertile(g, arrays_of(golden_text(g, "fastq"), 300))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_overrep_*"))
 def test_inline_overrep(name):
     g = golden(name)
-    check_overrep(g, arrays_of(g["fastq"].tobytes()))
-    check_overrep(g, arrays_of(g["fastq"].tobytes(), 1000))
+    check_overrep(g, arrays_of(golden_text(g, "fastq")))
+    check_overrep(g, arrays_of(golden_text(g, "fastq"), 1000))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_dedup_cap*"))
 def test_inline_dedup_caps(name):
     g = golden(name)
-    check_dedup(g, arrays_of(g["fastq"].tobytes()))
-    check_dedup(g, arrays_of(g["fastq"].tobytes(), 4096))
+    check_dedup(g, arrays_of(golden_text(g, "fastq")))
+    check_dedup(g, arrays_of(golden_text(g, "fastq"), 4096))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_dedup_geom_*"))
 def test_inline_dedup_geometry(name):
     g = golden(name)
-    check_dedup(g, arrays_of(g["fastq"].tobytes()))
-    a1, a2 = paired_arrays(g["fastq1"].tobytes(), g["fastq2"].tobytes())
+    check_dedup(g, arrays_of(golden_text(g, "fastq")))
+    a1, a2 = paired_arrays(golden_text(g, "fastq1"), golden_text(g, "fastq2"))
     check_dedup(g, a1, a2, prefix="ddp_")
 
 
 @pytest.mark.parametrize("name", golden_names("inline_insert_*"))
 def test_inline_insert(name):
     g = golden(name)
-    a1, a2 = paired_arrays(g["fastq1"].tobytes(), g["fastq2"].tobytes())
+    a1, a2 = paired_arrays(golden_text(g, "fastq1"), golden_text(g, "fastq2"))
     check_insert(g, a1, a2)
 
 

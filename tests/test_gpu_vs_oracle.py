@@ -569,3 +569,97 @@ def test_long_reads_in_segments(which):
     arr2 = FastqRecordArrayView._from_buffer(buf, metas.copy())
     gq2.add_record_array(arr2)
     compare_qc(rq, gq2, metas, arr2)
+
+
+def _pertile_equal(got, ref):
+    assert got.number_of_reads == ref.number_of_reads
+    assert got.max_length == ref.max_length
+    gt, rt = got.get_tile_counts(), ref.get_tile_counts()
+    assert [t for t, _, _ in gt] == [t for t, _, _ in rt]
+    for (t, e, c), (_, er, cr) in zip(gt, rt):
+        np.testing.assert_array_equal(u64(c), cr)
+        np.testing.assert_allclose(np.array(e), er, rtol=1e-6, atol=0)   # f64 sums, other order
+
+
+def _tile_batch(rng, n, U, tile_of, bad_at=None):
+    """n reads of length U, Illumina names with rotating lengths (sequence and quality starts walk
+    through every alignment), tile_of(i) the tile of read i, optionally one header without a tile"""
+    names, seqs, quals = [], [], []
+    for i in range(n):
+        name = f"M{'x' * (i % 61)}:1:F:{i % 4}:{tile_of(i)}:{i}:7 1:N:0:X"
+        if bad_at is not None and i == bad_at:
+            name = f"read{i} no tile here"
+        names.append(name)
+        seqs.append(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=U).tobytes().decode())
+        quals.append((rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode())
+    return oracle.make_batch(names, seqs, quals)
+
+
+@pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
+def test_ptq_kernel_every_length_and_alignment(U):
+    """PerTileQuality alone on a batch of one read length is k_ptq (_qcmodule.c:3124-3222 on the
+    qualities only, 64 bytes per row and visit, per-wave sums of the tile the groups are in):
+    the 16 length classes x rotating alignments with (a) random tiles in >= 4096 reads (the
+    tile-sorted walk), (b) tiles in runs with a seam inside a group of 64 and a trailing partial
+    group (walked as stored), (c) a header without a tile in the middle of the batch (the module
+    stops there for good, :3137-3148).  Every case also through the general kernel
+    (SQ_NO_PTQ=1) and against the oracle."""
+    from sequali_amd import FastqRecordArrayView, PerTileQuality
+    rng = np.random.default_rng(5000 + U)
+    tiles = [1101, 1102, 2205, 7, 99239, 1213]
+    cases = [
+        (64 * 66 + 37, lambda i: tiles[int(rng.integers(0, len(tiles)))], None),     # (a)
+        (64 * 9 + 21, lambda i: tiles[min(i // 150, len(tiles) - 1)], None),          # (b) seams at 150, 300, ...
+        (64 * 6 + 5, lambda i: tiles[(i // 97) % len(tiles)], 64 * 3 + 17),           # (c)
+    ]
+    for n, tile_of, bad_at in cases:
+        buf, metas = _tile_batch(rng, n, U, tile_of, bad_at)
+        ref = oracle.PerTileQuality()
+        ref.add(buf, metas)
+        for env in ({}, {"SQ_NO_PTQ": "1"}):
+            got = PerTileQuality()
+            arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+            _with_env(env, lambda: got.add_record_array(arr))
+            _pertile_equal(got, ref)
+            if bad_at is not None:
+                assert ref.skipped and ref.skipped_record == bad_at
+                assert got.skipped_reason == f"Can not parse header: 'read{bad_at} no tile here'"
+                # the module stays off: a later batch changes nothing
+                arr2 = FastqRecordArrayView._from_buffer(buf, metas.copy())
+                _with_env(env, lambda: got.add_record_array(arr2))
+                _pertile_equal(got, ref)
+
+
+def test_config4_nanopore_reads_through_the_segment_kernels():
+    """BASELINE config 4 at a size the oracle still finishes in seconds: 4500 reads of the
+    synthetic nanopore generator (about 43 M bases, lengths 200 .. 74489: one read longer than
+    64 kb, two blocks of 4096 reads) through FusedPass(QCMetrics, AdapterCounter(14 probes)),
+    which is k_read_sums + k_seg + k_adapter_first at that size: every table, the first
+    occurrences of the adapters and the bits of accumulated_error_rate against the oracle;
+    the stripes route (SQ_NO_SEGMENTS=1) as the cross-check"""
+    from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
+    first, n = 4562, 4500
+    probes = list(synth.NANOPORE_PROBES)
+    assert len(probes) == 14
+    buf, metas = synth.host_records(synth.NANOPORE, first, n)
+    assert metas["sequence_length"].max() > 65536 and n > 4096
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    for env in ({}, {"SQ_NO_SEGMENTS": "1"}):
+        dev = synth.device_array(synth.NANOPORE, first, n)
+        gq, ga = QCMetrics(), AdapterCounter(probes)
+        _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(dev), gq.flush()))
+        assert gq.number_of_reads == rq.number_of_reads and gq.max_length == rq.max_length
+        np.testing.assert_array_equal(u64(gq.base_count_table()), rq.base_count_table())
+        np.testing.assert_array_equal(u64(gq.phred_count_table()), rq.phred_count_table())
+        np.testing.assert_array_equal(u64(gq.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
+        np.testing.assert_array_equal(u64(gq.end_anchored_phred_count_table()), rq.end_anchored_phred_count_table())
+        np.testing.assert_array_equal(u64(gq.gc_content()), rq.gc_content())
+        np.testing.assert_array_equal(u64(gq.phred_scores()), rq.phred_scores())
+        np.testing.assert_array_equal(dev.accumulated_error_rates().view(np.uint64),
+                                      metas["accumulated_error_rate"].view(np.uint64))
+        for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(f), fr)
+            np.testing.assert_array_equal(u64(r), rr)
+    assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 10   # chance matches only: the generator plants no probes

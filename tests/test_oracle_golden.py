@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests.helpers import golden, golden_json, golden_names, kwargs_of, split_fastq
+from tests.helpers import golden, golden_json, golden_names, golden_text, kwargs_of, split_fastq
 
 
 def check_qc(g, buf, metas, prefix="qc_"):
@@ -101,7 +101,7 @@ def test_error_table_bits():
 @pytest.mark.parametrize("name", golden_names("ref_[!L]*") + golden_names("synth_*[!d]_[0-9]*"))
 def test_single_end_files(name):
     g = golden(name)
-    buf, metas = split_fastq(g["fastq"].tobytes())
+    buf, metas = split_fastq(golden_text(g, "fastq"))
     check_qc(g, buf, metas)
     check_adapter(g, buf, metas)
     check_pertile(g, buf, metas)
@@ -114,8 +114,8 @@ def test_single_end_files(name):
 @pytest.mark.parametrize("name", ["ref_LTB_paired"] + golden_names("synth_*paired*"))
 def test_paired_files(name):
     g = golden(name)
-    b1 = split_fastq(g["fastq1"].tobytes())
-    b2 = split_fastq(g["fastq2"].tobytes())
+    b1 = split_fastq(golden_text(g, "fastq1"))
+    b2 = split_fastq(golden_text(g, "fastq2"))
     check_qc(g, *b1, prefix="qc1_")
     check_qc(g, *b2, prefix="qc2_")
     check_pertile(g, *b1, prefix="pt1_")
@@ -134,7 +134,7 @@ def test_paired_files(name):
 @pytest.mark.parametrize("name", golden_names("inline_qc_[0-9]*"))
 def test_inline_qc(name):
     g = golden(name)
-    check_qc(g, *split_fastq(g["fastq"].tobytes()))
+    check_qc(g, *split_fastq(golden_text(g, "fastq")))
 
 
 def test_inline_qc_long_quality():
@@ -164,38 +164,38 @@ def test_h1_uniform_quality_grid():
 @pytest.mark.parametrize("name", golden_names("inline_adapter_*"))
 def test_inline_adapter(name):
     g = golden(name)
-    check_adapter(g, *split_fastq(g["fastq"].tobytes()))
+    check_adapter(g, *split_fastq(golden_text(g, "fastq")))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_pertile_*"))
 def test_inline_pertile(name):
     g = golden(name)
-    check_pertile(g, *split_fastq(g["fastq"].tobytes()))
+    check_pertile(g, *split_fastq(golden_text(g, "fastq")))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_overrep_*"))
 def test_inline_overrep(name):
     g = golden(name)
-    check_overrep(g, *split_fastq(g["fastq"].tobytes()))
+    check_overrep(g, *split_fastq(golden_text(g, "fastq")))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_dedup_cap*"))
 def test_inline_dedup_caps(name):
     g = golden(name)
-    check_dedup(g, split_fastq(g["fastq"].tobytes()))
+    check_dedup(g, split_fastq(golden_text(g, "fastq")))
 
 
 @pytest.mark.parametrize("name", golden_names("inline_dedup_geom_*"))
 def test_inline_dedup_geometry(name):
     g = golden(name)
-    check_dedup(g, split_fastq(g["fastq"].tobytes()))
-    check_dedup(g, split_fastq(g["fastq1"].tobytes()), split_fastq(g["fastq2"].tobytes()), prefix="ddp_")
+    check_dedup(g, split_fastq(golden_text(g, "fastq")))
+    check_dedup(g, split_fastq(golden_text(g, "fastq1")), split_fastq(golden_text(g, "fastq2")), prefix="ddp_")
 
 
 @pytest.mark.parametrize("name", golden_names("inline_insert_*"))
 def test_inline_insert(name):
     g = golden(name)
-    check_insert(g, split_fastq(g["fastq1"].tobytes()), split_fastq(g["fastq2"].tobytes()))
+    check_insert(g, split_fastq(golden_text(g, "fastq1")), split_fastq(golden_text(g, "fastq2")))
 
 
 def test_is_mate():
