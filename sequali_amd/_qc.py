@@ -557,36 +557,47 @@ class QCMetrics:
         view = _require_view(read)
         arr = FastqRecordArrayView([view])
         self.add_record_array(arr)
-        try:
-            self.flush()
-        except ValueError:
-            q = view.qualities()
-            bad = next((c for c in q if not 33 <= ord(c) <= 33 + PHRED_MAX), "?")
-            raise ValueError(f"Not a valid phred character: {bad}") from None
+        self.flush()
         view._meta["accumulated_error_rate"] = arr._metas["accumulated_error_rate"]
 
     def flush(self) -> None:
         """Waits for the enqueued passes, writes accumulated_error_rate back into the
-        arrays that went through (:2126) and raises a deferred ValueError."""
+        arrays that went through (:2126) and raises a deferred ValueError.
+
+        An invalid phred character (:2073-2075, 2102-2105): the reference raises inside the call
+        that brought the array, with the reads in front of the offending one counted, the
+        offender's bases and the phred counts in front of the character too, and nothing else.
+        The passes here run whole batches and flag the read; the flag is found at this point.
+        Every array since the last flush is then asked for its first offending record and has
+        its tail taken back (sq_qcmetrics_uncount_tail), so the tables are what the reference's
+        would be had each of those calls raised; the error of the first one is raised, and the
+        object stays usable."""
         pending, self._pending = self._pending, []
         rc = lib().sq_qcmetrics_flush(self._h)
+        error = None
+        if rc < 0:
+            msg = _lib.last_error()
+            for arr in pending:
+                if arr._batch is None or not len(arr):
+                    continue
+                idx = lib().sq_batch_first_invalid_phred(arr._batch.handle)
+                if idx < 0:
+                    continue
+                check(lib().sq_qcmetrics_uncount_tail(self._h, arr._batch.handle, idx))
+                if error is None:
+                    view = arr[int(idx)]
+                    q = view._slice("qualities_offset", int(view._meta[0]["sequence_length"]))
+                    bad = next((c for c in q if not 33 <= c <= 33 + PHRED_MAX), ord("?"))
+                    error = ValueError(f"Not a valid phred character: {chr(bad)}")
+            if error is None:
+                error = ValueError(msg)
+            check(lib().sq_qcmetrics_flush(self._h))    # the log of the handled batches ends here
         for arr in pending:
             if arr._metas is not None and arr._batch is not None and len(arr._metas):
                 arr._metas["accumulated_error_rate"] = arr._batch.error_rates()
             arr._writeback = None
-        if rc < 0:
-            msg = _lib.last_error()
-            # find the character the reference would name (:2102-2105)
-            for arr in pending:
-                if arr._metas is None:
-                    continue
-                for m in arr._metas:
-                    s = int(m["record_start"]) + int(m["qualities_offset"])
-                    q = np.frombuffer(arr.obj, dtype=np.uint8, count=int(m["sequence_length"]), offset=s)
-                    bad = np.nonzero((q < 33) | (q > 33 + PHRED_MAX))[0]
-                    if len(bad):
-                        raise ValueError(f"Not a valid phred character: {chr(q[int(bad[0])])}")
-            raise ValueError(msg)
+        if error is not None:
+            raise error
 
     @property
     def number_of_reads(self) -> int:

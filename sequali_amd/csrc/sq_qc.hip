@@ -2187,6 +2187,75 @@ __global__ void k_stripe_counts(const sq_meta *metas, const uint32_t *order, uin
     counts[w] = lo;
 }
 
+
+/* ---- an invalid phred byte (_qcmodule.c:2073-2075, 2102-2105) ---------------------------------
+ * The reference raises at the read that holds it: that read's bases (both tables) and GC bin are
+ * counted, its phred counts in front of the byte too; nothing behind the byte, not its
+ * end-anchored phred counts, not its phred_scores bin, no accumulated_error_rate; the reads
+ * behind it in the array are never looked at.  The passes above run the whole batch (an invalid
+ * byte counts in phred bin 11, its read's sum is NaN and lands in phred_scores[0]) and only
+ * flag the read.  When the flag is found the host runs these two kernels over that batch:
+ * k_first_invalid finds its first offending read, k_qc_uncount takes back, count by count, what
+ * the pass added for the reads behind it and for the part of the offender the reference never
+ * reached. */
+__global__ void k_first_invalid(const uint8_t *buf, const sq_meta *metas, uint64_t n, unsigned long long *first)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const sq_meta m = metas[r];
+        const uint8_t *q = buf + m.record_start + m.qualities_offset;
+        bool bad = false;
+        for (uint32_t p = 0; p < m.sequence_length && !bad; p++) bad = (uint8_t)(q[p] - 33) > SQ_PHRED_MAX;
+        if (bad) atomicMin(first, (unsigned long long)r);
+    }
+}
+
+__global__ void k_qc_uncount(PassParams P, uint64_t first)
+{
+    const unsigned long long minus1 = ~0ULL;
+    for (uint64_t r = first + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const sq_meta m = P.metas[r];
+        const uint32_t L = m.sequence_length;
+        const uint8_t *s = P.buf + m.record_start + m.sequence_offset, *q = P.buf + m.record_start + m.qualities_offset;
+        const uint32_t ean = min(P.ea_len, L), ea0 = P.ea_len - ean; /* :1971-1972 */
+        const bool offender = r == first;
+        uint32_t from = 0; /* phred counts are taken back from this position on */
+        if (offender) while (from < L && (uint8_t)(q[from] - 33) <= SQ_PHRED_MAX) from++;
+        uint32_t gc = 0, acgt = 0;
+        for (uint32_t p = 0; p < L; p++) {
+            const uint32_t c = sq_base_class(s[p]);
+            gc += c == 1 || c == 2;
+            acgt += c < 4;
+            if (!offender) {
+                atomicAdd(&P.qc_base[(uint64_t)p * 5 + c], minus1);
+                if (p >= L - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(ea0 + p - (L - ean)) * 5 + c], minus1);
+            }
+            const uint32_t bin = min((uint32_t)q[p] - 33u, 47u) >> 2; /* what the passes count, invalid bytes in bin 11 */
+            if (p >= from) atomicAdd(&P.qc_phred[(uint64_t)p * 12 + bin], minus1);
+            if (p >= L - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(ea0 + p - (L - ean)) * 12 + bin], minus1);
+        }
+        if (!offender && acgt > 0) atomicAdd(&P.qc_gc[(uint32_t)round((double)gc * 100.0 / (double)acgt)], minus1);
+        if (L > 0) { /* the bin the pass put the read's sum in (NaN: bin 0) */
+            const double avg = m.accumulated_error_rate / (double)L;
+            uint32_t lo = 0, hi = 93;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (avg <= P.thresholds[mid]) lo = mid; else hi = mid - 1;
+            }
+            atomicAdd(&P.qc_ps[lo], minus1);
+        }
+        P.metas[r].accumulated_error_rate = 0.0; /* never written by the reference: what the parser left */
+    }
+}
+
+__global__ void k_max_length(const sq_meta *metas, uint64_t n, unsigned long long *out)
+{
+    unsigned long long mx = 0;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        mx = max(mx, (unsigned long long)metas[r].sequence_length);
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+}
+
 int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
 {
     uint64_t groups = (n + 63) / 64;
@@ -2210,7 +2279,11 @@ struct sq_qcmetrics {
     double *d_thr = nullptr;
     unsigned long long *d_first_bad = nullptr;
     uint64_t records_seen = 0;
-    std::vector<sq_batch *> pending; /* batches whose host copy may be needed for the error text */
+    /* batches since the last flush (never dereferenced: identity only) and their longest read:
+       max_length after an invalid phred byte took the tail of one of them back */
+    struct Seen { const sq_batch *b; uint64_t max_length; };
+    std::vector<Seen> seen;
+    uint64_t max_length_flushed = 0;
 };
 
 struct sq_adaptercounter {
@@ -2941,7 +3014,11 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         }
         if (ring || wide || span_done) P = Pfull;
     }
-    if (m) { m->number_of_reads += b->n; m->records_seen += b->n; }
+    if (m) {
+        m->number_of_reads += b->n; m->records_seen += b->n;
+        if (m->seen.size() >= 4096) { m->max_length_flushed = m->max_length; m->seen.clear(); } /* a caller that never flushes */
+        m->seen.push_back({b, b->max_length});
+    }
     if (a) a->number_of_sequences += b->n;
     if (p) p->records_seen += b->n;
     return SQ_OK;
@@ -2959,11 +3036,65 @@ SQ_EXPORT int sq_qcmetrics_flush(sq_qcmetrics *m)
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->pinned[8] != UINT64_MAX) {
-        /* _qcmodule.c:2102-2105.  Deferred: the whole batch has been applied. */
-        sq_set_error("Not a valid phred character in record %llu",
-                     (unsigned long long)ctx->pinned[8]);
+        /* _qcmodule.c:2102-2105, deferred: every batch since the last flush has been applied in
+           full.  The caller names the batches (sq_batch_first_invalid_phred) and has their tails
+           taken back (sq_qcmetrics_uncount_tail); the flag is rearmed, the object stays usable as
+           the reference's does */
+        const unsigned long long bad = ctx->pinned[8];
+        SQ_HIP(hipMemsetAsync(m->d_first_bad, 0xFF, 8, ctx->stream));
+        sq_set_error("Not a valid phred character in record %llu", bad);
         return SQ_ERR_VALUE;
     }
+    m->max_length_flushed = m->max_length;
+    m->seen.clear();
+    return SQ_OK;
+}
+
+/* index of the first record of b with a quality byte outside 33 .. 126, -1: none */
+SQ_EXPORT int64_t sq_batch_first_invalid_phred(sq_batch *b)
+{
+    if (!b->n) return -1;
+    sq_ctx *ctx = b->ctx;
+    unsigned long long *d = (unsigned long long *)sq_scratch(ctx, 0, 64);
+    if (!d) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemsetAsync(d, 0xFF, 8, ctx->stream));
+    hipLaunchKernelGGL(k_first_invalid, dim3((unsigned)std::min<uint64_t>((b->n + 255) / 256, 4096)), dim3(256), 0,
+                       ctx->stream, b->d_buf, b->d_metas, (uint64_t)b->n, d);
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    return ctx->pinned[9] == UINT64_MAX ? -1 : (int64_t)ctx->pinned[9];
+}
+
+/* b went through this object since its last successful flush and record `first` of it holds an
+ * invalid phred byte: leaves the tables as the reference's are behind its ValueError (see
+ * k_qc_uncount).  Call sq_qcmetrics_flush again when every such batch has been handled. */
+SQ_EXPORT int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t first)
+{
+    if (first >= b->n) { sq_set_error("sq_qcmetrics_uncount_tail: record index out of range"); return SQ_ERR_VALUE; }
+    sq_ctx *ctx = m->ctx;
+    PassParams P{};
+    P.buf = b->d_buf; P.buf_len = b->buf_len; P.metas = b->d_metas; P.n = b->n;
+    P.qc_base = m->d_base; P.qc_phred = m->d_phred; P.qc_ea_base = m->d_ea_base; P.qc_ea_phred = m->d_ea_phred;
+    P.qc_gc = m->d_gc; P.qc_ps = m->d_ps; P.ea_len = (uint32_t)m->end_anchor; P.thresholds = m->d_thr;
+    const uint64_t tail = b->n - first;
+    hipLaunchKernelGGL(k_qc_uncount, dim3((unsigned)std::min<uint64_t>((tail + 255) / 256, 4096)), dim3(256), 0, ctx->stream, P, first);
+    SQ_HIP(hipGetLastError());
+    /* longest read among the records the reference did look at */
+    unsigned long long *d = (unsigned long long *)sq_scratch(ctx, 0, 64);
+    if (!d) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_max_length, dim3((unsigned)std::min<uint64_t>((first + 256) / 256, 4096)), dim3(256), 0, ctx->stream,
+                       b->d_metas, first + 1, d);
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    m->number_of_reads -= tail - 1;
+    uint64_t ml = m->max_length_flushed;
+    bool found = false;
+    for (auto &sn : m->seen) {
+        if (sn.b == b && !found) { sn.max_length = ctx->pinned[9]; found = true; }
+        ml = std::max(ml, sn.max_length);
+    }
+    if (found) m->max_length = ml;
     return SQ_OK;
 }
 
@@ -2972,27 +3103,34 @@ SQ_EXPORT int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_l
     sq_batch *b = sq_batch_upload(m->ctx, buf, buf_len, metas, n);
     if (!b) return SQ_ERR_MEMORY;
     int rc = sq_qcmetrics_add_batch(m, b);
-    if (rc == SQ_OK && n) {
-        std::vector<double> errs(n);
-        rc = sq_batch_error_rates(b, errs.data(), n);
-        for (size_t i = 0; i < n && rc == SQ_OK; i++) metas[i].accumulated_error_rate = errs[i];
-    }
     if (rc == SQ_OK) {
-        /* surface an invalid phred byte now, with the reference's message */
+        /* surface an invalid phred byte now, with the reference's message and its partial state */
         sq_ctx *ctx = m->ctx;
         hipError_t e = hipMemcpy(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost);
         if (e == hipSuccess && ctx->pinned[8] != UINT64_MAX) {
-            uint64_t idx = ctx->pinned[8] - (m->records_seen - n);
+            (void)hipMemset(m->d_first_bad, 0xFF, 8);
+            const int64_t idx = sq_batch_first_invalid_phred(b);
             char bad = '?';
-            if (idx < n) {
+            if (idx >= 0) {
+                rc = sq_qcmetrics_uncount_tail(m, b, (uint64_t)idx);
                 const uint8_t *q = buf + metas[idx].record_start + metas[idx].qualities_offset;
                 for (uint32_t k = 0; k < metas[idx].sequence_length; k++)
                     if ((uint8_t)(q[k] - 33) > SQ_PHRED_MAX) { bad = (char)q[k]; break; }
             }
-            sq_set_error("Not a valid phred character: %c", bad);
-            rc = SQ_ERR_VALUE;
+            if (rc == SQ_OK) {
+                sq_set_error("Not a valid phred character: %c", bad);
+                rc = SQ_ERR_VALUE;
+            }
         }
     }
+    if (n && (rc == SQ_OK || rc == SQ_ERR_VALUE)) {
+        std::vector<double> errs(n);
+        int rc2 = sq_batch_error_rates(b, errs.data(), n);
+        for (size_t i = 0; i < n && rc2 == SQ_OK; i++) metas[i].accumulated_error_rate = errs[i];
+        if (rc == SQ_OK) rc = rc2;
+    }
+    /* the batch dies here: nothing of it may stay in the log */
+    for (auto &sn : m->seen) if (sn.b == b) sn.b = nullptr;
     sq_batch_free(b);
     return rc;
 }

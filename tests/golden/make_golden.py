@@ -408,6 +408,58 @@ def main():
         json.dump([[a, b, bool(g)] for (a, b, _), g in zip(names, got)], f, indent=0)
 
 
+def invalid_phred():
+    """The state the reference's QCMetrics is left in behind `ValueError: Not a valid phred
+    character` (_qcmodule.c:2073-2075, 2102-2105), and that the object stays usable: arrays
+    before, the array that raises (bad byte in the unrolled part, in the trailing 1-4 qualities,
+    at position 0, two bad reads in one array, a longer read behind the offender), one array
+    after it.  -> inline_qc_invalid_phred_<k>.npz"""
+    rng = np.random.default_rng(99)
+
+    def fastq(n, L, bad=()):
+        recs = []
+        for i in range(n):
+            Li = L if isinstance(L, int) else int(L[i])
+            s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=Li, p=[.24, .24, .24, .24, .04]).tobytes()
+            q = bytearray((rng.integers(0, 94, size=Li) + 33).astype(np.uint8).tobytes())
+            for (r, pos, ch) in bad:
+                if r == i:
+                    q[pos] = ch
+            recs.append(b"@r%d\n%s\n+\n%s\n" % (i, s, bytes(q)))
+        return b"".join(recs)
+
+    cases = [
+        (150, [(70, 149, 32)]),            # the trailing qualities (:2100-2105)
+        (150, [(3, 0, 127)]),              # position 0, a byte above the range
+        (100, [(191, 64, 10 + 22)]),       # inside the unrolled part (:2073-2075)
+        (70, [(130, 67, 32), (150, 3, 32)]),   # a second bad read behind the first: never looked at
+        (np.r_[np.full(100, 40), 300, np.full(99, 40)].astype(int), [(50, 39, 31)]),  # the longest read lies behind the offender
+        (5, [(0, 4, 32)]),                 # the very first read of the array
+    ]
+    for k, (L, bad) in enumerate(cases):
+        n = 200
+        texts = [fastq(64, 60), fastq(n, L, bad), fastq(30, 90)]
+        m = _qc.QCMetrics()
+        raised = []
+        errs = []
+        for t in texts:
+            for a in arrays_of(t, 1 << 20):
+                try:
+                    m.add_record_array(a)
+                    raised.append("")
+                except ValueError as e:
+                    raised.append(str(e))
+                errs.append(error_rates_of(a))
+        save(f"inline_qc_invalid_phred_{k}", fastq0=np.frombuffer(texts[0], np.uint8), fastq1=np.frombuffer(texts[1], np.uint8),
+             fastq2=np.frombuffer(texts[2], np.uint8), raised=np.array(raised),
+             qc_base=np.array(m.base_count_table(), np.uint64), qc_phred=np.array(m.phred_count_table(), np.uint64),
+             qc_ea_base=np.array(m.end_anchored_base_count_table(), np.uint64),
+             qc_ea_phred=np.array(m.end_anchored_phred_count_table(), np.uint64),
+             qc_gc=np.array(m.gc_content(), np.uint64), qc_phred_scores=np.array(m.phred_scores(), np.uint64),
+             qc_number_of_reads=np.uint64(m.number_of_reads), qc_max_length=np.uint64(m.max_length),
+             qc_error_rates=np.concatenate(errs))
+
+
 def synthetic():
     """(3) slices of the build's own synthetic generator (needs libsqgpu.so's host
     generator; run after `python -c 'import __graft_entry__ as g; g.build()'`)."""
@@ -715,6 +767,8 @@ if __name__ == "__main__":
         bam()
     elif len(sys.argv) > 1 and sys.argv[1] == "nanostats":
         nanostats()
+    elif len(sys.argv) > 1 and sys.argv[1] == "invalid_phred":
+        invalid_phred()
     elif len(sys.argv) > 1 and sys.argv[1] == "synthetic":
         synthetic()
     elif len(sys.argv) > 1 and sys.argv[1] == "parser":

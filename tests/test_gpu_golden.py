@@ -270,3 +270,55 @@ def test_is_mate():
         x = FastqRecordArrayView([FastqRecordView(a, "A", "A")])
         y = FastqRecordArrayView([FastqRecordView(b, "A", "A")])
         assert x.is_mate(y) is want, (a, b)
+
+
+@pytest.mark.parametrize("name", golden_names("inline_qc_invalid_phred_*"))
+@pytest.mark.parametrize("env", [{}, {"SQ_NO_WIDE": "1", "SQ_NO_RING": "1"}, {"SQ_SPAN": "1"}])
+def test_qc_state_behind_an_invalid_phred_character(name, env):
+    """_qcmodule.c:2073-2075, 2102-2105.  The passes run whole batches and flag the read; the
+    ValueError comes out of the next flush, which first takes back what the reference would not
+    have counted (sq_qcmetrics_uncount_tail): every table, number_of_reads, max_length and the
+    accumulated_error_rate of every record as in the reference behind its exception, the
+    reference's message, and an object that goes on counting (the array behind the bad one).
+    Once with all three arrays enqueued before the flush, once with a flush per array."""
+    import os
+    from sequali_amd import FastqRecordArrayView, QCMetrics
+    from tests.helpers import split_fastq
+    g = golden(name)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for flush_each in (False, True):
+            m = QCMetrics()
+            arrays, first_msg = [], None
+            for k, msg in enumerate(g["raised"]):
+                buf, metas = split_fastq(golden_text(g, f"fastq{k}"))
+                arr = FastqRecordArrayView._from_buffer(buf, metas)
+                arrays.append(arr)
+                m.add_record_array(arr)
+                if flush_each:
+                    if msg:
+                        with pytest.raises(ValueError) as e:
+                            m.flush()
+                        assert str(e.value) == str(msg)
+                    else:
+                        m.flush()
+                elif msg and first_msg is None:
+                    first_msg = str(msg)
+            if not flush_each:
+                with pytest.raises(ValueError) as e:
+                    m.flush()
+                assert str(e.value) == first_msg
+            assert m.number_of_reads == int(g["qc_number_of_reads"]) and m.max_length == int(g["qc_max_length"])
+            for key, got in [("base", m.base_count_table()), ("phred", m.phred_count_table()),
+                             ("ea_base", m.end_anchored_base_count_table()), ("ea_phred", m.end_anchored_phred_count_table()),
+                             ("gc", m.gc_content()), ("phred_scores", m.phred_scores())]:
+                np.testing.assert_array_equal(np.array(got, np.uint64), g["qc_" + key], err_msg=key)
+            errs = np.concatenate([a.accumulated_error_rates() for a in arrays])
+            np.testing.assert_array_equal(errs.view(np.uint64), g["qc_error_rates"].view(np.uint64))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -201,3 +201,27 @@ def test_inline_insert(name):
 def test_is_mate():
     for a, b, want in golden_json("is_mate"):
         assert oracle.names_are_mates(a, b) is want, (a, b)
+
+
+@pytest.mark.parametrize("name", golden_names("inline_qc_invalid_phred_*"))
+def test_qc_state_behind_an_invalid_phred_character(name):
+    """_qcmodule.c:2073-2075, 2102-2105: what the reference has counted when it raises, and that
+    it goes on counting afterwards"""
+    g = golden(name)
+    m = oracle.QCMetrics()
+    errs = []
+    for k, msg in enumerate(g["raised"]):
+        buf, metas = split_fastq(golden_text(g, f"fastq{k}"))
+        if msg:
+            with pytest.raises(ValueError) as e:
+                m.add(buf, metas)
+            assert str(e.value) == str(msg)
+        else:
+            m.add(buf, metas)
+        errs.append(metas["accumulated_error_rate"])
+    assert m.number_of_reads == int(g["qc_number_of_reads"]) and m.max_length == int(g["qc_max_length"])
+    for key, got in [("base", m.base_count_table()), ("phred", m.phred_count_table()),
+                     ("ea_base", m.end_anchored_base_count_table()), ("ea_phred", m.end_anchored_phred_count_table()),
+                     ("gc", m.gc_content()), ("phred_scores", m.phred_scores())]:
+        np.testing.assert_array_equal(got, g["qc_" + key], err_msg=key)
+    np.testing.assert_array_equal(np.concatenate(errs).view(np.uint64), g["qc_error_rates"].view(np.uint64))
