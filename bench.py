@@ -46,10 +46,12 @@ def parse_args():
                     help="records per GPU (default 100 M illumina / 1 M nanopore)")
     ap.add_argument("--batch-reads", type=int, default=None,
                     help="records per launch (default 25 M illumina / 1 M nanopore)")
-    ap.add_argument("--cpu-passes", type=int, default=6,
-                    help="times the CPU baseline walks its sample (about 10 s of CPU work by default)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
+    ap.add_argument("--cpu-passes", type=int, default=3,
+                    help="times the CPU baseline walks its sample (about 12 s of CPU work by default)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="records of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip configs 3, 4 and the ragged variant (other_configs of the JSON line)")
     ap.add_argument("--modules", default="qc,adapter", help="qc,adapter[,pertile]")
     ap.add_argument("--kind", default="illumina", choices=["illumina", "nanopore"],
                     help="illumina: 150 bp (configs 2/5); nanopore: ~10 kb variable length (config 4)")
@@ -109,6 +111,31 @@ def dominant_kernel(kind, mods):
     return "k_pass (fused per-base pass)"
 
 
+def host_cpu():
+    """model name and core count of the box the CPU baseline ran on"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def csrc_sha():
+    """SHA-256 over the kernel sources: profiles/traffic.json records the one it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sequali_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(sample_reads: int, passes: int = 1):
     """One QC thread (the reference's second thread only decompresses,
     __main__.py:189-192) over the first `sample_reads` records of the workload."""
@@ -148,9 +175,113 @@ def cpu_baseline(sample_reads: int, passes: int = 1):
         dt = time.perf_counter() - t0
         check = int(m.base_count_table().sum())
     assert check == bases * passes
+    model, cores = host_cpu()
     return {"value": round(bases * passes / dt / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": kind,
+            "host_cpu": model, "host_cores": cores,
             "sample": f"first {sample_reads} records of the workload ({bases} bases) x {passes} passes, "
-                      f"QCMetrics+AdapterCounter, {dt:.2f} s"}
+                      f"QCMetrics+AdapterCounter on one thread (the reference's second thread only decompresses), {dt:.2f} s"}
+
+
+def other_configs(lib, ctx, steps, warmup):
+    """BASELINE configs 3 and 4 and the ragged variant of config 2, each timed like the headline:
+    records resident in HBM, `steps` passes behind `warmup`, HIP events on the library's stream
+    around every pass; achieved = algorithmic bytes / pass time."""
+    import numpy as np
+    from sequali_amd import (AdapterCounter, FusedPass, InsertSizeMetrics, PerTileQuality, QCMetrics, _lib, synth)
+
+    def run(name, workload, kernel, arrays_bases_reads, make, step, check):
+        bases, reads, algo = arrays_bases_reads
+        objs = make()
+        for _ in range(warmup):
+            step(objs)
+        _lib.synchronize()
+        ev = HipEvents(lib.sq_stream_handle(ctx))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ev.start()
+            step(objs)
+            ev.stop()
+        _lib.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ms = ev.durations_ms()
+        avg = sum(ms) / len(ms)
+        achieved = algo / (avg * 1e-3) / 1e9
+        return {"workload": workload, "value": round(bases / dt / 1e9, 3), "unit": "Gbases/s",
+                "ms_per_step": round(dt * 1e3, 3),
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBPS, 5), "kernel": kernel,
+                             "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_step": int(algo)},
+                "checks": check(objs, steps + warmup)}
+
+    def clear(f):
+        f.qc_metrics._pending.clear()
+
+    out = {}
+    # ---- ragged: the config-2 records cut to 50 .. 150 bases (what adapter trimming leaves) ----
+    n, per = 50_000_000, 25_000_000
+    batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
+    for k, b in enumerate(batches):
+        _lib.check(lib.sq_synth_trim(b._batch.handle, 77 + k, 50))
+    bases = sum(b._batch.total_bases for b in batches)
+
+    def ragged_step(f):
+        for b in batches:
+            f.add_record_array(b)
+            clear(f)
+
+    out["ragged_50_150"] = run(
+        "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
+        "QCMetrics + AdapterCounter fused, records resident in HBM",
+        "k_pass<QC,AD> (general fused per-base pass, length-sorted walk)", (bases, n, 2 * bases + 48 * n),
+        lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
+        lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                           "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+    del batches
+    # ---- config 3: 100 M pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics ----
+    n, per = 100_000_000, 25_000_000
+    r1 = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
+    r2 = [synth.device_array(synth.ILLUMINA_R2, k * per, per) for k in range(n // per)]
+    bases = sum(b._batch.total_bases for b in r1) + sum(b._batch.total_bases for b in r2)
+    name_len = 36
+
+    def c3_make():
+        return (FusedPass(QCMetrics(), None, PerTileQuality()), FusedPass(QCMetrics(), None, PerTileQuality()), InsertSizeMetrics())
+
+    def c3_step(o):
+        fa, fb, isz = o
+        for a, b in zip(r1, r2):
+            fa.add_record_array(a); clear(fa)
+            fb.add_record_array(b); clear(fb)
+            isz.add_record_array_pair(a, b)
+
+    def c3_check(o, passes):
+        fa, fb, isz = o
+        return {"base_table_sums_ok": bool(int(np.array(fa.qc_metrics.base_count_table(), np.uint64).sum()) +
+                                           int(np.array(fb.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                "pertile_reads_ok": bool(fa.per_tile_quality.number_of_reads == n * passes and fb.per_tile_quality.number_of_reads == n * passes),
+                "insert_size_pairs_ok": bool(isz.total_reads == n * passes)}
+
+    out["config3_paired"] = run(
+        "config3", f"{n} x 150 bp synthetic pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM",
+        "k_wide<false> + k_ptq per side (two reads of the batch), k_insert_size", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
+        c3_make, c3_step, c3_check)
+    del r1, r2
+    # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
+    n = 1_000_000
+    arr = synth.device_array(synth.NANOPORE, 0, n)
+    bases = arr._batch.total_bases
+
+    def c4_step(f):
+        f.add_record_array(arr)
+        clear(f)
+
+    out["config4_nanopore"] = run(
+        "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
+        "k_seg<true> (+ k_read_sums, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
+        lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
+        lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                           "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+    return out
 
 
 def main():
@@ -158,7 +289,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ["SQ_DEVICE"] = str(local_rank)
+    os.environ.setdefault("SQ_DEVICE", str(local_rank))   # tests put two ranks on one GPU
+    device_index = int(os.environ["SQ_DEVICE"])
 
     dist = None
     torch = None
@@ -166,8 +298,12 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        backend = os.environ.get("SQ_BENCH_BACKEND", "nccl")   # gloo: tests with both ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import numpy as np
     from sequali_amd import AdapterCounter, PerTileQuality, QCMetrics, _lib, synth
@@ -192,7 +328,7 @@ def main():
         done += n
     total_bases = sum(b._batch.total_bases for b in batches)
 
-    device = f"cuda:{local_rank}"
+    device = f"cuda:{device_index}"
     scratch = []
 
     def step(events=None):
@@ -206,18 +342,22 @@ def main():
         _lib.synchronize()
         if use_dist:
             # the job's one exchange step: sum the count tables of all ranks over RCCL, as ONE
-            # all-reduce over one flat buffer (on a copy, so that repeated steps keep
-            # accumulating the local counts); the aliases and the buffer are set up once
+            # all-reduce over one flat buffer (on a copy, so that repeated steps keep accumulating
+            # the local counts).  Set up once, behind the first pass: the ranks agree on the
+            # job's longest read and longest adapter row first (their shards may differ), so
+            # that every rank presents the same shapes
+            from sequali_amd import dist as sqdist
             if not scratch:
-                from sequali_amd import dist as sqdist
-                tables = (sqdist.qcmetrics_tables(qc, device) if qc else []) + \
+                ml = sqdist.agree_on_shapes(qc, ad, device)
+                tables = (sqdist.qcmetrics_tables(qc, device, ml) if qc else []) + \
                          (sqdist.adaptercounter_tables(ad, device) if ad else [])
                 tables = [t.reshape(-1) for t in tables if t.dtype == torch.int64]
                 flat = torch.empty(sum(t.numel() for t in tables), dtype=torch.int64, device=device)
                 scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables]))])
             tables, flat, parts = scratch
             torch._foreach_copy_(parts, tables)
-            dist.all_reduce(flat)
+            scratch.append(sqdist._all_reduce(flat))   # in place over RCCL (through the host under gloo)
+            del scratch[3:-1]
             torch.cuda.synchronize()
 
     def barrier():
@@ -237,10 +377,11 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms = events.durations_ms()
 
+    job_bases = world * total_bases
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from sequali_amd import dist as sqdist
+        elapsed = float(sqdist._all_reduce(torch.tensor([elapsed], dtype=torch.float64, device=device), dist.ReduceOp.MAX).item())
+        job_bases = int(sqdist._all_reduce(torch.tensor([total_bases], dtype=torch.int64, device=device)).item())
 
     # ---- size-independent checks at full size ----
     passes = args.warmup + args.steps
@@ -256,6 +397,10 @@ def main():
                                         <= args.reads * passes)
         checks["phred_scores_sum_ok"] = bool(int(np.array(qc.phred_scores(), dtype=np.uint64).sum())
                                              == args.reads * passes)
+        if use_dist and scratch and passes > 0:
+            # what the last step's all-reduce delivered: the base table of the whole job
+            reduced = scratch[-1][:scratch[0][0].numel()]   # the first table of the flat buffer is base_counts
+            checks["reduced_base_table_sum_ok"] = bool(int(reduced.sum().item()) == job_bases * passes)
     if ad is not None:
         counts = ad.get_counts()
         checks["adapter_fwd_eq_rev_ok"] = bool(all(
@@ -263,7 +408,7 @@ def main():
             for _, f, r in counts))
 
     if rank == 0:
-        value = world * total_bases * args.steps / elapsed / 1e9
+        value = job_bases * args.steps / elapsed / 1e9
         avg_ms = sum(launch_ms) / max(len(launch_ms), 1)
         reads_per_launch = sum(len(b) for b in batches) / len(batches)
         # 2 B/base + 40 B/read meta + 8 B/read error-rate write-back
@@ -273,8 +418,9 @@ def main():
         if os.path.exists(tpath):   # PMC passes cannot run inside this process; see profiles/README.md
             with open(tpath) as f:
                 tj = json.load(f)
+            # only a measurement of THIS build counts: the file names the kernel sources it was taken on
             if tj.get("reads_per_launch") == int(reads_per_launch) and tj.get("kind") == args.kind \
-                    and tj.get("modules") == sorted(mods):
+                    and tj.get("modules") == sorted(mods) and tj.get("csrc_sha") == csrc_sha():
                 traffic = tj.get("hbm_bytes_per_launch")
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -294,6 +440,12 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launch_ms)},
             "checks": checks,
         }
+        if world == 1 and not use_dist and args.other_configs and args.kind == "illumina":
+            del batches[:]
+            try:
+                out["other_configs"] = other_configs(lib, ctx, max(1, min(args.steps, 3)), 1)
+            except Exception as e:   # never a reason to lose the headline
+                out["other_configs"] = {"error": repr(e)}
         if world == 1 and args.cpu_sample > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.reads), max(1, args.cpu_passes))

@@ -349,6 +349,11 @@ int sq_qcmetrics_reserve(sq_qcmetrics *m, uint64_t length);
 int sq_qcmetrics_set_totals(sq_qcmetrics *m, uint64_t number_of_reads, uint64_t max_length);
 int sq_adaptercounter_reserve(sq_adaptercounter *a, uint64_t length);
 int sq_adaptercounter_set_totals(sq_adaptercounter *a, uint64_t number_of_sequences, uint64_t max_length);
+/* Row length (in counters) of the forward / reverse tables, and a regrow to exactly `row_length`
+ * (>= the current one): sq_adaptercounter_reserve grows geometrically, so ranks with different
+ * batch histories hold different row lengths; the merge agrees on the largest first. */
+uint64_t sq_adaptercounter_row_length(sq_adaptercounter *a);
+int sq_adaptercounter_set_row_length(sq_adaptercounter *a, uint64_t row_length);
 
 /* ---- synthetic FASTQ (bench / tests): counter-based, host == device bytes -- */
 #define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */
@@ -362,6 +367,11 @@ uint64_t sq_synth_bytes(int kind, uint64_t seed, uint64_t first, uint64_t n);
 int sq_synth_host(int kind, uint64_t seed, uint64_t first, uint64_t n, uint8_t *buf,
                   size_t buf_cap, sq_meta *metas);
 sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64_t first, uint64_t n);
+/* Cuts every read of a batch in HBM to a length in [lo, its length], by a hash of (seed, record
+ * index): what adapter trimming leaves of a file of one read length (bench / tests: the ragged
+ * variant of the synthetic workload).  Only sequence_length changes; the statistics of the batch
+ * are recomputed. */
+int sq_synth_trim(sq_batch *b, uint64_t seed, uint32_t lo);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 /* sq_api.hip -- context, batches, host-side record boundary, synthetic FASTQ */
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include "sq_common.h"
 #include "sq_synth_core.h"
 
@@ -952,4 +953,42 @@ SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64
     }
     if (d_offs) (void)hipFree(d_offs);
     return b;
+}
+
+namespace {
+__global__ void k_synth_trim(sq_meta *metas, uint64_t n, uint64_t seed, uint32_t lo)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t L = metas[i].sequence_length;
+        if (L <= lo) continue;
+        uint64_t h = (seed ^ i) * 0x9E3779B97F4A7C15ULL;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+        metas[i].sequence_length = lo + (uint32_t)(h % (L - lo + 1));
+    }
+}
+} // namespace
+
+SQ_EXPORT int sq_synth_trim(sq_batch *b, uint64_t seed, uint32_t lo)
+{
+    if (!b->n) return SQ_OK;
+    sq_ctx *ctx = b->ctx;
+    hipLaunchKernelGGL(k_synth_trim, dim3((unsigned)std::min<uint64_t>((b->n + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                       b->d_metas, (uint64_t)b->n, seed, lo);
+    unsigned long long *d_out = nullptr;
+    SQ_HIP(hipMalloc((void **)&d_out, 64));
+    SQ_HIP(hipMemsetAsync(d_out, 0, 64, ctx->stream));
+    int sb = (int)((b->n + 255) / 256);
+    if (sb > 4096) sb = 4096;
+    hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, b->n, d_out);
+    SQ_HIP(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_out);
+    b->total_bases = ctx->pinned[0];
+    b->max_length = ctx->pinned[1];
+    b->max_name_length = ctx->pinned[2];
+    b->max_record_span = ctx->pinned[3];
+    b->min_length = ~ctx->pinned[4];
+    b->h_metas.clear(); /* the host copy, if any, no longer describes the batch */
+    b->h_buf.clear();
+    return SQ_OK;
 }

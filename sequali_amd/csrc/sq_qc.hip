@@ -2540,6 +2540,21 @@ SQ_EXPORT int sq_adaptercounter_reserve(sq_adaptercounter *a, uint64_t length)
     return SQ_OK;
 }
 
+SQ_EXPORT uint64_t sq_adaptercounter_row_length(sq_adaptercounter *a) { return a->cap; }
+
+SQ_EXPORT int sq_adaptercounter_set_row_length(sq_adaptercounter *a, uint64_t row_length)
+{
+    if (row_length < a->cap) { sq_set_error("sq_adaptercounter_set_row_length: the tables only grow"); return SQ_ERR_VALUE; }
+    if (row_length == a->cap) return SQ_OK;
+    size_t rows = a->adapters.size();
+    int rc = regrow_rows(a->ctx, &a->d_fwd, rows, rows, a->cap, (size_t)row_length);
+    if (rc) return rc;
+    rc = regrow_rows(a->ctx, &a->d_rev, rows, rows, a->cap, (size_t)row_length);
+    if (rc) return rc;
+    a->cap = row_length;
+    return SQ_OK;
+}
+
 /* ---- PerTileQuality ---------------------------------------------------------------- */
 
 SQ_EXPORT sq_pertile *sq_pertile_new(sq_ctx *ctx)

@@ -31,19 +31,19 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def global_max(value: int, device=None, group=None) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return int(t.item())
+    return int(_all_reduce(t, dist.ReduceOp.MAX, group).item())
 
 
 def sum_tables(tables: Sequence[torch.Tensor], group=None) -> None:
     """In-place sum over ranks of equally shaped int64/float64 tensors, as ONE
-    collective per dtype (the tables are KBs: latency bound, so fewer, larger)."""
+    collective per dtype (the tables are KBs: latency bound, so fewer, larger).
+    RCCL reduces device tensors in place; gloo (tests, two ranks on one GPU) gets a host copy."""
     by_dtype = {}
     for t in tables:
         by_dtype.setdefault(t.dtype, []).append(t)
     for ts in by_dtype.values():
         flat = torch.cat([t.reshape(-1) for t in ts])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat = _all_reduce(flat, dist.ReduceOp.SUM, group)
         off = 0
         for t in ts:
             n = t.numel()
@@ -65,13 +65,14 @@ def device_tensor(ptr: int, count: int, device, typestr: str = "<i8") -> torch.T
     return torch.as_tensor(_Alias(ptr, count, typestr), device=device)
 
 
-def qcmetrics_tables(qc, device) -> List[torch.Tensor]:
-    """device tensors over a QCMetrics object's six tables, trimmed to max_length"""
+def qcmetrics_tables(qc, device, max_length: int = None) -> List[torch.Tensor]:
+    """device tensors over a QCMetrics object's six tables, trimmed to max_length rows (the
+    job's, once the ranks have agreed on it and the tables are padded to it)"""
     from ._lib import lib
     ptrs = (ctypes.c_void_p * 8)()
     counts = (ctypes.c_uint64 * 8)()
     k = lib().sq_qcmetrics_device_tables(qc._h, ptrs, counts, 8)
-    ml, ea = qc.max_length, qc.end_anchor_length
+    ml, ea = qc.max_length if max_length is None else max_length, qc.end_anchor_length
     want = [ml * 5, ml * 12, ea * 5, ea * 12, 101, 94]
     return [device_tensor(ptrs[i], want[i], device) for i in range(k) if ptrs[i] and want[i]]
 
@@ -84,12 +85,28 @@ def adaptercounter_tables(ad, device) -> List[torch.Tensor]:
     return [device_tensor(ptrs[i], int(counts[i]), device) for i in range(k) if ptrs[i] and counts[i]]
 
 
+def agree_on_shapes(qc, ad, device, group=None) -> int:
+    """Pads the count tables of this rank to the shapes of the job: QCMetrics to the longest read
+    any rank saw, AdapterCounter to the longest row any rank holds (its tables are
+    [adapter][row] and sq_adaptercounter_reserve grows rows geometrically, so ranks with
+    different batch histories differ).  Returns the job's max_length."""
+    from ._lib import check, lib, synchronize
+    ml = global_max(max(qc.max_length if qc is not None else 0, ad.max_length if ad is not None else 0), device, group)
+    if qc is not None:
+        check(lib().sq_qcmetrics_reserve(qc._h, ml))
+    if ad is not None:
+        check(lib().sq_adaptercounter_reserve(ad._h, ml))
+        row = global_max(int(lib().sq_adaptercounter_row_length(ad._h)), device, group)
+        check(lib().sq_adaptercounter_set_row_length(ad._h, row))
+    synchronize()
+    return ml
+
+
 def merge_qcmetrics(qc, device, group=None) -> None:
     """all ranks end up with the tables of the whole job"""
     from ._lib import check, lib, synchronize
     ml = global_max(qc.max_length, device, group)
-    reads = torch.tensor([qc.number_of_reads], dtype=torch.int64, device=device)
-    dist.all_reduce(reads, group=group)
+    reads = _all_reduce(torch.tensor([qc.number_of_reads], dtype=torch.int64, device=device), group=group)
     check(lib().sq_qcmetrics_set_totals(qc._h, qc.number_of_reads, ml))   # pads to ml rows
     synchronize()
     sum_tables(qcmetrics_tables(qc, device), group)
@@ -99,19 +116,11 @@ def merge_qcmetrics(qc, device, group=None) -> None:
 
 def merge_adaptercounter(ad, device, group=None) -> None:
     from ._lib import check, lib, synchronize
-    ml = global_max(ad.max_length, device, group)
-    seqs = torch.tensor([ad.number_of_sequences], dtype=torch.int64, device=device)
-    dist.all_reduce(seqs, group=group)
+    ml = agree_on_shapes(None, ad, device, group)   # same row length on every rank
+    seqs = _all_reduce(torch.tensor([ad.number_of_sequences], dtype=torch.int64, device=device), group=group)
     check(lib().sq_adaptercounter_set_totals(ad._h, ad.number_of_sequences, ml))
     synchronize()
-    # every rank must present the same row length: reserve() may have over-allocated
-    tables = adaptercounter_tables(ad, device)
-    caps = torch.tensor([t.numel() for t in tables], dtype=torch.int64, device=device)
-    lo = caps.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-    if not torch.equal(lo, caps) or global_max(int(caps[0].item()), device, group) != int(caps[0].item()):
-        raise RuntimeError("adapter tables differ in capacity across ranks; reserve() the same length first")
-    sum_tables(tables, group)
+    sum_tables(adaptercounter_tables(ad, device), group)
     torch.cuda.synchronize()
     check(lib().sq_adaptercounter_set_totals(ad._h, int(seqs.item()), ml))
 
