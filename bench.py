@@ -353,11 +353,10 @@ def main():
                          (sqdist.adaptercounter_tables(ad, device) if ad else [])
                 tables = [t.reshape(-1) for t in tables if t.dtype == torch.int64]
                 flat = torch.empty(sum(t.numel() for t in tables), dtype=torch.int64, device=device)
-                scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables]))])
-            tables, flat, parts = scratch
+                scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables])), None])
+            tables, flat, parts, _ = scratch
             torch._foreach_copy_(parts, tables)
-            scratch.append(sqdist._all_reduce(flat))   # in place over RCCL (through the host under gloo)
-            del scratch[3:-1]
+            scratch[3] = sqdist._all_reduce(flat)   # in place over RCCL (through the host under gloo)
             torch.cuda.synchronize()
 
     def barrier():
@@ -399,7 +398,7 @@ def main():
                                              == args.reads * passes)
         if use_dist and scratch and passes > 0:
             # what the last step's all-reduce delivered: the base table of the whole job
-            reduced = scratch[-1][:scratch[0][0].numel()]   # the first table of the flat buffer is base_counts
+            reduced = scratch[3][:scratch[0][0].numel()]   # the first table of the flat buffer is base_counts
             checks["reduced_base_table_sum_ok"] = bool(int(reduced.sum().item()) == job_bases * passes)
     if ad is not None:
         counts = ad.get_counts()

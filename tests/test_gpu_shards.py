@@ -279,3 +279,105 @@ def test_two_processes_merge_equals_one_run(tmp_path):
         np.testing.assert_allclose(g["pt_err"], np.array([e for _, e, _ in want]), rtol=1e-6)
         np.testing.assert_array_equal(g["pt_cnt"], u64([c for _, _, c in want]))
         assert int(g["pt_reads"]) == p.number_of_reads
+
+
+# ---- the config-5 collective on the device tables, two ranks -------------------------------
+def _rank_tables(rank, world, port, n, out_dir):
+    """config-2 modules on this rank's shard of 200 k synthetic reads cut to ragged lengths (the
+    ranks then hold different max_length and different AdapterCounter row lengths: rank 1 sees
+    a short batch first, so its rows were grown geometrically), then the merges on the DEVICE
+    tables"""
+    import torch.distributed as tdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SQ_DEVICE="0")
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from sequali_amd import AdapterCounter, FusedPass, QCMetrics, _lib, dist, synth
+    first, last = dist.shard_range(n, rank, world)
+    qc, ad = QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))
+    f = FusedPass(qc, ad)
+    cut = first + (last - first) // 3
+    for k, (a, b) in enumerate(((first, cut), (cut, last))):
+        arr = synth.device_array(synth.ILLUMINA, a, b - a)
+        # rank 0: 150 then at most 120 bases; rank 1: at most 100 then at most 140
+        lo, trim = [(150, None), (60, 120)][k] if rank == 0 else [(40, 100), (70, 140)][k]
+        if trim is not None:
+            _lib.check(_lib.lib().sq_synth_trim(arr._batch.handle, 1000 + a, lo))
+            # cap at `trim`: a second cut of the reads that are still longer
+            buf, metas = arr._batch.download()
+            metas = metas.copy()
+            metas["sequence_length"] = np.minimum(metas["sequence_length"], trim)
+            from sequali_amd import FastqRecordArrayView
+            arr = FastqRecordArrayView._from_buffer(buf, metas)
+            lengths = metas["sequence_length"]
+        else:
+            lengths = arr._batch.download()[1]["sequence_length"]
+        np.save(os.path.join(out_dir, f"len_{a}.npy"), lengths)
+        f.add_record_array(arr)
+    qc.flush()
+    rows_before = int(_lib.lib().sq_adaptercounter_row_length(ad._h))
+    dist.merge_qcmetrics(qc, DEV)
+    dist.merge_adaptercounter(ad, DEV)
+    np.savez(os.path.join(out_dir, f"tables{rank}.npz"), base=u64(qc.base_count_table()), phred=u64(qc.phred_count_table()),
+             ea_base=u64(qc.end_anchored_base_count_table()), ea_phred=u64(qc.end_anchored_phred_count_table()),
+             gc=u64(qc.gc_content()), ps=u64(qc.phred_scores()), reads=qc.number_of_reads, ml=qc.max_length,
+             fwd=np.array([u64(fw) for _, fw, _ in ad.get_counts()]), rev=np.array([u64(r) for _, _, r in ad.get_counts()]),
+             seqs=ad.number_of_sequences, rows_before=rows_before)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_processes_sum_the_device_tables(tmp_path):
+    """dist.merge_qcmetrics + dist.merge_adaptercounter between two ranks on
+    the tables in HBM (gloo, both ranks on cuda:0) equal the oracle's single run bit for bit,
+    with unequal max_length and unequal AdapterCounter row lengths across the ranks"""
+    import torch.multiprocessing as mp
+    from sequali_amd import synth
+    n, world = 200_000, 2
+    mp.spawn(_rank_tables, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    buf, metas = synth.host_records(synth.ILLUMINA, 0, n)
+    metas = metas.copy()
+    for f in sorted(os.listdir(tmp_path)):
+        if f.startswith("len_"):
+            a = int(f[4:-4])
+            L = np.load(tmp_path / f)
+            metas["sequence_length"][a:a + len(L)] = L
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(list(synth.ILLUMINA_PROBES))
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    rows = []
+    for rank in range(world):
+        g = np.load(tmp_path / f"tables{rank}.npz")
+        rows.append(int(g["rows_before"]))
+        assert int(g["reads"]) == rq.number_of_reads and int(g["ml"]) == rq.max_length == 150
+        np.testing.assert_array_equal(g["base"], rq.base_count_table())
+        np.testing.assert_array_equal(g["phred"], rq.phred_count_table())
+        np.testing.assert_array_equal(g["ea_base"], rq.end_anchored_base_count_table())
+        np.testing.assert_array_equal(g["ea_phred"], rq.end_anchored_phred_count_table())
+        np.testing.assert_array_equal(g["gc"], rq.gc_content())
+        np.testing.assert_array_equal(g["ps"], rq.phred_scores())
+        assert int(g["seqs"]) == ra.number_of_sequences
+        for i, (_, fw, rv) in enumerate(ra.get_counts()):
+            np.testing.assert_array_equal(g["fwd"][i], fw)
+            np.testing.assert_array_equal(g["rev"][i], rv)
+    assert rows[0] != rows[1], "the ranks were meant to hold different AdapterCounter row lengths"
+
+
+def test_bench_step_with_two_ranks(tmp_path):
+    """bench.py's N > 1 step (table shapes agreed first, ONE all-reduce over a flat copy of the
+    device tables) run by two ranks on one GPU through torch.distributed.run (gloo instead of
+    RCCL: RCCL does not take two ranks on one device); the reduced base table must hold the bases
+    of both shards, and the line must come out with n_gpus 2"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SQ_DEVICE="0", SQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "300000", "--batch-reads", "200000", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert all(d["checks"].values()), d["checks"]
+    assert "reduced_base_table_sum_ok" in d["checks"]
