@@ -281,6 +281,26 @@ def other_configs(lib, ctx, steps, warmup):
         lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
         lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+    del arr
+    # ---- end to end from host memory with the reference's call pattern (not HBM resident: PCIe bound) ----
+    import io
+    from sequali_amd import FastqParser
+    n = 2_000_000
+    text = synth.illumina_fastq(0, n)
+    t0 = time.perf_counter()
+    f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
+    arrays = 0
+    for a in FastqParser(io.BytesIO(text)):     # default initial_buffersize: 128 KiB, ~380 reads per array
+        f.add_record_array(a)
+        arrays += 1
+    f.qc_metrics.flush()
+    _lib.synchronize()
+    dt = time.perf_counter() - t0
+    out["e2e_host_fastq_default_buffer"] = {
+        "workload": f"{n} x 150 bp FASTQ text in host memory through FastqParser at its default 128 KiB ({arrays} arrays), "
+                    "QCMetrics + AdapterCounter; arrays staged and counted once per 64 MiB; host split, pageable upload and counting included",
+        "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+        "checks": {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)}}
     return out
 
 

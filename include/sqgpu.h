@@ -144,13 +144,16 @@ int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_len, sq_met
 int sq_qcmetrics_add_batch(sq_qcmetrics *m, sq_batch *b);
 int sq_qcmetrics_flush(sq_qcmetrics *m);
 /* Behind a flush that returned SQ_ERR_VALUE (an invalid phred character, _qcmodule.c:2102-2105:
- * the passes run whole batches and only flag the read): sq_batch_first_invalid_phred gives the
- * index of a batch's first offending record (-1: none), sq_qcmetrics_uncount_tail takes back what
- * the pass counted for the records behind it and for the part of that record the reference never
- * reached, so that tables, number_of_reads and max_length are the reference's behind its
- * ValueError.  The flag is rearmed by the failing flush: the object stays usable. */
-int64_t sq_batch_first_invalid_phred(sq_batch *b);
-int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t first);
+ * the passes run whole batches and only flag the read).  A batch may hold the records of several
+ * calls (small arrays are staged together); for every call's stretch [start, end) of it:
+ * sq_batch_first_invalid_phred gives the index of the first offending record (-1: none),
+ * sq_qcmetrics_uncount_tail(first, end, kept_max_length) takes back what the pass counted for
+ * the records behind it up to `end` and for the part of that record the reference never
+ * reached, so that tables, number_of_reads and max_length (kept_max_length: the longest read of
+ * the batch that stays counted) are the reference's behind its ValueError.  The flag is rearmed
+ * by the failing flush: the object stays usable. */
+int64_t sq_batch_first_invalid_phred(sq_batch *b, uint64_t start, uint64_t end);
+int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t first, uint64_t end, uint64_t kept_max_length);
 uint64_t sq_qcmetrics_number_of_reads(sq_qcmetrics *m);    /* members :2361-2369 */
 uint64_t sq_qcmetrics_max_length(sq_qcmetrics *m);
 uint64_t sq_qcmetrics_end_anchor_length(sq_qcmetrics *m);

@@ -15,6 +15,7 @@ from __future__ import annotations
 import array
 import ctypes as C
 import sys
+import os
 import warnings
 import weakref
 from typing import Dict, Iterable, Iterator, List, Optional, Tuple
@@ -323,6 +324,197 @@ def _array_of_sequences(seqs: List[str]) -> FastqRecordArrayView:
     return FastqRecordArrayView._from_buffer(b"".join(parts), metas)
 
 
+
+# ---------------------------------------------------------------------------------------------
+# Staging of small arrays (the reference hands over ~128 KiB of text per call, _qcmodule.c:915;
+# __main__.py:279-306 calls every module once per array).  A kernel launch per 380 reads is
+# launch bound, so arrays that only live on the host are copied (the caller's array is borrowed
+# for the call only, :575-607) into a staging block per source, and a module remembers which
+# stretch of which block it still has to count.  A block is uploaded once, by whoever needs it
+# first, when it holds _STAGE_LIMIT bytes, or when a getter, a flush or anything else that looks
+# at a module's state (its `_h`) asks for it: O(1) launches per 64 MiB and module whatever the
+# size of the arrays.  Deferred work surfaces errors and warnings when it runs, not in the call
+# that brought the array (already so for QCMetrics' invalid phred character).
+_STAGE_LIMIT = int(os.environ.get("SQ_STAGE_BYTES", str(64 << 20)))   # 0: no staging
+_STAGE_ARRAY_MAX = 8 << 20      # arrays from this size on are uploaded on their own
+_open_blocks: dict = {}         # source (parser) id -> the block arrays of that source go to
+staging_stats = {"blocks": 0, "runs": 0}   # blocks uploaded, module launches on (parts of) blocks
+
+
+class _Block:
+    """arrays of one source, back to back, as one record array"""
+
+    def __init__(self, source):
+        self.source = source
+        self.parts: List[bytes] = []
+        self.metas: List[np.ndarray] = []
+        self.arrays: List["FastqRecordArrayView"] = []
+        self.starts = [0]            # record index of every array, and the total behind the last
+        self.nbytes = 0
+        self.array: Optional["FastqRecordArrayView"] = None   # set by seal()
+        self.writers: List = []      # weakrefs of QCMetrics objects that still owe it error rates
+
+    @property
+    def sealed(self) -> bool:
+        return self.array is not None
+
+    def append(self, arr: "FastqRecordArrayView") -> int:
+        m = arr._metas.copy()
+        m["record_start"] += self.nbytes
+        self.parts.append(bytes(arr.obj))
+        self.metas.append(m)
+        self.arrays.append(arr)
+        self.starts.append(self.starts[-1] + len(m))
+        self.nbytes += len(arr.obj)
+        return len(self.arrays) - 1
+
+    def seal(self) -> None:
+        if self.array is None:
+            metas = np.concatenate(self.metas) if self.metas else np.zeros(0, dtype=META_DTYPE)
+            self.array = FastqRecordArrayView._from_buffer(b"".join(self.parts), metas)
+            staging_stats["blocks"] += 1
+            self.parts, self.metas = [], []
+            if _open_blocks.get(self.source) is self:
+                del _open_blocks[self.source]
+
+    def view(self, s0: int, s1: int) -> "FastqRecordArrayView":
+        """the arrays [s0, s1) of the block as one record array in HBM (the block itself when
+        that is all of them: the common case, every module sees every array)"""
+        self.seal()
+        if s0 == 0 and s1 == len(self.arrays):
+            v = self.array
+        else:
+            parent = self.array._device()
+            r0, r1 = self.starts[s0], self.starts[s1]
+            h = lib().sq_batch_wrap_device(context(), lib().sq_batch_device_text(parent.handle),
+                                           lib().sq_batch_bytes(parent.handle),
+                                           lib().sq_batch_device_metas(parent.handle) + 40 * r0, r1 - r0)
+            if not h:
+                raise MemoryError(_lib.last_error())
+            v = FastqRecordArrayView._from_device(_DeviceBatch(h))
+            v.obj = self.array.obj
+            v._metas = self.array._metas[r0:r1]
+            v._parent = parent          # the memory belongs to the block's batch
+        v._children = [(self.arrays[k], self.starts[k] - self.starts[s0], self.starts[k + 1] - self.starts[s0])
+                       for k in range(s0, s1)]
+        return v
+
+
+def _stage(arr: "FastqRecordArrayView"):
+    """(block, slot) of an array; an array is staged once, whoever sees it first"""
+    st = getattr(arr, "_staged", None)
+    if st is None:
+        source = getattr(arr, "_source", 0)
+        blk = _open_blocks.get(source)
+        if blk is None:
+            blk = _open_blocks[source] = _Block(source)
+        st = arr._staged = (blk, blk.append(arr))
+        if blk.nbytes >= _STAGE_LIMIT:
+            blk.seal()
+    return st
+
+
+class _Deferring:
+    """what a module needs to count staged arrays later: `_todo` holds [block, first array, behind
+    the last array] (or two of those for pairs), in call order; `_h` -- the C handle everything
+    else goes through -- runs it first, so nothing can look at the module's state in front of
+    work it still owes."""
+
+    def _init_defer(self, handle) -> None:
+        self._handle = handle
+        self._todo: List[list] = []
+        self._upstream: List = []       # FusedPass objects that feed this module (they may owe it work
+                                        # when the caller has let go of them)
+
+    @property
+    def _h(self):
+        self._drain()
+        return self._handle
+
+    @staticmethod
+    def _small(arr) -> bool:
+        return (_STAGE_LIMIT > 0 and arr._batch is None and arr._metas is not None and
+                len(arr.obj) < _STAGE_ARRAY_MAX and getattr(arr, "_parent", None) is None)
+
+    def _enqueue(self, arr) -> bool:
+        """True: the array is staged and will be counted later"""
+        if not self._small(arr):
+            self._drain()
+            return False
+        blk, slot = _stage(arr)
+        t = self._todo
+        if t and len(t[-1]) == 3 and t[-1][0] is blk and t[-1][2] == slot:
+            t[-1][2] = slot + 1
+        else:
+            t.append([blk, slot, slot + 1])
+        self._staged_in(blk, arr)
+        self._drain(sealed_only=True)
+        return True
+
+    def _enqueue_pair(self, a1, a2) -> bool:
+        if not (self._small(a1) and self._small(a2)):
+            self._drain()
+            return False
+        (b1, s1), (b2, s2) = _stage(a1), _stage(a2)
+        t = self._todo
+        if t and len(t[-1]) == 6 and t[-1][0] is b1 and t[-1][2] == s1 and t[-1][3] is b2 and t[-1][5] == s2:
+            t[-1][2], t[-1][5] = s1 + 1, s2 + 1
+        else:
+            t.append([b1, s1, s1 + 1, b2, s2, s2 + 1])
+        self._drain(sealed_only=True)
+        return True
+
+    def _staged_in(self, blk, arr) -> None:
+        pass
+
+    def flush(self) -> None:
+        """counts what is still staged (and raises / warns what that work raises / warns)"""
+        self._drain()
+
+    def _add_now(self, arr) -> None:
+        """the single-item entry points (add_read, add_sequence): counted inside the call, with its
+        warnings and exceptions, as the reference's tests use them"""
+        self._drain()
+        self._run(arr)
+
+    def _add_pair_now(self, a1, a2) -> None:
+        self._drain()
+        self._run_pair(a1, a2)
+
+    def _drain(self, sealed_only: bool = False, through=None) -> None:
+        """runs the owed work in order; sealed_only: only blocks that are full already;
+        through: stop once nothing of that block is left"""
+        for f in self._upstream:
+            f._drain_own(sealed_only, through)
+        self._drain_own(sealed_only, through)
+
+    def _drain_own(self, sealed_only: bool = False, through=None) -> None:
+        while self._todo:
+            e = self._todo[0]
+            blocks = [e[0]] + ([e[3]] if len(e) == 6 else [])
+            if sealed_only and not all(b.sealed for b in blocks):
+                break
+            if through is not None and not any(through is b for t in self._todo for b in ([t[0]] + ([t[3]] if len(t) == 6 else []))):
+                break
+            self._todo.pop(0)
+            staging_stats["runs"] += 1
+            if len(e) == 3:
+                self._before_run(e[0])
+                self._run(e[0].view(e[1], e[2]))
+            else:
+                self._before_run(e[0])
+                self._before_run(e[3])
+                self._run_pair(e[0].view(e[1], e[2]), e[3].view(e[4], e[5]))
+
+    def _before_run(self, blk) -> None:
+        """QCMetrics objects that write accumulated_error_rate into the block's metas go first
+        (NanoStats reads it, _qcmodule.c:5314, as the reference's driver orders its calls)"""
+        for w in list(blk.writers):
+            q = w()
+            if q is not None and q is not self:
+                q._drain(through=blk)
+
+
 class FastqParser:
     """FastqParser, _qcmodule.c:889-1244: iterates record arrays over a binary
     file object, ``initial_buffersize`` bytes at a time (memchr record split on
@@ -384,6 +576,7 @@ class FastqParser:
                 raise EOFError("Incomplete record at the end of file " + obj.decode("latin-1"))
         self._leftover = obj[consumed.value:]
         arr = FastqRecordArrayView._from_device(batch)
+        arr._source = id(self)
         arr.obj = obj
         return arr
 
@@ -435,7 +628,9 @@ class FastqParser:
                 break
         obj = bytes(buf)
         self._leftover = obj[consumed:]
-        return FastqRecordArrayView._from_buffer(obj, metas)
+        arr = FastqRecordArrayView._from_buffer(obj, metas)
+        arr._source = id(self)   # arrays of one parser are staged together
+        return arr
 
 
 class BamParser:
@@ -523,28 +718,38 @@ def _u64_array(fn, handle, n_hint: Optional[int] = None) -> array.array:
     return a
 
 
-class QCMetrics:
+class QCMetrics(_Deferring):
     """_qcmodule.c:1786-2385"""
 
     def __init__(self, end_anchor_length: int = DEFAULT_END_ANCHOR_LENGTH):
         if end_anchor_length < 0 or end_anchor_length > 0xFFFFFFFF:
             raise ValueError(f"end_anchor_length must be between 0 and {0xFFFFFFFF}, "
                              f"got {end_anchor_length}")
-        self._h = lib().sq_qcmetrics_new(context(), end_anchor_length)
-        if not self._h:
+        h = lib().sq_qcmetrics_new(context(), end_anchor_length)
+        if not h:
             raise MemoryError(_lib.last_error())
+        self._init_defer(h)
         self._pending: List[FastqRecordArrayView] = []
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_qcmetrics_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_qcmetrics_free(self._handle)
         except Exception:
             pass
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        check(lib().sq_qcmetrics_add_batch(self._h, arr._device().handle))
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _staged_in(self, blk, arr) -> None:
+        arr._writeback = weakref.ref(self)
+        if not any(w() is self for w in blk.writers):
+            blk.writers.append(weakref.ref(self))
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        check(lib().sq_qcmetrics_add_batch(self._handle, arr._device().handle))
         self._track(arr)
 
     def _track(self, arr: FastqRecordArrayView) -> None:
@@ -556,7 +761,7 @@ class QCMetrics:
     def add_read(self, read: FastqRecordView) -> None:
         view = _require_view(read)
         arr = FastqRecordArrayView([view])
-        self.add_record_array(arr)
+        self._add_now(arr)
         self.flush()
         view._meta["accumulated_error_rate"] = arr._metas["accumulated_error_rate"]
 
@@ -572,29 +777,43 @@ class QCMetrics:
         its tail taken back (sq_qcmetrics_uncount_tail), so the tables are what the reference's
         would be had each of those calls raised; the error of the first one is raised, and the
         object stays usable."""
+        self._drain()
         pending, self._pending = self._pending, []
-        rc = lib().sq_qcmetrics_flush(self._h)
+        rc = lib().sq_qcmetrics_flush(self._handle)
         error = None
         if rc < 0:
             msg = _lib.last_error()
             for arr in pending:
                 if arr._batch is None or not len(arr):
                     continue
-                idx = lib().sq_batch_first_invalid_phred(arr._batch.handle)
-                if idx < 0:
-                    continue
-                check(lib().sq_qcmetrics_uncount_tail(self._h, arr._batch.handle, idx))
-                if error is None:
-                    view = arr[int(idx)]
-                    q = view._slice("qualities_offset", int(view._meta[0]["sequence_length"]))
-                    bad = next((c for c in q if not 33 <= c <= 33 + PHRED_MAX), ord("?"))
-                    error = ValueError(f"Not a valid phred character: {chr(bad)}")
+                # one stretch per call that brought records of this batch (a staging block holds many)
+                calls = [(r0, r1) for _, r0, r1 in getattr(arr, "_children", ())] or [(0, len(arr))]
+                keep = None
+                for r0, r1 in calls:
+                    idx = lib().sq_batch_first_invalid_phred(arr._batch.handle, r0, r1)
+                    if idx < 0:
+                        continue
+                    if keep is None:
+                        keep = np.ones(len(arr), dtype=bool)
+                    keep[idx + 1:r1] = False
+                    lengths = arr._host_metas()["sequence_length"]
+                    kept_max = int(lengths[keep].max()) if keep.any() else 0
+                    check(lib().sq_qcmetrics_uncount_tail(self._handle, arr._batch.handle, idx, r1, kept_max))
+                    if error is None:
+                        view = arr[int(idx)]
+                        q = view._slice("qualities_offset", int(view._meta[0]["sequence_length"]))
+                        bad = next((c for c in q if not 33 <= c <= 33 + PHRED_MAX), ord("?"))
+                        error = ValueError(f"Not a valid phred character: {chr(bad)}")
             if error is None:
                 error = ValueError(msg)
-            check(lib().sq_qcmetrics_flush(self._h))    # the log of the handled batches ends here
+            check(lib().sq_qcmetrics_flush(self._handle))    # the log of the handled batches ends here
         for arr in pending:
             if arr._metas is not None and arr._batch is not None and len(arr._metas):
-                arr._metas["accumulated_error_rate"] = arr._batch.error_rates()
+                rates = arr._batch.error_rates()
+                arr._metas["accumulated_error_rate"] = rates
+                for child, r0, r1 in getattr(arr, "_children", ()):   # the arrays a staging block was made of
+                    child._metas["accumulated_error_rate"] = rates[r0:r1]
+                    child._writeback = None
             arr._writeback = None
         if error is not None:
             raise error
@@ -634,7 +853,7 @@ class QCMetrics:
         return self._table(lib().sq_qcmetrics_phred_scores)
 
 
-class AdapterCounter:
+class AdapterCounter(_Deferring):
     """_qcmodule.c:2391-2969"""
 
     def __init__(self, adapters: Iterable[str]):
@@ -657,24 +876,29 @@ class AdapterCounter:
         enc = [a.encode("ascii") for a in adapters]
         ptrs = (C.c_char_p * len(enc))(*enc)
         lens = (C.c_size_t * len(enc))(*[len(e) for e in enc])
-        self._h = lib().sq_adaptercounter_new(context(), C.cast(ptrs, C.c_void_p),
-                                              C.cast(lens, C.c_void_p), len(enc))
-        if not self._h:
+        h = lib().sq_adaptercounter_new(context(), C.cast(ptrs, C.c_void_p),
+                                        C.cast(lens, C.c_void_p), len(enc))
+        if not h:
             raise ValueError(_lib.last_error())
+        self._init_defer(h)
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_adaptercounter_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_adaptercounter_free(self._handle)
         except Exception:
             pass
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        check(lib().sq_adaptercounter_add_batch(self._h, arr._device().handle))
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        check(lib().sq_adaptercounter_add_batch(self._handle, arr._device().handle))
 
     def add_read(self, read: FastqRecordView) -> None:
-        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+        self._add_now(FastqRecordArrayView([_require_view(read)]))
 
     def flush(self) -> None:
         check(lib().sq_adaptercounter_flush(self._h))
@@ -701,31 +925,38 @@ class AdapterCounter:
         return out
 
 
-class PerTileQuality:
+class PerTileQuality(_Deferring):
     """_qcmodule.c:2975-3397"""
 
     def __init__(self):
-        self._h = lib().sq_pertile_new(context())
-        if not self._h:
+        h = lib().sq_pertile_new(context())
+        if not h:
             raise MemoryError(_lib.last_error())
+        self._init_defer(h)
+        self._off = False   # skipped for good (:3137-3148), as of the work that has run
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_pertile_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_pertile_free(self._handle)
         except Exception:
             pass
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        if self.skipped_reason is not None:
-            return
         arr = _require_array(record_array)
-        check(lib().sq_pertile_add_batch(self._h, arr._device().handle))
+        if self._off:      # :3126
+            return
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        if self._off:
+            return
+        check(lib().sq_pertile_add_batch(self._handle, arr._device().handle))
+        self._off = lib().sq_pertile_skipped_reason(self._handle) is not None
 
     def add_read(self, read: FastqRecordView) -> None:
-        if self.skipped_reason is not None:
-            return
-        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+        self._add_now(FastqRecordArrayView([_require_view(read)]))
 
     def flush(self) -> None:
         check(lib().sq_pertile_flush(self._h))
@@ -755,7 +986,7 @@ class PerTileQuality:
         return [(int(ids[i]), err[i].tolist(), [int(x) for x in cnt[i]]) for i in range(nt)]
 
 
-class FusedPass:
+class FusedPass(_Deferring):
     """One pass over each record array for any of QCMetrics / AdapterCounter /
     PerTileQuality (sq_fused_add_batch): the same results as calling the three
     add_record_array methods in turn, with the records read from HBM once."""
@@ -766,12 +997,33 @@ class FusedPass:
         self.qc_metrics = qc_metrics
         self.adapter_counter = adapter_counter
         self.per_tile_quality = per_tile_quality
+        self._init_defer(None)
+        for mod in (qc_metrics, adapter_counter, per_tile_quality):
+            if mod is not None:
+                mod._upstream.append(self)   # the module's getters run this pass first
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _staged_in(self, blk, arr) -> None:
+        if self.qc_metrics is not None:
+            self.qc_metrics._staged_in(blk, arr)
+
+    def _drain_own(self, sealed_only: bool = False, through=None) -> None:
+        # what the modules owe from calls of their own goes first
+        for mod in (self.qc_metrics, self.adapter_counter, self.per_tile_quality):
+            if mod is not None:
+                mod._drain_own(sealed_only, through)
+        _Deferring._drain_own(self, sealed_only, through)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
         m, a, p = self.qc_metrics, self.adapter_counter, self.per_tile_quality
-        check(lib().sq_fused_add_batch(arr._device().handle, m._h if m else None,
-                                       a._h if a else None, p._h if p else None))
+        check(lib().sq_fused_add_batch(arr._device().handle, m._handle if m else None,
+                                       a._handle if a else None, p._handle if p else None))
+        if p is not None:
+            p._off = lib().sq_pertile_skipped_reason(p._handle) is not None
         if m is not None:
             m._track(arr)
 
@@ -781,7 +1033,7 @@ def _kmer_to_sequence(kmer: int, k: int) -> str:
     return "".join("ACGT"[(kmer >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
-class OverrepresentedSequences:
+class OverrepresentedSequences(_Deferring):
     """_qcmodule.c:3435-4236"""
 
     def __init__(self, max_unique_fragments: int = DEFAULT_MAX_UNIQUE_FRAGMENTS,
@@ -789,10 +1041,11 @@ class OverrepresentedSequences:
                  sample_every: int = DEFAULT_UNIQUE_SAMPLE_EVERY,
                  bases_from_start: int = DEFAULT_BASES_FROM_START,
                  bases_from_end: int = DEFAULT_BASES_FROM_END):
-        self._h = lib().sq_overrep_new(context(), max_unique_fragments, fragment_length,
-                                       sample_every, bases_from_start, bases_from_end)
-        if not self._h:
+        h = lib().sq_overrep_new(context(), max_unique_fragments, fragment_length,
+                                 sample_every, bases_from_start, bases_from_end)
+        if not h:
             raise ValueError(_lib.last_error())
+        self._init_defer(h)
         self.max_unique_fragments = max_unique_fragments
         self.fragment_length = fragment_length
         self.sample_every = sample_every
@@ -807,25 +1060,29 @@ class OverrepresentedSequences:
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_overrep_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_overrep_free(self._handle)
         except Exception:
             pass
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        before = self._first_record + self.number_of_sequences
-        check(lib().sq_overrep_add_batch(self._h, arr._device().handle))
-        count = lib().sq_overrep_warning_count(self._h)
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        before = self._first_record + lib().sq_overrep_number_of_sequences(self._handle)
+        check(lib().sq_overrep_add_batch(self._handle, arr._device().handle))
+        count = lib().sq_overrep_warning_count(self._handle)
         if count != self._warned:  # :3931-3938, once per array here
             self._warned = count
-            idx = lib().sq_overrep_last_warning_record(self._h) - before
+            idx = lib().sq_overrep_last_warning_record(self._handle) - before
             culprit = arr[idx].sequence() if arr._metas is not None and 0 <= idx < len(arr) else "?"
             warnings.warn("Sequence contains a chacter that is not A, C, G, T or N: "
                           f"{culprit!r}", UserWarning, stacklevel=2)
 
     def add_read(self, read: FastqRecordView) -> None:
-        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+        self._add_now(FastqRecordArrayView([_require_view(read)]))
 
     def flush(self) -> None:
         check(lib().sq_overrep_flush(self._h))
@@ -885,7 +1142,7 @@ class OverrepresentedSequences:
         return res
 
 
-class DedupEstimator:
+class DedupEstimator(_Deferring):
     """_qcmodule.c:4270-4802"""
 
     def __init__(self, max_stored_fingerprints: int = DEFAULT_DEDUP_MAX_STORED_FINGERPRINTS, *,
@@ -893,11 +1150,12 @@ class DedupEstimator:
                  back_sequence_length: int = DEFAULT_FINGERPRINT_BACK_SEQUENCE_LENGTH,
                  front_sequence_offset: int = DEFAULT_FINGERPRINT_FRONT_SEQUENCE_OFFSET,
                  back_sequence_offset: int = DEFAULT_FINGERPRINT_BACK_SEQUENCE_OFFSET):
-        self._h = lib().sq_dedup_new(context(), max_stored_fingerprints, front_sequence_length,
-                                     back_sequence_length, front_sequence_offset,
-                                     back_sequence_offset)
-        if not self._h:
+        h = lib().sq_dedup_new(context(), max_stored_fingerprints, front_sequence_length,
+                               back_sequence_length, front_sequence_offset,
+                               back_sequence_offset)
+        if not h:
             raise ValueError(_lib.last_error())
+        self._init_defer(h)
         self.front_sequence_length = front_sequence_length
         self.back_sequence_length = back_sequence_length
         self.front_sequence_offset = front_sequence_offset
@@ -905,8 +1163,8 @@ class DedupEstimator:
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_dedup_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_dedup_free(self._handle)
         except Exception:
             pass
 
@@ -917,7 +1175,14 @@ class DedupEstimator:
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        check(lib().sq_dedup_add_batch(self._h, arr._device().handle))
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        check(lib().sq_dedup_add_batch(self._handle, arr._device().handle))
+
+    def _run_pair(self, a1: FastqRecordArrayView, a2: FastqRecordArrayView) -> None:
+        check(lib().sq_dedup_add_batch_pair(self._handle, a1._device().handle, a2._device().handle))
 
     def add_record_array_pair(self, record_array1, record_array2) -> None:
         a1 = _require_array(record_array1, "record_array1")
@@ -925,14 +1190,15 @@ class DedupEstimator:
         if len(a1) != len(a2):
             raise ValueError("record_array1 and record_array2 must be of the same size. "
                              f"Got {len(a1)} and {len(a2)} respectively.")
-        check(lib().sq_dedup_add_batch_pair(self._h, a1._device().handle, a2._device().handle))
+        if not self._enqueue_pair(a1, a2):
+            self._run_pair(a1, a2)
 
     def add_sequence(self, sequence: str) -> None:
         if type(sequence) is not str:
             raise TypeError(f"sequence should be a str object, got {type(sequence)!r}")
         if not sequence.isascii():
             raise ValueError("sequence should consist only of ASCII characters.")
-        self.add_record_array(_array_of_sequences([sequence]))
+        self._add_now(_array_of_sequences([sequence]))
 
     def add_sequence_pair(self, sequence1: str, sequence2: str) -> None:
         for s in (sequence1, sequence2):
@@ -940,7 +1206,7 @@ class DedupEstimator:
                 raise TypeError(f"add_sequence_pair() argument must be str, not {type(s).__name__}")
             if not s.isascii():
                 raise ValueError("sequence should consist only of ASCII characters.")
-        self.add_record_array_pair(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
+        self._add_pair_now(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
 
     @property
     def _modulo_bits(self) -> int:
@@ -958,18 +1224,22 @@ class DedupEstimator:
         return _u64_array(lib().sq_dedup_duplication_counts, self._h)
 
 
-class InsertSizeMetrics:
+class InsertSizeMetrics(_Deferring):
     """_qcmodule.c:5456-5982"""
 
     def __init__(self, max_adapters: int = 10000):
-        self._h = lib().sq_insertsize_new(context(), max_adapters)
-        if not self._h:
+        h = lib().sq_insertsize_new(context(), max_adapters)
+        if not h:
             raise ValueError(_lib.last_error())
+        self._init_defer(h)
+
+    def _run_pair(self, a1: FastqRecordArrayView, a2: FastqRecordArrayView) -> None:
+        check(lib().sq_insertsize_add_batch_pair(self._handle, a1._device().handle, a2._device().handle))
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_insertsize_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_insertsize_free(self._handle)
         except Exception:
             pass
 
@@ -979,7 +1249,8 @@ class InsertSizeMetrics:
         if len(a1) != len(a2):
             raise ValueError("record_array1 and record_array2 must be of the same size. "
                              f"Got {len(a1)} and {len(a2)} respectively.")
-        check(lib().sq_insertsize_add_batch_pair(self._h, a1._device().handle, a2._device().handle))
+        if not self._enqueue_pair(a1, a2):
+            self._run_pair(a1, a2)
 
     def set_shard(self, first_pair_index: int, table_bits: int = 22) -> None:
         """This object sees pairs [first_pair_index, ...) of a job that other ranks share
@@ -992,7 +1263,7 @@ class InsertSizeMetrics:
                 raise TypeError(f"add_sequence_pair() argument must be str, not {type(s).__name__}")
             if not s.isascii():
                 raise ValueError(f"{label} should consist only of ASCII characters.")
-        self.add_record_array_pair(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
+        self._add_pair_now(_array_of_sequences([sequence1]), _array_of_sequences([sequence2]))
 
     @property
     def total_reads(self) -> int:
@@ -1045,7 +1316,7 @@ class NanoporeReadInfo:
         self.parent_id_hash = int(rec["parent_id_hash"])
 
 
-class NanoStats:
+class NanoStats(_Deferring):
     """_qcmodule.c:4874-5430: per read start time, channel, duration, length,
     summed error rate and parent id hash, from the BAM tags when the record has any, else
     from the nanopore FASTQ header.  Reads FastqMeta.accumulated_error_rate where the
@@ -1053,31 +1324,41 @@ class NanoStats:
     driver does (__main__.py:279-306)."""
 
     def __init__(self):
-        self._h = lib().sq_nanostats_new(context())
-        if not self._h:
+        h = lib().sq_nanostats_new(context())
+        if not h:
             raise MemoryError(_lib.last_error())
+        self._init_defer(h)
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().sq_nanostats_free(self._h)
+            if getattr(self, "_handle", None):
+                lib().sq_nanostats_free(self._handle)
         except Exception:
             pass
 
     def add_record_array(self, record_array: FastqRecordArrayView) -> None:
         arr = _require_array(record_array)
-        rc = lib().sq_nanostats_add_batch(self._h, arr._device().handle)
-        n = lib().sq_nanostats_last_warnings(self._h, None, 0)
+        if not self._enqueue(arr):
+            self._run(arr)
+
+    def _run(self, arr: FastqRecordArrayView) -> None:
+        # the array's QCMetrics pass, if it has one enqueued, must have left accumulated_error_rate
+        # in its metas (:5314): arrays that were not staged
+        wb = arr._writeback() if arr._writeback is not None else None
+        if wb is not None:
+            wb._drain()
+        rc = lib().sq_nanostats_add_batch(self._handle, arr._device().handle)
+        n = lib().sq_nanostats_last_warnings(self._handle, None, 0)
         if n:
             lengths = np.zeros(n, dtype=np.uint64)
-            lib().sq_nanostats_last_warnings(self._h, lengths.ctypes.data, n)
+            lib().sq_nanostats_last_warnings(self._handle, lengths.ctypes.data, n)
             for counted in lengths:  # :5247-5252
                 warnings.warn("pi tag should have a valid uuid4 format with 36 characters. "
                               f"Counted {int(counted)}. Skipping tag.", UserWarning, stacklevel=2)
         check(rc)
 
     def add_read(self, read: FastqRecordView) -> None:
-        self.add_record_array(FastqRecordArrayView([_require_view(read)]))
+        self._add_now(FastqRecordArrayView([_require_view(read)]))
 
     @property
     def number_of_reads(self) -> int:

@@ -2198,9 +2198,9 @@ __global__ void k_stripe_counts(const sq_meta *metas, const uint32_t *order, uin
  * k_first_invalid finds its first offending read, k_qc_uncount takes back, count by count, what
  * the pass added for the reads behind it and for the part of the offender the reference never
  * reached. */
-__global__ void k_first_invalid(const uint8_t *buf, const sq_meta *metas, uint64_t n, unsigned long long *first)
+__global__ void k_first_invalid(const uint8_t *buf, const sq_meta *metas, uint64_t start, uint64_t n, unsigned long long *first)
 {
-    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t r = start + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
         const sq_meta m = metas[r];
         const uint8_t *q = buf + m.record_start + m.qualities_offset;
         bool bad = false;
@@ -2245,15 +2245,6 @@ __global__ void k_qc_uncount(PassParams P, uint64_t first)
         }
         P.metas[r].accumulated_error_rate = 0.0; /* never written by the reference: what the parser left */
     }
-}
-
-__global__ void k_max_length(const sq_meta *metas, uint64_t n, unsigned long long *out)
-{
-    unsigned long long mx = 0;
-    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
-        mx = max(mx, (unsigned long long)metas[r].sequence_length);
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
 }
 
 int grid_for(const sq_ctx *ctx, uint64_t n, int wgs_per_cu)
@@ -3065,48 +3056,45 @@ SQ_EXPORT int sq_qcmetrics_flush(sq_qcmetrics *m)
     return SQ_OK;
 }
 
-/* index of the first record of b with a quality byte outside 33 .. 126, -1: none */
-SQ_EXPORT int64_t sq_batch_first_invalid_phred(sq_batch *b)
+/* index of the first record among [start, end) of b with a quality byte outside 33 .. 126, -1: none */
+SQ_EXPORT int64_t sq_batch_first_invalid_phred(sq_batch *b, uint64_t start, uint64_t end)
 {
-    if (!b->n) return -1;
+    if (end > b->n) end = b->n;
+    if (start >= end) return -1;
     sq_ctx *ctx = b->ctx;
     unsigned long long *d = (unsigned long long *)sq_scratch(ctx, 0, 64);
     if (!d) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
     SQ_HIP(hipMemsetAsync(d, 0xFF, 8, ctx->stream));
-    hipLaunchKernelGGL(k_first_invalid, dim3((unsigned)std::min<uint64_t>((b->n + 255) / 256, 4096)), dim3(256), 0,
-                       ctx->stream, b->d_buf, b->d_metas, (uint64_t)b->n, d);
+    hipLaunchKernelGGL(k_first_invalid, dim3((unsigned)std::min<uint64_t>((end - start + 255) / 256, 4096)), dim3(256), 0,
+                       ctx->stream, b->d_buf, b->d_metas, start, end, d);
     SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], d, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     return ctx->pinned[9] == UINT64_MAX ? -1 : (int64_t)ctx->pinned[9];
 }
 
-/* b went through this object since its last successful flush and record `first` of it holds an
- * invalid phred byte: leaves the tables as the reference's are behind its ValueError (see
- * k_qc_uncount).  Call sq_qcmetrics_flush again when every such batch has been handled. */
-SQ_EXPORT int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t first)
+/* Records [first, end) of b went through this object since its last successful flush as the tail
+ * of one call, and record `first` holds an invalid phred byte: leaves the tables as the
+ * reference's are behind that call's ValueError (see k_qc_uncount).  kept_max_length: the
+ * longest read of b among the records that stay counted.  Call sq_qcmetrics_flush again when
+ * every such stretch has been handled. */
+SQ_EXPORT int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t first, uint64_t end, uint64_t kept_max_length)
 {
-    if (first >= b->n) { sq_set_error("sq_qcmetrics_uncount_tail: record index out of range"); return SQ_ERR_VALUE; }
+    if (end > b->n) end = b->n;
+    if (first >= end) { sq_set_error("sq_qcmetrics_uncount_tail: record index out of range"); return SQ_ERR_VALUE; }
     sq_ctx *ctx = m->ctx;
     PassParams P{};
-    P.buf = b->d_buf; P.buf_len = b->buf_len; P.metas = b->d_metas; P.n = b->n;
+    P.buf = b->d_buf; P.buf_len = b->buf_len; P.metas = b->d_metas; P.n = end;
     P.qc_base = m->d_base; P.qc_phred = m->d_phred; P.qc_ea_base = m->d_ea_base; P.qc_ea_phred = m->d_ea_phred;
     P.qc_gc = m->d_gc; P.qc_ps = m->d_ps; P.ea_len = (uint32_t)m->end_anchor; P.thresholds = m->d_thr;
-    const uint64_t tail = b->n - first;
+    const uint64_t tail = end - first;
     hipLaunchKernelGGL(k_qc_uncount, dim3((unsigned)std::min<uint64_t>((tail + 255) / 256, 4096)), dim3(256), 0, ctx->stream, P, first);
     SQ_HIP(hipGetLastError());
-    /* longest read among the records the reference did look at */
-    unsigned long long *d = (unsigned long long *)sq_scratch(ctx, 0, 64);
-    if (!d) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
-    SQ_HIP(hipMemsetAsync(d, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_max_length, dim3((unsigned)std::min<uint64_t>((first + 256) / 256, 4096)), dim3(256), 0, ctx->stream,
-                       b->d_metas, first + 1, d);
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], d, 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     m->number_of_reads -= tail - 1;
     uint64_t ml = m->max_length_flushed;
     bool found = false;
     for (auto &sn : m->seen) {
-        if (sn.b == b && !found) { sn.max_length = ctx->pinned[9]; found = true; }
+        if (sn.b == b && !found) { sn.max_length = kept_max_length; found = true; }
         ml = std::max(ml, sn.max_length);
     }
     if (found) m->max_length = ml;
@@ -3121,13 +3109,16 @@ SQ_EXPORT int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_l
     if (rc == SQ_OK) {
         /* surface an invalid phred byte now, with the reference's message and its partial state */
         sq_ctx *ctx = m->ctx;
-        hipError_t e = hipMemcpy(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpyAsync(&ctx->pinned[8], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && ctx->pinned[8] != UINT64_MAX) {
-            (void)hipMemset(m->d_first_bad, 0xFF, 8);
-            const int64_t idx = sq_batch_first_invalid_phred(b);
+            (void)hipMemsetAsync(m->d_first_bad, 0xFF, 8, ctx->stream);
+            const int64_t idx = sq_batch_first_invalid_phred(b, 0, n);
             char bad = '?';
             if (idx >= 0) {
-                rc = sq_qcmetrics_uncount_tail(m, b, (uint64_t)idx);
+                uint64_t kept = 0;
+                for (int64_t i = 0; i <= idx; i++) kept = std::max<uint64_t>(kept, metas[i].sequence_length);
+                rc = sq_qcmetrics_uncount_tail(m, b, (uint64_t)idx, n, kept);
                 const uint8_t *q = buf + metas[idx].record_start + metas[idx].qualities_offset;
                 for (uint32_t k = 0; k < metas[idx].sequence_length; k++)
                     if ((uint8_t)(q[k] - 33) > SQ_PHRED_MAX) { bad = (char)q[k]; break; }

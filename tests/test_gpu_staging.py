@@ -1,0 +1,98 @@
+"""The reference's own call pattern: FastqParser at its default 128 KiB (about 380 reads per
+array, _qcmodule.c:915) and every module called once per array (__main__.py:279-306).  The shim
+stages such arrays and launches once per 64 MiB and module; the results are those of the oracle
+on the whole file."""
+import io
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import golden, golden_text, split_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+def u64(a):
+    return np.array(a, dtype=np.uint64)
+
+
+def test_default_buffer_single_end_all_modules_few_launches():
+    from sequali_amd import (AdapterCounter, DedupEstimator, FastqParser, NanoStats, OverrepresentedSequences,
+                             PerTileQuality, QCMetrics, _qc, synth)
+    n = 200_000
+    text = synth.illumina_fastq(0, n)
+    probes = list(synth.ILLUMINA_PROBES)
+    qc, ad, pt, ov, dd, ns = (QCMetrics(), AdapterCounter(probes), PerTileQuality(), OverrepresentedSequences(),
+                              DedupEstimator(), NanoStats())
+    before = dict(_qc.staging_stats)
+    arrays, records = 0, 0
+    kept = []
+    for arr in FastqParser(io.BytesIO(text)):          # default initial_buffersize
+        arrays += 1
+        for mod in (qc, ad, pt, ov, dd, ns):
+            mod.add_record_array(arr)
+        if arrays in (1, 100):
+            kept.append((records, arr))
+        records += len(arr)
+    assert arrays > 400                                  # ~128 KiB of text each
+    # accumulated_error_rate of an array from the middle of a staging block (:2126)
+    buf, metas = split_fastq(text)
+    rq, ra, rp, ro, rd = (oracle.QCMetrics(), oracle.AdapterCounter(probes), oracle.PerTileQuality(),
+                          oracle.OverrepresentedSequences(), oracle.DedupEstimator())
+    for r in (rq, ra, rp, ro, rd):
+        r.add(buf, metas)
+    for first, arr in kept:
+        got = arr.accumulated_error_rates()
+        np.testing.assert_array_equal(got.view(np.uint64), metas["accumulated_error_rate"][first:first + len(arr)].view(np.uint64))
+    assert qc.number_of_reads == rq.number_of_reads == n and qc.max_length == rq.max_length
+    np.testing.assert_array_equal(u64(qc.base_count_table()), rq.base_count_table())
+    np.testing.assert_array_equal(u64(qc.phred_count_table()), rq.phred_count_table())
+    np.testing.assert_array_equal(u64(qc.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
+    np.testing.assert_array_equal(u64(qc.end_anchored_phred_count_table()), rq.end_anchored_phred_count_table())
+    np.testing.assert_array_equal(u64(qc.gc_content()), rq.gc_content())
+    np.testing.assert_array_equal(u64(qc.phred_scores()), rq.phred_scores())
+    for (_, f, r), (_, fr, rr) in zip(ad.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(f), fr)
+        np.testing.assert_array_equal(u64(r), rr)
+    assert pt.number_of_reads == rp.number_of_reads
+    for (t, e, c), (tr, er, cr) in zip(pt.get_tile_counts(), rp.get_tile_counts()):
+        assert t == tr
+        np.testing.assert_array_equal(u64(c), cr)
+        np.testing.assert_allclose(np.array(e), er, rtol=1e-6, atol=0)
+    assert ov.sequence_counts() == ro.sequence_counts() and ov.total_fragments == ro.total_fragments
+    np.testing.assert_array_equal(u64(dd.duplication_counts()), rd.duplication_counts())
+    assert ns.skipped_reason is not None and ns.number_of_reads == 0      # no nanopore header: off at the first read
+    # 70 MB of text: two staging blocks, at most one launch per block and module (NanoStats stops at its first)
+    blocks = _qc.staging_stats["blocks"] - before["blocks"]
+    runs = _qc.staging_stats["runs"] - before["runs"]
+    assert blocks == 2 and runs <= 6 * blocks, (blocks, runs)
+
+
+def test_default_buffer_paired_reference_files():
+    """the reference's 1000-pair test files through its driver's paired loop at the default
+    buffer: QCMetrics x 2, PerTileQuality x 2, paired DedupEstimator and InsertSizeMetrics against
+    the goldens captured from the compiled reference"""
+    from sequali_amd import DedupEstimator, FastqParser, InsertSizeMetrics, PerTileQuality, QCMetrics
+    g = golden("ref_LTB_paired")
+    t1, t2 = golden_text(g, "fastq1"), golden_text(g, "fastq2")
+    q1, q2, p1, p2, dd, isz = QCMetrics(), QCMetrics(), PerTileQuality(), PerTileQuality(), DedupEstimator(
+        front_sequence_offset=0, back_sequence_offset=0), InsertSizeMetrics()
+    r1, r2 = FastqParser(io.BytesIO(t1)), FastqParser(io.BytesIO(t2))
+    for a1 in r1:
+        a2 = r2.read(len(a1))
+        assert a1.is_mate(a2)
+        q1.add_record_array(a1); p1.add_record_array(a1)
+        q2.add_record_array(a2); p2.add_record_array(a2)
+        dd.add_record_array_pair(a1, a2)
+        isz.add_record_array_pair(a1, a2)
+    for q, pre in ((q1, "qc1_"), (q2, "qc2_")):
+        assert q.number_of_reads == int(g[pre + "number_of_reads"])
+        np.testing.assert_array_equal(u64(q.base_count_table()), g[pre + "base"])
+        np.testing.assert_array_equal(u64(q.phred_count_table()), g[pre + "phred"])
+        np.testing.assert_array_equal(u64(q.gc_content()), g[pre + "gc"])
+        np.testing.assert_array_equal(u64(q.phred_scores()), g[pre + "phred_scores"])
+    np.testing.assert_array_equal(u64(isz.insert_sizes()), g["is_insert_sizes"])
+    np.testing.assert_array_equal(u64(dd.duplication_counts()), g["dd_counts_slot_order"])
+    assert dd._modulo_bits == int(g["dd_modulo_bits"]) and isz.total_reads == int(g["is_total_reads"])

@@ -82,6 +82,7 @@ def test_gpu_nanostats_matches_reference(name):
         try:
             for obj, metas in arrays_of(name):
                 ns.add_record_array(FastqRecordArrayView._from_buffer(obj, metas))
+            ns.flush()   # small arrays are staged: their exceptions and warnings come out here
         except (ValueError, RuntimeError, SystemError) as e:
             error = (type(e).__name__, str(e))
     if "error" in res:
