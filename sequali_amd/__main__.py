@@ -1,4 +1,8 @@
-"""python -m sequali_amd reads.fastq[.gz]|reads.bam [mates.fastq[.gz]] [--json out.json]"""
+"""python -m sequali_amd reads.fastq[.gz]|reads.bam [mates.fastq[.gz]] [--json out.json] [--raw]
+
+Writes the reference's JSON report of the QC modules (sequali_amd.report: the key set of
+report_modules.py:2411-2428 as far as it is restated); --raw: every getter of every module
+instead (driver.raw_outputs)."""
 import argparse
 import json
 import sys
@@ -10,7 +14,8 @@ def main() -> None:
     ap = argparse.ArgumentParser(prog="python -m sequali_amd", description=driver.__doc__.splitlines()[0])
     ap.add_argument("input")
     ap.add_argument("input_reverse", nargs="?")
-    ap.add_argument("--json", help="write the raw module outputs here (default: stdout)")
+    ap.add_argument("--json", help="write the JSON here (default: stdout)")
+    ap.add_argument("--raw", action="store_true", help="the getters of the modules instead of the report modules")
     ap.add_argument("--overrepresentation-max-unique-fragments", type=int, default=driver.DEFAULT_MAX_UNIQUE_FRAGMENTS)
     ap.add_argument("--overrepresentation-fragment-length", type=int, default=driver.DEFAULT_FRAGMENT_LENGTH)
     ap.add_argument("--overrepresentation-sample-every", type=int, default=driver.DEFAULT_UNIQUE_SAMPLE_EVERY)
@@ -30,7 +35,11 @@ def main() -> None:
                          fingerprint_back_length=args.fingerprint_back_length,
                          fingerprint_front_offset=args.fingerprint_front_offset,
                          fingerprint_back_offset=args.fingerprint_back_offset)
-    text = json.dumps(driver.raw_outputs(modules))
+    if args.raw:
+        text = json.dumps(driver.raw_outputs(modules))
+    else:
+        from . import report
+        text = json.dumps(report.report(modules, args.input, args.input_reverse))
     if args.json:
         with open(args.json, "wt") as f:
             f.write(text)

@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 #endif
         if (s + stride < nspans) {
 #ifdef SQ_SPAN_PROBE
-            if (!(P.blocked & 1))
+            if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
+                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
+            else if (!(P.blocked & 1))
 #endif
             issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
             if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * SPAN_META_BYTES);

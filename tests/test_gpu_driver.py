@@ -126,8 +126,69 @@ def test_bam_file_and_cli(tmp_path):
     assert len(m["adapters"]) == 14
     out = tmp_path / "out.json"
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    subprocess.run([sys.executable, "-m", "sequali_amd", str(path), "--json", str(out)], check=True, env=env)
+    subprocess.run([sys.executable, "-m", "sequali_amd", str(path), "--json", str(out), "--raw"], check=True, env=env)
     report = json.loads(out.read_text())
     assert report["metrics"]["number_of_reads"] == 100
     assert report["nanostats"]["number_of_reads"] == 100
     assert report["adapter_counter"]["number_of_sequences"] == 100
+
+
+# ---- the JSON report (sequali_amd.report): the reference's integration expectations -------------
+def _report_of(tmp_path, name1, name2=None, **kw):
+    from sequali_amd import driver, report
+    from tests.helpers import golden_text
+    paths = []
+    for k, name in enumerate([name1] + ([name2] if name2 else [])):
+        g = golden(name[0])
+        p = tmp_path / f"reads{k}.fastq"
+        p.write_bytes(golden_text(g, name[1]))
+        paths.append(str(p))
+    modules = driver.run(*paths, **kw)
+    return json.loads(json.dumps(report.report(modules, *paths)))   # must be JSON serialisable
+
+
+def test_report_simple_fastq(tmp_path):
+    """tests/test_integration.py:29-42"""
+    r = _report_of(tmp_path, ("ref_simple", "fastq"))
+    assert r["summary"]["maximum_length"] == 8
+    assert r["summary"]["minimum_length"] == 7
+    assert r["summary"]["total_gc_bases"] == 4
+    assert r["summary"]["total_bases"] == 22
+    assert r["sequence_length_distribution"]["n50"] == 7
+    assert r["sequence_length_distribution"]["n90"] == 7
+    assert set(r) >= {"meta", "summary", "sequence_length_distribution", "per_sequence_quality_scores",
+                      "per_position_base_content", "per_position_n_content", "per_sequence_gc_content",
+                      "overrepresented_sequences", "duplication_fractions"}
+
+
+def test_report_empty_file(tmp_path):
+    """tests/test_integration.py:45-57 (there on summary of an empty file)"""
+    r = _report_of(tmp_path, ("ref_empty", "fastq"))
+    for key in ("maximum_length", "minimum_length", "total_gc_bases", "total_bases"):
+        assert r["summary"][key] == 0
+
+
+def test_report_adapters_only(tmp_path):
+    """tests/test_integration.py:97-124 (without the identification of the sequences against the
+    contaminant database, which is out of scope)"""
+    r = _report_of(tmp_path, ("ref_100_illumina_adapters", "fastq"), overrepresentation_sample_every=1)
+    assert r["summary"]["maximum_length"] == 33
+    assert r["summary"]["minimum_length"] == 33
+    assert r["summary"]["total_gc_bases"] == 1700
+    assert r["summary"]["total_bases"] == 3300
+    for adapter_name, quantities in r["adapter_content"]["adapter_content"]:
+        if adapter_name == "Illumina Universal Adapter":
+            assert quantities == [100.0] * 33
+        assert len(quantities) == 33
+    o = r["overrepresented_sequences"]
+    assert o["total_sequences"] == 100 and o["sampled_sequences"] == 100 and o["total_fragments"] == 200
+    assert o["overrepresented_sequences"] and all(d["count"] == 100 for d in o["overrepresented_sequences"])
+
+
+def test_report_paired_end(tmp_path):
+    """tests/test_integration.py:203-211"""
+    r = _report_of(tmp_path, ("ref_LTB_paired", "fastq1"), ("ref_LTB_paired", "fastq2"))
+    assert "summary_read2" in r and "insert_size_metrics" in r and "overrepresented_sequences_read2" in r
+    assert r["summary"]["total_reads"] == r["summary_read2"]["total_reads"] == 1000
+    assert r["summary"]["read_pair_info"] == "Read 1" and r["summary_read2"]["read_pair_info"] == "Read 2"
+    assert sum(r["insert_size_metrics"]["insert_sizes"]) == 1000
