@@ -11,12 +11,11 @@ OUT=$R/gpurun_out/probe
 rm -rf $OUT; mkdir -p $OUT
 cd $R
 cp sequali_amd/libsqgpu.so $OUT/libsqgpu_product.so
+trap 'cp $OUT/libsqgpu_product.so $R/sequali_amd/libsqgpu.so; rm -f $OUT/*.so $OUT/*.o' EXIT   # the product library comes back whatever happens
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -Wno-unused-function"
 hipcc $F -DSQ_PROBE -c sequali_amd/csrc/sq_qc.hip -o $OUT/sq_qc_probe.o || exit 1
-hipcc --offload-arch=gfx950 -shared -fPIC -o sequali_amd/libsqgpu.so sequali_amd/build/sq_api.o $OUT/sq_qc_probe.o sequali_amd/build/sq_ends.o sequali_amd/build/sq_nano.o || exit 1
+hipcc --offload-arch=gfx950 -shared -fPIC -o sequali_amd/libsqgpu.so sequali_amd/build/sq_api.o $OUT/sq_qc_probe.o sequali_amd/build/sq_span.o sequali_amd/build/sq_ends.o sequali_amd/build/sq_nano.o || exit 1
 for m in 32 64 128 33 65 1 2; do
-  SQ_PROBE_MODE=$m python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 | \
+  SQ_PROBE_MODE=$m python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-configs 2>/dev/null | tail -1 | \
     python -c "import sys,json; d=json.loads(sys.stdin.read()); ms=d['roofline']['avg_launch_ms']; print('probe $m: %.3f ms per launch = %.2f TB/s of records' % (ms, 8.7/ms))"
 done | tee $OUT/summary.txt
-cp $OUT/libsqgpu_product.so sequali_amd/libsqgpu.so
-rm -f $OUT/*.so $OUT/*.o

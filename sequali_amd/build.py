@@ -33,28 +33,39 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compiles and links under a file lock, into temporary names that are renamed into place:
+    ranks of one torchrun job that all find the library stale neither compile into the same
+    object files at once nor dlopen a half-written library."""
     if not force and not _stale():
         return LIB
+    import fcntl
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():     # another process built it while this one waited
+            return LIB
+        tag = f".{os.getpid()}.tmp"
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        def compile_one(src: str) -> str:
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj + tag]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+            if verbose and r.stderr:
+                print(r.stderr, file=sys.stderr)
+            os.replace(obj + tag, obj)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=5) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag, *objs],
+                           capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
-        if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=5) as pool:
-        objs = list(pool.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr}")
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+        os.replace(LIB + tag, LIB)
     return LIB
 
 
