@@ -2418,11 +2418,17 @@ int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
     /* outputs of a node are final only after its fail chain is: BFS order guarantees it.
        States some adapter ends in are numbered last, so that "is it a hit" can also be asked
        of a row's position (k_pass) instead of the flag bit */
+    /* Rows are numbered breadth first: on random sequence nearly every lane of a wave sits in a
+       state one or two characters deep, and rows next to each other lie in different LDS banks
+       (numbered adapter by adapter the shallow states were 12 rows apart, every other one on
+       the same banks). */
     std::vector<int> number(t.size());
+    std::vector<int> bfs(1, 0);
+    bfs.insert(bfs.end(), queue.begin(), queue.end());
     int next_number = 0;
-    for (size_t s = 0; s < t.size(); s++) if (!t[s].out) number[s] = next_number++;
+    for (int s : bfs) if (!t[s].out) number[s] = next_number++;
     *n_accept_first = (uint32_t)next_number;
-    for (size_t s = 0; s < t.size(); s++) if (t[s].out) number[s] = next_number++;
+    for (int s : bfs) if (t[s].out) number[s] = next_number++;
     dfa.assign(t.size() * 8, 0);
     out.assign(t.size(), 0);
     for (size_t s = 0; s < t.size(); s++) {

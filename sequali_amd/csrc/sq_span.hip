@@ -42,6 +42,7 @@ namespace {
 
 constexpr uint32_t SPAN_R = 16;              /* records per span */
 constexpr uint32_t CLS6_PAD4 = 0x1E1E1E1Eu;  /* code 30 */
+constexpr int SPAN_W4 = 3;  /* dwords an automaton is restarted in front of its piece: adapters of up to 13 characters */
 
 /* Four sequence bytes -> four class codes that are the shifts of the class's 6-bit counter
  * field: A 0, C 6, G 12, T 18, anything else 24 (NUCLEOTIDE_TO_INDEX, _qcmodule.c:1748-1763);
@@ -121,6 +122,8 @@ template <int OFF> __device__ __forceinline__ void inc_u32(uint32_t a, uint32_t 
     asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"(a), "v"(one), "i"(OFF) : "memory");
 }
 
+__device__ __forceinline__ void tie(uint32_t &x) { asm volatile("" : "+v"(x)); }   /* x is used behind this point only */
+__device__ __forceinline__ void tie_f64(double &x) { asm volatile("" : "+v"(x)); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_1(uint32_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_2(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory"); }
@@ -158,7 +161,7 @@ constexpr int span_max_waves(int nw) { return nw <= 3 ? 16 : 12; }
 __device__ unsigned long long g_span_stamps[4]; /* cycles summed over waves: top wait, DMA issue, counting; spans */
 #define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
 #endif
-template <int NW, bool AD>
+template <int NW, bool AD, int W4T = SPAN_W4>
 __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, uint32_t n_ad)
 {
 #ifdef SQ_SPAN_PROBE
@@ -254,17 +257,19 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         const uint32_t rel = (uint32_t)(m_rs - base);
         if (c == 0) { l_rows[2 * q] = rel + m_so; l_rows[2 * q + 1] = rel + m_qo; }
         const uint8_t *g0 = P.buf + base;
+        uint32_t pk[ND];
+        int32_t rr[ND];
 #pragma unroll
-        for (int k = 0; k < (int)ND; k++) {
-            const uint32_t pk = l_dma[64 * k + lane];
-            const int32_t r = (int32_t)lds_u32(lds_addr(l_rows) + (pk & 0xFFu));
-            if ((int32_t)pk < 0)
-                dma16(g0 + (long long)r + ((pk >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
-        }
+        for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(lds_addr(l_rows) + (pk[k] & 0xFFu));
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++)
+            if ((int32_t)pk[k] < 0)
+                dma16(g0 + (long long)rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
     };
 
     const uint32_t Lmain = 4 * ((U - 1) / 4), nsteps = Lmain / 4; /* _qcmodule.c:2062,2068 */
-    const uint32_t W4 = AD ? (P.ad_maxlen + 2) / 4 : 0;            /* dwords holding >= maxlen - 1 positions */
     const uint32_t npad = SB - U;                                  /* padding positions of a row */
     const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     uint32_t cnt[NW];
@@ -343,142 +348,175 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
             }
         }
-        /* (2) the automaton: W4 rounds over the dwords in front of the lane's quarter (state only),
-           then the Q4 dwords of the quarter.  Its four table reads per dword depend on each other;
-           everything else that is left to do for the span has no such chain and is spread over the
-           Q4 rounds, hand scheduled into the waits: four steps of the lane's f64 chain per round
-           (positions c, c + 4, ...) and phase H (lane = position, two rows x 32 positions per
-           instruction), HI (window, row pair) items per round.  What a round consumes was loaded
-           in the round before it (class dword, the bytes of its phase H items, the quality bytes of
-           its chain steps); the loads are asm the compiler does not wait for (rd_*, wait_*). */
-        uint32_t st = dfa_root;
+        /* (2) the automaton.  One table read per base that depends on the read before it is the
+           only chain of dependent LDS round trips in the span (a round trip under this load is a
+           few hundred cycles), so a lane cuts its quarter into S pieces of D dwords and walks S
+           automatons side by side, each restarted W4T dwords in front of its piece: W4T + D rounds
+           of four dependent steps instead of W4T + Q4.  Everything else that is left to do for
+           the span has no chain and is spread over those rounds, hand scheduled into the waits:
+           the lane's f64 chain (positions c, c + 4, ...; CG groups of four steps per round) and
+           phase H (lane = position, two rows x 32 positions per instruction; HI (window, row
+           pair) items per round).  What a round consumes was loaded in the round before it; the
+           loads are asm the compiler does not wait for (rd_*, wait_lgkm + tie). */
         bool any_hit = false;
-        double acc = 0.0;
+        double acc = 0.0, tail0, tail1, tail2, tail3;
         {
-            int32_t dwi = (int32_t)(Q4 * c) - (int32_t)W4;      /* dword of the row the next round looks at */
-            asm volatile("" : "+v"(dwi));                        /* opaque: no per-round masks kept across spans */
-            uint32_t addr = seq_row + 4u * (uint32_t)dwi;
+            constexpr int S = 4, D = ((int)Q4 + S - 1) / S, WT = AD ? W4T : 0;
+            constexpr int NR = AD ? WT + D : NW;   /* without the automaton: rounds of eight items and two groups */
+            constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = (ITEMS + NR - 1) / NR;
+            constexpr int KRG = 2 * (NW - 1), CG = (KRG + NR - 1) / NR;   /* groups of four chain steps that exist whatever U is */
+            constexpr int KR4 = 4 * KRG;                                  /* chain steps the rounds carry */
+            uint32_t co = c;   /* opaque: the padding masks of the rounds are made per span, not kept across spans */
+            asm volatile("" : "+v"(co));
+            const uint32_t abase = seq_row + 4u * (Q4 * c) - 4u * WT;     /* dword (piece s, round t): abase + 4 (s D + t) */
             const uint32_t qp = qual_row + c;
             const uint32_t bs = sa + h * ROWB + pl;
             const uint32_t hpp = lds_addr(l_hist_phred + pl);
-            constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = 4;
-            static_assert(HI * (int)Q4 >= ITEMS, "phase H does not fit the rounds");
-            constexpr int KR = (int)Q4 < 2 * (NW - 1) ? (int)Q4 : 2 * (NW - 1); /* rounds that carry chain steps whatever U is */
-            /* a lane's first match of the span is kept in `rec` (row of the automaton | end position
-               << 12 | 1 << 31) and looked at behind the rounds; a second one in the same lane sends
-               the wave through the rounds again, one dword at a time (walk_again) */
-            uint32_t rec = 0;
-            bool multi = false;
+            const uint32_t one = 1;
+            uint32_t rec = 0, st0 = dfa_root;   /* a lane's first match of the span: row of the automaton | end position << 12 | 1 << 31 */
+            bool multi = false;                  /* a second one: the wave walks its quarters again, one base at a time */
             wait_lgkm<0>();
-            /* what round 0 of the quarter consumes */
-            uint32_t cb[HI], qb[HI], qc[4];
+            /* what round 0 consumes */
+            uint32_t cb[HI], qb[HI], qc[4 * (CG > 0 ? CG : 1)], cl[S], st[S];
             static_for<0, HI>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                cb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF)>(bs);
-                qb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF) + (int)SB>(bs);
-            });
-            qc[0] = rd_u8<0>(qp); qc[1] = rd_u8<4>(qp); qc[2] = rd_u8<8>(qp); qc[3] = rd_u8<12>(qp);
-            uint32_t cl = AD ? rd_b32<0>(addr) : 0;
-            if (AD) {
-#pragma unroll 1
-                for (uint32_t i = 0; i < W4; i++) {
-                    uint32_t cln = rd_b32<4>(addr);
-                    wait_1<1>(cl);
-                    cl = (uint32_t)dwi < DW ? cl : CLS6_PAD4;   /* nothing in front of the read */
-                    uint32_t e = rd_u16<0>(or_byte<0>(st, cl));
-                    wait_1<0>(e);
-                    e = rd_u16<0>(or_byte<1>(e, cl));
-                    wait_1<0>(e);
-                    e = rd_u16<0>(or_byte<2>(e, cl));
-                    wait_1<0>(e);
-                    e = rd_u16<0>(or_byte<3>(e, cl));
-                    wait_2<0>(e, cln);
-                    st = e;
-                    cl = cln;
-                    addr += 4;
-                    dwi++;
+                if constexpr (m < ITEMS) {
+                    cb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF)>(bs);
+                    qb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF) + (int)SB>(bs);
                 }
-            }
-            wait_4<0>(cb[0], cb[1], cb[2], cb[3]);
-            wait_4<0>(qb[0], qb[1], qb[2], qb[3]);
-            wait_4<0>(qc[0], qc[1], qc[2], qc[3]);
-            wait_1<0>(cl);
-            const uint32_t one = 1, st0 = st; /* st0: the state in front of the quarter */
-            static_for<0, (int)Q4>([&](auto rc) {
-                constexpr int rr = decltype(rc)::value;
-                constexpr bool chain = rr < KR;
-                /* LDS operations of this round, for the hand-counted waits (at most 15 can be named) */
-                constexpr int n_l = ITEMS - rr * HI < 0 ? 0 : ITEMS - rr * HI < HI ? ITEMS - rr * HI : HI; /* items of this round */
-                constexpr int n_nx = ITEMS - (rr + 1) * HI < 0 ? 0 : ITEMS - (rr + 1) * HI < HI ? ITEMS - (rr + 1) * HI : HI;
-                constexpr int n_d = chain ? 4 : 0, n_cln = AD && rr + 1 < (int)Q4 ? 1 : 0, n_qc = rr + 1 < KR ? 4 : 0;
-                constexpr int n_pf = n_cln + 2 * n_nx + n_qc;     /* loads for the next round */
+            });
+            static_for<0, 4 * CG>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < KR4) qc[i] = rd_u8<4 * i>(qp);
+            });
+            static_for<0, S>([&](auto sc) {
+                constexpr int sI = decltype(sc)::value;
+                st[sI] = dfa_root;
+                cl[sI] = 0;
+                if constexpr (AD) cl[sI] = rd_b32<4 * (sI * D)>(abase);
+            });
+            wait_lgkm<0>();
+            static_for<0, HI>([&](auto mc) { tie(cb[decltype(mc)::value]); tie(qb[decltype(mc)::value]); });
+            static_for<0, 4 * (CG > 0 ? CG : 1)>([&](auto ic) { tie(qc[decltype(ic)::value]); });
+            static_for<0, S>([&](auto sc) { tie(cl[decltype(sc)::value]); });
+
+            static_for<0, NR>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr bool proper = t >= WT;
                 constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
-                /* the furthest lane's dword of this round lies behind the row's sequence: padding */
-                if (AD && 3 * (int)Q4 + rr >= (int)DW) cl = (uint32_t)dwi < DW ? cl : CLS6_PAD4;
-                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                if (AD) e0 = rd_u16<0>(or_byte<0>(st, cl));
+                constexpr auto items_of = [](int round) { return ITEMS - round * HI < 0 ? 0 : ITEMS - round * HI < HI ? ITEMS - round * HI : HI; };
+                constexpr auto groups_of = [](int round) { return KRG - round * CG < 0 ? 0 : KRG - round * CG < CG ? KRG - round * CG : CG; };
+                constexpr int n_l = items_of(t), n_nx = t + 1 < NR ? items_of(t + 1) : 0;
+                constexpr int g_now = groups_of(t), g_nx = t + 1 < NR ? groups_of(t + 1) : 0;
+                constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = AD ? S : 0;
+                static_assert(CG <= 2, "a round carries at most two groups of chain steps");
+                uint32_t e0[S], e1[S], e2[S], e3[S];
+                /* the class dwords of this round: padding in front of the read, behind the row's
+                   sequence, and (pieces may reach past the quarter) behind the lane's quarter */
+                if constexpr (AD) {
+                    if (t == WT) st0 = st[0];
+                    static_for<0, S>([&](auto sc) {
+                        constexpr int sI = decltype(sc)::value, idx = sI * D + t - WT;   /* dword of the quarter, < 0: in front of it */
+                        if constexpr (proper && idx >= (int)Q4) cl[sI] = CLS6_PAD4;
+                        else {
+                            if constexpr (idx < 0) cl[sI] = co == 0 ? CLS6_PAD4 : cl[sI];
+                            if constexpr (3 * (int)Q4 + idx >= (int)DW) cl[sI] = Q4 * co + idx < DW ? cl[sI] : CLS6_PAD4;
+                        }
+                        e0[sI] = rd_u16<0>(or_byte<0>(st[sI], cl[sI]));
+                    });
+                }
                 /* rows of the phred histogram of this round's items, error rates of its chain steps */
-                uint32_t l[HI] = {0, 0, 0, 0};
+                uint32_t l[HI];
                 static_for<0, HI>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(qb[m] << 1);
                 });
-                double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-                if constexpr (chain) { d0 = rd_f64(qc[0] << 3); d1 = rd_f64(qc[1] << 3); d2 = rd_f64(qc[2] << 3); d3 = rd_f64(qc[3] << 3); }
+                double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (nC1 && t > 0) { /* the quality bytes the round before asked for */
+                    wait_lgkm<cap(SA + n_l)>();
+                    static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
+                }
+                if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
                 /* base counts of this round's items: one shift-add per base into the window's register */
                 static_for<0, HI>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
-                    if constexpr (m < n_l) cnt[(rr * HI + m) / HALF] = one_shl_add(cb[m], cnt[(rr * HI + m) / HALF]);
+                    if constexpr (m < n_l) cnt[(t * HI + m) / HALF] = one_shl_add(cb[m], cnt[(t * HI + m) / HALF]);
                 });
-                /* what the next round consumes */
-                uint32_t cln = 0;
-                if constexpr (n_cln) cln = rd_b32<4>(addr);
+                if constexpr (AD) {
+                    wait_lgkm<cap(n_l + nC1)>();
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e0[sI]); e1[sI] = rd_u16<0>(or_byte<1>(e0[sI], cl[sI])); });
+                }
+                if constexpr (n_l > 0) {
+                    wait_lgkm<cap(nC1 + SA)>();
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        if constexpr (m < n_l) { tie(l[m]); inc_u32<128 * ((t * HI + m) / HALF)>(hpp + l[m], one); }
+                    });
+                }
+                if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
+                if constexpr (AD) {
+                    wait_lgkm<cap(n_l + nC2)>();
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e1[sI]); e2[sI] = rd_u16<0>(or_byte<2>(e1[sI], cl[sI])); });
+                } else if constexpr (nC1) {
+                    wait_lgkm<cap(n_l + nC2)>();
+                }
+                if constexpr (nC1) { tie_f64(d[0]); tie_f64(d[1]); tie_f64(d[2]); tie_f64(d[3]); acc += d[0]; acc += d[1]; acc += d[2]; acc += d[3]; }
+                /* what the next round consumes: the bytes of its phase H items ... */
                 static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value, it = (rr + 1) * HI + m;
+                    constexpr int m = decltype(mc)::value, it = (t + 1) * HI + m;
                     if constexpr (m < n_nx) {
                         cb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF)>(bs);
                         qb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF) + (int)SB>(bs);
                     }
                 });
-                if constexpr (n_qc) {
-                    qc[0] = rd_u8<16 * (rr + 1)>(qp); qc[1] = rd_u8<16 * (rr + 1) + 4>(qp);
-                    qc[2] = rd_u8<16 * (rr + 1) + 8>(qp); qc[3] = rd_u8<16 * (rr + 1) + 12>(qp);
+                if constexpr (AD) {
+                    wait_lgkm<cap(2 * n_nx)>();
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e2[sI]); e3[sI] = rd_u16<0>(or_byte<3>(e2[sI], cl[sI])); });
+                } else if constexpr (nC2) {
+                    wait_lgkm<cap(2 * n_nx)>();
                 }
-                if (AD) { wait_1<cap(n_l + n_d + n_pf)>(e0); e1 = rd_u16<0>(or_byte<1>(e0, cl)); }
-                if constexpr (n_l) {
-                    wait_4<cap(n_d + n_pf + (AD ? 1 : 0))>(l[0], l[1], l[2], l[3]);
-                    static_for<0, HI>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value;
-                        if constexpr (m < n_l) inc_u32<128 * ((rr * HI + m) / HALF)>(hpp + l[m], one);
-                    });
-                }
-                /* behind this wait only the atomics are in flight: e1, the error rates and the loads
-                   for the next round have arrived */
-                if (AD) { wait_1<n_l>(e1); e2 = rd_u16<0>(or_byte<2>(e1, cl)); }
-                if constexpr (chain) {
-                    wait_4d<AD ? n_l + 1 : cap(n_pf + n_l)>(d0, d1, d2, d3);
-                    acc += d0; acc += d1; acc += d2; acc += d3;
-                }
-                if (AD) { wait_1<0>(e2); e3 = rd_u16<0>(or_byte<3>(e2, cl)); }
-                if constexpr (n_nx) {
-                    wait_4<AD ? 1 : n_l>(cb[0], cb[1], cb[2], cb[3]);
-                    wait_4<AD ? 1 : n_l>(qb[0], qb[1], qb[2], qb[3]);
-                }
-                if constexpr (n_qc) wait_4<AD ? 1 : n_l>(qc[0], qc[1], qc[2], qc[3]);
-                if (AD) {
-                    wait_2<0>(e3, cln);
-                    st = e3;
-                    if (max(max(e0, e1), max(e2, e3)) >= dfa_hit) {
-                        const uint32_t nh = (e0 >= dfa_hit) + (e1 >= dfa_hit) + (e2 >= dfa_hit) + (e3 >= dfa_hit);
-                        const uint32_t j = e0 >= dfa_hit ? 0 : e1 >= dfa_hit ? 1 : e2 >= dfa_hit ? 2 : 3;
-                        const uint32_t ej = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
-                        if (rec || nh > 1) multi = true;
-                        else rec = 0x80000000u | ((4 * (uint32_t)dwi + j) << 12) | ((ej - dfa_root) >> 5);
+                if constexpr (nC2) { tie_f64(d[4]); tie_f64(d[5]); tie_f64(d[6]); tie_f64(d[7]); acc += d[4]; acc += d[5]; acc += d[6]; acc += d[7]; }
+                /* ... its class dwords and the quality bytes of its chain steps */
+                uint32_t cln[S];
+                static_for<0, S>([&](auto sc) {
+                    constexpr int sI = decltype(sc)::value;
+                    cln[sI] = 0;
+                    if constexpr (AD && t + 1 < NR) cln[sI] = rd_b32<4 * (sI * D + t + 1)>(abase);
+                });
+                static_for<0, 4 * CG>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
+                });
+                constexpr int n_cln = AD && t + 1 < NR ? S : 0;
+                if constexpr (AD) {
+                    wait_lgkm<cap(n_cln + 4 * g_nx)>();
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e3[sI]); st[sI] = e3[sI]; });
+                    if constexpr (proper) {
+                        uint32_t mx = 0;
+                        static_for<0, S>([&](auto sc) {
+                            constexpr int sI = decltype(sc)::value;
+                            mx = max(mx, max(max(e0[sI], e1[sI]), max(e2[sI], e3[sI])));
+                        });
+                        if (mx >= dfa_hit) {
+                            static_for<0, S>([&](auto sc) {
+                                constexpr int sI = decltype(sc)::value, idx = sI * D + t - WT;
+                                const uint32_t ee[4] = {e0[sI], e1[sI], e2[sI], e3[sI]};
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; j++) {
+                                    if (ee[j] < dfa_hit) continue;
+                                    if (rec) multi = true;
+                                    else rec = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | ((ee[j] - dfa_root) >> 5);
+                                }
+                            });
+                        }
                     }
-                    cl = cln;
-                    addr += 4;
-                    dwi++;
                 }
+                /* the loads for the next round have arrived by the time they are used: those of
+                   phase H are older than the last automaton step; the class dwords are waited for
+                   here, the quality bytes (younger) with the next round's first wait */
+                wait_lgkm<cap(4 * g_nx)>();
+                static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(cln[sI]); cl[sI] = cln[sI]; });
+                static_for<0, HI>([&](auto mc) { tie(cb[decltype(mc)::value]); tie(qb[decltype(mc)::value]); });
             });
             wait_lgkm<0>();
             if (AD && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
@@ -494,8 +532,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 if (__builtin_amdgcn_ballot_w64(multi)) {
                     uint32_t s2 = st0;
 #pragma unroll 1
-                    for (uint32_t t = 0; t < Q4; t++) {
-                        const uint32_t dw = Q4 * c + t;
+                    for (uint32_t tt = 0; tt < Q4; tt++) {
+                        const uint32_t dw = Q4 * c + tt;
                         uint32_t cl2 = lds_u32(seq_row + 4 * dw);
                         cl2 = dw < DW ? cl2 : CLS6_PAD4;
 #pragma unroll 1
@@ -508,12 +546,30 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                     matches(rec & 0xFFFu, (rec >> 12) & 0xFFFu);
                 }
             }
-            /* the chain steps the rounds did not carry */
-#pragma unroll 1
-            for (uint32_t k = 4 * KR; k < nsteps; k++) acc += lds_f64(lds_u8(qp + 4 * k) << 3);
+            /* the chain steps the rounds did not carry (at most 8: U <= 32 NW) and the 1-4 qualities
+               behind the chains (:2100-2112): all their bytes first, then all their error rates --
+               two round trips to LDS instead of two per step; what does not exist reads the
+               padding entry of the table, +0.0 */
+            uint32_t lb[8], tb[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) lb[j] = lds_u8(qp + 4 * (KR4 + j));
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) tb[j] = lds_u8(qual_row + Lmain + j);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? lb[j] << 3 : 128u << 3;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? tb[j] << 3 : 128u << 3;
+            double le[8], te[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) le[j] = lds_f64(lb[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) te[j] = lds_f64(tb[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) acc += le[j];
+            tail0 = te[0]; tail1 = te[1]; tail2 = te[2]; tail3 = te[3];
         }
         double total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
-        for (uint32_t p = Lmain; p < U; p++) total += lds_f64(lds_u8(qual_row + p) << 3); /* :2100-2112 */
+        total += tail0; total += tail1; total += tail2; total += tail3; /* :2100-2112 */
         uint32_t gsum = sum_bytes(gacc, 0), nsum = sum_bytes(nacc, 0);
         gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
         gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
@@ -525,11 +581,24 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             }
             if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
             if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+            /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i).  A float
+               logarithm names a candidate, the three thresholds around it (one round trip to LDS)
+               decide; the bisection of the other kernels only when they do not (NaN: bin 0) */
             const double avg = total / (double)U;
-            uint32_t lo = 0, hi = 93;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+            const int guess = (int)floorf(-10.0f * log10f((float)avg));
+            const uint32_t b0 = (uint32_t)min(max(guess, 1), 92);
+            const double t_lo = l_thr[b0 - 1], t_mid = l_thr[b0], t_hi = l_thr[b0 + 1];
+            uint32_t lo;
+            if (avg <= t_lo && !(avg <= t_mid)) lo = b0 - 1;
+            else if (avg <= t_mid && !(avg <= t_hi)) lo = b0;
+            else if (avg <= t_hi && (b0 + 1 == 93 || !(avg <= l_thr[b0 + 2]))) lo = b0 + 1;
+            else {
+                uint32_t hi = 93;
+                lo = 0;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+                }
             }
             atomicAdd(&l_ps[lo], 1u);
         }
@@ -618,7 +687,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     *done = 0;
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
-    if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || P.ad_maxlen > 64)) return SQ_OK;
+    if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return SQ_OK; /* W4T dwords hold >= maxlen - 1 positions */
     int nw = (int)((U + 31) / 32);
     if (nw > SPAN_NW_MAX || (ad && nw > 5)) return SQ_OK; /* the automaton's rounds spill registers from 161 positions on: k_wide */
     /* as many waves as LDS takes, at most 16 */
