@@ -273,7 +273,7 @@ def test_is_mate():
 
 
 @pytest.mark.parametrize("name", golden_names("inline_qc_invalid_phred_*"))
-@pytest.mark.parametrize("env", [{}, {"SQ_NO_WIDE": "1", "SQ_NO_RING": "1"}, {"SQ_SPAN": "1"}])
+@pytest.mark.parametrize("env", [{}, {"SQ_NO_WIDE": "1", "SQ_NO_RING": "1"}, {"SQ_SPAN": "0"}])
 def test_qc_state_behind_an_invalid_phred_character(name, env):
     """_qcmodule.c:2073-2075, 2102-2105.  The passes run whole batches and flag the read; the
     ValueError comes out of the next flush, which first takes back what the reference would not

@@ -357,7 +357,7 @@ def _with_env(env, fn):
 def test_two_million_reads_all_tables_equal_oracle():
     """bench-shaped input at a size the oracle still finishes in seconds: 2 M x 150 bp
     generated in HBM through every kernel that takes such a batch: the fused launch (k_wide),
-    the same forced through k_pass and through k_ring, and QCMetrics alone (k_ring)"""
+    the same forced through k_pass, k_ring and k_span, and QCMetrics alone (k_span, k_ring)"""
     from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
     n = 2_000_000
     dev = synth.device_array(synth.ILLUMINA, 12345, n)
@@ -371,6 +371,8 @@ def test_two_million_reads_all_tables_equal_oracle():
     errs = dev.accumulated_error_rates()
     gq2.add_record_array(dev)
     forced = []
+    gq3 = QCMetrics()   # QCMetrics alone through k_ring
+    _with_env({"SQ_SPAN": "0"}, lambda: (gq3.add_record_array(dev), gq3.flush()))
     for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}, {"SQ_SPAN": "1"}):
         q, a = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(q, a).add_record_array(dev), q.flush()))
@@ -379,7 +381,7 @@ def test_two_million_reads_all_tables_equal_oracle():
         for (_, f, r), (_, fr, rr) in zip(g.get_counts(), ra.get_counts()):
             np.testing.assert_array_equal(u64(f), fr)
             np.testing.assert_array_equal(u64(r), rr)
-    for g in (gq, gq2) + tuple(f[0] for f in forced):
+    for g in (gq, gq2, gq3) + tuple(f[0] for f in forced):
         np.testing.assert_array_equal(u64(g.base_count_table()), rq.base_count_table())
         np.testing.assert_array_equal(u64(g.phred_count_table()), rq.phred_count_table())
         np.testing.assert_array_equal(u64(g.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
@@ -394,7 +396,8 @@ def test_two_million_reads_all_tables_equal_oracle():
 
 @pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
 def test_uniform_length_kernels_every_alignment(U):
-    """Batches of one read length have three kernels.  k_ring cuts a read into 32-byte aligned
+    """Batches of one read length have four kernels.  k_span streams 16 records at a time
+    through LDS and counts them with four lanes per read, k_ring cuts a read into 32-byte aligned
     windows and rotates them back in registers, k_wide stages 64 positions at a time with four
     lanes per row and lets padding absorb the end of the reads, k_pass is the general one: every
     length class and every start alignment (names of rotating length, so sequence and quality
@@ -419,13 +422,13 @@ def test_uniform_length_kernels_every_alignment(U):
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    cases = [(False, {}),                                        # QCMetrics alone: k_ring
+    cases = [(False, {}),                                        # QCMetrics alone: k_span (records through LDS by LDS-DMA; k_ring from 257 positions on)
+             (False, {"SQ_SPAN": "0"}),                          # QCMetrics alone: k_ring
              (False, {"SQ_WIDE": "1"}),                          # QCMetrics alone: k_wide
              (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
              (True, {}),                                         # + AdapterCounter: k_wide
              (True, {"SQ_RING": "1"}),                           # k_ring
              (True, {"SQ_NO_WIDE": "1"}),                        # k_pass
-             (False, {"SQ_SPAN": "1"}),                          # QCMetrics alone: k_span (records through LDS by LDS-DMA)
              (True, {"SQ_SPAN": "1"})]                           # k_span with the automaton (k_wide from 161 positions on)
     for with_adapters, env in cases:
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
