@@ -2415,6 +2415,26 @@ int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
             else { t[v].fail = t[t[u].fail].next[c]; queue.push_back(v); }
         }
     }
+    /* A state some adapter ends in that leads back to itself (a poly-G probe on the poly-G tail
+       of a short insert) would report at every position of the run, and every report sends the
+       lanes through the hit path for an adapter they have counted already: only the first hit
+       of an adapter in a read counts (:2643-2672).  Such a state gets a twin that reports
+       nothing and is where it (and the twin) goes on that character; everything else leaves
+       the twin as it leaves the state. */
+    for (size_t s = 0, n0 = t.size(); s < n0; s++) {
+        if (!t[s].out) continue;
+        for (int c = 0; c < 5; c++) {
+            if (t[s].next[c] != (int)s) continue;
+            Node twin = t[s];
+            twin.out = 0;
+            twin.next[c] = (int)t.size();
+            t[s].next[c] = (int)t.size();
+            queue.push_back((int)t.size());
+            t.push_back(twin);
+            break; /* a state has one character it can loop on: the one all its characters are */
+        }
+    }
+    if (t.size() > 4095) return -1;
     /* outputs of a node are final only after its fail chain is: BFS order guarantees it.
        States some adapter ends in are numbered last, so that "is it a hit" can also be asked
        of a row's position (k_pass) instead of the flag bit */

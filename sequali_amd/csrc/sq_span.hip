@@ -373,8 +373,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             const uint32_t bs = sa + h * ROWB + pl;
             const uint32_t hpp = lds_addr(l_hist_phred + pl);
             const uint32_t one = 1;
-            uint32_t rec = 0, st0 = dfa_root;   /* a lane's first match of the span: row of the automaton | end position << 12 | 1 << 31 */
-            bool multi = false;                  /* a second one: the wave walks its quarters again, one base at a time */
+            uint32_t rec = 0, rec2 = 0, st0 = dfa_root; /* a lane's first two matches of the span: row of the automaton | end position << 12 | 1 << 31 */
+            bool multi = false;                  /* a third one: the wave walks its quarters again, one base at a time */
             wait_lgkm<0>();
             /* what round 0 consumes */
             uint32_t cb[HI], qb[HI], qc[4 * (CG > 0 ? CG : 1)], cl[S], st[S];
@@ -504,8 +504,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 #pragma unroll
                                 for (uint32_t j = 0; j < 4; j++) {
                                     if (ee[j] < dfa_hit) continue;
-                                    if (rec) multi = true;
-                                    else rec = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | ((ee[j] - dfa_root) >> 5);
+                                    const uint32_t v = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | ((ee[j] - dfa_root) >> 5);
+                                    if (!rec) rec = v;
+                                    else if (!rec2) rec2 = v;
+                                    else multi = true;
                                 }
                             });
                         }
@@ -544,6 +546,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                     }
                 } else if (rec) {
                     matches(rec & 0xFFFu, (rec >> 12) & 0xFFFu);
+                    if (rec2) matches(rec2 & 0xFFFu, (rec2 >> 12) & 0xFFFu);
                 }
             }
             /* the chain steps the rounds did not carry (at most 8: U <= 32 NW) and the 1-4 qualities
