@@ -43,6 +43,9 @@ namespace {
 constexpr uint32_t SPAN_R = 16;              /* records per span */
 constexpr uint32_t CLS6_PAD4 = 0x1E1E1E1Eu;  /* code 30 */
 constexpr int SPAN_W4 = 3;  /* dwords an automaton is restarted in front of its piece: adapters of up to 13 characters */
+#ifndef SPAN_S
+#define SPAN_S 1   /* pieces a lane cuts its quarter into, one automaton each (more pieces: shorter chains, more table reads; the reads cost more) */
+#endif
 
 /* Four sequence bytes -> four class codes that are the shifts of the class's 6-bit counter
  * field: A 0, C 6, G 12, T 18, anything else 24 (NUCLEOTIDE_TO_INDEX, _qcmodule.c:1748-1763);
@@ -117,6 +120,34 @@ __device__ __forceinline__ double rd_f64(uint32_t a)
     asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(a) : "memory");
     return r;
 }
+/* ds_read_b64_tr_b8: in a group of 16 lanes, lane 2 q + p hands in the address of 8 bytes
+ * (8-byte aligned): chunk p of row q; lane i < 8 gets byte i of chunk 0 of the 8 rows (row q in
+ * byte q of the 64 bits), lane 8 + i byte i of chunk 1 (scripts/ubench_tr8.hip,
+ * profiles/r2b/ubench_tr8.txt).  All 64 lanes must be active. */
+typedef uint32_t sq_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ sq_u32x2 rd_tr8(uint32_t a)
+{
+    sq_u32x2 r;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+    return r;
+}
+/* c + (1 << byte J of w) */
+template <int J> __device__ __forceinline__ uint32_t add_one_shl_byte(uint32_t w, uint32_t one, uint32_t c)
+{
+    uint32_t t; /* one statement: left to itself hipcc collects the shifted ones of a whole round in registers */
+    asm volatile("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_%4 src1_sel:DWORD\n\t"
+                 "v_add_u32 %1, %0, %1"
+                 : "=&v"(t), "+v"(c) : "v"(w), "v"(one), "i"(J));
+    return c;
+}
+/* byte J of w, times 2 */
+template <int J> __device__ __forceinline__ uint32_t shl1_byte(uint32_t w, uint32_t one)
+{
+    uint32_t t;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%3"
+        : "=v"(t) : "v"(one), "v"(w), "i"(J));
+    return t;
+}
 template <int OFF> __device__ __forceinline__ void inc_u32(uint32_t a, uint32_t one)
 {
     asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"(a), "v"(one), "i"(OFF) : "memory");
@@ -124,6 +155,7 @@ template <int OFF> __device__ __forceinline__ void inc_u32(uint32_t a, uint32_t 
 
 __device__ __forceinline__ void tie(uint32_t &x) { asm volatile("" : "+v"(x)); }   /* x is used behind this point only */
 __device__ __forceinline__ void tie_f64(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void tie2(sq_u32x2 &x) { asm volatile("" : "+v"(x)); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_1(uint32_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_2(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory"); }
@@ -355,36 +387,36 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
            of four dependent steps instead of W4T + Q4.  Everything else that is left to do for
            the span has no chain and is spread over those rounds, hand scheduled into the waits:
            the lane's f64 chain (positions c, c + 4, ...; CG groups of four steps per round) and
-           phase H (lane = position, two rows x 32 positions per instruction; HI (window, row
-           pair) items per round).  What a round consumes was loaded in the round before it; the
+           phase H (lane = position: lane (h, pl) counts position pl of every window of 32 for
+           the rows 8 h .. 8 h + 7, whose bytes at that position one transposing read per window
+           and stream hands it; HI of the 8 NW cells per round).  What a round consumes was loaded in the round before it; the
            loads are asm the compiler does not wait for (rd_*, wait_lgkm + tie). */
         bool any_hit = false;
         double acc = 0.0, tail0, tail1, tail2, tail3;
         {
-            constexpr int S = 4, D = ((int)Q4 + S - 1) / S, WT = AD ? W4T : 0;
+            constexpr int S = SPAN_S, D = ((int)Q4 + S - 1) / S, WT = AD ? W4T : 0;
             constexpr int NR = AD ? WT + D : NW;   /* without the automaton: rounds of eight items and two groups */
             constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = (ITEMS + NR - 1) / NR;
+            static_assert(HI <= HALF, "a round stays inside two windows");
             constexpr int KRG = 2 * (NW - 1), CG = (KRG + NR - 1) / NR;   /* groups of four chain steps that exist whatever U is */
             constexpr int KR4 = 4 * KRG;                                  /* chain steps the rounds carry */
             uint32_t co = c;   /* opaque: the padding masks of the rounds are made per span, not kept across spans */
             asm volatile("" : "+v"(co));
             const uint32_t abase = seq_row + 4u * (Q4 * c) - 4u * WT;     /* dword (piece s, round t): abase + 4 (s D + t) */
             const uint32_t qp = qual_row + c;
-            const uint32_t bs = sa + h * ROWB + pl;
+            /* transposing reads: lane 2 q + p of a group of 16 hands in row 8 h + q, bytes 8 p .. 8 p + 7 of
+               the group's 16 positions; window w and the quality stream by immediate offset */
+            const uint32_t trb = sa + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
             const uint32_t hpp = lds_addr(l_hist_phred + pl);
             const uint32_t one = 1;
             uint32_t rec = 0, rec2 = 0, st0 = dfa_root; /* a lane's first two matches of the span: row of the automaton | end position << 12 | 1 << 31 */
             bool multi = false;                  /* a third one: the wave walks its quarters again, one base at a time */
             wait_lgkm<0>();
             /* what round 0 consumes */
-            uint32_t cb[HI], qb[HI], qc[4 * (CG > 0 ? CG : 1)], cl[S], st[S];
-            static_for<0, HI>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (m < ITEMS) {
-                    cb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF)>(bs);
-                    qb[m] = rd_u8<(m % HALF) * 2 * (int)ROWB + 32 * (m / HALF) + (int)SB>(bs);
-                }
-            });
+            uint32_t qc[4 * (CG > 0 ? CG : 1)], cl[S], st[S];
+            sq_u32x2 ts[NW], tq[NW];   /* the 8 rows' class codes / qualities at the lane's position of window w */
+            ts[0] = rd_tr8<0>(trb);
+            tq[0] = rd_tr8<(int)SB>(trb);
             static_for<0, 4 * CG>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < KR4) qc[i] = rd_u8<4 * i>(qp);
@@ -396,7 +428,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 if constexpr (AD) cl[sI] = rd_b32<4 * (sI * D)>(abase);
             });
             wait_lgkm<0>();
-            static_for<0, HI>([&](auto mc) { tie(cb[decltype(mc)::value]); tie(qb[decltype(mc)::value]); });
+            tie2(ts[0]); tie2(tq[0]);
             static_for<0, 4 * (CG > 0 ? CG : 1)>([&](auto ic) { tie(qc[decltype(ic)::value]); });
             static_for<0, S>([&](auto sc) { tie(cl[decltype(sc)::value]); });
 
@@ -406,7 +438,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
                 constexpr auto items_of = [](int round) { return ITEMS - round * HI < 0 ? 0 : ITEMS - round * HI < HI ? ITEMS - round * HI : HI; };
                 constexpr auto groups_of = [](int round) { return KRG - round * CG < 0 ? 0 : KRG - round * CG < CG ? KRG - round * CG : CG; };
-                constexpr int n_l = items_of(t), n_nx = t + 1 < NR ? items_of(t + 1) : 0;
+                constexpr int n_l = items_of(t);
+                /* windows whose first cell the next round takes: their transposing reads go out in this one */
+                constexpr auto windows_through = [](int round) { /* windows the rounds up to `round` have touched */
+                    const int cells = (round + 1) * HI;
+                    return ((cells < ITEMS ? cells : ITEMS) + HALF - 1) / HALF;
+                };
+                constexpr int w_lo = windows_through(t), w_hi = t + 1 < NR ? windows_through(t + 1) : w_lo;
+                constexpr int n_nx = w_hi - w_lo;   /* pairs of reads */
                 constexpr int g_now = groups_of(t), g_nx = t + 1 < NR ? groups_of(t + 1) : 0;
                 constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = AD ? S : 0;
                 static_assert(CG <= 2, "a round carries at most two groups of chain steps");
@@ -428,8 +467,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 /* rows of the phred histogram of this round's items, error rates of its chain steps */
                 uint32_t l[HI];
                 static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(qb[m] << 1);
+                    constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                    if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(shl1_byte<k % 4>(k < 4 ? tq[w].x : tq[w].y, one));
                 });
                 double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if constexpr (nC1 && t > 0) { /* the quality bytes the round before asked for */
@@ -439,8 +478,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
                 /* base counts of this round's items: one shift-add per base into the window's register */
                 static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    if constexpr (m < n_l) cnt[(t * HI + m) / HALF] = one_shl_add(cb[m], cnt[(t * HI + m) / HALF]);
+                    constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                    if constexpr (m < n_l) cnt[w] = add_one_shl_byte<k % 4>(k < 4 ? ts[w].x : ts[w].y, one, cnt[w]);
                 });
                 if constexpr (AD) {
                     wait_lgkm<cap(n_l + nC1)>();
@@ -462,11 +501,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 }
                 if constexpr (nC1) { tie_f64(d[0]); tie_f64(d[1]); tie_f64(d[2]); tie_f64(d[3]); acc += d[0]; acc += d[1]; acc += d[2]; acc += d[3]; }
                 /* what the next round consumes: the bytes of its phase H items ... */
-                static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value, it = (t + 1) * HI + m;
-                    if constexpr (m < n_nx) {
-                        cb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF)>(bs);
-                        qb[m] = rd_u8<(it % HALF) * 2 * (int)ROWB + 32 * (it / HALF) + (int)SB>(bs);
+                static_for<0, NW>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    if constexpr (w >= w_lo && w < w_hi) {
+                        ts[w] = rd_tr8<32 * w>(trb);
+                        tq[w] = rd_tr8<32 * w + (int)SB>(trb);
                     }
                 });
                 if constexpr (AD) {
@@ -518,7 +557,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                    here, the quality bytes (younger) with the next round's first wait */
                 wait_lgkm<cap(4 * g_nx)>();
                 static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(cln[sI]); cl[sI] = cln[sI]; });
-                static_for<0, HI>([&](auto mc) { tie(cb[decltype(mc)::value]); tie(qb[decltype(mc)::value]); });
+                static_for<0, NW>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    if constexpr (w >= w_lo && w < w_hi) { tie2(ts[w]); tie2(tq[w]); }
+                });
             });
             wait_lgkm<0>();
             if (AD && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
@@ -611,6 +653,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 if (v == 0xFFFFFFFFu) continue;
                 l_first[i] = 0xFFFFFFFFu;
                 const uint32_t a = i % n_ad, start = v - l_adlen[a] + 1;
+#ifdef SQ_SPAN_DEBUG
+                if (start >= U) { printf("k_span: span %llu row %u adapter %u pos %u start %u\n", (unsigned long long)s, i / n_ad, a, v, start); continue; }
+#endif
                 if (P.ad_lds) {
                     atomicAdd(&l_adf[a * hs + start], 1u);
                 } else {
