@@ -106,7 +106,7 @@ def dominant_kernel(kind, mods):
         return "k_pass (fused per-base pass, tile-sorted order)"
     if "adapter" in mods and "qc" in mods:
         import os
-        if os.environ.get("SQ_SPAN", "0") != "0":
+        if os.environ.get("SQ_SPAN", "1") != "0":
             return "k_span<AD> (fused per-base pass, one read length, records streamed through LDS)"
         return "k_wide<AD> (fused per-base pass, one read length)"
     if "qc" in mods:

@@ -2925,13 +2925,13 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !getenv("SQ_NO_RING") &&
                           (!ad || getenv("SQ_RING"));
         /* - k_span (sq_span.hip) in front of both: the records come through LDS by LDS-DMA, 16 per
-             wave at a time, four lanes per read.  The kernel of QCMetrics alone up to 256
-             positions (1370 Gbases/s at 150 against k_ring's 1020); with the automaton it is
-             behind k_wide (570 against 865) and opt-in.  SQ_SPAN=1: both, SQ_SPAN=0: neither. */
+             wave at a time, four lanes per read: QCMetrics alone up to 256 positions (1495
+             Gbases/s at 150 against k_ring's 1020), with the automaton up to 160 (1015 against
+             k_wide's 1000; adapters of up to 13 characters).  SQ_SPAN=0: the other two. */
         bool span_done = false;
         const char *span_env = getenv("SQ_SPAN");
-        const bool span = span_env ? atoi(span_env) != 0 : !ad;
-        if (uniform_fast && b->owns && span && !getenv("SQ_RING") && !getenv("SQ_NO_RING") && !wide_env) {
+        const bool span = span_env ? atoi(span_env) != 0 : true;
+        if (uniform_fast && b->owns && span && !getenv("SQ_RING") && !getenv("SQ_NO_RING") && !getenv("SQ_NO_WIDE") && !wide_env) {
             uint64_t covered = 0;
 #ifdef SQ_SPAN_PROBE
             if (const char *pm = getenv("SQ_SPAN_PROBE")) P.blocked = (uint32_t)atoi(pm);

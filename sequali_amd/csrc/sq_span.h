@@ -27,7 +27,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.thr = o; o += 96 * 8;
     L.gc = o; o += 104 * 4;
     L.ps = o; o += 96 * 4;
-    L.dfa = o; o += states * 32;         /* 32-byte rows (o is a multiple of 32 here) */
+    L.dfa = o; o += ((states + 2) / 3 * 36 + 15u) & ~15u; /* three states to 36 bytes */
     L.out = o; o += states * 8;
     L.adlen = o; o += states ? 64 : 0;
     L.hist = o; o += hs * (5 + 12) * 4 + ad_lds * hs * 4;

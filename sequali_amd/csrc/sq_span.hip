@@ -70,6 +70,17 @@ __device__ __forceinline__ void lds_min(uint32_t a, uint32_t v)
 {
     __hip_atomic_fetch_min((SQ_LDS uint32_t *)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+/* byte offset of automaton state n from the root, and back (k_span) */
+__host__ __device__ constexpr uint32_t span_dfa_offset(uint32_t n) { return 36 * (n / 3) + 2 * (n % 3); }
+__device__ __forceinline__ uint32_t span_dfa_state(uint32_t off) { return 3 * (off / 36) + (off % 36) / 2; }
+/* a + byte J of w */
+template <int J> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t w)
+{
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%3"
+        : "=v"(r) : "v"(a), "v"(w), "i"(J));
+    return r;
+}
 /* (1 << sh) + c */
 __device__ __forceinline__ uint32_t one_shl_add(uint32_t sh, uint32_t c)
 {
@@ -214,7 +225,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
     uint32_t *l_gc = (uint32_t *)(smem + L.gc);            /* [104] */
     uint32_t *l_ps = (uint32_t *)(smem + L.ps);            /* [96] */
-    uint16_t *l_dfa = (uint16_t *)(smem + L.dfa);          /* [states][16]: rows of 32 bytes, entry at byte `code` */
+    /* The automaton: the entry of state n for the class with shift code k (0, 6, .. 30) is the
+       16-bit LDS address of the next state and lives at address(n) + k, so a step is one SDWA add
+       and one ds_read_u16.  Three states share 36 bytes (address(n) = root + 36 (n / 3) +
+       2 (n % 3): their entries interleave without a gap), which keeps the dozen shallow states
+       nearly every lane sits in (numbered first, build_dfa) in banks of their own: in rows of 32
+       bytes, four to the 32 banks, a table read took 5 extra LDS cycles on average
+       (SQ_LDS_BANK_CONFLICT, profiles/r2b). */
+    uint16_t *l_dfa = (uint16_t *)(smem + L.dfa);
     unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there */
     uint8_t *l_adlen = smem + L.adlen;                     /* [64] */
     uint32_t *l_hist_base = (uint32_t *)(smem + L.hist);   /* [5][hs] */
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
 
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
-    const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + P.dfa_accept * 32;
+    const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + span_dfa_offset(P.dfa_accept);
     for (int i = tid; i < 136; i += T) {
         double e;
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
@@ -239,12 +257,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += T) l_hist_base[i] = 0;
     if (AD) {
-        for (uint32_t i = tid; i < P.dfa_states * 16; i += T) {
-            const uint32_t st = i >> 4, k = i & 15;
-            /* byte offset 6 c holds the row behind class c; everything else (30: padding) the root */
-            uint32_t next = dfa_root;
-            if (k % 3 == 0 && k < 15) next = dfa_root + ((uint32_t)(P.dfa[st * 8 + k / 3] >> 4) << 5);
-            l_dfa[i] = (uint16_t)next;
+        for (uint32_t i = tid; i < P.dfa_states * 6; i += T) {
+            const uint32_t st = i / 6, c = i % 6;   /* class 5: padding, back to the root */
+            const uint32_t next = c < 5 ? span_dfa_offset((uint32_t)(P.dfa[st * 8 + c] >> 4)) : 0;
+            l_dfa[(span_dfa_offset(st) + 6 * c) >> 1] = (uint16_t)(dfa_root + next);
         }
         for (uint32_t i = tid; i < P.dfa_states; i += T) l_out[i] = P.dfa_out[i];
         for (uint32_t i = tid; i < 64; i += T) l_adlen[i] = P.ad_len[i];
@@ -461,7 +477,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                             if constexpr (idx < 0) cl[sI] = co == 0 ? CLS6_PAD4 : cl[sI];
                             if constexpr (3 * (int)Q4 + idx >= (int)DW) cl[sI] = Q4 * co + idx < DW ? cl[sI] : CLS6_PAD4;
                         }
-                        e0[sI] = rd_u16<0>(or_byte<0>(st[sI], cl[sI]));
+                        e0[sI] = rd_u16<0>(add_byte<0>(st[sI], cl[sI]));
                     });
                 }
                 /* rows of the phred histogram of this round's items, error rates of its chain steps */
@@ -483,7 +499,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 });
                 if constexpr (AD) {
                     wait_lgkm<cap(n_l + nC1)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e0[sI]); e1[sI] = rd_u16<0>(or_byte<1>(e0[sI], cl[sI])); });
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e0[sI]); e1[sI] = rd_u16<0>(add_byte<1>(e0[sI], cl[sI])); });
                 }
                 if constexpr (n_l > 0) {
                     wait_lgkm<cap(nC1 + SA)>();
@@ -495,7 +511,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
                 if constexpr (AD) {
                     wait_lgkm<cap(n_l + nC2)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e1[sI]); e2[sI] = rd_u16<0>(or_byte<2>(e1[sI], cl[sI])); });
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e1[sI]); e2[sI] = rd_u16<0>(add_byte<2>(e1[sI], cl[sI])); });
                 } else if constexpr (nC1) {
                     wait_lgkm<cap(n_l + nC2)>();
                 }
@@ -510,7 +526,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 });
                 if constexpr (AD) {
                     wait_lgkm<cap(2 * n_nx)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e2[sI]); e3[sI] = rd_u16<0>(or_byte<3>(e2[sI], cl[sI])); });
+                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e2[sI]); e3[sI] = rd_u16<0>(add_byte<3>(e2[sI], cl[sI])); });
                 } else if constexpr (nC2) {
                     wait_lgkm<cap(2 * n_nx)>();
                 }
@@ -543,7 +559,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 #pragma unroll
                                 for (uint32_t j = 0; j < 4; j++) {
                                     if (ee[j] < dfa_hit) continue;
-                                    const uint32_t v = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | ((ee[j] - dfa_root) >> 5);
+                                    const uint32_t v = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | span_dfa_state(ee[j] - dfa_root);
                                     if (!rec) rec = v;
                                     else if (!rec2) rec2 = v;
                                     else multi = true;
@@ -582,8 +598,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                         cl2 = dw < DW ? cl2 : CLS6_PAD4;
 #pragma unroll 1
                         for (uint32_t j = 0; j < 4; j++) {
-                            s2 = lds_u16(s2 | ((cl2 >> (8 * j)) & 0xFFu));
-                            if (s2 >= dfa_hit) matches((s2 - dfa_root) >> 5, 4 * dw + j);
+                            s2 = lds_u16(s2 + ((cl2 >> (8 * j)) & 0xFFu));
+                            if (s2 >= dfa_hit) matches(span_dfa_state(s2 - dfa_root), 4 * dw + j);
                         }
                     }
                 } else if (rec) {

@@ -356,8 +356,8 @@ def _with_env(env, fn):
 
 def test_two_million_reads_all_tables_equal_oracle():
     """bench-shaped input at a size the oracle still finishes in seconds: 2 M x 150 bp
-    generated in HBM through every kernel that takes such a batch: the fused launch (k_wide),
-    the same forced through k_pass, k_ring and k_span, and QCMetrics alone (k_span, k_ring)"""
+    generated in HBM through every kernel that takes such a batch: the fused launch (k_span),
+    the same forced through k_ring, k_pass and k_wide, and QCMetrics alone (k_span, k_ring)"""
     from sequali_amd import AdapterCounter, FusedPass, QCMetrics, synth
     n = 2_000_000
     dev = synth.device_array(synth.ILLUMINA, 12345, n)
@@ -373,7 +373,7 @@ def test_two_million_reads_all_tables_equal_oracle():
     forced = []
     gq3 = QCMetrics()   # QCMetrics alone through k_ring
     _with_env({"SQ_SPAN": "0"}, lambda: (gq3.add_record_array(dev), gq3.flush()))
-    for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}, {"SQ_SPAN": "1"}):
+    for env in ({"SQ_RING": "1"}, {"SQ_NO_WIDE": "1"}, {"SQ_SPAN": "0"}):
         q, a = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(q, a).add_record_array(dev), q.flush()))
         forced.append((q, a))
@@ -426,10 +426,10 @@ def test_uniform_length_kernels_every_alignment(U):
              (False, {"SQ_SPAN": "0"}),                          # QCMetrics alone: k_ring
              (False, {"SQ_WIDE": "1"}),                          # QCMetrics alone: k_wide
              (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
-             (True, {}),                                         # + AdapterCounter: k_wide
+             (True, {}),                                         # + AdapterCounter: k_span (k_wide from 161 positions on)
+             (True, {"SQ_SPAN": "0"}),                           # k_wide
              (True, {"SQ_RING": "1"}),                           # k_ring
-             (True, {"SQ_NO_WIDE": "1"}),                        # k_pass
-             (True, {"SQ_SPAN": "1"})]                           # k_span with the automaton (k_wide from 161 positions on)
+             (True, {"SQ_NO_WIDE": "1"})]                        # k_pass
     for with_adapters, env in cases:
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(probes)
