@@ -238,7 +238,7 @@ def other_configs(lib, ctx, steps, warmup):
     out["ragged_50_150"] = run(
         "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
         "QCMetrics + AdapterCounter fused, records resident in HBM",
-        "k_pass<QC,AD> (general fused per-base pass, length-sorted walk)", (bases, n, 2 * bases + 48 * n),
+        "k_span<NW,AD,SEG> x 4 window counts (reads sorted by length, spans of 16 reads of one length; radix sort of 16-byte rows in front)", (bases, n, 2 * bases + 48 * n),
         lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
         lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})

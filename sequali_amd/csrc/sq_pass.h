@@ -47,6 +47,11 @@ struct PassParams {
     double *pt_errors;
     uint64_t pt_cap;          /* row length of the two tables */
     uint64_t pt_first_bad;    /* records >= this are ignored */
+    /* k_span over reads sorted by length (sq_span.h): spans of 16 reads of ONE length */
+    const struct SpanSeg *span_segs; /* the length classes of this launch, in span order */
+    uint32_t span_nsegs;
+    uint32_t span_total;       /* spans of the launch */
+    const struct SpanRow *span_rows; /* the batch's reads sorted by length, longest first */
 };
 
 namespace {

@@ -2795,6 +2795,13 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             stripes = (uint32_t)((b->max_length + STRIPE - 1) / STRIPE);
         }
     }
+    /* reads of many lengths, none longer than k_span takes: sorted by length inside sq_span_launch_sorted */
+    const bool span_sorted =
+        m && !pt_active && !stripes && !P.uniform_len && b->owns && b->min_length >= 1 && b->n < (1ull << 31) &&
+        (!a || a->groups[0].states <= DFA_LDS_MAX_STATES) && b->max_length <= 32u * (a ? SPAN_NW_AD : SPAN_NW_MAX) &&
+        !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN"))) && !getenv("SQ_RING") && !getenv("SQ_NO_RING") &&
+        !getenv("SQ_NO_WIDE") && !getenv("SQ_WIDE") &&
+        (getenv("SQ_SPAN_SORTED") ? atoi(getenv("SQ_SPAN_SORTED")) != 0 : b->n >= 65536);
     P.pos_end = UINT32_MAX;
     if (b->n >= 4096 && b->n < (1ull << 31)) {
         if (pt_active) {
@@ -2806,7 +2813,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                 P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
             P.blocked = P.order != nullptr; /* stored order: waves move through the batch together */
         }
-        else if ((m || a) && b->max_length > 2 * b->min_length + 64)
+        else if ((m || a) && b->max_length > 2 * b->min_length + 64 && !span_sorted)
             P.order = sorted_order(ctx, b, nullptr, (uint32_t)b->max_length);
     }
     const uint32_t ea_rows = (m && P.ea_in_lds && !P.uniform_len) ? P.ea_len : 0;
@@ -2915,6 +2922,20 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
              wrapped device memory keeps k_pass.  SQ_NO_WIDE=1: k_pass; SQ_WIDE=1: also QCMetrics alone.
            - QCMetrics alone: k_ring (every 64-byte sector fetched once), 8 % ahead of k_wide there.
              SQ_NO_RING=1: k_pass; SQ_RING=1: also with the automaton. */
+        /* Reads of many lengths, none longer than k_span takes (what adapter trimming leaves of a
+           file of one read length): sorted by length and cut into spans of 16 reads of one length,
+           they are batches of one read length to k_span, one length after the other.  SQ_SPAN=0 or
+           SQ_SPAN_SORTED=0: the general k_pass. */
+        if (span_sorted && qc && !pt && (!ad || dfa_lds)) {
+            PassParams S = P;
+            S.order = nullptr;
+            if (ad && dfa_lds && a->groups[gi].count * hist_stride(32u * (((uint32_t)b->max_length + 31) / 32)) * 4 <= 8192)
+                S.ad_lds = (uint32_t)a->groups[gi].count;
+            uint64_t covered = 0;
+            int rc = sq_span_launch_sorted(ctx, S, ad, ad ? (uint32_t)a->groups[gi].count : 0, (uint32_t)b->max_length, &covered);
+            if (rc) return rc;
+            if (covered == b->n) continue;
+        }
         PassParams Pfull = P;
         const bool uniform_fast = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && (!ad || dfa_lds);
         const char *wide_env = getenv("SQ_WIDE");

@@ -4,9 +4,11 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
 constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
+constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass */
 constexpr uint32_t SPAN_BIN_OFF = 136 * 8;
 constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
 
@@ -30,9 +32,9 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.dfa = o; o += ((states + 2) / 3 * 36 + 15u) & ~15u; /* three states to 36 bytes */
     L.out = o; o += states * 8;
     L.adlen = o; o += states ? 64 : 0;
-    L.hist = o; o += hs * (5 + 12) * 4 + ad_lds * hs * 4;
+    L.hist = o; o += hs * (5 + 13) * 4 + ad_lds * hs * 4; /* a 13th phred row takes the qualities of filler rows */
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
-    L.rows = o; o += (uint32_t)waves * 32 * 4;
+    L.rows = o; o += (uint32_t)waves * 64 * 4;
     L.dma = o; o += ((16u * (4 * (uint32_t)nw + 1) + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
     L.meta = o; o += (uint32_t)waves * 2 * SPAN_META_BYTES;
@@ -41,8 +43,26 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     return L;
 }
 
+/* k_span over a batch of many read lengths: the records are sorted by length and cut into spans
+ * of 16 reads of one length (the last span of a length is filled up with copies of its last
+ * read, which the kernel turns into padding).  A launch takes the lengths of one window count. */
+struct SpanSeg {           /* one read length */
+    uint32_t span0;        /* its first span (of the launch) */
+    uint32_t nspans;
+    uint32_t U;            /* the length */
+    uint32_t last_rows;    /* reads in its last span (1 .. 16) */
+    uint32_t first;        /* its first read among the sorted rows */
+    uint32_t pad[3];
+};
+struct SpanRow {           /* one row of a span: 16 bytes */
+    uint64_t seq;          /* offset of the sequence in the batch's buffer */
+    uint32_t qual_delta;   /* qualities start that many bytes behind the sequence */
+    uint32_t record;       /* index of the record in the batch */
+};
+
 struct sq_ctx;
 struct PassParams;
 int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint64_t *done);
+int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 
 #endif

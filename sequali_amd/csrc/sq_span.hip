@@ -37,6 +37,7 @@
 
 #include "sq_pass.h"
 #include "sq_span.h"
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -204,7 +205,12 @@ constexpr int span_max_waves(int nw) { return nw <= 3 ? 16 : 12; }
 __device__ unsigned long long g_span_stamps[4]; /* cycles summed over waves: top wait, DMA issue, counting; spans */
 #define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
 #endif
-template <int NW, bool AD, int W4T = SPAN_W4>
+/* SEG: the batch holds reads of many lengths; P.span_rows lists them sorted by length, 16 reads of
+   one length per span, P.span_segs the lengths in span order.  A workgroup takes a contiguous
+   stretch of the spans (a handful of lengths at most) and merges its histograms whenever the
+   length changes, so that inside a stretch everything is as for a batch of one read length: the
+   end-anchored tables a window of the positional ones, no question asked per row. */
+template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4>
 __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, uint32_t n_ad)
 {
 #ifdef SQ_SPAN_PROBE
@@ -217,7 +223,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     constexpr uint32_t SB = 32 * NW, PR = 4 * NW + 1, ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
     constexpr uint32_t DW = 8 * NW, Q4 = 2 * NW + 1, ND = (SPAN_R * PR + 63) / 64;
     extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t U = P.uniform_len, hs = hist_stride(U);
+    uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
+    const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
     const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W);
     double *l_err = (double *)smem;                        /* [136] by raw quality byte */
@@ -236,10 +243,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there */
     uint8_t *l_adlen = smem + L.adlen;                     /* [64] */
     uint32_t *l_hist_base = (uint32_t *)(smem + L.hist);   /* [5][hs] */
-    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12][hs] */
-    uint32_t *l_adf = l_hist_phred + hs * PHRED_COLS;      /* [ad_lds][hs] */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12 + 1][hs]: the last row takes the qualities of filler rows */
+    uint32_t *l_adf = l_hist_phred + hs * (PHRED_COLS + 1); /* [ad_lds][hs] */
     uint32_t *l_first = (uint32_t *)(smem + L.first) + wave * SPAN_R * (AD ? n_ad : 0); /* [16][n_ad] */
-    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * 2 * SPAN_R;                 /* [16][2] */
+    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * 4 * SPAN_R;                 /* [16][2] (SEG: [16][2] of 64 bits) */
     const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
 
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
@@ -251,11 +258,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         else e = __longlong_as_double(0x7FF8000000000000LL);
         l_err[i] = e;
     }
-    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((min((uint32_t)i - 33u, 47u) >> 2) * hs * 4);
+    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((i < 128 ? min((uint32_t)i - 33u, 47u) >> 2 : PHRED_COLS) * hs * 4);
     for (int i = tid; i < 96; i += T) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
-    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS); i += T) l_hist_base[i] = 0;
+    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS + 1); i += T) l_hist_base[i] = 0;
     if (AD) {
         for (uint32_t i = tid; i < P.dfa_states * 6; i += T) {
             const uint32_t st = i / 6, c = i % 6;   /* class 5: padding, back to the root */
@@ -280,12 +287,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         for (int k = 0; k < (int)ND; k++) {
             const uint32_t i = 64 * k + lane, row = i / PR, pir = i % PR, stream = pir >= 2 * NW;
             const bool on = i < SPAN_R * PR && pir < 4 * NW;
-            l_dma[64 * k + lane] = on ? (row * 8 + stream * 4) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u : 0;
+            l_dma[64 * k + lane] = on ? (row * (SEG ? 16 : 8) + stream * (SEG ? 8 : 4)) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u : 0;
         }
     }
     __syncthreads();
-    const uint64_t nspans = P.n / SPAN_R;
-    const uint64_t stride = (uint64_t)gridDim.x * W;
+    /* the spans of this wave: s, s + stride, ... < s_end (SEG: set per length below) */
+    uint64_t s_end = P.n / SPAN_R;
+    uint64_t s_last = ~0ull, seg_first = 0, seg_span0 = 0;   /* SEG: the last span of the length (last_rows reads in it), its first read and span */
+    uint32_t last_rows = SPAN_R;
+    const uint64_t stride = SEG ? (uint64_t)W : (uint64_t)gridDim.x * W;
     uint64_t s = (uint64_t)blockIdx.x * W + wave;
 
     /* The 640 bytes of a span's metas come through LDS too (one more DMA of 40 lanes, two buffers
@@ -293,10 +303,40 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
        order) would wait for the DMA issued in front of it.  Meta buffer k goes with slot k. */
     const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 2 * SPAN_META_BYTES;
     auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
-        if (lane < (int)(SPAN_META_BYTES / 16))
-            dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+        if constexpr (SEG) {   /* row k of span sp: read first + 16 (sp - span0) + k of the length, the last one again behind the end */
+            if (lane < (int)SPAN_R) {
+                const uint32_t valid = sp == s_last ? last_rows : SPAN_R;
+                dma16((const uint8_t *)(P.span_rows + seg_first + (sp - seg_span0) * SPAN_R + min((uint32_t)lane, valid - 1)),
+                      __builtin_amdgcn_readfirstlane(maddr));
+            }
+        } else {
+            if (lane < (int)(SPAN_META_BYTES / 16))
+                dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+        }
     };
+    uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
     auto issue = [&](uint32_t slot_addr, uint32_t maddr) {
+        if constexpr (SEG) {
+            const uint32_t ma = maddr + 16 * q;
+            const unsigned long long seq = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
+            const uint32_t qd = lds_u32(ma + 8);
+            rec_next = lds_u32(ma + 12);
+            if (c == 0) {
+                *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q) = seq;
+                *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q + 8) = seq + qd;
+            }
+            uint32_t pk[ND];
+            unsigned long long rr[ND];
+#pragma unroll
+            for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
+#pragma unroll
+            for (int k = 0; k < (int)ND; k++) rr[k] = *(SQ_LDS const unsigned long long *)(uintptr_t)(lds_addr(l_rows) + (pk[k] & 0xFFu));
+#pragma unroll
+            for (int k = 0; k < (int)ND; k++)
+                if ((int32_t)pk[k] < 0)
+                    dma16(P.buf + rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
+            return;
+        }
         const uint32_t ma = maddr + 40 * q;
         const unsigned long long m_rs = *(SQ_LDS const unsigned long long *)(uintptr_t)ma; /* record_start */
         const uint32_t m_so = lds_u32(ma + 12), m_qo = lds_u32(ma + 20);             /* sequence_offset, qualities_offset */
@@ -317,8 +357,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 dma16(g0 + (long long)rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
     };
 
-    const uint32_t Lmain = 4 * ((U - 1) / 4), nsteps = Lmain / 4; /* _qcmodule.c:2062,2068 */
-    const uint32_t npad = SB - U;                                  /* padding positions of a row */
+    uint32_t Lmain = 4 * ((U - 1) / 4), nsteps = Lmain / 4; /* _qcmodule.c:2062,2068 */
+    uint32_t npad = SB - U;                                  /* padding positions of a row */
     const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     uint32_t cnt[NW];
 #pragma unroll
@@ -339,14 +379,70 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         }
     };
 
+    /* the workgroup's positional histograms to the device tables (end-anchored = a window of the
+       positional ones: every read counted since the last merge has length U), then zeroed again */
+    auto merge_hist = [&](bool zero) {
+        if (AD)
+            for (uint32_t i = tid; i < P.ad_lds * hs; i += T) {
+                const uint32_t v = l_adf[i];
+                if (!v) continue;
+                if (zero) l_adf[i] = 0;
+                const uint32_t a = i / hs, start = i % hs;
+                atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
+                atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
+            }
+        const uint32_t ean = min(P.ea_len, U);
+        for (uint32_t i = tid; i < hs * BASE_COLS; i += T) {
+            const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
+            if (zero) l_hist_base[i] = 0;
+            if (!v || pos >= U) continue;
+            atomicAdd(&P.qc_base[(uint64_t)pos * 5 + cc], (unsigned long long)v);
+            if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
+        }
+        for (uint32_t i = tid; i < hs * (PHRED_COLS + 1); i += T) {
+            const uint32_t v = l_hist_phred[i], cc = i / hs, pos = i % hs;
+            if (zero) l_hist_phred[i] = 0;
+            if (!v || pos >= U || cc >= PHRED_COLS) continue;
+            atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + cc], (unsigned long long)v);
+            if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
+        }
+    };
+
+    /* SEG: the workgroup's stretch of the launch's spans, one length after the other */
+    uint64_t c_lo = 0, c_hi = 0;
+    uint32_t seg_i = 0;
+    if constexpr (SEG) {
+        const uint64_t chunk = ((uint64_t)P.span_total + gridDim.x - 1) / gridDim.x;
+        c_lo = min((uint64_t)P.span_total, blockIdx.x * chunk);
+        c_hi = min((uint64_t)P.span_total, c_lo + chunk);
+        while (seg_i < P.span_nsegs && (uint64_t)P.span_segs[seg_i].span0 + P.span_segs[seg_i].nspans <= c_lo) seg_i++;
+    }
+    for (;;) {
+    if constexpr (SEG) {
+        if (seg_i >= P.span_nsegs) break;
+        const SpanSeg g = P.span_segs[seg_i];
+        if (g.span0 >= c_hi) break;
+        U = g.U;
+        Lmain = 4 * ((U - 1) / 4);
+        nsteps = Lmain / 4;
+        npad = SB - U;
+        s = max((uint64_t)g.span0, c_lo) + wave;
+        s_end = min((uint64_t)g.span0 + g.nspans, c_hi);
+        s_last = (uint64_t)g.span0 + g.nspans - 1;
+        last_rows = g.last_rows;
+        seg_first = g.first;
+        seg_span0 = g.span0;
+    }
     int cur = 0;
-    if (s < nspans) {
+    uint32_t rec_cur = 0;
+    if (s < s_end) {
         issue_meta(s, meta_base);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue(slot_base, meta_base);
-        if (s + stride < nspans) issue_meta(s + stride, meta_base + SPAN_META_BYTES);
+        rec_cur = rec_next;
+        if (s + stride < s_end) issue_meta(s + stride, meta_base + SPAN_META_BYTES);
     }
-    while (s < nspans) {
+    while (s < s_end) {
         /* the span in slot `cur` has landed, and so have the metas of the one after it */
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t0);
@@ -355,21 +451,22 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t1);
 #endif
-        if (s + stride < nspans) {
+        if (s + stride < s_end) {
 #ifdef SQ_SPAN_PROBE
             if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
                 issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
             else if (!(P.blocked & 1))
 #endif
             issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
-            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * SPAN_META_BYTES);
+            if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base + cur * SPAN_META_BYTES);
         }
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t2);
         if (P.blocked & 2) { cur ^= 1; s += stride; a_wait += t1 - t0; a_issue += t2 - t1; a_spans++; continue; }
 #endif
         const uint32_t sa = slot_base + cur * SLOT;
-        const uint64_t r = s * SPAN_R + q;
+        const uint64_t r = SEG ? (uint64_t)rec_cur : s * SPAN_R + q;
+        const uint32_t nv = SEG && s == s_last ? last_rows : SPAN_R;   /* rows q >= nv are filler */
         const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + SB;
 
         /* ---------------- phase S: four lanes per read ----------------
@@ -394,6 +491,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 lds_store_u32(cb + 16 * t, cl);
                 gacc += cl & 0x04040404u;                 /* C, G and padding */
                 nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
+            }
+            if (SEG && nv < SPAN_R) {   /* the last span of a length: filler rows become padding, bases and qualities */
+                if (q >= nv) {
+#pragma unroll
+                    for (int t = 0; t < 2 * NW; t++) {
+                        lds_store_u32(cb + 16 * t, CLS6_PAD4);
+                        lds_store_u32(cb + 16 * t + SB, PAD4);
+                    }
+                    gacc = 2 * NW * 0x04040404u;
+                    nacc = 2 * NW * 0x08080808u;
+                }
             }
         }
         /* (2) the automaton.  One table read per base that depends on the read before it is the
@@ -634,7 +742,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         uint32_t gsum = sum_bytes(gacc, 0), nsum = sum_bytes(nacc, 0);
         gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
         gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
-        if (c == 0) {
+        if (c == 0 && q < nv) {
             const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
             {   /* :2126; a store hipcc does not count either */
                 double *dst = &P.metas[r].accumulated_error_rate;
@@ -684,10 +792,20 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         if (++since_flush == 7) { flush_counts(); since_flush = 0; }
         cur ^= 1;
         s += stride;
+        rec_cur = rec_next;
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t3);
         a_wait += t1 - t0; a_issue += t2 - t1; a_comp += t3 - t2; a_spans++;
 #endif
+    }
+    if constexpr (!SEG) break;
+    /* the length changes: what the workgroup counted goes to the device tables */
+    flush_counts();
+    since_flush = 0;
+    __syncthreads();
+    merge_hist(true);
+    __syncthreads();
+    seg_i++;
     }
 #ifdef SQ_SPAN_PROBE
     if (lane == 0) {
@@ -695,30 +813,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         atomicAdd(&g_span_stamps[2], a_comp); atomicAdd(&g_span_stamps[3], a_spans);
     }
 #endif
-    flush_counts();
-
-    /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
-    __syncthreads();
-    if (AD)
-        for (uint32_t i = tid; i < P.ad_lds * hs; i += T) {
-            const uint32_t v = l_adf[i];
-            if (!v) continue;
-            const uint32_t a = i / hs, start = i % hs;
-            atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
-            atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
-        }
-    const uint32_t ean = min(P.ea_len, U);
-    for (uint32_t i = tid; i < hs * BASE_COLS; i += T) {
-        const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
-        if (!v || pos >= U) continue;
-        atomicAdd(&P.qc_base[(uint64_t)pos * 5 + cc], (unsigned long long)v);
-        if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
-    }
-    for (uint32_t i = tid; i < hs * PHRED_COLS; i += T) {
-        const uint32_t v = l_hist_phred[i], cc = i / hs, pos = i % hs;
-        if (!v || pos >= U) continue;
-        atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + cc], (unsigned long long)v);
-        if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
+    if constexpr (!SEG) {
+        flush_counts();
+        __syncthreads();
+        merge_hist(false);
     }
     for (uint32_t i = tid; i < 101; i += T)
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
@@ -726,19 +824,78 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
-template <int NW>
+template <int NW, bool SEG>
 int launch_nw(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
 {
     static bool attr = false;
     if (!attr) {
-        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (NW <= SPAN_NW_AD)
+            SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (ad) hipLaunchKernelGGL((k_span<NW, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
-    else hipLaunchKernelGGL((k_span<NW, false>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
+    if (ad) {
+        if constexpr (NW <= SPAN_NW_AD)
+            hipLaunchKernelGGL((k_span<NW, true, SEG>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
+        else
+            return SQ_ERR_SYSTEM;
+    } else {
+        hipLaunchKernelGGL((k_span<NW, false, SEG>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
+    }
     SQ_HIP(hipGetLastError());
     return SQ_OK;
+}
+template <bool SEG>
+int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
+{
+    switch (nw) {
+        case 1: return launch_nw<1, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 2: return launch_nw<2, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 3: return launch_nw<3, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 4: return launch_nw<4, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 5: return launch_nw<5, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 6: return launch_nw<6, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 7: return launch_nw<7, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        default: return launch_nw<8, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+    }
+}
+
+/* does k_span take this pass at all, and with how many waves per workgroup */
+int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad)
+{
+    if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > SPAN_NW_AD)) return 0; /* the automaton's rounds spill registers from 161 positions on */
+    if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
+    int waves = span_max_waves(nw);   /* as many as LDS takes */
+    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total > 160 * 1024) waves--;
+    if (waves < 4) return 0;
+    if (const char *e = getenv("SQ_SPAN_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
+    return waves;
+}
+
+/* sort keys (longest first) and rows of the records of a batch, in stored order */
+__global__ void k_span_keys(const sq_meta *metas, uint64_t n, uint32_t max_len, uint32_t *keys, SpanRow *rows)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const sq_meta m = metas[i];
+        keys[i] = max_len - m.sequence_length;
+        SpanRow r;
+        r.seq = m.record_start + m.sequence_offset;
+        r.qual_delta = m.qualities_offset - m.sequence_offset;
+        r.record = (uint32_t)i;
+        rows[i] = r;
+    }
+}
+/* keys sorted ascending: longer[w] = how many reads are longer than w (w = 0 .. max_len) */
+__global__ void k_span_longer(const uint32_t *keys, uint64_t n, uint32_t max_len, unsigned long long *longer)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > max_len) return;
+    uint64_t lo = 0, hi = n;   /* first index whose read is not longer than w: key >= max_len - w */
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (keys[mid] < max_len - w) lo = mid + 1; else hi = mid;
+    }
+    longer[w] = lo;
 }
 
 } // namespace
@@ -751,30 +908,15 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     *done = 0;
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
-    if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return SQ_OK; /* W4T dwords hold >= maxlen - 1 positions */
-    int nw = (int)((U + 31) / 32);
-    if (nw > SPAN_NW_MAX || (ad && nw > 5)) return SQ_OK; /* the automaton's rounds spill registers from 161 positions on: k_wide */
-    /* as many waves as LDS takes, at most 16 */
-    int waves = span_max_waves(nw);
-    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total > 160 * 1024) waves--;
-    if (waves < 4) return SQ_OK;
-    if (const char *e = getenv("SQ_SPAN_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
+    const int nw = (int)((U + 31) / 32);
+    const int waves = span_waves(P, nw, U, ad, n_ad);
+    if (!waves) return SQ_OK;
     const size_t lds = span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;
     const uint64_t nspans = C.n / SPAN_R;
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
-    int rc;
-    switch (nw) {
-        case 1: rc = launch_nw<1>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 2: rc = launch_nw<2>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 3: rc = launch_nw<3>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 4: rc = launch_nw<4>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 5: rc = launch_nw<5>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 6: rc = launch_nw<6>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        case 7: rc = launch_nw<7>(ctx, C, ad, n_ad, waves, lds, grid); break;
-        default: rc = launch_nw<8>(ctx, C, ad, n_ad, waves, lds, grid); break;
-    }
+    int rc = launch_any<false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
 #ifdef SQ_SPAN_PROBE
     if (getenv("SQ_SPAN_STAMPS")) {
@@ -788,5 +930,81 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     }
 #endif
     *done = C.n;
+    return SQ_OK;
+}
+
+/* A batch of many read lengths (none longer than k_span takes; what adapter trimming leaves of a
+ * file of one read length): its reads are sorted by length, longest first (one pass of a radix sort
+ * that moves a 16-byte row per read: where its sequence and qualities lie, which record it is),
+ * and the reads of the lengths that share a window count go through one launch of
+ * k_span<NW, ., SEG>, cut into spans of 16 reads of one length.  *done = records covered: all of
+ * them or none. */
+int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done)
+{
+    *done = 0;
+    const uint64_t n = P.n;
+    if (!max_len || max_len > 32u * (ad ? SPAN_NW_AD : SPAN_NW_MAX) || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
+    for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
+        if (!span_waves(P, nw, 32 * nw, ad, n_ad)) return SQ_OK;
+    uint32_t *keys_in = (uint32_t *)sq_scratch(ctx, 0, n * 4), *keys_out = (uint32_t *)sq_scratch(ctx, 1, n * 4);
+    SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow)), *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
+    unsigned long long *d_longer = (unsigned long long *)sq_scratch(ctx, 3, ((size_t)max_len + 1) * 8);
+    if (!keys_in || !keys_out || !rows_in || !rows_out || !d_longer) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
+    hipLaunchKernelGGL(k_span_keys, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                       P.metas, n, max_len, keys_in, rows_in);
+    int bits = 1;
+    while ((1ull << bits) <= max_len) bits++;
+    size_t temp_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, rows_in, rows_out, (int)n, 0, bits, ctx->stream) != hipSuccess)
+        return SQ_OK;
+    void *temp = sq_scratch(ctx, 4, temp_bytes ? temp_bytes : 8);
+    if (!temp) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, rows_in, rows_out, (int)n, 0, bits, ctx->stream) != hipSuccess) {
+        sq_set_error("radix sort failed");
+        return SQ_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_span_longer, dim3((max_len + 256) / 256), dim3(256), 0, ctx->stream, keys_out, n, max_len, d_longer);
+    std::vector<uint64_t> longer((size_t)max_len + 1);
+    SQ_HIP(hipMemcpyAsync(longer.data(), d_longer, longer.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (longer[0] != n) return SQ_OK;   /* a read without bases: the general pass knows what to do with it */
+    struct Launch { int nw, waves; std::vector<SpanSeg> segs; uint32_t spans; };
+    std::vector<Launch> launches;
+    for (uint32_t U = max_len; U >= 1; U--) {      /* the order of the sorted rows */
+        const uint64_t first = U == max_len ? 0 : longer[U], count = longer[U - 1] - first;
+        if (!count) continue;
+        const int nw = (int)((U + 31) / 32);
+        if (launches.empty() || launches.back().nw != nw)
+            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad), {}, 0});
+        Launch &l = launches.back();
+        SpanSeg g{};
+        g.span0 = l.spans;
+        g.nspans = (uint32_t)((count + SPAN_R - 1) / SPAN_R);
+        g.U = U;
+        g.last_rows = (uint32_t)(count - (uint64_t)(g.nspans - 1) * SPAN_R);
+        g.first = (uint32_t)first;
+        l.segs.push_back(g);
+        l.spans += g.nspans;
+    }
+    size_t total_segs = 0;
+    for (const Launch &l : launches) total_segs += l.segs.size();
+    SpanSeg *d_segs = (SpanSeg *)sq_scratch(ctx, 5, total_segs * sizeof(SpanSeg));
+    if (!d_segs) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
+    size_t seg_off = 0;
+    for (const Launch &l : launches) {   /* pageable memory: the copy is done when the call returns */
+        SQ_HIP(hipMemcpyAsync(d_segs + seg_off, l.segs.data(), l.segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
+        PassParams C = P;
+        C.uniform_len = 0;
+        C.span_segs = d_segs + seg_off;
+        C.span_nsegs = (uint32_t)l.segs.size();
+        C.span_total = l.spans;
+        C.span_rows = rows_out;
+        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves).total;
+        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + l.waves - 1) / l.waves, (uint64_t)ctx->num_cus));
+        int rc = launch_any<true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
+        if (rc) return rc;
+        seg_off += l.segs.size();
+    }
+    *done = n;
     return SQ_OK;
 }

@@ -448,6 +448,87 @@ def test_uniform_length_kernels_every_alignment(U):
                 np.testing.assert_array_equal(u64(r), rr)
 
 
+@pytest.mark.parametrize("max_len,with_adapters,ea", [(160, True, 100), (151, True, 20), (33, True, 100),
+                                                      (256, False, 100), (97, False, 300), (12, True, 5)])
+def test_sorted_spans_every_length(max_len, with_adapters, ea):
+    """reads of many lengths through k_span (sorted by length, spans of 16 reads of one length;
+    SQ_SPAN_SORTED=1 takes the path at this size): every length from 1 to max_len with a number
+    of reads that is no multiple of 16 (the last span of a length is filled up with padding rows),
+    several lengths with a single read, adapters at the very end of short and long reads, a probe
+    with an N, an end-anchor length shorter and longer than the reads; against the general k_pass
+    (SQ_SPAN=0) too"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(4000 + max_len)
+    probes = ["ACGTACGTACGT"[:min(max_len, 12)], "GGGGG", "TTNAC"]
+    names, seqs, quals = [], [], []
+    lengths = list(range(1, max_len + 1)) * 3 + list(rng.integers(1, max_len + 1, size=700)) + [max_len] * 37
+    rng.shuffle(lengths)
+    for i, L in enumerate(lengths):
+        L = int(L)
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[.24, .24, .24, .24, .04]).tobytes().decode()
+        if L >= 12 and i % 3 == 0:
+            at = int(rng.integers(0, L - 11)) if i % 2 else L - 12
+            s = s[:at] + "ACGTACGTACGT" + s[at + 12:]
+        if L >= 5 and i % 7 == 0:
+            s = s[:L - 5] + ("GGGGG" if i % 2 else "TTNAC")
+        names.append("r" * (1 + i % 67))
+        seqs.append(s)
+        quals.append((rng.integers(0, 94, size=L) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(ea), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    for env in ({"SQ_SPAN_SORTED": "1"}, {"SQ_SPAN": "0"}):
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(ea), AdapterCounter(probes)
+
+        def run():
+            if with_adapters:
+                FusedPass(gq, ga).add_record_array(arr)
+            else:
+                gq.add_record_array(arr)
+            gq.flush()
+        _with_env(env, run)
+        compare_qc(rq, gq, metas, arr)
+        assert gq.number_of_reads == len(lengths) and gq.max_length == max_len
+        if with_adapters:
+            for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+                np.testing.assert_array_equal(u64(f), fr)
+                np.testing.assert_array_equal(u64(r), rr)
+
+
+def test_sorted_spans_two_million_trimmed_reads():
+    """the ragged variant of the bench workload at a size the oracle finishes in seconds: 2 M
+    device-generated 150 bp records cut to 50..150 bases, QCMetrics + AdapterCounter; the default
+    path at this size is k_span over the sorted reads; then a second batch into the same objects
+    through the general k_pass"""
+    from sequali_amd import AdapterCounter, FusedPass, QCMetrics, _lib, synth
+    n = 2_000_000
+    dev = synth.device_array(synth.ILLUMINA, 777, n)
+    _lib.check(_lib.lib().sq_synth_trim(dev._batch.handle, 99, 50))
+    buf, metas = dev._batch.download()
+    probes = list(synth.ILLUMINA_PROBES)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    gq, ga = QCMetrics(), AdapterCounter(probes)
+    f = FusedPass(gq, ga)
+    for env in ({}, {"SQ_SPAN": "0"}):
+        rq.add(buf, metas)
+        ra.add(buf, metas)
+        _with_env(env, lambda: (f.add_record_array(dev), gq.flush()))
+        for (_, fw, rv), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(fw), fr)
+            np.testing.assert_array_equal(u64(rv), rr)
+        np.testing.assert_array_equal(u64(gq.base_count_table()), rq.base_count_table())
+        np.testing.assert_array_equal(u64(gq.phred_count_table()), rq.phred_count_table())
+        np.testing.assert_array_equal(u64(gq.end_anchored_base_count_table()), rq.end_anchored_base_count_table())
+        np.testing.assert_array_equal(u64(gq.end_anchored_phred_count_table()), rq.end_anchored_phred_count_table())
+        np.testing.assert_array_equal(u64(gq.gc_content()), rq.gc_content())
+        np.testing.assert_array_equal(u64(gq.phred_scores()), rq.phred_scores())
+        np.testing.assert_array_equal(dev.accumulated_error_rates().view(np.uint64),
+                                      metas["accumulated_error_rate"].view(np.uint64))
+    assert sum(int(fw.sum()) for _, fw, _ in ra.get_counts()) > 50_000
+
+
 def test_uniform_length_many_adapters_counted_in_device_tables():
     """with more adapters than the per-workgroup LDS hit table takes (8 KB), k_wide counts hits
     straight into the device tables; 150 bp and 250 bp (the longest k_wide's LDS still fits)"""
