@@ -2734,9 +2734,11 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
     /* QCMetrics + AdapterCounter + PerTileQuality on a batch of one read length: k_wide for the
        first two and a PerTileQuality pass of its own (qualities only) read the batch twice and
        still beat the one k_pass that carries all three (3.5 against 3.7 ms per 10 M reads) */
-    if (m && a && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
+    /* ... and since k_span and k_ptspan (sq_span.hip) QCMetrics + PerTileQuality without the
+       adapters too: 2.5 + 1.5 ms per 25 M reads against 7.0 for k_pass<QC,PT> */
+    if (m && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
         b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !getenv("SQ_NO_WIDE") && !getenv("SQ_RING") &&
-        !getenv("SQ_NO_SPLIT")) {
+        !getenv("SQ_NO_SPLIT") && (a || (b->max_length <= 32u * SPAN_NW_MAX && !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")))))) {
         int rc = fused_add_batch(b, m, a, nullptr);
         return rc ? rc : fused_add_batch(b, nullptr, nullptr, p);
     }
@@ -2802,6 +2804,16 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN"))) && !getenv("SQ_RING") && !getenv("SQ_NO_RING") &&
         !getenv("SQ_NO_WIDE") && !getenv("SQ_WIDE") &&
         (getenv("SQ_SPAN_SORTED") ? atoi(getenv("SQ_SPAN_SORTED")) != 0 : b->n >= 65536);
+    /* PerTileQuality alone on a batch of one read length whose table fits LDS: k_ptspan streams the
+       batch as it lies (no sort by tile) */
+    uint64_t pt_covered = 0;
+    const bool ptspan = !m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes &&
+                        p->n_slots > 0 && !getenv("SQ_NO_PTQ") && !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")));
+    if (ptspan) {
+        int rc = sq_ptspan_launch(ctx, P, (uint32_t)p->n_slots, &pt_covered);
+        if (rc) return rc;
+        if (pt_covered == b->n) return SQ_OK;
+    }
     P.pos_end = UINT32_MAX;
     if (b->n >= 4096 && b->n < (1ull << 31)) {
         if (pt_active) {
@@ -2809,7 +2821,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                takes a contiguous run of groups, and nearly every group is of one tile).  Only a
                batch whose tiles are mixed (on average fewer than 256 reads between two changes)
                is walked in tile-sorted order, which costs the sort and makes every load a gather */
-            if (getenv("SQ_PT_SORT") || ((uint64_t)p->tile_changes * 256 > b->n && !getenv("SQ_PT_STORED")))
+            if (!ptspan && (getenv("SQ_PT_SORT") || ((uint64_t)p->tile_changes * 256 > b->n && !getenv("SQ_PT_STORED"))))
                 P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
             P.blocked = P.order != nullptr; /* stored order: waves move through the batch together */
         }
@@ -2867,7 +2879,13 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     /* PerTileQuality alone on a batch of one read length: k_ptq for the full groups, k_pass for
        a trailing partial one (SQ_NO_PTQ=1: k_pass for all) */
     bool ptq_done = false;
-    if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !getenv("SQ_NO_PTQ") &&
+    if (pt_covered) {   /* k_ptspan took the full spans: the last few records go through k_pass */
+        P.order = nullptr;
+        P.metas += pt_covered;
+        P.pt_slot += pt_covered;
+        P.first_read_index += pt_covered;
+        P.n = b->n - pt_covered;
+    } else if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !getenv("SQ_NO_PTQ") &&
         ptq_lds_bytes(P.uniform_len) <= 80 * 1024) {
         PassParams C = P;
         C.n = (b->n / 64) * 64;

@@ -63,6 +63,7 @@ struct SpanRow {           /* one row of a span: 16 bytes */
 struct sq_ctx;
 struct PassParams;
 int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint64_t *done);
+int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done);
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 
 #endif

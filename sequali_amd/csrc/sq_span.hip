@@ -898,6 +898,187 @@ __global__ void k_span_longer(const uint32_t *keys, uint64_t n, uint32_t max_len
     longer[w] = lo;
 }
 
+
+/* ---- k_ptspan: PerTileQuality alone on a batch of one read length, the whole table in LDS ----
+ * PerTileQuality_add_meta (:3123-3222) adds the error rate of every quality to the row of the
+ * read's tile.  With reads of random tiles the round-1 kernels sort the batch by tile first and
+ * gather.  Here the batch is streamed as it lies (spans of 16 records by LDS-DMA, the qualities
+ * only) and the table of the workgroup -- [tiles + 1][positions] doubles, 123 KB for 96 tiles of
+ * 150 positions -- lives in LDS: lane (h, pl) gets the qualities of rows 8 h .. 8 h + 7 at its
+ * position by one transposing read per window, looks their error rates up and adds each to the
+ * row of that read's tile with ds_add_f64 (32 consecutive doubles per half wave: no bank
+ * conflict; the sums are order-free within the 1e-6 the module is checked to).  Reads that do
+ * not count (no tile, or behind the first header that did not parse, :3137-3148) go to a row
+ * nobody reads.  Merged into the device tables once per workgroup. */
+struct PtSpanLds { uint32_t table, cnt, dma, meta, rows, slots; size_t total; };
+constexpr uint32_t PTSPAN_META = SPAN_META_BYTES + 64;   /* the metas of a span and the tile slots of its records */
+__host__ __device__ inline PtSpanLds ptspan_lds_layout(int nw, uint32_t nslots, int waves)
+{
+    PtSpanLds L;
+    const uint32_t hs = 32 * (uint32_t)nw, qpr = 2 * (uint32_t)nw + 1;
+    uint32_t o = 256 * 8;                      /* error rates by quality byte, at LDS address 0 */
+    L.table = o; o += (nslots + 1) * hs * 8;
+    L.cnt = o; o += ((nslots + 1) * 4 + 15u) & ~15u;
+    L.dma = o; o += ((16 * qpr + 63) / 64) * 64 * 4;
+    L.meta = o; o += (uint32_t)waves * 2 * PTSPAN_META;
+    L.rows = o; o += (uint32_t)waves * 16 * 4;
+    L.slots = o;
+    L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * qpr;
+    return L;
+}
+
+__device__ __forceinline__ void add_f64_lds(uint32_t a, double v)
+{
+    asm volatile("ds_add_f64 %0, %1" :: "v"(a), "v"(v) : "memory");
+}
+/* byte J of w, times 8 */
+template <int J> __device__ __forceinline__ uint32_t shl3_byte_of(uint32_t w, uint32_t three)
+{
+    uint32_t t;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%3"
+        : "=v"(t) : "v"(three), "v"(w), "i"(J));
+    return t;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
+{
+    constexpr uint32_t SB = 32 * NW, QPR = 2 * NW + 1, ROWB = 16 * QPR, SLOT = SPAN_R * ROWB, ND = (SPAN_R * QPR + 63) / 64, hs = 32 * NW;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t U = P.uniform_len;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
+    const PtSpanLds L = ptspan_lds_layout(NW, nslots, W);
+    double *l_err = (double *)smem;                        /* [256] by raw quality byte */
+    double *l_pt = (double *)(smem + L.table);             /* [nslots + 1][hs] */
+    uint32_t *l_cnt = (uint32_t *)(smem + L.cnt);          /* [nslots + 1] reads per tile */
+    uint32_t *l_dma = (uint32_t *)(smem + L.dma);
+    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * SPAN_R;
+    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 2 * PTSPAN_META;
+    const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
+    if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
+    for (int i = tid; i < 256; i += T) {
+        double e = __longlong_as_double(0x7FF8000000000000LL);   /* not a phred character: NaN, as in the other kernels */
+        if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
+        else if (i >= 128 && i < 136) e = 0.0;
+        l_err[i] = e;
+    }
+    for (uint32_t i = tid; i < (nslots + 1) * hs; i += T) l_pt[i] = 0.0;
+    for (uint32_t i = tid; i <= nslots; i += T) l_cnt[i] = 0;
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) {   /* piece i = 64 k + lane: 16 bytes of the qualities of row i / QPR */
+            const uint32_t i = 64 * k + lane, row = i / QPR, pir = i % QPR;
+            l_dma[64 * k + lane] = (i < SPAN_R * QPR && pir < 2 * NW) ? (row * 4) | ((pir * 16) << 8) | 0x80000000u : 0;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
+    const uint64_t nspans = P.n / SPAN_R, stride = (uint64_t)gridDim.x * W;
+    uint64_t s = (uint64_t)blockIdx.x * W + wave;
+    auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
+        if (lane < (int)(SPAN_META_BYTES / 16))
+            dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+        if (lane < 4)
+            dma16((const uint8_t *)(P.pt_slot + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr + SPAN_META_BYTES));
+    };
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr) {
+        const uint32_t ma = maddr + 40 * q;
+        const unsigned long long m_rs = *(SQ_LDS const unsigned long long *)(uintptr_t)ma; /* record_start */
+        const uint32_t m_qo = lds_u32(ma + 20);                                            /* qualities_offset */
+        const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m_rs >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m_rs);
+        if (c == 0) l_rows[q] = (uint32_t)(m_rs - base) + m_qo;
+        const uint8_t *g0 = P.buf + base;
+        uint32_t pk[ND];
+        int32_t rr[ND];
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(lds_addr(l_rows) + (pk[k] & 0xFFu));
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++)
+            if ((int32_t)pk[k] < 0)
+                dma16(g0 + (long long)rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
+    };
+
+    const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t three = 3, one = 1;
+    const uint32_t dummy = nslots * hs * 8;
+    int cur = 0;
+    if (s < nspans) {
+        issue_meta(s, meta_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(slot_base, meta_base);
+        if (s + stride < nspans) issue_meta(s + stride, meta_base + PTSPAN_META);
+    }
+    while (s < nspans) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        /* the tile rows of this span's records, before their buffer is handed to the span after next */
+        const uint32_t mcur = meta_base + cur * PTSPAN_META + SPAN_META_BYTES;
+        uint32_t toff[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t sl = (int32_t)lds_u32(mcur + 4 * (8 * h + k));
+            const bool on = sl >= 0 && P.first_read_index + s * SPAN_R + 8 * h + k < P.pt_first_bad;
+            toff[k] = lds_addr(l_pt) + (on ? (uint32_t)sl * hs * 8 : dummy) + 8 * pl;
+        }
+        if (lane < (int)SPAN_R) {
+            const int32_t sl = (int32_t)lds_u32(mcur + 4 * lane);
+            const bool on = sl >= 0 && P.first_read_index + s * SPAN_R + lane < P.pt_first_bad;
+            lds_add(lds_addr(l_cnt) + 4 * (on ? (uint32_t)sl : nslots), one);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + stride < nspans) {
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * PTSPAN_META);
+            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * PTSPAN_META);
+        }
+        const uint32_t sa = slot_base + cur * SLOT;
+        /* transposing reads: lane 2 q' + p of a group of 16 hands in row 8 h + q', bytes 8 p .. 8 p + 7 */
+        const uint32_t trb = sa + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
+        static_for<0, NW>([&](auto wc) {
+            constexpr int w = decltype(wc)::value;
+            sq_u32x2 t = rd_tr8<32 * w>(trb);
+            wait_lgkm<0>();
+            tie2(t);
+            double e[8];
+            static_for<0, 8>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                e[k] = rd_f64(shl3_byte_of<k % 4>(k < 4 ? t.x : t.y, three));
+            });
+            wait_lgkm<0>();
+            static_for<0, 8>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                tie_f64(e[k]);
+                add_f64_lds(toff[k] + 256 * w, e[k]);
+            });
+        });
+        cur ^= 1;
+        s += stride;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nslots; i += T)
+        if (l_cnt[i]) atomicAdd(&P.pt_len_counts[(uint64_t)i * P.pt_cap + (U - 1)], (unsigned long long)l_cnt[i]);
+    for (uint32_t i = tid; i < nslots * hs; i += T) {
+        const uint32_t pos = i % hs;
+        const double v = l_pt[i];
+        if (pos < U && v != 0.0) unsafeAtomicAdd(&P.pt_errors[(uint64_t)(i / hs) * P.pt_cap + pos], v);
+    }
+}
+
+template <int NW>
+int launch_ptspan(sq_ctx *ctx, const PassParams &P, uint32_t nslots, int waves, size_t lds, int grid)
+{
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP(hipFuncSetAttribute((const void *)k_ptspan<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_ptspan<NW>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, nslots);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
 } // namespace
 
 /* Runs k_span over the first 16 * (n / 16) records of the pass described by P (QCMetrics, with
@@ -1006,5 +1187,38 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         seg_off += l.segs.size();
     }
     *done = n;
+    return SQ_OK;
+}
+
+/* PerTileQuality alone over the first 16 * (n / 16) records of a batch of one read length with the
+ * table in LDS (k_ptspan).  *done = records covered, 0 when the table does not fit or the reads
+ * are too long. */
+int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done)
+{
+    *done = 0;
+    const uint32_t U = P.uniform_len;
+    if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R || !nslots) return SQ_OK;
+    const int nw = (int)((U + 31) / 32);
+    int waves = 16;
+    while (waves >= 4 && ptspan_lds_layout(nw, nslots, waves).total > 160 * 1024) waves--;
+    if (waves < 4) return SQ_OK;
+    const size_t lds = ptspan_lds_layout(nw, nslots, waves).total;
+    PassParams C = P;
+    C.n = (P.n / SPAN_R) * SPAN_R;
+    const uint64_t nspans = C.n / SPAN_R;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
+    int rc;
+    switch (nw) {
+        case 1: rc = launch_ptspan<1>(ctx, C, nslots, waves, lds, grid); break;
+        case 2: rc = launch_ptspan<2>(ctx, C, nslots, waves, lds, grid); break;
+        case 3: rc = launch_ptspan<3>(ctx, C, nslots, waves, lds, grid); break;
+        case 4: rc = launch_ptspan<4>(ctx, C, nslots, waves, lds, grid); break;
+        case 5: rc = launch_ptspan<5>(ctx, C, nslots, waves, lds, grid); break;
+        case 6: rc = launch_ptspan<6>(ctx, C, nslots, waves, lds, grid); break;
+        case 7: rc = launch_ptspan<7>(ctx, C, nslots, waves, lds, grid); break;
+        default: rc = launch_ptspan<8>(ctx, C, nslots, waves, lds, grid); break;
+    }
+    if (rc) return rc;
+    *done = C.n;
     return SQ_OK;
 }
