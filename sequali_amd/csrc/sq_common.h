@@ -47,8 +47,8 @@ struct sq_ctx {
     uint64_t *pinned = nullptr; /* 64 words */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
-    void *scratch[16] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads */
-    size_t scratch_bytes[16] = {};
+    void *scratch[18] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span */
+    size_t scratch_bytes[18] = {};
 };
 
 inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)

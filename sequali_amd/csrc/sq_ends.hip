@@ -10,6 +10,7 @@
  * small ordered remainder.
  */
 #include <hipcub/hipcub.hpp>
+#include "sq_span.h"
 
 #include <algorithm>
 #include <thread>
@@ -616,7 +617,7 @@ __device__ void isz_table_add(const IszTable &T, const unsigned long long key[4]
  * A workgroup therefore counts them in a small LDS table first (write-once entries: hash,
  * key, count, earliest rank) and brings each entry to the device table once, instead of
  * hammering one device address with two atomics per read. */
-constexpr uint32_t ISZ_CACHE = 32;
+constexpr uint32_t ISZ_CACHE = 256;   /* 32 held the full-length remainder and little else: the shorter ones (one key per length) went to the device table, all workgroups on the same few slots */
 struct IszCache {
     unsigned long long hash[2][ISZ_CACHE], rank[2][ISZ_CACHE], key[2][ISZ_CACHE][4];
     unsigned int count[2][ISZ_CACHE], ready[2][ISZ_CACHE];
@@ -810,13 +811,56 @@ __global__ void k_insert_size(IszParams P)
     if (local_max) atomicMax(&l_max, (unsigned int)local_max);
     __syncthreads();
     if (threadIdx.x == 0 && l_max) atomicMax(P.max_insert, (unsigned long long)l_max);
-    if (threadIdx.x < 2 * ISZ_CACHE) { /* the workgroup's remainders, each once */
-        const uint32_t w = threadIdx.x / ISZ_CACHE, e = threadIdx.x % ISZ_CACHE;
+    for (uint32_t t = threadIdx.x; t < 2 * ISZ_CACHE; t += blockDim.x) { /* the workgroup's remainders, each once */
+        const uint32_t w = t / ISZ_CACHE, e = t % ISZ_CACHE;
         if (cache.hash[w][e] && cache.count[w][e])
             isz_table_add(P.tab[w], cache.key[w][e], cache.hash[w][e], cache.count[w][e], cache.rank[w][e], P.closed);
     }
     for (uint32_t i = threadIdx.x; i < P.lds_sizes; i += blockDim.x)
         if (l_sizes[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_sizes[i]);
+    if (threadIdx.x < 2 && l_events[threadIdx.x])
+        atomicAdd(P.tab[threadIdx.x].n_events, (unsigned long long)l_events[threadIdx.x]);
+}
+
+/* The adapter remainders of the pairs k_isz_span found one for (results[r] = their insert size):
+ * InsertSizeMetrics_add_sequence_pair_ptr :5729-5742, as at the end of k_insert_size */
+__global__ void k_isz_adapters(IszParams P, const uint32_t *results)
+{
+    __shared__ unsigned int l_events[2];
+    __shared__ IszCache cache;
+    if (threadIdx.x < 2) l_events[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * ISZ_CACHE; i += blockDim.x) {
+        cache.hash[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+        cache.rank[i / ISZ_CACHE][i % ISZ_CACHE] = ~0ULL;
+        cache.count[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+        cache.ready[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
+    }
+    __syncthreads();
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t result = results[r];
+        if (!result) continue;
+        const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
+        const uint8_t *s1 = P.buf1 + m1.record_start + m1.sequence_offset;
+        const uint8_t *s2 = P.buf2 + m2.record_start + m2.sequence_offset;
+        const uint32_t L1 = m1.sequence_length, L2 = m2.sequence_length;
+        const unsigned long long rank = 2 * (P.rank_base + r);
+        if (L1 > result) {
+            atomicAdd(&l_events[0], 1u);
+            isz_count_adapter(P.tab[0], cache, 0, s1 + result, min(L1 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE),
+                              rank, P.closed, P.buf1 + P.len1);
+        }
+        if (L2 > result) {
+            atomicAdd(&l_events[1], 1u);
+            isz_count_adapter(P.tab[1], cache, 1, s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE),
+                              rank + 1, P.closed, P.buf2 + P.len2);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 2 * ISZ_CACHE; t += blockDim.x) { /* the workgroup's remainders, each once */
+        const uint32_t w = t / ISZ_CACHE, e = t % ISZ_CACHE;
+        if (cache.hash[w][e] && cache.count[w][e])
+            isz_table_add(P.tab[w], cache.key[w][e], cache.hash[w][e], cache.count[w][e], cache.rank[w][e], P.closed);
+    }
     if (threadIdx.x < 2 && l_events[threadIdx.x])
         atomicAdd(P.tab[threadIdx.x].n_events, (unsigned long long)l_events[threadIdx.x]);
 }
@@ -2050,8 +2094,37 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
     P.rank_base = z->first_pair + z->total_reads;
     P.closed = z->closed ? 1 : 0;
     P.lds_sizes = (uint32_t)std::min<size_t>(z->cap, 8192);
-    hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(n, 2048)), dim3(256), P.lds_sizes * 4, ctx->stream, P);
-    SQ_HIP(hipGetLastError());
+    /* pairs of one read length each: the scan streams read 1 through LDS (k_isz_span, sq_span.hip)
+       and leaves the adapter remainders to k_isz_adapters; the last few pairs (and everything
+       else) go through k_insert_size.  SQ_SPAN=0: k_insert_size for all. */
+    uint64_t covered = 0;
+    if (b1->owns && b2->owns && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
+        !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")))) {
+        uint32_t *d_results = (uint32_t *)sq_scratch(ctx, 16, n * 4);
+        if (d_results) {
+            IszSpanParams S{};
+            S.buf1 = P.buf1; S.buf2 = P.buf2; S.metas1 = P.metas1; S.metas2 = P.metas2; S.n = n;
+            S.L1 = (uint32_t)b1->max_length; S.L2 = (uint32_t)b2->max_length;
+            S.insert_sizes = P.insert_sizes; S.lds_sizes = (uint32_t)std::min<size_t>(z->cap, 1024);
+            S.max_insert = P.max_insert; S.results = d_results;
+            rc = sq_isz_span_launch(ctx, S, &covered);
+            if (rc) return rc;
+            if (covered) {
+                IszParams A = P;
+                A.n = covered;
+                /* a workgroup per CU: every workgroup brings its cache of remainders to the device tables when it
+                   is done, all of them at about the same time and most of them the same few keys */
+                hipLaunchKernelGGL(k_isz_adapters, dim3(blocks_for(covered, 4 * ctx->num_cus)), dim3(256), 0, ctx->stream, A, (const uint32_t *)d_results);
+                SQ_HIP(hipGetLastError());
+            }
+        }
+    }
+    if (covered < n) {
+        IszParams R = P;
+        R.metas1 += covered; R.metas2 += covered; R.n = n - covered; R.rank_base += covered;
+        hipLaunchKernelGGL(k_insert_size, dim3(blocks_for(R.n, 2048)), dim3(256), R.lds_sizes * 4, ctx->stream, R);
+        SQ_HIP(hipGetLastError());
+    }
     z->total_reads += n;
     if (!z->closed) {
         /* once max_adapters distinct remainders exist in both tables, later batches can

@@ -60,9 +60,24 @@ struct SpanRow {           /* one row of a span: 16 bytes */
     uint32_t record;       /* index of the record in the batch */
 };
 
+/* k_isz_span: the overlap scan of InsertSizeMetrics (calculate_insert_size, _qcmodule.c:5667-5707)
+ * on pairs of one read length each, read 1 streamed through LDS */
+struct sq_meta;
+struct IszSpanParams {
+    const uint8_t *buf1, *buf2;
+    const sq_meta *metas1, *metas2;
+    uint64_t n;
+    uint32_t L1, L2;                     /* the read lengths (both >= 16, L1 <= 256) */
+    unsigned long long *insert_sizes;    /* [>= L1 + L2 + 17] */
+    uint32_t lds_sizes;                  /* entries of it a workgroup counts in LDS first */
+    unsigned long long *max_insert;
+    uint32_t *results;                   /* [n]: the insert size where the pair leaves an adapter remainder, else 0 */
+};
+
 struct sq_ctx;
 struct PassParams;
 int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint64_t *done);
+int sq_isz_span_launch(sq_ctx *ctx, const IszSpanParams &P, uint64_t *done);
 int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done);
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 

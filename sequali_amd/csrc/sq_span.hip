@@ -1036,21 +1036,30 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
         const uint32_t sa = slot_base + cur * SLOT;
         /* transposing reads: lane 2 q' + p of a group of 16 hands in row 8 h + q', bytes 8 p .. 8 p + 7 */
         const uint32_t trb = sa + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
+        /* all windows' bytes first; then the error rates of window w + 1 are on their way while
+           those of window w are added (LDS answers in order: behind the 8 adds of the window
+           before, the 8 lookups in front of them have arrived) */
+        sq_u32x2 t[NW];
+        static_for<0, NW>([&](auto wc) { constexpr int w = decltype(wc)::value; t[w] = rd_tr8<32 * w>(trb); });
+        wait_lgkm<0>();
+        static_for<0, NW>([&](auto wc) { tie2(t[decltype(wc)::value]); });
+        double e[2][8];
+        static_for<0, 8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            e[0][k] = rd_f64(shl3_byte_of<k % 4>(k < 4 ? t[0].x : t[0].y, three));
+        });
         static_for<0, NW>([&](auto wc) {
             constexpr int w = decltype(wc)::value;
-            sq_u32x2 t = rd_tr8<32 * w>(trb);
-            wait_lgkm<0>();
-            tie2(t);
-            double e[8];
+            if constexpr (w == 0) wait_lgkm<0>(); else wait_lgkm<8>();
+            static_for<0, 8>([&](auto kc) { tie_f64(e[w & 1][decltype(kc)::value]); });
+            if constexpr (w + 1 < NW)
+                static_for<0, 8>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    e[(w + 1) & 1][k] = rd_f64(shl3_byte_of<k % 4>(k < 4 ? t[w + 1].x : t[w + 1].y, three));
+                });
             static_for<0, 8>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                e[k] = rd_f64(shl3_byte_of<k % 4>(k < 4 ? t.x : t.y, three));
-            });
-            wait_lgkm<0>();
-            static_for<0, 8>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                tie_f64(e[k]);
-                add_f64_lds(toff[k] + 256 * w, e[k]);
+                add_f64_lds(toff[k] + 256 * w, e[w & 1][k]);
             });
         });
         cur ^= 1;
@@ -1075,6 +1084,220 @@ int launch_ptspan(sq_ctx *ctx, const PassParams &P, uint32_t nslots, int waves, 
         attr = true;
     }
     hipLaunchKernelGGL((k_ptspan<NW>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, nslots);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
+
+/* ---- k_isz_span: the overlap scan of InsertSizeMetrics on pairs of one read length each ----
+ * calculate_insert_size (_qcmodule.c:5667-5707) slides a 16-byte window over read 1 and compares
+ * it with the reverse complements of the first and of the last 16 bases of read 2.  A lane per
+ * pair streaming its own read (k_insert_size) is the least efficient way to ask memory: 5.6 ms
+ * per 25 M pairs for 1.4 ms of arithmetic.  Here a wave takes 16 pairs per span: the sequences
+ * of read 1 come by LDS-DMA as in k_span (16-byte pieces from any alignment), of read 2 only the
+ * two ends; four lanes share a pair, lane c scans the windows [8 NW c, 8 NW (c + 1)) from LDS
+ * (all its bytes are read up front: the scan itself is registers only), the first match of the
+ * quad in window order is the pair's.  The adapter remainders of the pairs that have one
+ * (InsertSizeMetrics_add_adapter :5570-5611; they need the device hash tables) are left to
+ * k_isz_adapters: this kernel only notes the insert size of such a pair in `results`. */
+struct IszSpanLds { uint32_t sizes, dma, meta, rows, ends, slots; size_t total; };
+__host__ __device__ inline IszSpanLds isz_span_lds_layout(int nw, uint32_t lds_sizes, int waves)
+{
+    IszSpanLds L;
+    const uint32_t qpr = 2 * (uint32_t)nw + 1;
+    uint32_t o = 16;                                  /* the workgroup's largest insert size */
+    L.sizes = o; o += (lds_sizes * 4 + 15u) & ~15u;
+    L.dma = o; o += ((16 * qpr + 63) / 64) * 64 * 4;
+    L.meta = o; o += (uint32_t)waves * 2 * 2 * SPAN_META_BYTES;
+    L.rows = o; o += (uint32_t)waves * 16 * 4;
+    L.ends = o; o += (uint32_t)waves * 2 * 512;       /* per row the first and the last 16 bases of read 2 */
+    L.slots = o;
+    L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * qpr;
+    return L;
+}
+
+__device__ __forceinline__ uint32_t isz_nonzero_bytes_of(uint32_t v)
+{
+    return (uint32_t)__popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
+}
+/* NUCLEOTIDE_COMPLEMENT, _qcmodule.c:5613-5631: reverse complement of 8 bases (0 for what is no base) */
+__device__ __forceinline__ unsigned long long isz_revcomp8(unsigned long long a)
+{
+    unsigned long long r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned l = ((unsigned)(a >> (8 * i)) & 0xFFu) | 0x20u;
+        const unsigned long long cc = l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : l == 't' ? 'A' : 0;
+        r |= cc << (8 * (7 - i));
+    }
+    return r;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(1024) k_isz_span(IszSpanParams P)
+{
+    constexpr uint32_t QPR = 2 * NW + 1, ROWB = 16 * QPR, SLOT = SPAN_R * ROWB, ND = (SPAN_R * QPR + 63) / 64, WQ = 8 * NW;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
+    const IszSpanLds L = isz_span_lds_layout(NW, P.lds_sizes, W);
+    uint32_t *l_max = (uint32_t *)smem;
+    uint32_t *l_sizes = (uint32_t *)(smem + L.sizes);
+    uint32_t *l_dma = (uint32_t *)(smem + L.dma);
+    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * SPAN_R;
+    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 4 * SPAN_META_BYTES;   /* [2 buffers][read 1, read 2] */
+    const uint32_t ends_base = lds_addr(smem + L.ends) + wave * 2 * 512;
+    const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
+    for (uint32_t i = tid; i < P.lds_sizes; i += T) l_sizes[i] = 0;
+    if (tid == 0) *l_max = 0;
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) {   /* piece i = 64 k + lane: 16 bytes of the sequence of row i / QPR */
+            const uint32_t i = 64 * k + lane, row = i / QPR, pir = i % QPR;
+            l_dma[64 * k + lane] = (i < SPAN_R * QPR && 16 * pir < P.L1) ? (row * 4) | ((pir * 16) << 8) | 0x80000000u : 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
+    const uint64_t nspans = P.n / SPAN_R, stride = (uint64_t)gridDim.x * W;
+    uint64_t s = (uint64_t)blockIdx.x * W + wave;
+    auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
+        if (lane < (int)(SPAN_META_BYTES / 16)) {
+            dma16((const uint8_t *)(P.metas1 + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+            dma16((const uint8_t *)(P.metas2 + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr + SPAN_META_BYTES));
+        }
+    };
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint32_t ends_addr) {
+        const uint32_t ma = maddr + 40 * q;
+        const unsigned long long rs1 = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
+        const uint32_t so1 = lds_u32(ma + 12);
+        const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rs1 >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rs1);
+        if (c == 0) l_rows[q] = (uint32_t)(rs1 - base) + so1;
+        /* the ends of read 2: lane (row, e) with row = lane / 2 */
+        if (lane < 32) {
+            const uint32_t m2 = maddr + SPAN_META_BYTES + 40 * ((uint32_t)lane >> 1);
+            const unsigned long long rs2 = *(SQ_LDS const unsigned long long *)(uintptr_t)m2;
+            const uint32_t so2 = lds_u32(m2 + 12);
+            dma16(P.buf2 + rs2 + so2 + ((lane & 1) ? P.L2 - 16 : 0), __builtin_amdgcn_readfirstlane(ends_addr));
+        }
+        const uint8_t *g0 = P.buf1 + base;
+        uint32_t pk[ND];
+        int32_t rr[ND];
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(lds_addr(l_rows) + (pk[k] & 0xFFu));
+#pragma unroll
+        for (int k = 0; k < (int)ND; k++)
+            if ((int32_t)pk[k] < 0)
+                dma16(g0 + (long long)rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
+    };
+
+    const uint32_t last = P.L1 - 16, UP4 = 0xDFDFDFDFu;
+    uint32_t local_max = 0;
+    int cur = 0;
+    if (s < nspans) {
+        issue_meta(s, meta_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(slot_base, meta_base, ends_base);
+        if (s + stride < nspans) issue_meta(s + stride, meta_base + 2 * SPAN_META_BYTES);
+    }
+    while (s < nspans) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (s + stride < nspans) {
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * 2 * SPAN_META_BYTES, ends_base + (cur ^ 1) * 512);
+            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * 2 * SPAN_META_BYTES);
+        }
+        /* the needles: lane c makes one of the four halves (h_lo, h_hi, t_lo, t_hi), the quad shares them */
+        const uint32_t ea = ends_base + cur * 512 + 32 * q + ((c & 1) ? 0 : 8) + ((c & 2) ? 16 : 0);
+        const unsigned long long mine = isz_revcomp8(*(SQ_LDS const unsigned long long *)(uintptr_t)ea);
+        const uint32_t m_lo = (uint32_t)mine, m_hi = (uint32_t)(mine >> 32);
+        const uint32_t hl = quad_bcast<0x00>(m_lo), hl2 = quad_bcast<0x00>(m_hi), hh = quad_bcast<0x55>(m_lo), hh2 = quad_bcast<0x55>(m_hi);
+        const uint32_t tl = quad_bcast<0xAA>(m_lo), tl2 = quad_bcast<0xAA>(m_hi), th = quad_bcast<0xFF>(m_lo), th2 = quad_bcast<0xFF>(m_hi);
+        /* This lane's windows of read 1 start at bytes [WQ c, WQ c + WQ).  The scan proper only asks
+           whether a window can match at all -- a needle half matches (:5695) only if its low dword
+           does -- and keeps the answers as a bit per window: five byte-aligns, two ands, four
+           compares and an or per base, no branch (with the verdict inline the unrolled scan was
+           35 KB of code and ran at a third of its issue rate).  The rare candidates are looked
+           at again below, in window order. */
+        const uint32_t ra = slot_base + cur * SLOT + q * ROWB + WQ * c;
+        const unsigned long long p0 = *(SQ_LDS const unsigned long long *)(uintptr_t)ra, p1 = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8);
+        uint32_t w0 = (uint32_t)p0, w1 = (uint32_t)(p0 >> 32), w2 = (uint32_t)p1, w3 = (uint32_t)(p1 >> 32);
+        unsigned long long nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 16);
+        uint32_t cand_lo = 0, cand_hi = 0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < (uint32_t)NW; k++) {
+            uint32_t n0 = (uint32_t)nxt, n1 = (uint32_t)(nxt >> 32);
+            if (k + 1 < (uint32_t)NW) nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 24 + 8 * k);   /* the last lane's last one lies in the spare piece of the row */
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
+                const bool maybe = (u0 == hl) | (u2 == hh) | (u0 == tl) | (u2 == th);
+                bits |= maybe ? 1u << j : 0u;
+                w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); /* slide the window by one base */
+                w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+                w2 = __builtin_amdgcn_alignbyte(w3, w2, 1);
+                w3 = __builtin_amdgcn_alignbyte(n0, w3, 1);
+                n0 = __builtin_amdgcn_alignbyte(n1, n0, 1);
+                n1 >>= 8;
+            }
+            if (k < 4) cand_lo |= bits << (8 * k); else cand_hi |= bits << (8 * (k - 4));
+        }
+        uint32_t result = 0;
+        unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
+        while (cand) {   /* :5695-5704: a half matches case-insensitively, then at most one raw byte of the 16 may differ */
+            const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1, i = WQ * c + j;
+            cand &= cand - 1;
+            if (i > last) break;
+            uint32_t b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t a = ra + j + 4 * t;   /* any alignment */
+                b[t] = lds_u8(a) | (lds_u8(a + 1) << 8) | (lds_u8(a + 2) << 16) | (lds_u8(a + 3) << 24);
+            }
+            const uint32_t u0 = b[0] & UP4, u1 = b[1] & UP4, u2 = b[2] & UP4, u3 = b[3] & UP4;
+            if ((u0 == hl && u1 == hl2) || (u2 == hh && u3 == hh2)) {
+                const uint32_t d = isz_nonzero_bytes_of(b[0] ^ hl) + isz_nonzero_bytes_of(b[1] ^ hl2) +
+                                   isz_nonzero_bytes_of(b[2] ^ hh) + isz_nonzero_bytes_of(b[3] ^ hh2);
+                if (d <= 1) { result = i + 16; break; }
+            }
+            if ((u0 == tl && u1 == tl2) || (u2 == th && u3 == th2)) {
+                const uint32_t d = isz_nonzero_bytes_of(b[0] ^ tl) + isz_nonzero_bytes_of(b[1] ^ tl2) +
+                                   isz_nonzero_bytes_of(b[2] ^ th) + isz_nonzero_bytes_of(b[3] ^ th2);
+                if (d <= 1) { result = i + P.L2; break; }
+            }
+        }
+        /* the first match in window order: the lowest quarter that has one */
+        const uint32_t r0 = quad_bcast<0x00>(result), r1 = quad_bcast<0x55>(result), r2 = quad_bcast<0xAA>(result), r3 = quad_bcast<0xFF>(result);
+        result = r0 ? r0 : r1 ? r1 : r2 ? r2 : r3;
+        if (c == 0) {
+            if (result < P.lds_sizes) lds_add(lds_addr(l_sizes + result), 1u);
+            else atomicAdd(&P.insert_sizes[result], 1ULL);
+            local_max = max(local_max, result);
+            const uint32_t note = (result && (P.L1 > result || P.L2 > result)) ? result : 0;
+            uint32_t *dst = P.results + s * SPAN_R + q;
+            asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(note) : "memory");
+        }
+        cur ^= 1;
+        s += stride;
+    }
+    if (local_max) atomicMax(l_max, local_max);
+    __syncthreads();
+    if (tid == 0 && *l_max) atomicMax(P.max_insert, (unsigned long long)*l_max);
+    for (uint32_t i = tid; i < P.lds_sizes; i += T)
+        if (l_sizes[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_sizes[i]);
+}
+
+template <int NW>
+int launch_isz_span(sq_ctx *ctx, const IszSpanParams &P, int waves, size_t lds, int grid)
+{
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP(hipFuncSetAttribute((const void *)k_isz_span<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_isz_span<NW>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P);
     SQ_HIP(hipGetLastError());
     return SQ_OK;
 }
@@ -1217,6 +1440,38 @@ int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t
         case 6: rc = launch_ptspan<6>(ctx, C, nslots, waves, lds, grid); break;
         case 7: rc = launch_ptspan<7>(ctx, C, nslots, waves, lds, grid); break;
         default: rc = launch_ptspan<8>(ctx, C, nslots, waves, lds, grid); break;
+    }
+    if (rc) return rc;
+    *done = C.n;
+    return SQ_OK;
+}
+
+/* The overlap scan of InsertSizeMetrics over the first 16 * (n / 16) pairs of two batches of one
+ * read length each (k_isz_span).  *done = pairs covered (0: the kernel does not take these
+ * lengths). */
+int sq_isz_span_launch(sq_ctx *ctx, const IszSpanParams &P, uint64_t *done)
+{
+    *done = 0;
+    if (P.L1 < 16 || P.L2 < 16 || P.L1 > 32u * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
+    const int nw = (int)((P.L1 + 31) / 32);
+    int waves = 16;
+    while (waves >= 4 && isz_span_lds_layout(nw, P.lds_sizes, waves).total > 160 * 1024) waves--;
+    if (waves < 4) return SQ_OK;
+    const size_t lds = isz_span_lds_layout(nw, P.lds_sizes, waves).total;
+    IszSpanParams C = P;
+    C.n = (P.n / SPAN_R) * SPAN_R;
+    const uint64_t nspans = C.n / SPAN_R;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
+    int rc;
+    switch (nw) {
+        case 1: rc = launch_isz_span<1>(ctx, C, waves, lds, grid); break;
+        case 2: rc = launch_isz_span<2>(ctx, C, waves, lds, grid); break;
+        case 3: rc = launch_isz_span<3>(ctx, C, waves, lds, grid); break;
+        case 4: rc = launch_isz_span<4>(ctx, C, waves, lds, grid); break;
+        case 5: rc = launch_isz_span<5>(ctx, C, waves, lds, grid); break;
+        case 6: rc = launch_isz_span<6>(ctx, C, waves, lds, grid); break;
+        case 7: rc = launch_isz_span<7>(ctx, C, waves, lds, grid); break;
+        default: rc = launch_isz_span<8>(ctx, C, waves, lds, grid); break;
     }
     if (rc) return rc;
     *done = C.n;

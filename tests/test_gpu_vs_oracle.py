@@ -681,8 +681,10 @@ def _tile_batch(rng, n, U, tile_of, bad_at=None):
 
 @pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
 def test_ptq_kernel_every_length_and_alignment(U):
-    """PerTileQuality alone on a batch of one read length is k_ptq (_qcmodule.c:3124-3222 on the
-    qualities only, 64 bytes per row and visit, per-wave sums of the tile the groups are in):
+    """PerTileQuality alone on a batch of one read length is k_ptspan up to 256 positions (the
+    batch streamed as stored, the workgroup's whole table in LDS) and k_ptq beyond or with
+    SQ_SPAN=0 (_qcmodule.c:3124-3222 on the qualities only, 64 bytes per row and visit, per-wave
+    sums of the tile the groups are in):
     the 16 length classes x rotating alignments with (a) random tiles in >= 4096 reads (the
     tile-sorted walk), (b) tiles in runs with a seam inside a group of 64 and a trailing partial
     group (walked as stored), (c) a header without a tile in the middle of the batch (the module
@@ -700,7 +702,7 @@ def test_ptq_kernel_every_length_and_alignment(U):
         buf, metas = _tile_batch(rng, n, U, tile_of, bad_at)
         ref = oracle.PerTileQuality()
         ref.add(buf, metas)
-        for env in ({}, {"SQ_NO_PTQ": "1"}):
+        for env in ({}, {"SQ_SPAN": "0"}, {"SQ_NO_PTQ": "1"}):
             got = PerTileQuality()
             arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
             _with_env(env, lambda: got.add_record_array(arr))
