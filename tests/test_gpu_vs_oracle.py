@@ -282,6 +282,75 @@ def test_insert_size_vs_oracle():
     assert int(ref.insert_sizes()[1:].sum()) > 1000
 
 
+def _revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGTacgtN", "TGCAtgcaN"))
+
+
+@pytest.mark.parametrize("L1,L2,n", [(150, 150, 16 * 40 + 7), (100, 75, 16 * 25), (16, 16, 16 * 9 + 15),
+                                     (33, 250, 16 * 12 + 1), (256, 40, 16 * 10 + 3), (40, 151, 16 * 8)])
+def test_insert_size_pairs_of_one_read_length(L1, L2, n):
+    """pairs whose reads have one length each go through k_isz_span (read 1 streamed through LDS,
+    four lanes per pair, a candidate bit per window) + k_isz_adapters, the pairs behind the last
+    full span of 16 through k_insert_size: inserts of every size from 16 up to longer than both
+    reads (the match in every quarter of read 1 and at its very end, found by the head or only by
+    the tail needle), one mismatch in the overlap (still a match), two (no match), an N in the
+    needle of read 2 and in the window of read 1, lower case bases, a decoy that matches one needle half
+    only; histogram, adapter remainders and their order against the oracle, and against
+    k_insert_size alone (SQ_SPAN=0)"""
+    from sequali_amd import FastqRecordArrayView, InsertSizeMetrics
+    rng = np.random.default_rng(L1 * 1000 + L2)
+    ad1, ad2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+
+    def rand(k):
+        return rng.choice(np.frombuffer(b"ACGT", np.uint8), size=k).tobytes().decode()
+    n1, s1, q1, n2, s2, q2 = [], [], [], [], [], []
+    for i in range(n):
+        flen = 16 + (i * 7) % (L1 + L2) if i % 5 else int(rng.integers(16, L1 + L2 + 40))
+        frag = rand(flen)
+        r1 = (frag + ad1 + "G" * 300)[:L1]
+        r2 = (_revcomp(frag) + ad2 + "G" * 300)[:L2]
+        kind = i % 11
+        if kind == 1 and flen >= 16:      # one mismatch inside what the head needle covers in read 1
+            at = min(flen - 16 + 5, L1 - 1)
+            r1 = r1[:at] + ("A" if r1[at] != "A" else "C") + r1[at + 1:]
+        elif kind == 2 and flen >= 16:    # two of them
+            for at in (min(flen - 16 + 2, L1 - 1), min(flen - 16 + 9, L1 - 1)):
+                r1 = r1[:at] + ("A" if r1[at] != "A" else "C") + r1[at + 1:]
+        elif kind == 3:
+            r2 = r2[:3] + "N" + r2[4:]
+        elif kind == 4:
+            at = int(rng.integers(0, L1))
+            r1 = r1[:at] + "N" + r1[at + 1:]
+        elif kind == 5:
+            r1, r2 = r1.lower(), r2
+        elif kind == 6 and L1 >= 40:      # half of the head needle somewhere it does not belong
+            half = _revcomp(r2[:16])[:8]
+            r1 = r1[:20] + half + r1[28:]
+        n1.append(f"p{i}/1"); s1.append(r1[:L1]); q1.append("I" * L1)
+        n2.append(f"p{i}/2"); s2.append(r2[:L2]); q2.append("I" * L2)
+    b1, m1 = oracle.make_batch(n1, s1, q1)
+    b2, m2 = oracle.make_batch(n2, s2, q2)
+    ref = oracle.InsertSizeMetrics(50)
+    ref.add_pair(b1, m1, b2, m2)
+    ref.add_pair(b1, m1, b2, m2)
+    assert int(ref.insert_sizes()[1:].sum()) > 0
+    for env in ({}, {"SQ_SPAN": "0"}):
+        got = InsertSizeMetrics(50)
+
+        def run():
+            for _ in range(2):
+                got.add_record_array_pair(FastqRecordArrayView._from_buffer(b1, m1.copy()),
+                                          FastqRecordArrayView._from_buffer(b2, m2.copy()))
+            got.insert_sizes()
+        _with_env(env, run)
+        np.testing.assert_array_equal(u64(got.insert_sizes()), ref.insert_sizes())
+        assert got.adapters_read1() == ref.adapters_read1()
+        assert got.adapters_read2() == ref.adapters_read2()
+        assert got.number_of_adapters_read1 == ref.number_of_adapters_read1
+        assert got.number_of_adapters_read2 == ref.number_of_adapters_read2
+        assert got.total_reads == ref.total_reads
+
+
 def test_device_generator_matches_host_generator():
     """the GPU-resident synthetic batches hold exactly the host generator's bytes"""
     from sequali_amd import QCMetrics, synth
