@@ -11,6 +11,7 @@ constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
 constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass */
 constexpr uint32_t SPAN_BIN_OFF = 136 * 8;
 constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
+constexpr uint32_t SPAN_META_LDS = 16 * 32;     /* what k_span keeps of them: the first 32 bytes of each (SEG: 16 bytes per row) */
 
 struct SpanLds {
     uint32_t thr, gc, ps, dfa, out, adlen, hist, first, rows, dma, meta, slots;
@@ -20,7 +21,7 @@ struct SpanLds {
 /* nw: 32-position windows per read; U: read length; states / n_ad / ad_lds: the automaton, its
  * adapters, how many of them are counted in LDS (0 without AdapterCounter); waves per workgroup */
 __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t states, uint32_t n_ad,
-                                                   uint32_t ad_lds, int waves)
+                                                   uint32_t ad_lds, int waves, bool seg = false)
 {
     SpanLds L;
     const uint32_t hs = (U + 31u) & ~31u;
@@ -32,12 +33,12 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.dfa = o; o += ((states + 2) / 3 * 36 + 15u) & ~15u; /* three states to 36 bytes */
     L.out = o; o += states * 8;
     L.adlen = o; o += states ? 64 : 0;
-    L.hist = o; o += hs * (5 + 13) * 4 + ad_lds * hs * 4; /* a 13th phred row takes the qualities of filler rows */
+    L.hist = o; o += hs * (5 + 12 + (seg ? 1 : 0)) * 4 + ad_lds * hs * 4; /* seg: a 13th phred row takes the qualities of filler rows */
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
-    L.rows = o; o += (uint32_t)waves * 64 * 4;
+    L.rows = o; o += (uint32_t)waves * (seg ? 64 : 32) * 4;
     L.dma = o; o += ((16u * (4 * (uint32_t)nw + 1) + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
-    L.meta = o; o += (uint32_t)waves * 2 * SPAN_META_BYTES;
+    L.meta = o; o += (uint32_t)waves * (seg ? 256 : SPAN_META_LDS);   /* one buffer: the metas of span k + 2 land where those of k + 1 were read */
     L.slots = o;
     L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * (4 * (size_t)nw + 1); /* two slots of 16 rows of 4 nw + 1 pieces */
     return L;

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
     const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W);
+    const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG);
     double *l_err = (double *)smem;                        /* [136] by raw quality byte */
     uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
@@ -243,10 +243,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there */
     uint8_t *l_adlen = smem + L.adlen;                     /* [64] */
     uint32_t *l_hist_base = (uint32_t *)(smem + L.hist);   /* [5][hs] */
-    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [12 + 1][hs]: the last row takes the qualities of filler rows */
-    uint32_t *l_adf = l_hist_phred + hs * (PHRED_COLS + 1); /* [ad_lds][hs] */
+    constexpr uint32_t PROWS = PHRED_COLS + (SEG ? 1 : 0);   /* SEG: one more row takes the qualities of filler rows */
+    uint32_t *l_hist_phred = l_hist_base + hs * BASE_COLS; /* [PROWS][hs] */
+    uint32_t *l_adf = l_hist_phred + hs * PROWS;           /* [ad_lds][hs] */
     uint32_t *l_first = (uint32_t *)(smem + L.first) + wave * SPAN_R * (AD ? n_ad : 0); /* [16][n_ad] */
-    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * 4 * SPAN_R;                 /* [16][2] (SEG: [16][2] of 64 bits) */
+    uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * (SEG ? 4 : 2) * SPAN_R;     /* [16][2] (SEG: [16][2] of 64 bits) */
     const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
 
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
@@ -258,11 +259,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         else e = __longlong_as_double(0x7FF8000000000000LL);
         l_err[i] = e;
     }
-    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((i < 128 ? min((uint32_t)i - 33u, 47u) >> 2 : PHRED_COLS) * hs * 4);
+    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((i < 128 || !SEG ? min((uint32_t)i - 33u, 47u) >> 2 : PHRED_COLS) * hs * 4);
     for (int i = tid; i < 96; i += T) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
-    for (uint32_t i = tid; i < hs * (BASE_COLS + PHRED_COLS + 1); i += T) l_hist_base[i] = 0;
+    for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
     if (AD) {
         for (uint32_t i = tid; i < P.dfa_states * 6; i += T) {
             const uint32_t st = i / 6, c = i % 6;   /* class 5: padding, back to the root */
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     /* The 640 bytes of a span's metas come through LDS too (one more DMA of 40 lanes, two buffers
        per wave): the loop below holds no load hipcc counts, or its waits for one (vmcnt counts in
        order) would wait for the DMA issued in front of it.  Meta buffer k goes with slot k. */
-    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 2 * SPAN_META_BYTES;
+    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * (SEG ? 256 : SPAN_META_LDS);
     auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
         if constexpr (SEG) {   /* row k of span sp: read first + 16 (sp - span0) + k of the length, the last one again behind the end */
             if (lane < (int)SPAN_R) {
@@ -310,8 +311,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                       __builtin_amdgcn_readfirstlane(maddr));
             }
         } else {
-            if (lane < (int)(SPAN_META_BYTES / 16))
-                dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+            if (lane < 2 * (int)SPAN_R)   /* bytes 0 .. 31 of every meta: record_start, sequence_offset, qualities_offset */
+                dma16((const uint8_t *)(P.metas + sp * SPAN_R + ((uint32_t)lane >> 1)) + 16 * (lane & 1), __builtin_amdgcn_readfirstlane(maddr));
         }
     };
     uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                     dma16(P.buf + rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
             return;
         }
-        const uint32_t ma = maddr + 40 * q;
+        const uint32_t ma = maddr + 32 * q;
         const unsigned long long m_rs = *(SQ_LDS const unsigned long long *)(uintptr_t)ma; /* record_start */
         const uint32_t m_so = lds_u32(ma + 12), m_qo = lds_u32(ma + 20);             /* sequence_offset, qualities_offset */
         const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m_rs >> 32)) << 32) |
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             atomicAdd(&P.qc_base[(uint64_t)pos * 5 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
-        for (uint32_t i = tid; i < hs * (PHRED_COLS + 1); i += T) {
+        for (uint32_t i = tid; i < hs * PROWS; i += T) {
             const uint32_t v = l_hist_phred[i], cc = i / hs, pos = i % hs;
             if (zero) l_hist_phred[i] = 0;
             if (!v || pos >= U || cc >= PHRED_COLS) continue;
@@ -440,7 +441,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue(slot_base, meta_base);
         rec_cur = rec_next;
-        if (s + stride < s_end) issue_meta(s + stride, meta_base + SPAN_META_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
+        if (s + stride < s_end) issue_meta(s + stride, meta_base);
     }
     while (s < s_end) {
         /* the span in slot `cur` has landed, and so have the metas of the one after it */
@@ -454,11 +456,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         if (s + stride < s_end) {
 #ifdef SQ_SPAN_PROBE
             if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
-                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
+                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base);
             else if (!(P.blocked & 1))
 #endif
-            issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * SPAN_META_BYTES);
-            if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base + cur * SPAN_META_BYTES);
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
+            if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base);
         }
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t2);
@@ -861,12 +864,12 @@ int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad,
 }
 
 /* does k_span take this pass at all, and with how many waves per workgroup */
-int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad)
+int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg = false)
 {
     if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > SPAN_NW_AD)) return 0; /* the automaton's rounds spill registers from 161 positions on */
     if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
     int waves = span_max_waves(nw);   /* as many as LDS takes */
-    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total > 160 * 1024) waves--;
+    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg).total > 160 * 1024) waves--;
     if (waves < 4) return 0;
     if (const char *e = getenv("SQ_SPAN_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
     return waves;
@@ -1349,7 +1352,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     const uint64_t n = P.n;
     if (!max_len || max_len > 32u * (ad ? SPAN_NW_AD : SPAN_NW_MAX) || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
     for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
-        if (!span_waves(P, nw, 32 * nw, ad, n_ad)) return SQ_OK;
+        if (!span_waves(P, nw, 32 * nw, ad, n_ad, true)) return SQ_OK;
     uint32_t *keys_in = (uint32_t *)sq_scratch(ctx, 0, n * 4), *keys_out = (uint32_t *)sq_scratch(ctx, 1, n * 4);
     SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow)), *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     unsigned long long *d_longer = (unsigned long long *)sq_scratch(ctx, 3, ((size_t)max_len + 1) * 8);
@@ -1379,7 +1382,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         if (!count) continue;
         const int nw = (int)((U + 31) / 32);
         if (launches.empty() || launches.back().nw != nw)
-            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad), {}, 0});
+            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad, true), {}, 0});
         Launch &l = launches.back();
         SpanSeg g{};
         g.span0 = l.spans;
@@ -1403,7 +1406,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         C.span_nsegs = (uint32_t)l.segs.size();
         C.span_total = l.spans;
         C.span_rows = rows_out;
-        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves).total;
+        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true).total;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + l.waves - 1) / l.waves, (uint64_t)ctx->num_cus));
         int rc = launch_any<true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
         if (rc) return rc;
