@@ -82,13 +82,6 @@ template <int J> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32
         : "=v"(r) : "v"(a), "v"(w), "i"(J));
     return r;
 }
-/* (1 << sh) + c */
-__device__ __forceinline__ uint32_t one_shl_add(uint32_t sh, uint32_t c)
-{
-    uint32_t r;
-    asm("v_lshl_add_u32 %0, 1, %1, %2" : "=v"(r) : "v"(sh), "v"(c));
-    return r;
-}
 /* sum of the four bytes of x, + c */
 __device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t c)
 {
@@ -169,16 +162,6 @@ __device__ __forceinline__ void tie(uint32_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void tie_f64(double &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void tie2(sq_u32x2 &x) { asm volatile("" : "+v"(x)); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_1(uint32_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_2(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
-{
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_4d(double &a, double &b, double &c, double &d)
-{
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
-}
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
 {
     if constexpr (I < N) {
