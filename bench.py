@@ -269,7 +269,7 @@ def other_configs(lib, ctx, steps, warmup):
 
     out["config3_paired"] = run(
         "config3", f"{n} x 150 bp synthetic pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM",
-        "k_span<QC> + k_ptspan per side (k_tile_parse + k_tile_assign in front), k_insert_size", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
+        "k_span<QC> + k_ptspan per side (k_tile_parse + k_tile_assign in front), k_isz_span + k_isz_adapters", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
         c3_make, c3_step, c3_check)
     del r1, r2
     # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
