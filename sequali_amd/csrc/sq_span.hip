@@ -897,16 +897,18 @@ __global__ void k_span_longer(const uint32_t *keys, uint64_t n, uint32_t max_len
  * not count (no tile, or behind the first header that did not parse, :3137-3148) go to a row
  * nobody reads.  Merged into the device tables once per workgroup. */
 struct PtSpanLds { uint32_t table, cnt, dma, meta, rows, slots; size_t total; };
-constexpr uint32_t PTSPAN_META = SPAN_META_BYTES + 64;   /* the metas of a span and the tile slots of its records */
-__host__ __device__ inline PtSpanLds ptspan_lds_layout(int nw, uint32_t nslots, int waves)
+constexpr uint32_t PTSPAN_META = SPAN_META_LDS + 64;   /* the first 32 bytes of a span's metas and the tile slots of its records */
+/* U: read length = doubles per table row (the row nobody reads is a full 32 nw long: lanes of the
+   last window that lie behind the end of the reads add there) */
+__host__ __device__ inline PtSpanLds ptspan_lds_layout(int nw, uint32_t U, uint32_t nslots, int waves)
 {
     PtSpanLds L;
-    const uint32_t hs = 32 * (uint32_t)nw, qpr = 2 * (uint32_t)nw + 1;
+    const uint32_t qpr = 2 * (uint32_t)nw + 1;
     uint32_t o = 256 * 8;                      /* error rates by quality byte, at LDS address 0 */
-    L.table = o; o += (nslots + 1) * hs * 8;
+    L.table = o; o += (nslots * U + 32 * (uint32_t)nw) * 8;
     L.cnt = o; o += ((nslots + 1) * 4 + 15u) & ~15u;
     L.dma = o; o += ((16 * qpr + 63) / 64) * 64 * 4;
-    L.meta = o; o += (uint32_t)waves * 2 * PTSPAN_META;
+    L.meta = o; o += (uint32_t)waves * PTSPAN_META;   /* one buffer: what is needed of it is taken when the rows are requested */
     L.rows = o; o += (uint32_t)waves * 16 * 4;
     L.slots = o;
     L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * qpr;
@@ -929,17 +931,17 @@ template <int J> __device__ __forceinline__ uint32_t shl3_byte_of(uint32_t w, ui
 template <int NW>
 __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
 {
-    constexpr uint32_t SB = 32 * NW, QPR = 2 * NW + 1, ROWB = 16 * QPR, SLOT = SPAN_R * ROWB, ND = (SPAN_R * QPR + 63) / 64, hs = 32 * NW;
+    constexpr uint32_t QPR = 2 * NW + 1, ROWB = 16 * QPR, SLOT = SPAN_R * ROWB, ND = (SPAN_R * QPR + 63) / 64;
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t U = P.uniform_len;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const PtSpanLds L = ptspan_lds_layout(NW, nslots, W);
+    const PtSpanLds L = ptspan_lds_layout(NW, U, nslots, W);
     double *l_err = (double *)smem;                        /* [256] by raw quality byte */
-    double *l_pt = (double *)(smem + L.table);             /* [nslots + 1][hs] */
+    double *l_pt = (double *)(smem + L.table);             /* [nslots][U], then 32 NW doubles nobody reads */
     uint32_t *l_cnt = (uint32_t *)(smem + L.cnt);          /* [nslots + 1] reads per tile */
     uint32_t *l_dma = (uint32_t *)(smem + L.dma);
     uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * SPAN_R;
-    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * 2 * PTSPAN_META;
+    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * PTSPAN_META;
     const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
     for (int i = tid; i < 256; i += T) {
@@ -948,7 +950,7 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
         else if (i >= 128 && i < 136) e = 0.0;
         l_err[i] = e;
     }
-    for (uint32_t i = tid; i < (nslots + 1) * hs; i += T) l_pt[i] = 0.0;
+    for (uint32_t i = tid; i < nslots * U + 32 * NW; i += T) l_pt[i] = 0.0;
     for (uint32_t i = tid; i <= nslots; i += T) l_cnt[i] = 0;
     if (wave == 0) {
 #pragma unroll
@@ -960,21 +962,39 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
     __syncthreads();
 
     const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
+    const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
+    const uint32_t three = 3, one = 1;
+    const uint32_t dummy = lds_addr(l_pt) + nslots * U * 8 + 8 * pl;
     const uint64_t nspans = P.n / SPAN_R, stride = (uint64_t)gridDim.x * W;
     uint64_t s = (uint64_t)blockIdx.x * W + wave;
     auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
-        if (lane < (int)(SPAN_META_BYTES / 16))
-            dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr));
+        if (lane < 2 * (int)SPAN_R)   /* bytes 0 .. 31 of every meta: record_start, qualities_offset */
+            dma16((const uint8_t *)(P.metas + sp * SPAN_R + ((uint32_t)lane >> 1)) + 16 * (lane & 1), __builtin_amdgcn_readfirstlane(maddr));
         if (lane < 4)
-            dma16((const uint8_t *)(P.pt_slot + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr + SPAN_META_BYTES));
+            dma16((const uint8_t *)(P.pt_slot + sp * SPAN_R) + 16 * lane, __builtin_amdgcn_readfirstlane(maddr + SPAN_META_LDS));
     };
-    auto issue = [&](uint32_t slot_addr, uint32_t maddr) {
-        const uint32_t ma = maddr + 40 * q;
+    /* the rows of span sp are requested; what the counting of that span needs of its metas (the
+       tile rows of this lane's eight reads, the tile of read `lane` for the read counts) is
+       taken along: the buffer is handed to the span after it */
+    uint32_t toff_n[8], cnt_n = 0;
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint64_t sp) {
+        const uint32_t ma = maddr + 32 * q;
         const unsigned long long m_rs = *(SQ_LDS const unsigned long long *)(uintptr_t)ma; /* record_start */
         const uint32_t m_qo = lds_u32(ma + 20);                                            /* qualities_offset */
         const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m_rs >> 32)) << 32) |
                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m_rs);
         if (c == 0) l_rows[q] = (uint32_t)(m_rs - base) + m_qo;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t sl = (int32_t)lds_u32(maddr + SPAN_META_LDS + 4 * (8 * h + k));
+            const bool on = sl >= 0 && P.first_read_index + sp * SPAN_R + 8 * h + k < P.pt_first_bad;
+            toff_n[k] = on ? lds_addr(l_pt) + (uint32_t)sl * U * 8 + 8 * pl : dummy;
+        }
+        {
+            const int32_t sl = (int32_t)lds_u32(maddr + SPAN_META_LDS + 4 * (lane & 15));
+            const bool on = sl >= 0 && P.first_read_index + sp * SPAN_R + (lane & 15) < P.pt_first_bad;
+            cnt_n = lds_addr(l_cnt) + 4 * (on ? (uint32_t)sl : nslots);
+        }
         const uint8_t *g0 = P.buf + base;
         uint32_t pk[ND];
         int32_t rr[ND];
@@ -988,37 +1008,26 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
                 dma16(g0 + (long long)rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
     };
 
-    const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
-    const uint32_t three = 3, one = 1;
-    const uint32_t dummy = nslots * hs * 8;
+    uint32_t toff[8], cnt_a = 0;
     int cur = 0;
     if (s < nspans) {
         issue_meta(s, meta_base);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue(slot_base, meta_base);
-        if (s + stride < nspans) issue_meta(s + stride, meta_base + PTSPAN_META);
+        issue(slot_base, meta_base, s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + stride < nspans) issue_meta(s + stride, meta_base);
     }
     while (s < nspans) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        /* the tile rows of this span's records, before their buffer is handed to the span after next */
-        const uint32_t mcur = meta_base + cur * PTSPAN_META + SPAN_META_BYTES;
-        uint32_t toff[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int32_t sl = (int32_t)lds_u32(mcur + 4 * (8 * h + k));
-            const bool on = sl >= 0 && P.first_read_index + s * SPAN_R + 8 * h + k < P.pt_first_bad;
-            toff[k] = lds_addr(l_pt) + (on ? (uint32_t)sl * hs * 8 : dummy) + 8 * pl;
-        }
-        if (lane < (int)SPAN_R) {
-            const int32_t sl = (int32_t)lds_u32(mcur + 4 * lane);
-            const bool on = sl >= 0 && P.first_read_index + s * SPAN_R + lane < P.pt_first_bad;
-            lds_add(lds_addr(l_cnt) + 4 * (on ? (uint32_t)sl : nslots), one);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = 0; k < 8; k++) toff[k] = toff_n[k];
+        cnt_a = cnt_n;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (s + stride < nspans) {
-            issue(slot_base + (cur ^ 1) * SLOT, meta_base + (cur ^ 1) * PTSPAN_META);
-            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base + cur * PTSPAN_META);
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base, s + stride);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
+            if (s + 2 * stride < nspans) issue_meta(s + 2 * stride, meta_base);
         }
+        if (lane < (int)SPAN_R) lds_add(cnt_a, one);
         const uint32_t sa = slot_base + cur * SLOT;
         /* transposing reads: lane 2 q' + p of a group of 16 hands in row 8 h + q', bytes 8 p .. 8 p + 7 */
         const uint32_t trb = sa + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
@@ -1043,9 +1052,11 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
                     constexpr int k = decltype(kc)::value;
                     e[(w + 1) & 1][k] = rd_f64(shl3_byte_of<k % 4>(k < 4 ? t[w + 1].x : t[w + 1].y, three));
                 });
+            const bool inside = 32 * w + pl < U;   /* the last window reaches behind the end of the reads */
             static_for<0, 8>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                add_f64_lds(toff[k] + 256 * w, e[w & 1][k]);
+                if constexpr (w + 1 < NW) add_f64_lds(toff[k] + 256 * w, e[w & 1][k]);
+                else add_f64_lds((inside ? toff[k] : dummy) + 256 * w, e[w & 1][k]);
             });
         });
         cur ^= 1;
@@ -1054,10 +1065,9 @@ __global__ void __launch_bounds__(1024) k_ptspan(PassParams P, uint32_t nslots)
     __syncthreads();
     for (uint32_t i = tid; i < nslots; i += T)
         if (l_cnt[i]) atomicAdd(&P.pt_len_counts[(uint64_t)i * P.pt_cap + (U - 1)], (unsigned long long)l_cnt[i]);
-    for (uint32_t i = tid; i < nslots * hs; i += T) {
-        const uint32_t pos = i % hs;
+    for (uint32_t i = tid; i < nslots * U; i += T) {
         const double v = l_pt[i];
-        if (pos < U && v != 0.0) unsafeAtomicAdd(&P.pt_errors[(uint64_t)(i / hs) * P.pt_cap + pos], v);
+        if (v != 0.0) unsafeAtomicAdd(&P.pt_errors[(uint64_t)(i / U) * P.pt_cap + i % U], v);
     }
 }
 
@@ -1409,9 +1419,9 @@ int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R || !nslots) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
     int waves = 16;
-    while (waves >= 4 && ptspan_lds_layout(nw, nslots, waves).total > 160 * 1024) waves--;
+    while (waves >= 4 && ptspan_lds_layout(nw, U, nslots, waves).total > 160 * 1024) waves--;
     if (waves < 4) return SQ_OK;
-    const size_t lds = ptspan_lds_layout(nw, nslots, waves).total;
+    const size_t lds = ptspan_lds_layout(nw, U, nslots, waves).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;
     const uint64_t nspans = C.n / SPAN_R;
