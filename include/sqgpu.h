@@ -77,6 +77,10 @@ void sq_shutdown(sq_ctx *ctx);
 int sq_synchronize(sq_ctx *ctx);
 /* hipStream_t of the context, for event timing / interop by the caller. */
 void *sq_stream_handle(sq_ctx *ctx);
+/* The library reads its SQ_* route / experiment switches from the environment once, at first
+ * use; call this after changing one (the tests do).  No reference counterpart: sequali has no
+ * kernel routes to choose from. */
+void sq_knobs_reload(void);
 
 /* ---- record boundary, host side (no GPU involved) ---------------------- */
 /* The record loop of FastqParser_create_record_array, _qcmodule.c:1093-1171:

@@ -17,6 +17,44 @@ void sq_set_error(const char *fmt, ...)
     g_last_error = tmp;
 }
 
+/* the switches of SqKnobs (sq_common.h) */
+static SqKnobs g_knobs;
+static bool g_knobs_loaded = false;
+static void knobs_load()
+{
+    SqKnobs k;
+    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, int unset) { const char *v = getenv(name); return v ? atoi(v) : unset; };
+    k.span = num("SQ_SPAN", 1) != 0;
+    k.span_split = num("SQ_SPAN_SPLIT", 1) != 0;
+    k.span_sorted = num("SQ_SPAN_SORTED", -1);
+    k.span_waves = num("SQ_SPAN_WAVES", 0);
+    k.span_probe = num("SQ_SPAN_PROBE", -1);
+    k.span_stamps = flag("SQ_SPAN_STAMPS");
+    k.wide = num("SQ_WIDE", -1);
+    k.no_wide = flag("SQ_NO_WIDE");
+    k.ring = flag("SQ_RING");
+    k.no_ring = flag("SQ_NO_RING");
+    k.no_split = flag("SQ_NO_SPLIT");
+    k.no_ptq = flag("SQ_NO_PTQ");
+    k.pt_sort = flag("SQ_PT_SORT");
+    k.pt_stored = flag("SQ_PT_STORED");
+    k.no_segments = flag("SQ_NO_SEGMENTS");
+    k.long_spans = num("SQ_LONG", 1) != 0;
+    k.lds_pad = num("SQ_LDS_PAD", 0);
+    k.probe_mode = num("SQ_PROBE_MODE", -1);
+    k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
+    k.dedup_debug = flag("SQ_DEDUP_DEBUG");
+    g_knobs = k;
+    g_knobs_loaded = true;
+}
+const SqKnobs &sq_knobs()
+{
+    if (!g_knobs_loaded) knobs_load();
+    return g_knobs;
+}
+SQ_EXPORT void sq_knobs_reload(void) { knobs_load(); }
+
 SQ_EXPORT int sq_abi_version(void) { return SQ_ABI_VERSION; }
 SQ_EXPORT const char *sq_last_error(void) { return g_last_error.c_str(); }
 

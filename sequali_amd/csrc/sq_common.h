@@ -39,6 +39,30 @@ void sq_set_error(const char *fmt, ...);
         }                                                                               \
     } while (0)
 
+/* Route selection and experiment switches, read from the environment ONCE (first use) or when
+ * sq_knobs_reload() is called (the tests flip a switch, reload, run, flip it back): the
+ * dispatchers consult this struct, never getenv().  Defaults = what production runs.
+ *   SQ_SPAN=0         no k_span / k_ptspan / k_isz_span: the round-1 kernels (cross-checks)
+ *   SQ_SPAN_SPLIT=0   k_span with one wave for both streams of a span (round 2)
+ *   SQ_SPAN_SORTED    1 / 0: force / forbid the length-sorted k_span route for ragged batches
+ *   SQ_SPAN_WAVES     cap on k_span's waves per workgroup (occupancy experiments)
+ *   SQ_WIDE / SQ_NO_WIDE / SQ_RING / SQ_NO_RING   force / forbid k_wide, k_ring
+ *   SQ_NO_SPLIT       QCMetrics + PerTileQuality in one k_pass instead of two kernels
+ *   SQ_NO_PTQ, SQ_PT_SORT, SQ_PT_STORED, SQ_NO_SEGMENTS, SQ_LDS_PAD, SQ_DEDUP_SEQUENTIAL,
+ *   SQ_DEDUP_DEBUG, SQ_LONG=0 (no k_long: k_read_sums + k_seg)  experiment switches */
+struct SqKnobs {
+    bool span = true, span_split = true;
+    int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span_stamps = false;
+    int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
+    bool no_wide = false, ring = false, no_ring = false, no_split = false;
+    bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
+    bool long_spans = true;
+    int lds_pad = 0, probe_mode = -1;
+    bool dedup_sequential = false, dedup_debug = false;
+};
+const SqKnobs &sq_knobs();
+
 struct sq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -69,8 +93,11 @@ inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)
     return ctx->scratch[i];
 }
 
+inline uint64_t sq_next_batch_id() { static uint64_t next = 0; return ++next; }   /* objects are used from one thread (sqgpu.h) */
+
 struct sq_batch {
     sq_ctx *ctx = nullptr;
+    uint64_t id = sq_next_batch_id();   /* identity that survives the address being reused by a later batch */
     uint8_t *d_buf = nullptr;
     sq_meta *d_metas = nullptr;
     size_t buf_len = 0;

@@ -1576,7 +1576,7 @@ int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned c
     memset(state, 0, n_keep);
     const unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (d->parallel_skip) d->parallel_skip--;
-    else if (n_keep >= 32768 && n_threads > 1 && !getenv("SQ_DEDUP_SEQUENTIAL")) {
+    else if (n_keep >= 32768 && n_threads > 1 && !sq_knobs().dedup_sequential) {
         const uint64_t bits = d->modulo_bits, mask = d->table_size - 1;
         const uint64_t per = (n_keep + n_threads - 1) / n_threads;
         std::vector<uint64_t> missing(n_threads, 0);
@@ -1629,8 +1629,8 @@ int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned c
                 }
             });
             d->parallel_skip = 4;
-            if (getenv("SQ_DEDUP_DEBUG")) fprintf(stderr, "dedup piece: %llu kept, %llu new, taken back\n", (unsigned long long)n_keep, (unsigned long long)not_found);
-        } else if (getenv("SQ_DEDUP_DEBUG")) {
+            if (sq_knobs().dedup_debug) fprintf(stderr, "dedup piece: %llu kept, %llu new, taken back\n", (unsigned long long)n_keep, (unsigned long long)not_found);
+        } else if (sq_knobs().dedup_debug) {
             fprintf(stderr, "dedup piece: %llu kept, %llu new, counted by threads\n", (unsigned long long)n_keep, (unsigned long long)not_found);
         }
     }
@@ -2099,7 +2099,7 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
        else) go through k_insert_size.  SQ_SPAN=0: k_insert_size for all. */
     uint64_t covered = 0;
     if (b1->owns && b2->owns && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
-        !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")))) {
+        sq_knobs().span) {
         uint32_t *d_results = (uint32_t *)sq_scratch(ctx, 16, n * 4);
         if (d_results) {
             IszSpanParams S{};

@@ -2270,9 +2270,9 @@ struct sq_qcmetrics {
     double *d_thr = nullptr;
     unsigned long long *d_first_bad = nullptr;
     uint64_t records_seen = 0;
-    /* batches since the last flush (never dereferenced: identity only) and their longest read:
-       max_length after an invalid phred byte took the tail of one of them back */
-    struct Seen { const sq_batch *b; uint64_t max_length; };
+    /* batches since the last flush (by id: a freed batch's address may be handed out again) and
+       their longest read: max_length after an invalid phred byte took the tail of one of them back */
+    struct Seen { uint64_t id; uint64_t max_length; };
     std::vector<Seen> seen;
     uint64_t max_length_flushed = 0;
 };
@@ -2731,14 +2731,15 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
 
 SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
 {
+    const SqKnobs &K = sq_knobs();
     /* QCMetrics + AdapterCounter + PerTileQuality on a batch of one read length: k_wide for the
        first two and a PerTileQuality pass of its own (qualities only) read the batch twice and
        still beat the one k_pass that carries all three (3.5 against 3.7 ms per 10 M reads) */
     /* ... and since k_span and k_ptspan (sq_span.hip) QCMetrics + PerTileQuality without the
        adapters too: 2.5 + 1.5 ms per 25 M reads against 7.0 for k_pass<QC,PT> */
     if (m && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
-        b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !getenv("SQ_NO_WIDE") && !getenv("SQ_RING") &&
-        !getenv("SQ_NO_SPLIT") && (a || (b->max_length <= 32u * SPAN_NW_MAX && !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")))))) {
+        b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !K.no_wide && !K.ring &&
+        !K.no_split && (a || (b->max_length <= 32u * SPAN_NW_MAX && K.span))) {
         int rc = fused_add_batch(b, m, a, nullptr);
         return rc ? rc : fused_add_batch(b, nullptr, nullptr, p);
     }
@@ -2747,6 +2748,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
 
 static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
 {
+    const SqKnobs &K = sq_knobs();
     sq_ctx *ctx = b->ctx;
     bool pt_active = false;
     if (p) {
@@ -2800,19 +2802,21 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     /* reads of many lengths, none longer than k_span takes: sorted by length inside sq_span_launch_sorted */
     const bool span_sorted =
         m && !pt_active && !stripes && !P.uniform_len && b->owns && b->min_length >= 1 && b->n < (1ull << 31) &&
-        (!a || a->groups[0].states <= DFA_LDS_MAX_STATES) && b->max_length <= 32u * (a ? SPAN_NW_AD : SPAN_NW_MAX) &&
-        !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN"))) && !getenv("SQ_RING") && !getenv("SQ_NO_RING") &&
-        !getenv("SQ_NO_WIDE") && !getenv("SQ_WIDE") &&
-        (getenv("SQ_SPAN_SORTED") ? atoi(getenv("SQ_SPAN_SORTED")) != 0 : b->n >= 65536);
+        (!a || a->groups[0].states <= DFA_LDS_MAX_STATES) && b->max_length <= 32u * (a ? (K.span_split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD) : SPAN_NW_MAX) &&
+        K.span && !K.ring && !K.no_ring && !K.no_wide && K.wide < 0 &&
+        (K.span_sorted >= 0 ? K.span_sorted != 0 : b->n >= 65536);
     /* PerTileQuality alone on a batch of one read length whose table fits LDS: k_ptspan streams the
        batch as it lies (no sort by tile) */
     uint64_t pt_covered = 0;
     const bool ptspan = !m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes &&
-                        p->n_slots > 0 && !getenv("SQ_NO_PTQ") && !(getenv("SQ_SPAN") && !atoi(getenv("SQ_SPAN")));
+                        p->n_slots > 0 && !K.no_ptq && K.span;
     if (ptspan) {
         int rc = sq_ptspan_launch(ctx, P, (uint32_t)p->n_slots, &pt_covered);
         if (rc) return rc;
-        if (pt_covered == b->n) return SQ_OK;
+        if (pt_covered == b->n) {   /* nothing left for the passes below; m and a are null here */
+            p->records_seen += b->n;
+            return SQ_OK;
+        }
     }
     P.pos_end = UINT32_MAX;
     if (b->n >= 4096 && b->n < (1ull << 31)) {
@@ -2821,7 +2825,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                takes a contiguous run of groups, and nearly every group is of one tile).  Only a
                batch whose tiles are mixed (on average fewer than 256 reads between two changes)
                is walked in tile-sorted order, which costs the sort and makes every load a gather */
-            if (!ptspan && (getenv("SQ_PT_SORT") || ((uint64_t)p->tile_changes * 256 > b->n && !getenv("SQ_PT_STORED"))))
+            if (!ptspan && (K.pt_sort || ((uint64_t)p->tile_changes * 256 > b->n && !K.pt_stored)))
                 P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
             P.blocked = P.order != nullptr; /* stored order: waves move through the batch together */
         }
@@ -2840,7 +2844,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     /* long reads.  Sorted longest first and without PerTileQuality: the segment kernels
        (k_read_sums + k_seg + k_adapter_first).  Else stripes: one launch per 512 positions,
        the per-read state carried from launch to launch. */
-    const bool segments = stripes && P.order && !P.blocked && !pt_active && !getenv("SQ_NO_SEGMENTS") &&
+    const bool segments = stripes && P.order && !P.blocked && !pt_active && !K.no_segments &&
                           (!a || a->groups[0].states <= DFA_LDS_MAX_STATES);
     const uint32_t span = segments ? SEG : STRIPE;
     if (stripes) stripes = (uint32_t)((b->max_length + span - 1) / span);
@@ -2862,9 +2866,9 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         }
     }
 #ifdef SQ_PROBE
-    if (const char *pm = getenv("SQ_PROBE_MODE")) {
+    if (K.probe_mode >= 0) {
         unsigned long long *sink = (unsigned long long *)sq_scratch(ctx, 0, 64);
-        const int mode = atoi(pm), grid = ctx->num_cus * 4;
+        const int mode = K.probe_mode, grid = ctx->num_cus * 4;
         if (mode == 32) hipLaunchKernelGGL((k_probe<32>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
         else if (mode == 64) hipLaunchKernelGGL((k_probe<64>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
         else if (mode == 128) hipLaunchKernelGGL((k_probe<128>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
@@ -2885,7 +2889,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         P.pt_slot += pt_covered;
         P.first_read_index += pt_covered;
         P.n = b->n - pt_covered;
-    } else if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !getenv("SQ_NO_PTQ") &&
+    } else if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !K.no_ptq &&
         ptq_lds_bytes(P.uniform_len) <= 80 * 1024) {
         PassParams C = P;
         C.n = (b->n / 64) * 64;
@@ -2956,24 +2960,22 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         }
         PassParams Pfull = P;
         const bool uniform_fast = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && (!ad || dfa_lds);
-        const char *wide_env = getenv("SQ_WIDE");
+        const bool wide_set = K.wide >= 0;
         const size_t wlds = wide_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
-        const bool wide = uniform_fast && b->owns && wlds <= 160 * 1024 && !getenv("SQ_NO_WIDE") &&
-                          (ad ? !getenv("SQ_RING") : (wide_env && atoi(wide_env)));
+        const bool wide = uniform_fast && b->owns && wlds <= 160 * 1024 && !K.no_wide &&
+                          (ad ? !K.ring : K.wide > 0);
         const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
-        const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !getenv("SQ_NO_RING") &&
-                          (!ad || getenv("SQ_RING"));
+        const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !K.no_ring &&
+                          (!ad || K.ring);
         /* - k_span (sq_span.hip) in front of both: the records come through LDS by LDS-DMA, 16 per
              wave at a time, four lanes per read: QCMetrics alone up to 256 positions (1495
              Gbases/s at 150 against k_ring's 1020), with the automaton up to 160 (1015 against
              k_wide's 1000; adapters of up to 13 characters).  SQ_SPAN=0: the other two. */
         bool span_done = false;
-        const char *span_env = getenv("SQ_SPAN");
-        const bool span = span_env ? atoi(span_env) != 0 : true;
-        if (uniform_fast && b->owns && span && !getenv("SQ_RING") && !getenv("SQ_NO_RING") && !getenv("SQ_NO_WIDE") && !wide_env) {
+        if (uniform_fast && b->owns && K.span && !K.ring && !K.no_ring && !K.no_wide && !wide_set) {
             uint64_t covered = 0;
 #ifdef SQ_SPAN_PROBE
-            if (const char *pm = getenv("SQ_SPAN_PROBE")) P.blocked = (uint32_t)atoi(pm);
+            if (K.span_probe >= 0) P.blocked = (uint32_t)K.span_probe;
 #endif
             int rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
 #ifdef SQ_SPAN_PROBE
@@ -3028,7 +3030,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             P.n = b->n - C.n;
         }
         size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, ad ? P.ad_lds : 0, pt ? P.lds_len : 0);
-        if (const char *pad = getenv("SQ_LDS_PAD")) lds += (size_t)atoi(pad); /* occupancy experiments */
+        lds += (size_t)K.lds_pad; /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         if (qc && segments) {
             /* (1) what is sequential per read */
@@ -3092,7 +3094,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     if (m) {
         m->number_of_reads += b->n; m->records_seen += b->n;
         if (m->seen.size() >= 4096) { m->max_length_flushed = m->max_length; m->seen.clear(); } /* a caller that never flushes */
-        m->seen.push_back({b, b->max_length});
+        m->seen.push_back({b->id, b->max_length});
     }
     if (a) a->number_of_sequences += b->n;
     if (p) p->records_seen += b->n;
@@ -3163,7 +3165,7 @@ SQ_EXPORT int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t f
     uint64_t ml = m->max_length_flushed;
     bool found = false;
     for (auto &sn : m->seen) {
-        if (sn.b == b && !found) { sn.max_length = kept_max_length; found = true; }
+        if (sn.id == b->id && !found) { sn.max_length = kept_max_length; found = true; }
         ml = std::max(ml, sn.max_length);
     }
     if (found) m->max_length = ml;
@@ -3204,8 +3206,6 @@ SQ_EXPORT int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_l
         for (size_t i = 0; i < n && rc2 == SQ_OK; i++) metas[i].accumulated_error_rate = errs[i];
         if (rc == SQ_OK) rc = rc2;
     }
-    /* the batch dies here: nothing of it may stay in the log */
-    for (auto &sn : m->seen) if (sn.b == b) sn.b = nullptr;
     sq_batch_free(b);
     return rc;
 }

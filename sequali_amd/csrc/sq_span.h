@@ -8,8 +8,11 @@
 
 constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
 constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
-constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass */
-constexpr uint32_t SPAN_BIN_OFF = 136 * 8;
+constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass (one wave for both streams) */
+constexpr int SPAN_NW_AD_SPLIT = 8;   /* the same with a wave per stream: the whole range */
+constexpr uint32_t SPAN_ERR_N = 264;      /* error rates by raw quality byte, NaN for what is no phred character ... */
+constexpr uint32_t SPAN_ERR_PAD = 256;    /* ... and one entry that no byte reaches: +0.0, for chain steps that do not exist */
+constexpr uint32_t SPAN_BIN_OFF = SPAN_ERR_N * 8;
 constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
 constexpr uint32_t SPAN_META_LDS = 16 * 32;     /* what k_span keeps of them: the first 32 bytes of each (SEG: 16 bytes per row) */
 
@@ -21,11 +24,11 @@ struct SpanLds {
 /* nw: 32-position windows per read; U: read length; states / n_ad / ad_lds: the automaton, its
  * adapters, how many of them are counted in LDS (0 without AdapterCounter); waves per workgroup */
 __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t states, uint32_t n_ad,
-                                                   uint32_t ad_lds, int waves, bool seg = false)
+                                                   uint32_t ad_lds, int waves, bool seg = false, bool split = false)
 {
     SpanLds L;
     const uint32_t hs = (U + 31u) & ~31u;
-    uint32_t o = 136 * 8;               /* error rates by quality byte, at LDS address 0 */
+    uint32_t o = SPAN_ERR_N * 8;        /* error rates by quality byte, at LDS address 0 */
     o += 256 * 2;                        /* SPAN_BIN_OFF: phred histogram row by quality byte */
     L.thr = o; o += 96 * 8;
     L.gc = o; o += 104 * 4;
@@ -36,11 +39,13 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.hist = o; o += hs * (5 + 12 + (seg ? 1 : 0)) * 4 + ad_lds * hs * 4; /* seg: a 13th phred row takes the qualities of filler rows */
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
     L.rows = o; o += (uint32_t)waves * (seg ? 64 : 32) * 4;
-    L.dma = o; o += ((16u * (4 * (uint32_t)nw + 1) + 63) / 64) * 64 * 4;
+    /* split: a wave holds one stream of a span at a time (sequence or qualities): rows of 2 nw + 1 pieces */
+    const uint32_t pr = (split ? 2 : 4) * (uint32_t)nw + 1;
+    L.dma = o; o += ((16u * pr + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
     L.meta = o; o += (uint32_t)waves * (seg ? 256 : SPAN_META_LDS);   /* one buffer: the metas of span k + 2 land where those of k + 1 were read */
     L.slots = o;
-    L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * (4 * (size_t)nw + 1); /* two slots of 16 rows of 4 nw + 1 pieces */
+    L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * (size_t)pr; /* two slots of 16 rows of pr pieces */
     return L;
 }
 

@@ -180,37 +180,48 @@ template <int CTRL> __device__ __forceinline__ double quad_bcast_f64(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-/* waves per workgroup: LDS leaves at most 12 of them from 128 positions per read on, which is
- * 168 registers per lane instead of 128 */
-constexpr int span_max_waves(int nw) { return nw <= 3 ? 16 : 12; }
+/* waves per workgroup.  One wave for both streams of a span: LDS leaves at most 12 of them from 128
+ * positions per read on, which is 168 registers per lane instead of 128.  SPLIT (a wave holds one
+ * stream of a span at a time): 16 waves of 128 registers up to 160 positions (128 when the batch
+ * holds many lengths), 12 beyond */
+constexpr int span_max_waves(int nw, bool split = false, bool seg = false) { return nw <= (split ? (seg ? 4 : 5) : 3) ? 16 : 12; }
 
 #ifdef SQ_SPAN_PROBE
-__device__ unsigned long long g_span_stamps[4]; /* cycles summed over waves: top wait, DMA issue, counting; spans */
+__device__ unsigned long long g_span_stamps[6]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
 #define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
 #endif
 /* SEG: the batch holds reads of many lengths; P.span_rows lists them sorted by length, 16 reads of
    one length per span, P.span_segs the lengths in span order.  A workgroup takes a contiguous
    stretch of the spans (a handful of lengths at most) and merges its histograms whenever the
    length changes, so that inside a stretch everything is as for a batch of one read length: the
-   end-anchored tables a window of the positional ones, no question asked per row. */
-template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4>
-__global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, uint32_t n_ad)
+   end-anchored tables a window of the positional ones, no question asked per row.
+
+   SPLIT: what is counted of a read's bases (class codes, base counts, GC, the automaton) and what
+   of its qualities (the f64 chains, the phred histogram, the bins of the average) have nothing
+   to do with each other, so a wave takes ONE stream of a span at a time: half the LDS per slot
+   and half the live registers, 16 waves per CU instead of 12.  The waves of a workgroup work in
+   pairs on one sequence of spans: wave 2 j takes the bases of the pair's spans 0, 2, 4 .. and the
+   qualities of 1, 3, 5 .., wave 2 j + 1 the other halves -- every wave alternates between the two
+   roles, so the two kinds of work need no balancing. */
+template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false>
+__global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(PassParams P, uint32_t n_ad)
 {
 #ifdef SQ_SPAN_PROBE
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0, a_compq = 0, a_spansq = 0;
 #endif
-    /* Row r of a slot: sequence at r * ROWB, qualities at r * ROWB + SB.  A row is an odd number
-       of 16-byte pieces (the last one is never loaded) and a lane's quarter an odd number of
-       dwords, so that the 32 lanes of an LDS instruction of phase S (8 rows x 4 quarters) fall
-       into 32 different banks */
-    constexpr uint32_t SB = 32 * NW, PR = 4 * NW + 1, ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
+    /* Row r of a slot: sequence at r * ROWB, qualities at r * ROWB + QOFF (SPLIT: the slot holds
+       one of the two streams, at r * ROWB).  A row is an odd number of 16-byte pieces (the last one
+       is never loaded) and a lane's quarter an odd number of dwords, so that the 32 lanes of an LDS
+       instruction of phase S (8 rows x 4 quarters) fall into 32 different banks */
+    constexpr uint32_t SB = 32 * NW, PR = (SPLIT ? 2 : 4) * NW + 1, ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
+    constexpr uint32_t QOFF = SPLIT ? 0 : SB;
     constexpr uint32_t DW = 8 * NW, Q4 = 2 * NW + 1, ND = (SPAN_R * PR + 63) / 64;
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
     const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG);
-    double *l_err = (double *)smem;                        /* [136] by raw quality byte */
+    const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT);
+    double *l_err = (double *)smem;                        /* [SPAN_ERR_N] by raw quality byte; [SPAN_ERR_PAD]: +0.0 */
     uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
     uint32_t *l_gc = (uint32_t *)(smem + L.gc);            /* [104] */
@@ -235,14 +246,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
     const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + span_dfa_offset(P.dfa_accept);
-    for (int i = tid; i < 136; i += T) {
-        double e;
+    for (int i = tid; i < (int)SPAN_ERR_N; i += T) {   /* every byte that is no phred character: NaN (:2073-2075), also >= 128 (BAM qualities + 33) */
+        double e = __longlong_as_double(0x7FF8000000000000LL);
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
-        else if (i >= 128) e = 0.0;
-        else e = __longlong_as_double(0x7FF8000000000000LL);
+        else if (i >= 256) e = 0.0;
         l_err[i] = e;
     }
-    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((i < 128 || !SEG ? min((uint32_t)i - 33u, 47u) >> 2 : PHRED_COLS) * hs * 4);
+    /* SEG: filler rows hold quality 0x80, which goes to a row of its own (a real 0x80 too: the merge tells them apart) */
+    for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((SEG && i == 0x80 ? PHRED_COLS : min((uint32_t)i - 33u, 47u) >> 2) * hs * 4);
     for (int i = tid; i < 96; i += T) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
@@ -262,25 +273,29 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
 
     const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
     /* DMA: piece i = 64 k + lane of a slot is 16 bytes of row i / PR: of its sequence (the first
-       2 NW pieces), of its qualities (the next 2 NW), or the unused last one; where a row's
-       streams start (relative to the span's first record) is read from l_rows */
+       2 NW pieces), of its qualities (the next 2 NW; SPLIT: the stream the wave's role names), or
+       the unused last one; where a row's streams start (relative to the span's first record) is
+       read from l_rows */
     /* per piece (l_dma[k][lane]): byte offset into l_rows | offset inside the stream << 8 | loaded at all << 31 */
     uint32_t *l_dma = (uint32_t *)(smem + L.dma);
     if (wave == 0) {
 #pragma unroll
         for (int k = 0; k < (int)ND; k++) {
-            const uint32_t i = 64 * k + lane, row = i / PR, pir = i % PR, stream = pir >= 2 * NW;
-            const bool on = i < SPAN_R * PR && pir < 4 * NW;
+            const uint32_t i = 64 * k + lane, row = i / PR, pir = i % PR, stream = !SPLIT && pir >= 2 * NW;
+            const bool on = i < SPAN_R * PR && pir < PR - 1;
             l_dma[64 * k + lane] = on ? (row * (SEG ? 16 : 8) + stream * (SEG ? 8 : 4)) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u : 0;
         }
     }
     __syncthreads();
-    /* the spans of this wave: s, s + stride, ... < s_end (SEG: set per length below) */
+    /* the spans of this wave (SPLIT: of this pair of waves): s, s + stride, ... < s_end (SEG: set per length below) */
+    constexpr int WPS = SPLIT ? 2 : 1;   /* waves per sequence of spans */
+    const int seqs = W / WPS, my_seq = wave / WPS;
     uint64_t s_end = P.n / SPAN_R;
     uint64_t s_last = ~0ull, seg_first = 0, seg_span0 = 0;   /* SEG: the last span of the length (last_rows reads in it), its first read and span */
     uint32_t last_rows = SPAN_R;
-    const uint64_t stride = SEG ? (uint64_t)W : (uint64_t)gridDim.x * W;
-    uint64_t s = (uint64_t)blockIdx.x * W + wave;
+    const uint64_t stride = SEG ? (uint64_t)seqs : (uint64_t)gridDim.x * seqs;
+    uint64_t s = (uint64_t)blockIdx.x * seqs + my_seq;
+    uint32_t role = SPLIT ? (uint32_t)wave & 1 : 0;   /* SPLIT: 0 = the bases of the span, 1 = its qualities; flips with every span */
 
     /* The 640 bytes of a span's metas come through LDS too (one more DMA of 40 lanes, two buffers
        per wave): the loop below holds no load hipcc counts, or its waits for one (vmcnt counts in
@@ -299,7 +314,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         }
     };
     uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
-    auto issue = [&](uint32_t slot_addr, uint32_t maddr) {
+    /* rl: SPLIT: the stream to fetch (the role the wave has in that span) */
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint32_t rl) {
         if constexpr (SEG) {
             const uint32_t ma = maddr + 16 * q;
             const unsigned long long seq = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
@@ -309,12 +325,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q) = seq;
                 *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q + 8) = seq + qd;
             }
+            const uint32_t roff = lds_addr(l_rows) + (SPLIT ? 8 * rl : 0);
             uint32_t pk[ND];
             unsigned long long rr[ND];
 #pragma unroll
             for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
 #pragma unroll
-            for (int k = 0; k < (int)ND; k++) rr[k] = *(SQ_LDS const unsigned long long *)(uintptr_t)(lds_addr(l_rows) + (pk[k] & 0xFFu));
+            for (int k = 0; k < (int)ND; k++) rr[k] = *(SQ_LDS const unsigned long long *)(uintptr_t)(roff + (pk[k] & 0xFFu));
 #pragma unroll
             for (int k = 0; k < (int)ND; k++)
                 if ((int32_t)pk[k] < 0)
@@ -329,12 +346,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         const uint32_t rel = (uint32_t)(m_rs - base);
         if (c == 0) { l_rows[2 * q] = rel + m_so; l_rows[2 * q + 1] = rel + m_qo; }
         const uint8_t *g0 = P.buf + base;
+        const uint32_t roff = lds_addr(l_rows) + (SPLIT ? 4 * rl : 0);
         uint32_t pk[ND];
         int32_t rr[ND];
 #pragma unroll
         for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
 #pragma unroll
-        for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(lds_addr(l_rows) + (pk[k] & 0xFFu));
+        for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(roff + (pk[k] & 0xFFu));
 #pragma unroll
         for (int k = 0; k < (int)ND; k++)
             if ((int32_t)pk[k] < 0)
@@ -364,8 +382,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     };
 
     /* the workgroup's positional histograms to the device tables (end-anchored = a window of the
-       positional ones: every read counted since the last merge has length U), then zeroed again */
-    auto merge_hist = [&](bool zero) {
+       positional ones: every read counted since the last merge has length U), then zeroed again.
+       fill: SEG: filler rows the workgroup counted in this stretch (their qualities sit in row 12
+       of every position; what else is there are real 0x80 bytes, bin 11 like every invalid byte) */
+    auto merge_hist = [&](bool zero, uint32_t fill) {
         if (AD)
             for (uint32_t i = tid; i < P.ad_lds * hs; i += T) {
                 const uint32_t v = l_adf[i];
@@ -384,83 +404,33 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
         for (uint32_t i = tid; i < hs * PROWS; i += T) {
-            const uint32_t v = l_hist_phred[i], cc = i / hs, pos = i % hs;
+            uint32_t v = l_hist_phred[i], cc = i / hs;
+            const uint32_t pos = i % hs;
             if (zero) l_hist_phred[i] = 0;
-            if (!v || pos >= U || cc >= PHRED_COLS) continue;
+            if (pos >= U) continue;
+            if (cc >= PHRED_COLS) { v -= fill; cc = PHRED_COLS - 1; }
+            if (!v) continue;
             atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
         }
     };
 
-    /* SEG: the workgroup's stretch of the launch's spans, one length after the other */
-    uint64_t c_lo = 0, c_hi = 0;
-    uint32_t seg_i = 0;
-    if constexpr (SEG) {
-        const uint64_t chunk = ((uint64_t)P.span_total + gridDim.x - 1) / gridDim.x;
-        c_lo = min((uint64_t)P.span_total, blockIdx.x * chunk);
-        c_hi = min((uint64_t)P.span_total, c_lo + chunk);
-        while (seg_i < P.span_nsegs && (uint64_t)P.span_segs[seg_i].span0 + P.span_segs[seg_i].nspans <= c_lo) seg_i++;
-    }
-    for (;;) {
-    if constexpr (SEG) {
-        if (seg_i >= P.span_nsegs) break;
-        const SpanSeg g = P.span_segs[seg_i];
-        if (g.span0 >= c_hi) break;
-        U = g.U;
-        Lmain = 4 * ((U - 1) / 4);
-        nsteps = Lmain / 4;
-        npad = SB - U;
-        s = max((uint64_t)g.span0, c_lo) + wave;
-        s_end = min((uint64_t)g.span0 + g.nspans, c_hi);
-        s_last = (uint64_t)g.span0 + g.nspans - 1;
-        last_rows = g.last_rows;
-        seg_first = g.first;
-        seg_span0 = g.span0;
-    }
+    /* ---- one span, or one stream of it: DS: what is counted of the bases, DQ: of the qualities ---- */
     int cur = 0;
     uint32_t rec_cur = 0;
-    if (s < s_end) {
-        issue_meta(s, meta_base);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue(slot_base, meta_base);
-        rec_cur = rec_next;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
-        if (s + stride < s_end) issue_meta(s + stride, meta_base);
-    }
-    while (s < s_end) {
-        /* the span in slot `cur` has landed, and so have the metas of the one after it */
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t0);
-#endif
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t1);
-#endif
-        if (s + stride < s_end) {
-#ifdef SQ_SPAN_PROBE
-            if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
-                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base);
-            else if (!(P.blocked & 1))
-#endif
-            issue(slot_base + (cur ^ 1) * SLOT, meta_base);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
-            if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base);
-        }
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t2);
-        if (P.blocked & 2) { cur ^= 1; s += stride; a_wait += t1 - t0; a_issue += t2 - t1; a_spans++; continue; }
-#endif
+    auto body = [&](auto ds_c, auto dq_c) {
+        constexpr bool DS = decltype(ds_c)::value, DQ = decltype(dq_c)::value, ADr = AD && DS;
         const uint32_t sa = slot_base + cur * SLOT;
         const uint64_t r = SEG ? (uint64_t)rec_cur : s * SPAN_R + q;
         const uint32_t nv = SEG && s == s_last ? last_rows : SPAN_R;   /* rows q >= nv are filler */
-        const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + SB;
+        const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + QOFF;
 
         /* ---------------- phase S: four lanes per read ----------------
            (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
            x 4 lanes of an instruction in 32 banks), writes the codes back in place (phase H and the
            automaton read them) and counts G/C and non-ACGT bases */
         uint32_t gacc = 0, nacc = 0;
-        {
+        if constexpr (DS) {
             const uint32_t cb = seq_row + 4 * c;
             uint32_t Uv = U, cv = c; /* opaque: hipcc would keep the padding masks of all 2 NW dwords in registers across spans */
             asm volatile("" : "+s"(Uv), "+v"(cv));
@@ -478,16 +448,19 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 gacc += cl & 0x04040404u;                 /* C, G and padding */
                 nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
             }
-            if (SEG && nv < SPAN_R) {   /* the last span of a length: filler rows become padding, bases and qualities */
+            if (SEG && nv < SPAN_R) {   /* the last span of a length: filler rows become padding */
                 if (q >= nv) {
 #pragma unroll
-                    for (int t = 0; t < 2 * NW; t++) {
-                        lds_store_u32(cb + 16 * t, CLS6_PAD4);
-                        lds_store_u32(cb + 16 * t + SB, PAD4);
-                    }
+                    for (int t = 0; t < 2 * NW; t++) lds_store_u32(cb + 16 * t, CLS6_PAD4);
                     gacc = 2 * NW * 0x04040404u;
                     nacc = 2 * NW * 0x08080808u;
                 }
+            }
+        }
+        if constexpr (DQ && SEG) {
+            if (nv < SPAN_R && q >= nv) {
+#pragma unroll
+                for (int t = 0; t < 2 * NW; t++) lds_store_u32(qual_row + 4 * c + 16 * t, PAD4);
             }
         }
         /* (2) the automaton.  One table read per base that depends on the read before it is the
@@ -502,14 +475,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
            and stream hands it; HI of the 8 NW cells per round).  What a round consumes was loaded in the round before it; the
            loads are asm the compiler does not wait for (rd_*, wait_lgkm + tie). */
         bool any_hit = false;
-        double acc = 0.0, tail0, tail1, tail2, tail3;
+        double acc = 0.0, tail0 = 0.0, tail1 = 0.0, tail2 = 0.0, tail3 = 0.0;
         {
-            constexpr int S = SPAN_S, D = ((int)Q4 + S - 1) / S, WT = AD ? W4T : 0;
-            constexpr int NR = AD ? WT + D : NW;   /* without the automaton: rounds of eight items and two groups */
+            constexpr int S = SPAN_S, D = ((int)Q4 + S - 1) / S, WT = ADr ? W4T : 0;
+            constexpr int NR = ADr ? WT + D : NW;   /* without the automaton: rounds of eight items and two groups */
             constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = (ITEMS + NR - 1) / NR;
             static_assert(HI <= HALF, "a round stays inside two windows");
             constexpr int KRG = 2 * (NW - 1), CG = (KRG + NR - 1) / NR;   /* groups of four chain steps that exist whatever U is */
             constexpr int KR4 = 4 * KRG;                                  /* chain steps the rounds carry */
+            constexpr int TRN = (DS ? 1 : 0) + (DQ ? 1 : 0);              /* transposing reads per window */
             uint32_t co = c;   /* opaque: the padding masks of the rounds are made per span, not kept across spans */
             asm volatile("" : "+v"(co));
             const uint32_t abase = seq_row + 4u * (Q4 * c) - 4u * WT;     /* dword (piece s, round t): abase + 4 (s D + t) */
@@ -525,21 +499,25 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
             /* what round 0 consumes */
             uint32_t qc[4 * (CG > 0 ? CG : 1)], cl[S], st[S];
             sq_u32x2 ts[NW], tq[NW];   /* the 8 rows' class codes / qualities at the lane's position of window w */
-            ts[0] = rd_tr8<0>(trb);
-            tq[0] = rd_tr8<(int)SB>(trb);
-            static_for<0, 4 * CG>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i < KR4) qc[i] = rd_u8<4 * i>(qp);
-            });
+            if constexpr (DS) ts[0] = rd_tr8<0>(trb);
+            if constexpr (DQ) tq[0] = rd_tr8<(int)QOFF>(trb);
+            if constexpr (DQ)
+                static_for<0, 4 * CG>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i < KR4) qc[i] = rd_u8<4 * i>(qp);
+                });
             static_for<0, S>([&](auto sc) {
                 constexpr int sI = decltype(sc)::value;
                 st[sI] = dfa_root;
                 cl[sI] = 0;
-                if constexpr (AD) cl[sI] = rd_b32<4 * (sI * D)>(abase);
+                if constexpr (ADr) cl[sI] = rd_b32<4 * (sI * D)>(abase);
             });
             wait_lgkm<0>();
-            tie2(ts[0]); tie2(tq[0]);
-            static_for<0, 4 * (CG > 0 ? CG : 1)>([&](auto ic) { tie(qc[decltype(ic)::value]); });
+            if constexpr (DS) tie2(ts[0]);
+            if constexpr (DQ) {
+                tie2(tq[0]);
+                static_for<0, 4 * (CG > 0 ? CG : 1)>([&](auto ic) { tie(qc[decltype(ic)::value]); });
+            }
             static_for<0, S>([&](auto sc) { tie(cl[decltype(sc)::value]); });
 
             static_for<0, NR>([&](auto tc) {
@@ -548,21 +526,21 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
                 constexpr auto items_of = [](int round) { return ITEMS - round * HI < 0 ? 0 : ITEMS - round * HI < HI ? ITEMS - round * HI : HI; };
                 constexpr auto groups_of = [](int round) { return KRG - round * CG < 0 ? 0 : KRG - round * CG < CG ? KRG - round * CG : CG; };
-                constexpr int n_l = items_of(t);
+                constexpr int n_l = items_of(t), n_lq = DQ ? n_l : 0;   /* phase H items of the round; those that touch LDS (qualities) */
                 /* windows whose first cell the next round takes: their transposing reads go out in this one */
                 constexpr auto windows_through = [](int round) { /* windows the rounds up to `round` have touched */
                     const int cells = (round + 1) * HI;
                     return ((cells < ITEMS ? cells : ITEMS) + HALF - 1) / HALF;
                 };
                 constexpr int w_lo = windows_through(t), w_hi = t + 1 < NR ? windows_through(t + 1) : w_lo;
-                constexpr int n_nx = w_hi - w_lo;   /* pairs of reads */
-                constexpr int g_now = groups_of(t), g_nx = t + 1 < NR ? groups_of(t + 1) : 0;
-                constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = AD ? S : 0;
+                constexpr int n_nx = w_hi - w_lo;   /* windows */
+                constexpr int g_now = DQ ? groups_of(t) : 0, g_nx = DQ && t + 1 < NR ? groups_of(t + 1) : 0;
+                constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = ADr ? S : 0;
                 static_assert(CG <= 2, "a round carries at most two groups of chain steps");
                 uint32_t e0[S], e1[S], e2[S], e3[S];
                 /* the class dwords of this round: padding in front of the read, behind the row's
                    sequence, and (pieces may reach past the quarter) behind the lane's quarter */
-                if constexpr (AD) {
+                if constexpr (ADr) {
                     if (t == WT) st0 = st[0];
                     static_for<0, S>([&](auto sc) {
                         constexpr int sI = decltype(sc)::value, idx = sI * D + t - WT;   /* dword of the quarter, < 0: in front of it */
@@ -576,26 +554,28 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 }
                 /* rows of the phred histogram of this round's items, error rates of its chain steps */
                 uint32_t l[HI];
-                static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
-                    if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(shl1_byte<k % 4>(k < 4 ? tq[w].x : tq[w].y, one));
-                });
+                if constexpr (DQ)
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                        if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(shl1_byte<k % 4>(k < 4 ? tq[w].x : tq[w].y, one));
+                    });
                 double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if constexpr (nC1 && t > 0) { /* the quality bytes the round before asked for */
-                    wait_lgkm<cap(SA + n_l)>();
+                    wait_lgkm<cap(SA + n_lq)>();
                     static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
                 }
                 if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
                 /* base counts of this round's items: one shift-add per base into the window's register */
-                static_for<0, HI>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
-                    if constexpr (m < n_l) cnt[w] = add_one_shl_byte<k % 4>(k < 4 ? ts[w].x : ts[w].y, one, cnt[w]);
-                });
-                if constexpr (AD) {
-                    wait_lgkm<cap(n_l + nC1)>();
+                if constexpr (DS)
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                        if constexpr (m < n_l) cnt[w] = add_one_shl_byte<k % 4>(k < 4 ? ts[w].x : ts[w].y, one, cnt[w]);
+                    });
+                if constexpr (ADr) {
+                    wait_lgkm<cap(n_lq + nC1)>();
                     static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e0[sI]); e1[sI] = rd_u16<0>(add_byte<1>(e0[sI], cl[sI])); });
                 }
-                if constexpr (n_l > 0) {
+                if constexpr (n_lq > 0) {
                     wait_lgkm<cap(nC1 + SA)>();
                     static_for<0, HI>([&](auto mc) {
                         constexpr int m = decltype(mc)::value;
@@ -603,26 +583,26 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                     });
                 }
                 if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
-                if constexpr (AD) {
-                    wait_lgkm<cap(n_l + nC2)>();
+                if constexpr (ADr) {
+                    wait_lgkm<cap(n_lq + nC2)>();
                     static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e1[sI]); e2[sI] = rd_u16<0>(add_byte<2>(e1[sI], cl[sI])); });
                 } else if constexpr (nC1) {
-                    wait_lgkm<cap(n_l + nC2)>();
+                    wait_lgkm<cap(n_lq + nC2)>();
                 }
                 if constexpr (nC1) { tie_f64(d[0]); tie_f64(d[1]); tie_f64(d[2]); tie_f64(d[3]); acc += d[0]; acc += d[1]; acc += d[2]; acc += d[3]; }
                 /* what the next round consumes: the bytes of its phase H items ... */
                 static_for<0, NW>([&](auto wc) {
                     constexpr int w = decltype(wc)::value;
                     if constexpr (w >= w_lo && w < w_hi) {
-                        ts[w] = rd_tr8<32 * w>(trb);
-                        tq[w] = rd_tr8<32 * w + (int)SB>(trb);
+                        if constexpr (DS) ts[w] = rd_tr8<32 * w>(trb);
+                        if constexpr (DQ) tq[w] = rd_tr8<32 * w + (int)QOFF>(trb);
                     }
                 });
-                if constexpr (AD) {
-                    wait_lgkm<cap(2 * n_nx)>();
+                if constexpr (ADr) {
+                    wait_lgkm<cap(TRN * n_nx)>();
                     static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e2[sI]); e3[sI] = rd_u16<0>(add_byte<3>(e2[sI], cl[sI])); });
                 } else if constexpr (nC2) {
-                    wait_lgkm<cap(2 * n_nx)>();
+                    wait_lgkm<cap(TRN * n_nx)>();
                 }
                 if constexpr (nC2) { tie_f64(d[4]); tie_f64(d[5]); tie_f64(d[6]); tie_f64(d[7]); acc += d[4]; acc += d[5]; acc += d[6]; acc += d[7]; }
                 /* ... its class dwords and the quality bytes of its chain steps */
@@ -630,14 +610,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 static_for<0, S>([&](auto sc) {
                     constexpr int sI = decltype(sc)::value;
                     cln[sI] = 0;
-                    if constexpr (AD && t + 1 < NR) cln[sI] = rd_b32<4 * (sI * D + t + 1)>(abase);
+                    if constexpr (ADr && t + 1 < NR) cln[sI] = rd_b32<4 * (sI * D + t + 1)>(abase);
                 });
-                static_for<0, 4 * CG>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
-                });
-                constexpr int n_cln = AD && t + 1 < NR ? S : 0;
-                if constexpr (AD) {
+                if constexpr (DQ)
+                    static_for<0, 4 * CG>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
+                    });
+                constexpr int n_cln = ADr && t + 1 < NR ? S : 0;
+                if constexpr (ADr) {
                     wait_lgkm<cap(n_cln + 4 * g_nx)>();
                     static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e3[sI]); st[sI] = e3[sI]; });
                     if constexpr (proper) {
@@ -669,11 +650,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(cln[sI]); cl[sI] = cln[sI]; });
                 static_for<0, NW>([&](auto wc) {
                     constexpr int w = decltype(wc)::value;
-                    if constexpr (w >= w_lo && w < w_hi) { tie2(ts[w]); tie2(tq[w]); }
+                    if constexpr (w >= w_lo && w < w_hi) {
+                        if constexpr (DS) tie2(ts[w]);
+                        if constexpr (DQ) tie2(tq[w]);
+                    }
                 });
             });
             wait_lgkm<0>();
-            if (AD && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
+            if (ADr && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
                 any_hit = true;
                 auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton */
                     unsigned long long hits = l_out[row];
@@ -705,59 +689,71 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                behind the chains (:2100-2112): all their bytes first, then all their error rates --
                two round trips to LDS instead of two per step; what does not exist reads the
                padding entry of the table, +0.0 */
-            uint32_t lb[8], tb[4];
+            if constexpr (DQ) {
+                uint32_t lb[8], tb[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) lb[j] = lds_u8(qp + 4 * (KR4 + j));
+                for (uint32_t j = 0; j < 8; j++) lb[j] = lds_u8(qp + 4 * (KR4 + j));
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) tb[j] = lds_u8(qual_row + Lmain + j);
+                for (uint32_t j = 0; j < 4; j++) tb[j] = lds_u8(qual_row + Lmain + j);
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? lb[j] << 3 : 128u << 3;
+                for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? lb[j] << 3 : SPAN_ERR_PAD << 3;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? tb[j] << 3 : 128u << 3;
-            double le[8], te[4];
+                for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? tb[j] << 3 : SPAN_ERR_PAD << 3;
+                double le[8], te[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) le[j] = lds_f64(lb[j]);
+                for (uint32_t j = 0; j < 8; j++) le[j] = lds_f64(lb[j]);
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) te[j] = lds_f64(tb[j]);
+                for (uint32_t j = 0; j < 4; j++) te[j] = lds_f64(tb[j]);
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) acc += le[j];
-            tail0 = te[0]; tail1 = te[1]; tail2 = te[2]; tail3 = te[3];
+                for (uint32_t j = 0; j < 8; j++) acc += le[j];
+                tail0 = te[0]; tail1 = te[1]; tail2 = te[2]; tail3 = te[3];
+            }
         }
-        double total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
-        total += tail0; total += tail1; total += tail2; total += tail3; /* :2100-2112 */
-        uint32_t gsum = sum_bytes(gacc, 0), nsum = sum_bytes(nacc, 0);
-        gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
-        gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
+        double total = 0.0;
+        if constexpr (DQ) {
+            total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
+            total += tail0; total += tail1; total += tail2; total += tail3; /* :2100-2112 */
+        }
+        uint32_t gsum = 0, nsum = 0;
+        if constexpr (DS) {
+            gsum = sum_bytes(gacc, 0); nsum = sum_bytes(nacc, 0);
+            gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
+            gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
+        }
         if (c == 0 && q < nv) {
-            const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
-            {   /* :2126; a store hipcc does not count either */
-                double *dst = &P.metas[r].accumulated_error_rate;
-                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(total) : "memory");
+            if constexpr (DS) {
+                const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
+                if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
             }
-            if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
-            if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
-            /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i).  A float
-               logarithm names a candidate, the three thresholds around it (one round trip to LDS)
-               decide; the bisection of the other kernels only when they do not (NaN: bin 0) */
-            const double avg = total / (double)U;
-            const int guess = (int)floorf(-10.0f * log10f((float)avg));
-            const uint32_t b0 = (uint32_t)min(max(guess, 1), 92);
-            const double t_lo = l_thr[b0 - 1], t_mid = l_thr[b0], t_hi = l_thr[b0 + 1];
-            uint32_t lo;
-            if (avg <= t_lo && !(avg <= t_mid)) lo = b0 - 1;
-            else if (avg <= t_mid && !(avg <= t_hi)) lo = b0;
-            else if (avg <= t_hi && (b0 + 1 == 93 || !(avg <= l_thr[b0 + 2]))) lo = b0 + 1;
-            else {
-                uint32_t hi = 93;
-                lo = 0;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+            if constexpr (DQ) {
+                {   /* :2126; a store hipcc does not count either */
+                    double *dst = &P.metas[r].accumulated_error_rate;
+                    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(total) : "memory");
                 }
+                if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+                /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i).  A float
+                   logarithm names a candidate, the three thresholds around it (one round trip to LDS)
+                   decide; the bisection of the other kernels only when they do not (NaN: bin 0) */
+                const double avg = total / (double)U;
+                const int guess = (int)floorf(-10.0f * log10f((float)avg));
+                const uint32_t b0 = (uint32_t)min(max(guess, 1), 92);
+                const double t_lo = l_thr[b0 - 1], t_mid = l_thr[b0], t_hi = l_thr[b0 + 1];
+                uint32_t lo;
+                if (avg <= t_lo && !(avg <= t_mid)) lo = b0 - 1;
+                else if (avg <= t_mid && !(avg <= t_hi)) lo = b0;
+                else if (avg <= t_hi && (b0 + 1 == 93 || !(avg <= l_thr[b0 + 2]))) lo = b0 + 1;
+                else {
+                    uint32_t hi = 93;
+                    lo = 0;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+                    }
+                }
+                atomicAdd(&l_ps[lo], 1u);
             }
-            atomicAdd(&l_ps[lo], 1u);
         }
-        if (AD && __builtin_amdgcn_ballot_w64(any_hit)) { /* update_adapter_count_array, :2643-2672 */
+        if (ADr && __builtin_amdgcn_ballot_w64(any_hit)) { /* update_adapter_count_array, :2643-2672 */
             for (uint32_t i = lane; i < SPAN_R * n_ad; i += 64) {
                 const uint32_t v = l_first[i];
                 if (v == 0xFFFFFFFFu) continue;
@@ -774,22 +770,94 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
                 }
             }
         }
+        if constexpr (DS) {
+            if (++since_flush == 7) { flush_counts(); since_flush = 0; }
+        }
+    };
 
-        if (++since_flush == 7) { flush_counts(); since_flush = 0; }
+    /* SEG: the workgroup's stretch of the launch's spans, one length after the other */
+    uint64_t c_lo = 0, c_hi = 0;
+    uint32_t seg_i = 0;
+    if constexpr (SEG) {
+        const uint64_t chunk = ((uint64_t)P.span_total + gridDim.x - 1) / gridDim.x;
+        c_lo = min((uint64_t)P.span_total, blockIdx.x * chunk);
+        c_hi = min((uint64_t)P.span_total, c_lo + chunk);
+        while (seg_i < P.span_nsegs && (uint64_t)P.span_segs[seg_i].span0 + P.span_segs[seg_i].nspans <= c_lo) seg_i++;
+    }
+    for (;;) {
+    uint32_t fill = 0;   /* SEG: filler rows of this length that this workgroup counts */
+    if constexpr (SEG) {
+        if (seg_i >= P.span_nsegs) break;
+        const SpanSeg g = P.span_segs[seg_i];
+        if (g.span0 >= c_hi) break;
+        U = g.U;
+        Lmain = 4 * ((U - 1) / 4);
+        nsteps = Lmain / 4;
+        npad = SB - U;
+        s = max((uint64_t)g.span0, c_lo) + my_seq;
+        s_end = min((uint64_t)g.span0 + g.nspans, c_hi);
+        s_last = (uint64_t)g.span0 + g.nspans - 1;
+        last_rows = g.last_rows;
+        seg_first = g.first;
+        seg_span0 = g.span0;
+        if (s_last >= c_lo && s_last < s_end) fill = SPAN_R - last_rows;
+        if constexpr (SPLIT) role = (uint32_t)wave & 1;
+    }
+    cur = 0;
+    rec_cur = 0;
+    if (s < s_end) {
+        issue_meta(s, meta_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(slot_base, meta_base, role);
+        rec_cur = rec_next;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
+        if (s + stride < s_end) issue_meta(s + stride, meta_base);
+    }
+    while (s < s_end) {
+        /* the span in slot `cur` has landed, and so have the metas of the one after it */
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t0);
+#endif
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t1);
+#endif
+        if (s + stride < s_end) {
+#ifdef SQ_SPAN_PROBE
+            if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
+                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u));
+            else if (!(P.blocked & 1))
+#endif
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
+            if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base);
+        }
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(t2);
+        if (P.blocked & 2) { cur ^= 1; s += stride; role ^= SPLIT ? 1u : 0u; a_wait += t1 - t0; a_issue += t2 - t1; a_spans++; continue; }
+#endif
+#ifdef SQ_SPAN_PROBE
+        if (SPLIT && (P.blocked & (role ? 16 : 8))) { /* 8: nothing is counted of the bases, 16: of the qualities */ } else
+#endif
+        if constexpr (!SPLIT) body(std::true_type{}, std::true_type{});
+        else if (role == 0) body(std::true_type{}, std::false_type{});
+        else body(std::false_type{}, std::true_type{});
         cur ^= 1;
         s += stride;
         rec_cur = rec_next;
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t3);
-        a_wait += t1 - t0; a_issue += t2 - t1; a_comp += t3 - t2; a_spans++;
+        a_wait += t1 - t0; a_issue += t2 - t1;
+        if (SPLIT && role) { a_compq += t3 - t2; a_spansq++; } else { a_comp += t3 - t2; a_spans++; }
 #endif
+        if constexpr (SPLIT) role ^= 1;
     }
     if constexpr (!SEG) break;
     /* the length changes: what the workgroup counted goes to the device tables */
     flush_counts();
     since_flush = 0;
     __syncthreads();
-    merge_hist(true);
+    merge_hist(true, fill);
     __syncthreads();
     seg_i++;
     }
@@ -797,12 +865,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
     if (lane == 0) {
         atomicAdd(&g_span_stamps[0], a_wait); atomicAdd(&g_span_stamps[1], a_issue);
         atomicAdd(&g_span_stamps[2], a_comp); atomicAdd(&g_span_stamps[3], a_spans);
+        atomicAdd(&g_span_stamps[4], a_compq); atomicAdd(&g_span_stamps[5], a_spansq);
     }
 #endif
     if constexpr (!SEG) {
         flush_counts();
         __syncthreads();
-        merge_hist(false);
+        merge_hist(false, 0);
     }
     for (uint32_t i = tid; i < 101; i += T)
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
@@ -810,51 +879,58 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW)) k_span(PassParams P, 
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
-template <int NW, bool SEG>
+template <int NW, bool SEG, bool SPLIT>
 int launch_nw(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
 {
     static bool attr = false;
+    constexpr bool HAS_AD = NW <= (SPLIT ? SPAN_NW_AD_SPLIT : SPAN_NW_AD);
     if (!attr) {
-        if constexpr (NW <= SPAN_NW_AD)
-            SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (HAS_AD)
+            SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, SEG, SPAN_W4, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, SEG, SPAN_W4, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     if (ad) {
-        if constexpr (NW <= SPAN_NW_AD)
-            hipLaunchKernelGGL((k_span<NW, true, SEG>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
+        if constexpr (HAS_AD)
+            hipLaunchKernelGGL((k_span<NW, true, SEG, SPAN_W4, SPLIT>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
         else
             return SQ_ERR_SYSTEM;
     } else {
-        hipLaunchKernelGGL((k_span<NW, false, SEG>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
+        hipLaunchKernelGGL((k_span<NW, false, SEG, SPAN_W4, SPLIT>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
     }
     SQ_HIP(hipGetLastError());
     return SQ_OK;
 }
-template <bool SEG>
+template <bool SEG, bool SPLIT>
 int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
 {
+#ifdef SQ_SPAN_ONLY_NW   /* experiment builds: one window count, a quarter of the compile time */
+    if (nw != SQ_SPAN_ONLY_NW) { sq_set_error("this build holds k_span<%d> only", SQ_SPAN_ONLY_NW); return SQ_ERR_SYSTEM; }
+    return launch_nw<SQ_SPAN_ONLY_NW, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+#else
     switch (nw) {
-        case 1: return launch_nw<1, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 2: return launch_nw<2, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 3: return launch_nw<3, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 4: return launch_nw<4, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 5: return launch_nw<5, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 6: return launch_nw<6, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        case 7: return launch_nw<7, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
-        default: return launch_nw<8, SEG>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 1: return launch_nw<1, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 2: return launch_nw<2, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 3: return launch_nw<3, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 4: return launch_nw<4, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 5: return launch_nw<5, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 6: return launch_nw<6, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        case 7: return launch_nw<7, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
+        default: return launch_nw<8, SEG, SPLIT>(ctx, P, ad, n_ad, waves, lds, grid);
     }
+#endif
 }
 
-/* does k_span take this pass at all, and with how many waves per workgroup */
-int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg = false)
+/* does k_span take this pass at all, and with how many waves per workgroup (split: an even number) */
+int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg, bool split)
 {
-    if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > SPAN_NW_AD)) return 0; /* the automaton's rounds spill registers from 161 positions on */
+    if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > (split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD))) return 0; /* unsplit: the automaton's rounds spill registers from 161 positions on */
     if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
-    int waves = span_max_waves(nw);   /* as many as LDS takes */
-    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg).total > 160 * 1024) waves--;
+    const int step = split ? 2 : 1;
+    int waves = span_max_waves(nw, split, seg);   /* as many as LDS takes */
+    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;
     if (waves < 4) return 0;
-    if (const char *e = getenv("SQ_SPAN_WAVES")) waves = std::max(1, std::min(waves, atoi(e)));
+    if (sq_knobs().span_waves > 0) waves = std::max(step, std::min(waves, sq_knobs().span_waves / step * step));
     return waves;
 }
 
@@ -1309,23 +1385,27 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
-    const int waves = span_waves(P, nw, U, ad, n_ad);
+    bool split = sq_knobs().span_split;
+    int waves = span_waves(P, nw, U, ad, n_ad, false, split);
+    if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
     if (!waves) return SQ_OK;
-    const size_t lds = span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves).total;
+    const size_t lds = span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, false, split).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;
     const uint64_t nspans = C.n / SPAN_R;
-    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
-    int rc = launch_any<false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
+    const int seqs = split ? waves / 2 : waves;   /* sequences of spans per workgroup */
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
+    int rc = split ? launch_any<false, true>(nw, ctx, C, ad, n_ad, waves, lds, grid) : launch_any<false, false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
 #ifdef SQ_SPAN_PROBE
-    if (getenv("SQ_SPAN_STAMPS")) {
-        unsigned long long h[4];
+    if (sq_knobs().span_stamps) {
+        unsigned long long h[6];
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
-        fprintf(stderr, "k_span stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans)\n",
-                (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], h[3]);
-        unsigned long long z[4] = {0, 0, 0, 0};
+        const double all = (double)(h[3] + h[5]);
+        fprintf(stderr, "k_span stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
+                (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+        unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
     }
 #endif
@@ -1343,9 +1423,16 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
 {
     *done = 0;
     const uint64_t n = P.n;
-    if (!max_len || max_len > 32u * (ad ? SPAN_NW_AD : SPAN_NW_MAX) || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
-    for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
-        if (!span_waves(P, nw, 32 * nw, ad, n_ad, true)) return SQ_OK;
+    bool split = sq_knobs().span_split;
+    if (!max_len || max_len > 32u * SPAN_NW_MAX || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
+    for (int pass = 0; pass < 2; pass++) {   /* every window count of the batch must be one the kernel takes */
+        bool all = true;
+        for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
+            if (!span_waves(P, nw, 32 * nw, ad, n_ad, true, split)) all = false;
+        if (all) break;
+        if (!split || pass == 1) return SQ_OK;
+        split = false;
+    }
     uint32_t *keys_in = (uint32_t *)sq_scratch(ctx, 0, n * 4), *keys_out = (uint32_t *)sq_scratch(ctx, 1, n * 4);
     SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow)), *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     unsigned long long *d_longer = (unsigned long long *)sq_scratch(ctx, 3, ((size_t)max_len + 1) * 8);
@@ -1375,7 +1462,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         if (!count) continue;
         const int nw = (int)((U + 31) / 32);
         if (launches.empty() || launches.back().nw != nw)
-            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad, true), {}, 0});
+            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad, true, split), {}, 0});
         Launch &l = launches.back();
         SpanSeg g{};
         g.span0 = l.spans;
@@ -1399,9 +1486,10 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         C.span_nsegs = (uint32_t)l.segs.size();
         C.span_total = l.spans;
         C.span_rows = rows_out;
-        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true).total;
-        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + l.waves - 1) / l.waves, (uint64_t)ctx->num_cus));
-        int rc = launch_any<true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
+        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
+        const int seqs = split ? l.waves / 2 : l.waves;
+        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
+        int rc = split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
         if (rc) return rc;
         seg_off += l.segs.size();
     }

@@ -66,3 +66,21 @@ def split_fastq(text: bytes) -> Tuple[bytes, np.ndarray]:
 
 def kwargs_of(g, prefix: str) -> dict:
     return json.loads(str(g[prefix + "kwargs"]))
+
+
+def with_env(env: dict, fn):
+    """Runs fn with the SQ_* switches of `env` in force: the library reads them once, so it is
+    told to read them again (sq_knobs_reload) after every change."""
+    from sequali_amd._lib import lib
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    lib().sq_knobs_reload()
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib().sq_knobs_reload()

@@ -285,8 +285,10 @@ def test_qc_state_behind_an_invalid_phred_character(name, env):
     from sequali_amd import FastqRecordArrayView, QCMetrics
     from tests.helpers import split_fastq
     g = golden(name)
+    from sequali_amd._lib import lib
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    lib().sq_knobs_reload()
     try:
         for flush_each in (False, True):
             m = QCMetrics()
@@ -322,3 +324,4 @@ def test_qc_state_behind_an_invalid_phred_character(name, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        lib().sq_knobs_reload()

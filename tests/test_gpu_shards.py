@@ -248,10 +248,13 @@ def _rank_main(rank, world, port, n, out_dir):
     tdist.destroy_process_group()
 
 
-def test_two_processes_merge_equals_one_run(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_merge_equals_one_run(tmp_path, world):
+    """world 4: the DedupEstimator relay and the candidate selection of OverrepresentedSequences /
+    InsertSizeMetrics run over more than one hop (four processes on cuda:0, gloo)"""
     import torch.multiprocessing as mp
     from sequali_amd import synth
-    n, world = 20000, 2
+    n = 20000
     mp.spawn(_rank_main, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     b1, m1 = synth.host_records(synth.ILLUMINA, 0, n)
     b2, m2 = synth.host_records(synth.ILLUMINA_R2, 0, n)
@@ -325,13 +328,14 @@ def _rank_tables(rank, world, port, n, out_dir):
     tdist.destroy_process_group()
 
 
-def test_two_processes_sum_the_device_tables(tmp_path):
-    """dist.merge_qcmetrics + dist.merge_adaptercounter between two ranks on
-    the tables in HBM (gloo, both ranks on cuda:0) equal the oracle's single run bit for bit,
-    with unequal max_length and unequal AdapterCounter row lengths across the ranks"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_sum_the_device_tables(tmp_path, world):
+    """dist.merge_qcmetrics + dist.merge_adaptercounter between two / four
+    ranks on the tables in HBM (gloo, all ranks on cuda:0) equal the oracle's single run bit for
+    bit, with unequal max_length and unequal AdapterCounter row lengths across the ranks"""
     import torch.multiprocessing as mp
     from sequali_amd import synth
-    n, world = 200_000, 2
+    n = 200_000
     mp.spawn(_rank_tables, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     buf, metas = synth.host_records(synth.ILLUMINA, 0, n)
     metas = metas.copy()

@@ -410,17 +410,8 @@ def test_nanopore_long_reads_all_modules():
 
 
 def _with_env(env, fn):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    from tests.helpers import with_env
+    return with_env(env, fn)
 
 
 def test_two_million_reads_all_tables_equal_oracle():
