@@ -66,6 +66,7 @@ typedef struct sq_pertile sq_pertile;
 typedef struct sq_overrep sq_overrep;
 typedef struct sq_dedup sq_dedup;
 typedef struct sq_insertsize sq_insertsize;
+typedef struct sq_feeder sq_feeder;
 
 /* ---- library / context ------------------------------------------------ */
 int sq_abi_version(void);
@@ -96,6 +97,43 @@ int64_t sq_first_non_ascii(const uint8_t *buf, size_t len);
  * :777-800): 1 if every pair of names matches, else 0. */
 int sq_names_are_mates(const uint8_t *buf1, const sq_meta *metas1, const uint8_t *buf2,
                        const sq_meta *metas2, size_t n);
+
+/* ---- FastqParser's buffer logic over pinned staging blocks (host side) ---- */
+/* FastqParser (_qcmodule.c:889-1244) hands out record arrays that are windows of the file of
+ * `initial_buffersize` bytes.  sq_feeder keeps that chunking (same arrays, same errors) while the
+ * file's text is read once into pinned blocks of up to `block_bytes` (0: 64 MiB) that go to HBM
+ * with one asynchronous copy each: see csrc/sq_feed.hip.  ctx may be NULL (host parsing only). */
+#define SQ_FEED_MORE 1
+typedef struct sq_feed_array {
+    uint64_t block_id;      /* the staging block the array lies in */
+    uint64_t byte_start;    /* its window of the block: what the reference's buffer object holds */
+    uint64_t byte_len;
+    uint64_t first_record;  /* its records among the block's */
+    uint64_t n_records;     /* 0: the file is exhausted (FastqParser__next__ :1201 stops) */
+} sq_feed_array;
+/* FastqParser__new__ :905-945 */
+sq_feeder *sq_feeder_new(sq_ctx *ctx, size_t read_in_size, size_t block_bytes);
+void sq_feeder_free(sq_feeder *f);
+/* where the caller's file.readinto() puts the next bytes, and how many fit (:1022-1030) */
+uint8_t *sq_feeder_fill(sq_feeder *f, size_t *room);
+int sq_feeder_filled(sq_feeder *f, size_t n);
+/* FastqParser_create_record_array :964-1184 (min 1, max SIZE_MAX: __next__; n, n: read(n)).
+ * SQ_FEED_MORE: fill and call again; SQ_OK: *out is the array; < 0: the reference's exception. */
+int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_records, sq_feed_array *out);
+/* closes the open block behind its last array, so that it can be uploaded */
+int sq_feeder_seal(sq_feeder *f);
+const uint8_t *sq_feeder_block_text(sq_feeder *f, uint64_t block_id);
+const sq_meta *sq_feeder_block_metas(sq_feeder *f, uint64_t block_id);
+uint64_t sq_feeder_block_records(sq_feeder *f, uint64_t block_id);
+int sq_feeder_block_is_open(sq_feeder *f, uint64_t block_id);
+/* a sealed block as a record array in HBM (one async copy from pinned memory); NULL on failure */
+sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
+/* the host copy of a sealed block is no longer needed */
+void sq_feeder_release(sq_feeder *f, uint64_t block_id);
+
+/* page-locked host memory (uploads from it run at the bus rate); plain memory without a device */
+void *sq_host_alloc(size_t bytes, int *pinned);
+void sq_host_free(void *p, int pinned);
 
 /* ---- batches: a record array resident in HBM --------------------------- */
 /* Copies buf and metas to the device (the reference's modules borrow the
@@ -172,6 +210,16 @@ int64_t sq_qcmetrics_gc_content(sq_qcmetrics *m, uint64_t *out, size_t cap);
 int64_t sq_qcmetrics_phred_scores(sq_qcmetrics *m, uint64_t *out, size_t cap);
 
 /* ---- AdapterCounter, _qcmodule.c:2391-2969 ------------------------------ */
+/* Test hook (host only): the automaton tables the kernels walk in place of the shift-AND words of
+ * populate_bitmask (_qcmodule.c:2451-2609) for the first <= 64 adapters: one character per step
+ * (dfa [states][8]: next << 4 | reports; out [states]: adapters ending there; states >=
+ * *accept_first report) and two characters per step (dfa2 [states2][36] indexed first class +
+ * 6 * second class, classes A C G T other padding; out2 [states2][2]: adapters ending on the
+ * second / on the first character).  Returns the number of states, -1 if a capacity is too small. */
+int64_t sq_adapter_automaton_tables(const char *const *adapters, const size_t *lengths, size_t n,
+                                    uint16_t *dfa, uint64_t *out, size_t cap, uint32_t *accept_first,
+                                    uint16_t *dfa2, uint64_t *out2, size_t cap2, uint32_t *states2);
+
 /* AdapterCounter__new__ :2464: n ASCII adapters, each at most 64 bytes. */
 sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *const *adapters,
                                          const size_t *lengths, size_t n);

@@ -337,8 +337,19 @@ def _array_of_sequences(seqs: List[str]) -> FastqRecordArrayView:
 # that brought the array (already so for QCMetrics' invalid phred character).
 _STAGE_LIMIT = int(os.environ.get("SQ_STAGE_BYTES", str(64 << 20)))   # 0: no staging
 _STAGE_ARRAY_MAX = 8 << 20      # arrays from this size on are uploaded on their own
-_open_blocks: dict = {}         # source (parser) id -> the block arrays of that source go to
 staging_stats = {"blocks": 0, "runs": 0}   # blocks uploaded, module launches on (parts of) blocks
+_USE_FEEDER = os.environ.get("SQ_FEEDER", "1") != "0"   # FastqParser over pinned staging blocks (csrc/sq_feed.hip)
+
+
+class _Source:
+    """what arrays that are staged together have in common (a parser); its open block dies with it"""
+    __slots__ = ("open_block", "__weakref__")
+
+    def __init__(self):
+        self.open_block = None
+
+
+_DEFAULT_SOURCE = _Source()      # arrays the caller built himself
 
 
 class _Block:
@@ -348,7 +359,7 @@ class _Block:
         self.source = source
         self.parts: List[bytes] = []
         self.metas: List[np.ndarray] = []
-        self.arrays: List["FastqRecordArrayView"] = []
+        self.arrays: List = []       # weak references: a block must not keep the caller's arrays alive (nor they each other)
         self.starts = [0]            # record index of every array, and the total behind the last
         self.nbytes = 0
         self.array: Optional["FastqRecordArrayView"] = None   # set by seal()
@@ -358,15 +369,19 @@ class _Block:
     def sealed(self) -> bool:
         return self.array is not None
 
+    @property
+    def n_arrays(self) -> int:
+        return len(self.starts) - 1
+
     def append(self, arr: "FastqRecordArrayView") -> int:
         m = arr._metas.copy()
         m["record_start"] += self.nbytes
         self.parts.append(bytes(arr.obj))
         self.metas.append(m)
-        self.arrays.append(arr)
+        self.arrays.append(weakref.ref(arr))
         self.starts.append(self.starts[-1] + len(m))
         self.nbytes += len(arr.obj)
-        return len(self.arrays) - 1
+        return self.n_arrays - 1
 
     def seal(self) -> None:
         if self.array is None:
@@ -374,14 +389,19 @@ class _Block:
             self.array = FastqRecordArrayView._from_buffer(b"".join(self.parts), metas)
             staging_stats["blocks"] += 1
             self.parts, self.metas = [], []
-            if _open_blocks.get(self.source) is self:
-                del _open_blocks[self.source]
+            if self.source.open_block is self:
+                self.source.open_block = None
+
+    def _children_of(self, s0: int, s1: int):
+        """(weak reference to the array or None, first record, behind its last record) relative to array s0"""
+        return [(self.arrays[k] if k < len(self.arrays) else None, self.starts[k] - self.starts[s0],
+                 self.starts[k + 1] - self.starts[s0]) for k in range(s0, s1)]
 
     def view(self, s0: int, s1: int) -> "FastqRecordArrayView":
         """the arrays [s0, s1) of the block as one record array in HBM (the block itself when
         that is all of them: the common case, every module sees every array)"""
         self.seal()
-        if s0 == 0 and s1 == len(self.arrays):
+        if s0 == 0 and s1 == self.n_arrays:
             v = self.array
         else:
             parent = self.array._device()
@@ -393,21 +413,164 @@ class _Block:
                 raise MemoryError(_lib.last_error())
             v = FastqRecordArrayView._from_device(_DeviceBatch(h))
             v.obj = self.array.obj
-            v._metas = self.array._metas[r0:r1]
+            v._metas = self.array._metas[r0:r1] if self.array._metas is not None else None
             v._parent = parent          # the memory belongs to the block's batch
-        v._children = [(self.arrays[k], self.starts[k] - self.starts[s0], self.starts[k + 1] - self.starts[s0])
-                       for k in range(s0, s1)]
+            v._blk, v._blk_r0 = getattr(self.array, "_blk", None), r0
+        v._children = self._children_of(s0, s1)
         return v
+
+
+class _Feeder:
+    """sq_feeder (csrc/sq_feed.hip): FastqParser's buffer logic over pinned staging blocks"""
+
+    KEEP = 2     # sealed blocks whose pinned host copy is kept (an array the caller still holds may be asked for its bytes)
+
+    def __init__(self, read_in_size: int):
+        try:
+            ctx = context()
+        except Exception:      # no device: the host parser still works (plain memory, no upload)
+            ctx = None
+        self.h = lib().sq_feeder_new(ctx, read_in_size, _STAGE_LIMIT)
+        if not self.h:
+            raise MemoryError(_lib.last_error())
+        self.sealed: List[int] = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().sq_feeder_free(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+    def retire(self, block_id: int) -> None:
+        """a block has been closed: the oldest host copies go back to the pool"""
+        self.sealed.append(block_id)
+        while len(self.sealed) > self.KEEP:
+            lib().sq_feeder_release(self.h, self.sealed.pop(0))
+
+
+class _FeedArrayInfo(C.Structure):
+    _fields_ = [("block_id", C.c_uint64), ("byte_start", C.c_uint64), ("byte_len", C.c_uint64),
+                ("first_record", C.c_uint64), ("n_records", C.c_uint64)]
+
+
+class _FeedBlock(_Block):
+    """a pinned staging block of a FastqParser: its arrays are windows of it, its metas were
+    written once, relative to the block (what the device wants)"""
+
+    def __init__(self, source, feeder: _Feeder, block_id: int):
+        _Block.__init__(self, source)
+        self.feeder, self.block_id = feeder, block_id
+        self.closed = False          # the parser has moved on to another block
+        self.rates_version = 0       # bumped when a QCMetrics pass has left error rates in the block's metas in HBM
+        self._host_text = None
+        self._host_metas = None
+
+    @property
+    def sealed(self) -> bool:
+        return self.closed or self.array is not None
+
+    def add(self, n_records: int) -> int:
+        self.starts.append(self.starts[-1] + n_records)
+        return self.n_arrays - 1
+
+    def seal(self) -> None:
+        if self.array is None:
+            f = self.feeder
+            if not self.closed:
+                check(lib().sq_feeder_seal(f.h))     # the parser's next array opens a new block
+                self.closed = True
+                f.retire(self.block_id)
+            h = lib().sq_feeder_upload(f.h, self.block_id)
+            if not h:
+                raise MemoryError(_lib.last_error())
+            self.array = FastqRecordArrayView._from_device(_DeviceBatch(h))
+            self.array._blk = self
+            staging_stats["blocks"] += 1
+            if self.source.open_block is self:
+                self.source.open_block = None
+
+    def _children_of(self, s0: int, s1: int):
+        return [(None, self.starts[k] - self.starts[s0], self.starts[k + 1] - self.starts[s0]) for k in range(s0, s1)]
+
+    # -- what an array of the block asks for when the caller looks at its records ------------
+    def text(self, b0: int, n: int) -> bytes:
+        p = lib().sq_feeder_block_text(self.feeder.h, self.block_id) if self._host_text is None else None
+        if p:
+            return C.string_at(p + b0, n)
+        if self._host_text is None:     # the pinned copy is gone: from HBM
+            self._host_text, self._host_metas = self.array._batch.download()
+            self._host_text = self._host_text.tobytes()
+        return self._host_text[b0:b0 + n]
+
+    def host_metas(self, r0: int, r1: int) -> np.ndarray:
+        """the metas of records [r0, r1), record_start relative to the block (a copy)"""
+        if self._host_metas is None:
+            p = lib().sq_feeder_block_metas(self.feeder.h, self.block_id)
+            if p:
+                return np.ctypeslib.as_array((C.c_uint8 * (40 * (r1 - r0))).from_address(p + 40 * r0)).view(META_DTYPE).copy()
+            self._host_metas = self.array._batch.download_metas()
+        return self._host_metas[r0:r1].copy()
+
+    def error_rates(self, r0: int, r1: int) -> Optional[np.ndarray]:
+        if self.array is None or self.array._batch is None:
+            return None
+        return self.array._batch.error_rates()[r0:r1]
+
+
+class _FedArray(FastqRecordArrayView):
+    """a record array of a FastqParser: a window of a pinned staging block.  `obj` and the metas
+    are made when somebody looks at them; the modules only note which block and slot it is."""
+
+    def __init__(self, blk: _FeedBlock, slot: int, b0: int, blen: int, r0: int, n: int):
+        self._blk, self._slot, self._b0, self._blen, self._r0, self._n = blk, slot, b0, blen, r0, n
+        self._batch = None
+        self._writeback = None
+        self._staged = (blk, slot)
+        self._obj = None
+        self._m = None
+        self._m_version = -1
+
+    def __len__(self) -> int:
+        return self._n
+
+    @property
+    def obj(self):
+        if self._obj is None:
+            self._obj = self._blk.text(self._b0, self._blen)
+        return self._obj
+
+    @obj.setter
+    def obj(self, v):
+        self._obj = v
+
+    @property
+    def _metas(self):
+        if self._m is None:
+            m = self._blk.host_metas(self._r0, self._r0 + self._n)
+            m["record_start"] -= self._b0
+            self._m = m
+        if self._m_version != self._blk.rates_version:      # a QCMetrics pass has been through (:2126)
+            rates = self._blk.error_rates(self._r0, self._r0 + self._n)
+            if rates is not None:
+                self._m["accumulated_error_rate"] = rates
+            self._m_version = self._blk.rates_version
+        return self._m
+
+    @_metas.setter
+    def _metas(self, v):
+        self._m = v
 
 
 def _stage(arr: "FastqRecordArrayView"):
     """(block, slot) of an array; an array is staged once, whoever sees it first"""
     st = getattr(arr, "_staged", None)
     if st is None:
-        source = getattr(arr, "_source", 0)
-        blk = _open_blocks.get(source)
+        source = getattr(arr, "_source", None) or _DEFAULT_SOURCE
+        blk = source.open_block
         if blk is None:
-            blk = _open_blocks[source] = _Block(source)
+            blk = source.open_block = _Block(source)
         st = arr._staged = (blk, blk.append(arr))
         if blk.nbytes >= _STAGE_LIMIT:
             blk.seal()
@@ -433,6 +596,8 @@ class _Deferring:
 
     @staticmethod
     def _small(arr) -> bool:
+        if type(arr) is _FedArray:
+            return True
         return (_STAGE_LIMIT > 0 and arr._batch is None and arr._metas is not None and
                 len(arr.obj) < _STAGE_ARRAY_MAX and getattr(arr, "_parent", None) is None)
 
@@ -496,15 +661,17 @@ class _Deferring:
                 break
             if through is not None and not any(through is b for t in self._todo for b in ([t[0]] + ([t[3]] if len(t) == 6 else []))):
                 break
+            # what can fail without anything having been counted (the upload of a block) comes
+            # first: the stretch stays owed; once the pass itself runs it is off the list
+            views = [e[0].view(e[1], e[2])] + ([e[3].view(e[4], e[5])] if len(e) == 6 else [])
             self._todo.pop(0)
             staging_stats["runs"] += 1
+            for b in blocks:
+                self._before_run(b)
             if len(e) == 3:
-                self._before_run(e[0])
-                self._run(e[0].view(e[1], e[2]))
+                self._run(views[0])
             else:
-                self._before_run(e[0])
-                self._before_run(e[3])
-                self._run_pair(e[0].view(e[1], e[2]), e[3].view(e[4], e[5]))
+                self._run_pair(views[0], views[1])
 
     def _before_run(self, blk) -> None:
         """QCMetrics objects that write accumulated_error_rate into the block's metas go first
@@ -513,6 +680,77 @@ class _Deferring:
             q = w()
             if q is not None and q is not self:
                 q._drain(through=blk)
+
+
+class _HostBuffer:
+    """page-locked host memory (sq_host_alloc)"""
+
+    def __init__(self, nbytes: int):
+        pinned = C.c_int(0)
+        self.address = lib().sq_host_alloc(nbytes, C.byref(pinned))
+        if not self.address:
+            raise MemoryError("out of host memory")
+        self.nbytes, self.pinned = nbytes, pinned.value
+
+    def __del__(self):
+        try:
+            if self.address:
+                lib().sq_host_free(self.address, self.pinned)
+        except Exception:
+            pass
+        self.address = None
+
+
+class PinnedReader:
+    """A binary file object over FASTQ text held in page-locked host memory (the text is copied
+    there once, when the object is made).  Any parser can read() / readinto() it;
+    FastqParser(..., split_on_device=True) takes the pages as they are: the upload is the only
+    time the bytes move."""
+
+    def __init__(self, data):
+        view = memoryview(data).cast("B")
+        self._hold = _HostBuffer(len(view))
+        self._address, self._size, self._pos = self._hold.address, len(view), 0
+        C.memmove(self._address, _addr(np.frombuffer(view, dtype=np.uint8)) if len(view) else 0, len(view))
+
+    def _skip(self, n: int) -> int:
+        n = min(n, self._size - self._pos)
+        self._pos += n
+        return n
+
+    def readinto(self, b) -> int:
+        out = memoryview(b).cast("B")
+        at = self._pos
+        n = self._skip(len(out))
+        out[:n] = (C.c_char * n).from_address(self._address + at).raw if n else b""
+        return n
+
+    def read(self, n: int = -1) -> bytes:
+        at = self._pos
+        n = self._skip(self._size - self._pos if n is None or n < 0 else n)
+        return C.string_at(self._address + at, n)
+
+
+class _DeviceSplitArray(FastqRecordArrayView):
+    """an array whose records were split on the device.  `obj` (the buffer the reference's array
+    would hold) is copied at once when it is small and fetched back from HBM, where all of it went,
+    when somebody asks for it and it is big: the parser's host buffer is reused by the next array."""
+
+    def __init__(self, batch: _DeviceBatch, address: int, nbytes: int):
+        self._metas = None
+        self._batch = batch
+        self._writeback = None
+        self._obj = C.string_at(address, nbytes) if nbytes <= (1 << 20) else None
+
+    @property
+    def obj(self):
+        if self._obj is None:
+            self._obj = self._batch.download()[0].tobytes()
+        return self._obj
+
+    @obj.setter
+    def obj(self, v):
+        self._obj = v
 
 
 class FastqParser:
@@ -526,6 +764,10 @@ class FastqParser:
         self._file = fileobj
         self._read_in_size = int(initial_buffersize)
         self._leftover = b""
+        self._token = _Source()      # arrays of one parser are staged together
+        self._dev_left, self._dev_hold = 0, None   # split_on_device: leftover bytes, page-locked buffer
+        self._feeder: Optional[_Feeder] = None
+        self._blk: Optional[_FeedBlock] = None
         # extension: iterate with the record split done on the GPU (sq_batch_from_fastq);
         # the text is uploaded once and the metas never exist on the host unless a
         # record is indexed.  read(n) keeps the host splitter.
@@ -545,42 +787,94 @@ class FastqParser:
             raise ValueError(f"number_of_records should be greater than 1, got {number_of_records}")
         return self._create(number_of_records, number_of_records)
 
+    def _create(self, min_records: int, max_records: int) -> FastqRecordArrayView:
+        if _USE_FEEDER and _STAGE_LIMIT > 0:
+            return self._create_fed(min_records, max_records)
+        return self._create_py(min_records, max_records)
+
+    def _create_fed(self, min_records: int, max_records: int) -> FastqRecordArrayView:
+        """FastqParser_create_record_array (_qcmodule.c:964-1184) by sq_feeder_next: the file's bytes
+        go straight into a pinned staging block, the array is a window of it (csrc/sq_feed.hip)"""
+        f = self._feeder
+        if f is None:
+            f = self._feeder = _Feeder(self._read_in_size)
+        info = _FeedArrayInfo()
+        room = C.c_size_t(0)
+        while True:
+            rc = lib().sq_feeder_next(f.h, min_records, min(max_records, (1 << 63) - 1), C.byref(info))
+            if rc != 1:
+                break
+            p = lib().sq_feeder_fill(f.h, C.byref(room))
+            if not p:
+                raise MemoryError(_lib.last_error())
+            got = self._file.readinto((C.c_char * room.value).from_address(p)) or 0
+            check(lib().sq_feeder_filled(f.h, got))
+        check(rc)
+        if info.n_records == 0:
+            return FastqRecordArrayView._from_buffer(b"", np.zeros(0, dtype=META_DTYPE))
+        blk = self._blk
+        if blk is None or blk.block_id != info.block_id:
+            if blk is not None and not blk.closed:     # the feeder went on to a new block by itself: the old one is complete
+                blk.closed = True
+                f.retire(blk.block_id)
+            blk = self._blk = _FeedBlock(self._token, f, info.block_id)
+        slot = blk.add(info.n_records)
+        return _FedArray(blk, slot, info.byte_start, info.byte_len, info.first_record, info.n_records)
+
     def _create_on_device(self) -> FastqRecordArrayView:
         """The loop of FastqParser_create_record_array (_qcmodule.c:964-1184) with the
-        ASCII check and the record split done by sq_batch_from_fastq."""
-        buf = bytearray(self._leftover)
+        ASCII check and the record split done by sq_batch_from_fastq.  The buffer is page-locked
+        (the upload runs at the bus rate); a PinnedReader hands its own pages over, no copy at all."""
+        src = self._file if isinstance(self._file, PinnedReader) else None
+        left = self._dev_left            # bytes of the previous buffer no complete record covered
         first, eof = True, False
+        have = left
         while True:
-            want = max(self._read_in_size - len(buf), 0) if first else self._read_in_size
+            want = max(self._read_in_size - have, 0) if first else self._read_in_size
             first = False
             if want > 0:
-                chunk = self._file.read(want)
-                if chunk:
-                    buf += chunk
+                if src is not None:
+                    got = src._skip(want)
+                else:
+                    buf = self._dev_buffer(have + want)
+                    got = self._file.readinto((C.c_char * want).from_address(buf + have)) or 0
+                if got:
+                    have += got
                 else:
                     eof = True
-            if len(buf) == 0:
-                self._leftover = b""
+            if have == 0:
+                self._dev_left = 0
                 return FastqRecordArrayView._from_buffer(b"", np.zeros(0, dtype=META_DTYPE))
-            if eof and buf.count(b"\n") < 4:  # :1073-1081
-                raise EOFError("Incomplete record at the end of file " + bytes(buf).decode("latin-1"))
-            obj = bytes(buf)
+            addr = src._address + src._pos - have if src is not None else self._dev_buffer(have)
+            if eof and C.string_at(addr, have).count(b"\n") < 4:  # :1073-1081
+                raise EOFError("Incomplete record at the end of file " + C.string_at(addr, have).decode("latin-1"))
             consumed = C.c_size_t(0)
-            h = lib().sq_batch_from_fastq(context(), _addr(obj), len(obj), C.byref(consumed))
+            h = lib().sq_batch_from_fastq(context(), addr, have, C.byref(consumed))
             if not h:
                 raise ValueError(_lib.last_error())
             batch = _DeviceBatch(h)
             if batch.number_of_records >= 1:
                 break
             if eof:
-                raise EOFError("Incomplete record at the end of file " + obj.decode("latin-1"))
-        self._leftover = obj[consumed.value:]
-        arr = FastqRecordArrayView._from_device(batch)
-        arr._source = id(self)
-        arr.obj = obj
+                raise EOFError("Incomplete record at the end of file " + C.string_at(addr, have).decode("latin-1"))
+        arr = _DeviceSplitArray(batch, addr, have)
+        arr._source = self._token
+        self._dev_left = have - consumed.value
+        if src is None and self._dev_left:     # the leftover moves to the front of the buffer
+            C.memmove(self._dev_buffer(self._dev_left), addr + consumed.value, self._dev_left)
         return arr
 
-    def _create(self, min_records: int, max_records: int) -> FastqRecordArrayView:
+    def _dev_buffer(self, nbytes: int) -> int:
+        """address of the parser's page-locked buffer, at least nbytes long (contents kept)"""
+        hold = self._dev_hold
+        if hold is None or hold.nbytes < nbytes:
+            new = _HostBuffer(max(nbytes, 2 * (hold.nbytes if hold else 0)))
+            if hold is not None:
+                C.memmove(new.address, hold.address, hold.nbytes)
+            hold = self._dev_hold = new
+        return hold.address
+
+    def _create_py(self, min_records: int, max_records: int) -> FastqRecordArrayView:
         """FastqParser_create_record_array, _qcmodule.c:964-1184: a new buffer of
         ``initial_buffersize`` bytes seeded with the leftover of the previous call,
         enlarged by the same amount until ``min_records`` records fit."""
@@ -629,7 +923,7 @@ class FastqParser:
         obj = bytes(buf)
         self._leftover = obj[consumed:]
         arr = FastqRecordArrayView._from_buffer(obj, metas)
-        arr._source = id(self)   # arrays of one parser are staged together
+        arr._source = self._token   # arrays of one parser are staged together
         return arr
 
 
@@ -669,6 +963,10 @@ class BamParser:
         self._file = fileobj
         self._read_in_size = int(initial_buffersize)
         self._leftover = b""
+        self._token = _Source()      # arrays of one parser are staged together
+        self._dev_left, self._dev_hold = 0, None   # split_on_device: leftover bytes, page-locked buffer
+        self._feeder: Optional[_Feeder] = None
+        self._blk: Optional[_FeedBlock] = None
 
     def __iter__(self) -> "BamParser":
         return self
@@ -808,12 +1106,17 @@ class QCMetrics(_Deferring):
                 error = ValueError(msg)
             check(lib().sq_qcmetrics_flush(self._handle))    # the log of the handled batches ends here
         for arr in pending:
+            blk = getattr(arr, "_blk", None)
+            if blk is not None:
+                blk.rates_version += 1      # its arrays fetch the rates from HBM when somebody asks for them
             if arr._metas is not None and arr._batch is not None and len(arr._metas):
                 rates = arr._batch.error_rates()
                 arr._metas["accumulated_error_rate"] = rates
-                for child, r0, r1 in getattr(arr, "_children", ()):   # the arrays a staging block was made of
-                    child._metas["accumulated_error_rate"] = rates[r0:r1]
-                    child._writeback = None
+                for ref, r0, r1 in getattr(arr, "_children", ()):   # the arrays a staging block was made of
+                    child = ref() if ref is not None else None
+                    if child is not None:
+                        child._metas["accumulated_error_rate"] = rates[r0:r1]
+                        child._writeback = None
             arr._writeback = None
         if error is not None:
             raise error

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsqgpu.so")
-SOURCES = ["sq_api.hip", "sq_qc.hip", "sq_span.hip", "sq_ends.hip", "sq_nano.hip"]
+SOURCES = ["sq_api.hip", "sq_qc.hip", "sq_span.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.replace(obj + tag, obj)
             return obj
 
-        with ThreadPoolExecutor(max_workers=5) as pool:
+        with ThreadPoolExecutor(max_workers=6) as pool:
             objs = list(pool.map(compile_one, SOURCES))
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag, *objs],
                            capture_output=True, text=True)

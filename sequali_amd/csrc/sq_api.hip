@@ -101,12 +101,14 @@ SQ_EXPORT void *sq_stream_handle(sq_ctx *ctx) { return (void *)ctx->stream; }
 
 /* ---- host-side record boundary ------------------------------------------- */
 
-/* FastqParser_create_record_array, the record loop _qcmodule.c:1093-1171 */
-SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas, size_t cap,
-                                 size_t *consumed)
+/* FastqParser_create_record_array, the record loop _qcmodule.c:1093-1171, over bytes
+ * [start, end) of `base`; record_start is relative to `base`.  stats (may be NULL): bases,
+ * longest read, longest name, longest record span, ~(shortest read) of the records so far */
+int64_t sq_split_range(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                       uint64_t stats[5])
 {
-    const uint8_t *end = buf + len;
-    const uint8_t *rec = buf;
+    const uint8_t *end = base + end_off;
+    const uint8_t *rec = base + start;
     int64_t n = 0;
     while ((size_t)n < cap) {
         if (rec + 2 >= end) break; /* :1094 */
@@ -142,7 +144,7 @@ SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas,
             return SQ_ERR_OVERFLOW;
         }
         sq_meta *m = &metas[n++];
-        m->record_start = (uint64_t)(name - buf);
+        m->record_start = (uint64_t)(name - base);
         m->name_length = (uint32_t)(name_end - name);
         m->sequence_offset = (uint32_t)(seq - name);
         m->sequence_length = (uint32_t)(seq_end - seq);
@@ -150,10 +152,24 @@ SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas,
         m->tags_offset = (uint32_t)(qual_end - name);
         m->tags_length = 0;
         m->accumulated_error_rate = 0.0;
+        if (stats) {
+            const uint64_t L = m->sequence_length, span = (uint64_t)m->qualities_offset + L;
+            stats[0] += L;
+            if (L > stats[1]) stats[1] = L;
+            if (m->name_length > stats[2]) stats[2] = m->name_length;
+            if (span > stats[3]) stats[3] = span;
+            if (~L > stats[4]) stats[4] = ~L;
+        }
         rec = qual_end + 1;
     }
-    if (consumed) *consumed = (size_t)(rec - buf);
+    if (consumed) *consumed = (size_t)(rec - (base + start));
     return n;
+}
+
+SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas, size_t cap,
+                                 size_t *consumed)
+{
+    return sq_split_range(buf, 0, len, metas, cap, consumed, nullptr);
 }
 
 SQ_EXPORT int64_t sq_first_non_ascii(const uint8_t *buf, size_t len)

@@ -35,6 +35,9 @@ struct PassParams {
     uint32_t dfa_states;
     uint32_t dfa_accept;      /* states >= this one are the ones some adapter ends in */
     const unsigned long long *dfa_out; /* [states] adapters ending in that state */
+    const uint16_t *dfa2;     /* [dfa2_states][36]: the automaton two characters at a time (build_pair_dfa) */
+    uint32_t dfa2_states;     /* states >= dfa_accept report, as in the one-character automaton */
+    const unsigned long long *dfa2_out; /* [dfa2_states][2] adapters ending on the second / the first character of the step */
     const uint8_t *ad_len;    /* [n_adapters] */
     unsigned long long *ad_fwd, *ad_rev; /* [n_adapters][ad_cap] */
     uint64_t ad_cap;

@@ -2291,6 +2291,10 @@ struct sq_adaptercounter {
         uint16_t *d_dfa = nullptr;
         unsigned long long *d_out = nullptr;
         uint8_t *d_len = nullptr;
+        /* the same automaton walking two characters per step (k_span, build_pair_dfa) */
+        uint32_t states2 = 0, accept2 = 0;
+        uint16_t *d_dfa2 = nullptr;           /* [states2][36]: next state for (first class, second class) */
+        unsigned long long *d_out2 = nullptr; /* [states2][2]: adapters ending on the second / on the first character */
     };
     std::vector<Group> groups;
 };
@@ -2462,7 +2466,71 @@ int build_dfa(const std::vector<std::string> &ads, size_t first, size_t count,
     return 0;
 }
 
+/* The automaton of build_dfa taking two characters per step (k_span: half as many dependent
+ * table reads per read).  State n on (c1, c2) goes to f = next[next[n][c1]][c2]; classes are the
+ * five of build_dfa plus 5 = padding (back to the root).  What must not get lost is a report of
+ * the state in between, m = next[n][c1]: such a step ends in an *alias* of f -- a state of its
+ * own that reports the adapters of m one character back (out2[.][1]) besides f's own
+ * (out2[.][0]) and goes on like f.  Numbering: build_dfa's states keep their numbers (the ones
+ * some adapter ends in last), aliases follow: every state >= accept_first reports something.
+ * dfa2[n][c1 + 6 c2] = number of the next state. */
+void build_pair_dfa(const std::vector<uint16_t> &dfa, const std::vector<unsigned long long> &out, uint32_t states,
+                    std::vector<uint16_t> &dfa2, std::vector<unsigned long long> &out2)
+{
+    auto next1 = [&](uint32_t n, int c) { return c == 5 ? 0u : (uint32_t)(dfa[n * 8 + c] >> 4); };
+    std::vector<uint32_t> base;                                  /* state -> the build_dfa state it behaves like */
+    std::vector<std::pair<unsigned long long, uint32_t>> alias;   /* (adapters of the state in between, f) */
+    for (uint32_t n = 0; n < states; n++) base.push_back(n);
+    out2.clear();
+    for (uint32_t n = 0; n < states; n++) { out2.push_back(out[n]); out2.push_back(0); }
+    dfa2.clear();
+    for (uint32_t n = 0; n < base.size(); n++) {   /* grows while aliases are added: they get rows too */
+        const uint32_t b = base[n];
+        for (int k = 0; k < 36; k++) {
+            const int c1 = k % 6, c2 = k / 6;
+            const uint32_t m = next1(b, c1), f = next1(m, c2);
+            uint32_t target = f;
+            if (out[m]) {
+                size_t i = 0;
+                while (i < alias.size() && !(alias[i].first == out[m] && alias[i].second == f)) i++;
+                if (i == alias.size()) {
+                    alias.push_back({out[m], f});
+                    base.push_back(f);
+                    out2.push_back(out[f]);
+                    out2.push_back(out[m]);
+                }
+                target = states + (uint32_t)i;
+            }
+            dfa2.push_back((uint16_t)target);
+        }
+    }
+}
+
 } // namespace
+
+/* The tables the kernels walk for the first (up to 64) adapters, for inspection on the host (no
+ * GPU involved; tests/test_boundary_cpu.py walks both over random text): dfa [states][8] with
+ * entries next << 4 | reports, out [states]; dfa2 [states2][36] and out2 [states2][2] of
+ * build_pair_dfa.  Returns the number of states, or -1 when a capacity is too small. */
+SQ_EXPORT int64_t sq_adapter_automaton_tables(const char *const *adapters, const size_t *lengths, size_t n,
+                                              uint16_t *dfa_o, uint64_t *out_o, size_t cap, uint32_t *accept_first,
+                                              uint16_t *dfa2_o, uint64_t *out2_o, size_t cap2, uint32_t *states2)
+{
+    std::vector<std::string> ads;
+    for (size_t i = 0; i < n && i < 64; i++) ads.emplace_back(adapters[i], lengths[i]);
+    std::vector<uint16_t> dfa, dfa2;
+    std::vector<unsigned long long> out, out2;
+    uint32_t states = 0;
+    if (build_dfa(ads, 0, ads.size(), dfa, out, &states, accept_first) != 0) return -1;
+    build_pair_dfa(dfa, out, states, dfa2, out2);
+    *states2 = (uint32_t)(out2.size() / 2);
+    if (states > cap || *states2 > cap2) return -1;
+    memcpy(dfa_o, dfa.data(), dfa.size() * 2);
+    memcpy(out_o, out.data(), out.size() * 8);
+    memcpy(dfa2_o, dfa2.data(), dfa2.size() * 2);
+    memcpy(out2_o, out2.data(), out2.size() * 8);
+    return (int64_t)states;
+}
 
 SQ_EXPORT sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *const *adapters,
                                                    const size_t *lengths, size_t n)
@@ -2506,6 +2574,17 @@ SQ_EXPORT sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *cons
         SQ_HIP_NULL(hipMemcpy(g.d_dfa, dfa.data(), dfa.size() * 2, hipMemcpyHostToDevice));
         SQ_HIP_NULL(hipMemcpy(g.d_out, out.data(), out.size() * 8, hipMemcpyHostToDevice));
         SQ_HIP_NULL(hipMemcpy(g.d_len, lens.data(), 64, hipMemcpyHostToDevice));
+        {
+            std::vector<uint16_t> dfa2;
+            std::vector<unsigned long long> out2;
+            build_pair_dfa(dfa, out, g.states, dfa2, out2);
+            g.states2 = (uint32_t)(out2.size() / 2);
+            g.accept2 = g.accept_first;
+            SQ_HIP_NULL(hipMalloc((void **)&g.d_dfa2, dfa2.size() * 2));
+            SQ_HIP_NULL(hipMalloc((void **)&g.d_out2, out2.size() * 8));
+            SQ_HIP_NULL(hipMemcpy(g.d_dfa2, dfa2.data(), dfa2.size() * 2, hipMemcpyHostToDevice));
+            SQ_HIP_NULL(hipMemcpy(g.d_out2, out2.data(), out2.size() * 8, hipMemcpyHostToDevice));
+        }
         a->groups.push_back(g);
         first += count;
     }
@@ -2518,6 +2597,8 @@ SQ_EXPORT void sq_adaptercounter_free(sq_adaptercounter *a)
     (void)hipStreamSynchronize(a->ctx->stream);
     for (auto &g : a->groups) {
         (void)hipFree(g.d_dfa);
+        (void)hipFree(g.d_dfa2);
+        (void)hipFree(g.d_out2);
         (void)hipFree(g.d_out);
         (void)hipFree(g.d_len);
     }
@@ -2923,6 +3004,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         if (ad) {
             auto &g = a->groups[gi];
             P.dfa = g.d_dfa; P.dfa_states = g.states; P.dfa_accept = g.accept_first; P.dfa_out = g.d_out; P.ad_len = g.d_len;
+            P.dfa2 = g.d_dfa2; P.dfa2_states = g.states2; P.dfa2_out = g.d_out2;
             P.ad_fwd = a->d_fwd + g.first * a->cap;
             P.ad_rev = a->d_rev + g.first * a->cap;
             states = g.states;

@@ -44,6 +44,14 @@ namespace {
 constexpr uint32_t SPAN_R = 16;              /* records per span */
 constexpr uint32_t CLS6_PAD4 = 0x1E1E1E1Eu;  /* code 30 */
 constexpr int SPAN_W4 = 3;  /* dwords an automaton is restarted in front of its piece: adapters of up to 13 characters */
+#ifndef SPAN_PAIR
+#define SPAN_PAIR 1   /* the automaton takes two characters per step (half the dependent table reads) */
+#endif
+#if SPAN_PAIR
+#define SPAN_STATES(P) ((P).dfa2_states)
+#else
+#define SPAN_STATES(P) ((P).dfa_states)
+#endif
 #ifndef SPAN_S
 #define SPAN_S 1   /* pieces a lane cuts its quarter into, one automaton each (more pieces: shorter chains, more table reads; the reads cost more) */
 #endif
@@ -71,9 +79,10 @@ __device__ __forceinline__ void lds_min(uint32_t a, uint32_t v)
 {
     __hip_atomic_fetch_min((SQ_LDS uint32_t *)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-/* byte offset of automaton state n from the root, and back (k_span) */
-__host__ __device__ constexpr uint32_t span_dfa_offset(uint32_t n) { return 36 * (n / 3) + 2 * (n % 3); }
-__device__ __forceinline__ uint32_t span_dfa_state(uint32_t off) { return 3 * (off / 36) + (off % 36) / 2; }
+/* byte offset of automaton state n from the root, and back (k_span): three states share
+   SPAN_DFA_ROW bytes, their entries interleaved (span_lds_layout knows the same number) */
+__host__ __device__ constexpr uint32_t span_dfa_offset(uint32_t n) { return SPAN_DFA_ROW * (n / 3) + 2 * (n % 3); }
+__device__ __forceinline__ uint32_t span_dfa_state(uint32_t off) { return 3 * (off / SPAN_DFA_ROW) + (off % SPAN_DFA_ROW) / 2; }
 /* a + byte J of w */
 template <int J> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t w)
 {
@@ -187,8 +196,12 @@ template <int CTRL> __device__ __forceinline__ double quad_bcast_f64(double v)
 constexpr int span_max_waves(int nw, bool split = false, bool seg = false) { return nw <= (split ? (seg ? 4 : 5) : 3) ? 16 : 12; }
 
 #ifdef SQ_SPAN_PROBE
-__device__ unsigned long long g_span_stamps[6]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
+__device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
 #define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+/* phases inside a span: cycles since the stamp before go to ph[5 * (quality role) + k] */
+#define SPAN_PHASE(k) do { SPAN_STAMP(tq_); ph[(DS ? 0 : 5) + (k)] += tq_ - tp; tp = tq_; } while (0)
+#else
+#define SPAN_PHASE(k) do { } while (0)
 #endif
 /* SEG: the batch holds reads of many lengths; P.span_rows lists them sorted by length, 16 reads of
    one length per span, P.span_segs the lengths in span order.  A workgroup takes a contiguous
@@ -207,7 +220,7 @@ template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = fal
 __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(PassParams P, uint32_t n_ad)
 {
 #ifdef SQ_SPAN_PROBE
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0, a_compq = 0, a_spansq = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0, a_compq = 0, a_spansq = 0, ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp = 0, tq_ = 0;
 #endif
     /* Row r of a slot: sequence at r * ROWB, qualities at r * ROWB + QOFF (SPLIT: the slot holds
        one of the two streams, at r * ROWB).  A row is an odd number of 16-byte pieces (the last one
@@ -220,7 +233,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
     uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
     const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const SpanLds L = span_lds_layout(NW, U, AD ? P.dfa_states : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT);
+    const SpanLds L = span_lds_layout(NW, U, AD ? SPAN_STATES(P) : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT);
     double *l_err = (double *)smem;                        /* [SPAN_ERR_N] by raw quality byte; [SPAN_ERR_PAD]: +0.0 */
     uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
@@ -233,8 +246,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
        nearly every lane sits in (numbered first, build_dfa) in banks of their own: in rows of 32
        bytes, four to the 32 banks, a table read took 5 extra LDS cycles on average
        (SQ_LDS_BANK_CONFLICT, profiles/r2b). */
+    /* SPAN_PAIR: the automaton takes TWO characters per step (build_pair_dfa, sq_qc.hip): the entry
+       of state n for the classes with codes (k1, k2) lives at address(n) + k1 + 6 k2 (multiples of
+       6 up to 210: three states share 216 bytes), half as many dependent reads per read; a state
+       that reports (>= dfa_hit) names the adapters that end on the step's second character
+       (l_out[.][0]) and on its first (l_out[.][1]) */
     uint16_t *l_dfa = (uint16_t *)(smem + L.dfa);
-    unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there */
+    unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there (SPAN_PAIR: [states][2]) */
     uint8_t *l_adlen = smem + L.adlen;                     /* [64] */
     uint32_t *l_hist_base = (uint32_t *)(smem + L.hist);   /* [5][hs] */
     constexpr uint32_t PROWS = PHRED_COLS + (SEG ? 1 : 0);   /* SEG: one more row takes the qualities of filler rows */
@@ -259,12 +277,20 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
     if (AD) {
+#if SPAN_PAIR
+        for (uint32_t i = tid; i < P.dfa2_states * 36; i += T) {
+            const uint32_t st = i / 36, k = i % 36;   /* k = first class + 6 * second class */
+            l_dfa[(span_dfa_offset(st) + 6 * k) >> 1] = (uint16_t)(dfa_root + span_dfa_offset(P.dfa2[i]));
+        }
+        for (uint32_t i = tid; i < 2 * P.dfa2_states; i += T) l_out[i] = P.dfa2_out[i];
+#else
         for (uint32_t i = tid; i < P.dfa_states * 6; i += T) {
             const uint32_t st = i / 6, c = i % 6;   /* class 5: padding, back to the root */
             const uint32_t next = c < 5 ? span_dfa_offset((uint32_t)(P.dfa[st * 8 + c] >> 4)) : 0;
             l_dfa[(span_dfa_offset(st) + 6 * c) >> 1] = (uint16_t)(dfa_root + next);
         }
         for (uint32_t i = tid; i < P.dfa_states; i += T) l_out[i] = P.dfa_out[i];
+#endif
         for (uint32_t i = tid; i < 64; i += T) l_adlen[i] = P.ad_len[i];
         for (uint32_t i = tid; i < P.ad_lds * hs; i += T) l_adf[i] = 0;
         for (uint32_t i = lane; i < SPAN_R * n_ad; i += 64) l_first[i] = 0xFFFFFFFFu;
@@ -424,6 +450,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         const uint64_t r = SEG ? (uint64_t)rec_cur : s * SPAN_R + q;
         const uint32_t nv = SEG && s == s_last ? last_rows : SPAN_R;   /* rows q >= nv are filler */
         const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + QOFF;
+#ifdef SQ_SPAN_PROBE
+        SPAN_STAMP(tp);
+#endif
 
         /* ---------------- phase S: four lanes per read ----------------
            (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
@@ -463,6 +492,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 for (int t = 0; t < 2 * NW; t++) lds_store_u32(qual_row + 4 * c + 16 * t, PAD4);
             }
         }
+        SPAN_PHASE(0);   /* class codes */
         /* (2) the automaton.  One table read per base that depends on the read before it is the
            only chain of dependent LDS round trips in the span (a round trip under this load is a
            few hundred cycles), so a lane cuts its quarter into S pieces of D dwords and walks S
@@ -520,6 +550,125 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             }
             static_for<0, S>([&](auto sc) { tie(cl[decltype(sc)::value]); });
 
+#if SPAN_PAIR
+            static_for<0, NR>([&](auto tc) {
+                /* one round = one dword of the lane's quarter = two steps of the two-character
+                   automaton; the schedule is the one of the one-character rounds (#else) with the
+                   second and fourth step gone */
+                constexpr int t = decltype(tc)::value;
+                constexpr bool proper = t >= WT;
+                constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
+                constexpr auto items_of = [](int round) { return ITEMS - round * HI < 0 ? 0 : ITEMS - round * HI < HI ? ITEMS - round * HI : HI; };
+                constexpr auto groups_of = [](int round) { return KRG - round * CG < 0 ? 0 : KRG - round * CG < CG ? KRG - round * CG : CG; };
+                constexpr int n_l = items_of(t), n_lq = DQ ? n_l : 0;
+                constexpr auto windows_through = [](int round) {
+                    const int cells = (round + 1) * HI;
+                    return ((cells < ITEMS ? cells : ITEMS) + HALF - 1) / HALF;
+                };
+                constexpr int w_lo = windows_through(t), w_hi = t + 1 < NR ? windows_through(t + 1) : w_lo;
+                constexpr int n_nx = w_hi - w_lo;
+                constexpr int g_now = DQ ? groups_of(t) : 0, g_nx = DQ && t + 1 < NR ? groups_of(t + 1) : 0;
+                constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = ADr ? S : 0;
+                static_assert(CG <= 2, "a round carries at most two groups of chain steps");
+                static_assert(S == 1, "the two-character automaton walks one piece per lane");
+                uint32_t e0 = 0, e1 = 0, pc = 0;   /* pc: byte 0 / byte 2 = code of the first + 6 * code of the second character of the dword's two pairs */
+                if constexpr (ADr) {
+                    if (t == WT) st0 = st[0];
+                    constexpr int idx = t - WT;   /* dword of the quarter, < 0: in front of it */
+                    if constexpr (proper && idx >= (int)Q4) cl[0] = CLS6_PAD4;
+                    else {
+                        if constexpr (idx < 0) cl[0] = co == 0 ? CLS6_PAD4 : cl[0];
+                        if constexpr (3 * (int)Q4 + idx >= (int)DW) cl[0] = Q4 * co + idx < DW ? cl[0] : CLS6_PAD4;
+                    }
+                    pc = __umul24(cl[0] >> 8, 6u) + cl[0];
+                    e0 = rd_u16<0>(add_byte<0>(st[0], pc));
+                }
+                uint32_t l[HI];
+                if constexpr (DQ)
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                        if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(shl1_byte<k % 4>(k < 4 ? tq[w].x : tq[w].y, one));
+                    });
+                double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (nC1 && t > 0) { /* the quality bytes the round before asked for */
+                    wait_lgkm<cap(SA + n_lq)>();
+                    static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
+                }
+                if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
+                if constexpr (DS)
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
+                        if constexpr (m < n_l) cnt[w] = add_one_shl_byte<k % 4>(k < 4 ? ts[w].x : ts[w].y, one, cnt[w]);
+                    });
+                if constexpr (n_lq > 0) {
+                    wait_lgkm<cap(nC1)>();   /* the histogram rows (and, older, the first step) */
+                    static_for<0, HI>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        if constexpr (m < n_l) { tie(l[m]); inc_u32<128 * ((t * HI + m) / HALF)>(hpp + l[m], one); }
+                    });
+                }
+                if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
+                if constexpr (ADr) {   /* the second step: behind the first one are d[0..3], the increments, d[4..7] */
+                    wait_lgkm<cap(nC1 + n_lq + nC2)>();
+                    tie(e0);
+                    e1 = rd_u16<0>(add_byte<2>(e0, pc));
+                }
+                if constexpr (nC1) {
+                    wait_lgkm<cap(n_lq + nC2 + SA)>();
+                    tie_f64(d[0]); tie_f64(d[1]); tie_f64(d[2]); tie_f64(d[3]); acc += d[0]; acc += d[1]; acc += d[2]; acc += d[3];
+                }
+                /* what the next round consumes: the bytes of its phase H items ... */
+                static_for<0, NW>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    if constexpr (w >= w_lo && w < w_hi) {
+                        if constexpr (DS) ts[w] = rd_tr8<32 * w>(trb);
+                        if constexpr (DQ) tq[w] = rd_tr8<32 * w + (int)QOFF>(trb);
+                    }
+                });
+                if constexpr (nC2) {
+                    wait_lgkm<cap(SA + TRN * n_nx)>();
+                    tie_f64(d[4]); tie_f64(d[5]); tie_f64(d[6]); tie_f64(d[7]); acc += d[4]; acc += d[5]; acc += d[6]; acc += d[7];
+                }
+                /* ... its class dword and the quality bytes of its chain steps */
+                uint32_t cln = 0;
+                if constexpr (ADr && t + 1 < NR) cln = rd_b32<4 * (t + 1)>(abase);
+                if constexpr (DQ)
+                    static_for<0, 4 * CG>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
+                    });
+                constexpr int n_cln = ADr && t + 1 < NR ? 1 : 0;
+                if constexpr (ADr) {
+                    wait_lgkm<cap(TRN * n_nx + n_cln + 4 * g_nx)>();
+                    tie(e1);
+                    st[0] = e1;
+                    if constexpr (proper) {
+                        if (max(e0, e1) >= dfa_hit) {
+                            constexpr int idx = t - WT;
+                            const uint32_t ee[2] = {e0, e1};
+#pragma unroll
+                            for (uint32_t j = 0; j < 2; j++) {
+                                if (ee[j] < dfa_hit) continue;   /* position: of the step's second character */
+                                const uint32_t v = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + 2 * j + 1) << 12) | span_dfa_state(ee[j] - dfa_root);
+                                if (!rec) rec = v;
+                                else if (!rec2) rec2 = v;
+                                else multi = true;
+                            }
+                        }
+                    }
+                }
+                wait_lgkm<cap(4 * g_nx)>();
+                tie(cln);
+                cl[0] = cln;
+                static_for<0, NW>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    if constexpr (w >= w_lo && w < w_hi) {
+                        if constexpr (DS) tie2(ts[w]);
+                        if constexpr (DQ) tie2(tq[w]);
+                    }
+                });
+            });
+#else
             static_for<0, NR>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr bool proper = t >= WT;
@@ -656,9 +805,24 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                     }
                 });
             });
+#endif
             wait_lgkm<0>();
+            SPAN_PHASE(1);   /* the rounds */
             if (ADr && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
                 any_hit = true;
+#if SPAN_PAIR
+                auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton: on the step's second character (pos), on its first */
+#pragma unroll
+                    for (uint32_t back = 0; back < 2; back++) {
+                        unsigned long long hits = l_out[2 * row + back];
+                        while (hits) {
+                            const int a = __ffsll((long long)hits) - 1;
+                            hits &= hits - 1;
+                            lds_min(lds_addr(l_first + q * n_ad + a), pos - back);
+                        }
+                    }
+                };
+#else
                 auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton */
                     unsigned long long hits = l_out[row];
                     while (hits) {
@@ -667,6 +831,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                         lds_min(lds_addr(l_first + q * n_ad + a), pos);
                     }
                 };
+#endif
                 if (__builtin_amdgcn_ballot_w64(multi)) {
                     uint32_t s2 = st0;
 #pragma unroll 1
@@ -674,11 +839,20 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                         const uint32_t dw = Q4 * c + tt;
                         uint32_t cl2 = lds_u32(seq_row + 4 * dw);
                         cl2 = dw < DW ? cl2 : CLS6_PAD4;
+#if SPAN_PAIR
+                        const uint32_t pc2 = __umul24(cl2 >> 8, 6u) + cl2;
+#pragma unroll 1
+                        for (uint32_t j = 0; j < 2; j++) {
+                            s2 = lds_u16(s2 + ((pc2 >> (16 * j)) & 0xFFu));
+                            if (s2 >= dfa_hit) matches(span_dfa_state(s2 - dfa_root), 4 * dw + 2 * j + 1);
+                        }
+#else
 #pragma unroll 1
                         for (uint32_t j = 0; j < 4; j++) {
                             s2 = lds_u16(s2 + ((cl2 >> (8 * j)) & 0xFFu));
                             if (s2 >= dfa_hit) matches(span_dfa_state(s2 - dfa_root), 4 * dw + j);
                         }
+#endif
                     }
                 } else if (rec) {
                     matches(rec & 0xFFFu, (rec >> 12) & 0xFFFu);
@@ -709,6 +883,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 tail0 = te[0]; tail1 = te[1]; tail2 = te[2]; tail3 = te[3];
             }
         }
+        SPAN_PHASE(2);   /* matches; the chain steps and qualities behind the rounds */
         double total = 0.0;
         if constexpr (DQ) {
             total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
@@ -753,6 +928,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 atomicAdd(&l_ps[lo], 1u);
             }
         }
+        SPAN_PHASE(3);   /* per read: bins, the error rate */
         if (ADr && __builtin_amdgcn_ballot_w64(any_hit)) { /* update_adapter_count_array, :2643-2672 */
             for (uint32_t i = lane; i < SPAN_R * n_ad; i += 64) {
                 const uint32_t v = l_first[i];
@@ -773,6 +949,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         if constexpr (DS) {
             if (++since_flush == 7) { flush_counts(); since_flush = 0; }
         }
+        SPAN_PHASE(4);   /* first hits to the tables, base counts to LDS */
     };
 
     /* SEG: the workgroup's stretch of the launch's spans, one length after the other */
@@ -866,6 +1043,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         atomicAdd(&g_span_stamps[0], a_wait); atomicAdd(&g_span_stamps[1], a_issue);
         atomicAdd(&g_span_stamps[2], a_comp); atomicAdd(&g_span_stamps[3], a_spans);
         atomicAdd(&g_span_stamps[4], a_compq); atomicAdd(&g_span_stamps[5], a_spansq);
+        for (int k = 0; k < 10; k++) atomicAdd(&g_span_stamps[6 + k], ph[k]);
     }
 #endif
     if constexpr (!SEG) {
@@ -925,10 +1103,10 @@ int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad,
 int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg, bool split)
 {
     if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > (split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD))) return 0; /* unsplit: the automaton's rounds spill registers from 161 positions on */
-    if (ad && (P.dfa_states > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
+    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
     const int step = split ? 2 : 1;
     int waves = span_max_waves(nw, split, seg);   /* as many as LDS takes */
-    while (waves >= 4 && span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;
+    while (waves >= 4 && span_lds_layout(nw, U, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;
     if (waves < 4) return 0;
     if (sq_knobs().span_waves > 0) waves = std::max(step, std::min(waves, sq_knobs().span_waves / step * step));
     return waves;
@@ -1389,7 +1567,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
     if (!waves) return SQ_OK;
-    const size_t lds = span_lds_layout(nw, U, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, false, split).total;
+    const size_t lds = span_lds_layout(nw, U, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, false, split).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;
     const uint64_t nspans = C.n / SPAN_R;
@@ -1399,13 +1577,16 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     if (rc) return rc;
 #ifdef SQ_SPAN_PROBE
     if (sq_knobs().span_stamps) {
-        unsigned long long h[6];
+        unsigned long long h[16];
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
         const double all = (double)(h[3] + h[5]);
         fprintf(stderr, "k_span stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
                 (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
-        unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+        fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
+                h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
+                h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
+        unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
     }
 #endif
@@ -1486,7 +1667,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         C.span_nsegs = (uint32_t)l.segs.size();
         C.span_total = l.spans;
         C.span_rows = rows_out;
-        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? P.dfa_states : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
+        const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
         const int seqs = split ? l.waves / 2 : l.waves;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
         int rc = split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);

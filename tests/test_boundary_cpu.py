@@ -187,3 +187,88 @@ def test_synthetic_data_has_the_intended_features():
     assert quals == set(b"F:,#")
     tiles = set(oracle.tile_id(text[int(m["record_start"]):][:int(m["name_length"])].decode()) for m in metas)
     assert len(tiles) == 96 and min(tiles) == 1101 and max(tiles) == 2224
+
+
+# ---- the adapter automatons (host tables, no GPU) ---------------------------------------
+def _automaton_tables(adapters):
+    import ctypes as C
+    from sequali_amd._lib import lib
+    enc = [a.encode("ascii") for a in adapters]
+    arr = (C.c_char_p * len(enc))(*enc)
+    lens = (C.c_size_t * len(enc))(*[len(e) for e in enc])
+    cap = 4096
+    dfa, out = np.zeros(cap * 8, np.uint16), np.zeros(cap, np.uint64)
+    dfa2, out2 = np.zeros(cap * 36, np.uint16), np.zeros(cap * 2, np.uint64)
+    accept, states2 = C.c_uint32(0), C.c_uint32(0)
+    n = lib().sq_adapter_automaton_tables(arr, lens, len(enc), dfa.ctypes.data, out.ctypes.data, cap, C.byref(accept),
+                                          dfa2.ctypes.data, out2.ctypes.data, cap, C.byref(states2))
+    assert n > 0
+    return (dfa[:n * 8].reshape(n, 8), out[:n], int(accept.value),
+            dfa2[:states2.value * 36].reshape(-1, 36), out2[:states2.value * 2].reshape(-1, 2))
+
+
+def _classes(text: bytes):
+    return [{"a": 0, "c": 1, "g": 2, "t": 3}.get(chr(b).lower(), 4) for b in text]
+
+
+@pytest.mark.parametrize("adapters", [
+    ["AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA", "GGGGGGGGGGGG", "AAAAAAAAAAAA"],
+    ["ACGT", "CGTA", "GT", "A", "TTTT", "ACGTACGTACGTA"],
+    ["GGGG", "GGGGG", "GG", "ANA", "NN"],
+])
+def test_pair_automaton_reports_what_the_single_step_one_reports(adapters):
+    """k_span walks the automaton two characters per step (build_pair_dfa): on random text, from
+    every phase, it reports the same (adapter, end position) events as the one-character automaton
+    -- itself checked here against a plain search -- except for what the silent twins swallow in
+    both: repeats of an adapter inside a run of its own characters, which AdapterCounter never
+    counts twice in a read anyway (update_adapter_count_array, _qcmodule.c:2643-2672: first hit per
+    adapter and read).  So the comparison is on first hits."""
+    dfa, out, accept, dfa2, out2 = _automaton_tables(adapters)
+    assert (np.nonzero(out)[0] >= accept).all() and len(dfa2) >= len(dfa)
+    assert (out2[:len(out), 0] == out).all() and (out2[:len(out), 1] == 0).all()
+    rng = np.random.default_rng(len(adapters[0]))
+    for trial in range(300):
+        L = int(rng.integers(1, 90))
+        text = rng.choice(np.frombuffer(b"ACGTNacgtn", np.uint8), size=L, p=[.2, .2, .2, .2, .02, .04, .04, .04, .04, .02]).tobytes()
+        if trial % 3 == 0:   # plant adapters and runs
+            for _ in range(3):
+                w = adapters[int(rng.integers(0, len(adapters)))].encode()
+                if len(w) <= L:
+                    at = int(rng.integers(0, L - len(w) + 1))
+                    text = text[:at] + w + text[at + len(w):]
+        if trial % 5 == 0:
+            text = text[:L // 2] + b"G" * (L - L // 2)
+        cls = _classes(text)
+        # plain search: first end position of every adapter (N in an adapter matches class 4, :2451-2462)
+        want = {}
+        for a, ad in enumerate(adapters):
+            ac = _classes(ad.encode())
+            for e in range(len(ac) - 1, L):
+                if cls[e - len(ac) + 1:e + 1] == ac:
+                    want[a] = e
+                    break
+        def first_hits(events):
+            first = {}
+            for a, e in events:
+                first[a] = min(first.get(a, e), e)
+            return first
+        # one character per step
+        s, ev1 = 0, []
+        for i, c in enumerate(cls):
+            s = int(dfa[s, c]) >> 4
+            ev1 += [(a, i) for a in range(len(adapters)) if int(out[s]) >> a & 1]
+        assert first_hits(ev1) == want
+        # two characters per step, from both phases (the second one starts with a lone first character:
+        # (padding, c) from the root is a one-character step)
+        for phase in (0, 1):
+            seq = ([5] if phase else []) + cls
+            if len(seq) % 2:
+                seq = seq + [5]
+            s, ev2 = 0, []
+            for i in range(0, len(seq), 2):
+                s = int(dfa2[s, seq[i] + 6 * seq[i + 1]])
+                pos = i + 1 - phase   # position of the step's second character in the text
+                ev2 += [(a, pos) for a in range(len(adapters)) if int(out2[s, 0]) >> a & 1]
+                ev2 += [(a, pos - 1) for a in range(len(adapters)) if int(out2[s, 1]) >> a & 1]
+                assert (s >= accept) == bool(out2[s, 0] or out2[s, 1])
+            assert first_hits(ev2) == want, (text, phase)
