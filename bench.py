@@ -288,25 +288,46 @@ def other_configs(lib, ctx, steps, warmup):
         lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
     del arr
-    # ---- end to end from host memory with the reference's call pattern (not HBM resident: PCIe bound) ----
+    # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
     import io
-    from sequali_amd import FastqParser
+    from sequali_amd import FastqParser, PinnedReader
     n = 2_000_000
     text = synth.illumina_fastq(0, n)
-    t0 = time.perf_counter()
-    f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
-    arrays = 0
-    for a in FastqParser(io.BytesIO(text)):     # default initial_buffersize: 128 KiB, ~380 reads per array
-        f.add_record_array(a)
-        arrays += 1
-    f.qc_metrics.flush()
-    _lib.synchronize()
-    dt = time.perf_counter() - t0
+
+    def e2e(make_file, **parser_kw):
+        f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
+        fobj = make_file()
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        arrays = 0
+        for a in FastqParser(fobj, **parser_kw):
+            f.add_record_array(a)
+            arrays += 1
+        f.qc_metrics.flush()
+        _lib.synchronize()
+        dt = time.perf_counter() - t0
+        ok = bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)
+        return dt, arrays, ok
+
+    e2e(lambda: io.BytesIO(text[:len(text) // 8]))       # first use: page-locked blocks, kernel modules
+    dt, arrays, ok = e2e(lambda: io.BytesIO(text))       # the reference's call pattern: default initial_buffersize
     out["e2e_host_fastq_default_buffer"] = {
-        "workload": f"{n} x 150 bp FASTQ text in host memory through FastqParser at its default 128 KiB ({arrays} arrays), "
-                    "QCMetrics + AdapterCounter; arrays staged and counted once per 64 MiB; host split, pageable upload and counting included",
+        "workload": f"{n} x 150 bp FASTQ text in host memory (io.BytesIO) through FastqParser at its default 128 KiB ({arrays} arrays, "
+                    "~380 reads each), QCMetrics + AdapterCounter called once per array as __main__.py:279-306 does; the parser's buffer logic "
+                    "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), one upload and one launch per block; file read, record "
+                    "split, upload and counting included",
         "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
-        "checks": {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)}}
+        "checks": {"base_table_sum_ok": ok}}
+    big = dict(initial_buffersize=64 << 20, split_on_device=True)
+    e2e(lambda: PinnedReader(text[:len(text) // 8]), **big)
+    reader = PinnedReader(text)                            # the text in page-locked memory, as a file object
+    dt, arrays, ok = e2e(lambda: reader, **big)
+    out["e2e_pinned_64MiB_device_split"] = {
+        "workload": f"the same {n} reads as text in page-locked host memory (PinnedReader) through FastqParser(initial_buffersize=64 MiB, "
+                    f"split_on_device=True): {arrays} arrays, uploaded from where they lie, records split on the GPU (k_split_*), "
+                    "QCMetrics + AdapterCounter; upload, split and counting included",
+        "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+        "checks": {"base_table_sum_ok": ok}}
     return out
 
 
@@ -356,6 +377,7 @@ def main():
 
     device = f"cuda:{device_index}"
     scratch = []
+    reduce_ms = []
 
     def step(events=None):
         for b in batches:
@@ -382,8 +404,13 @@ def main():
                 scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables])), None])
             tables, flat, parts, _ = scratch
             torch._foreach_copy_(parts, tables)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
             scratch[3] = sqdist._all_reduce(flat)   # in place over RCCL (through the host under gloo)
+            ev1.record()
             torch.cuda.synchronize()
+            if events is not None:
+                reduce_ms.append(ev0.elapsed_time(ev1))   # the collective alone (it runs on torch's stream)
 
     def barrier():
         if use_dist:
@@ -403,8 +430,16 @@ def main():
     launch_ms = events.durations_ms()
 
     job_bases = world * total_bases
+    rank_ms = None
     if use_dist:
         from sequali_amd import dist as sqdist
+        # where the time goes, rank by rank: ms per step, of which kernels, of which the collective
+        mine = torch.tensor([elapsed / args.steps * 1e3, sum(launch_ms) / args.steps, sum(reduce_ms) / max(len(reduce_ms), 1)],
+                            dtype=torch.float64, device=device)
+        mine = sqdist._wire(mine)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [[round(float(x), 3) for x in t.tolist()] for t in every]
         elapsed = float(sqdist._all_reduce(torch.tensor([elapsed], dtype=torch.float64, device=device), dist.ReduceOp.MAX).item())
         job_bases = int(sqdist._all_reduce(torch.tensor([total_bases], dtype=torch.int64, device=device)).item())
 
@@ -465,6 +500,9 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launch_ms)},
             "checks": checks,
         }
+        if rank_ms is not None:
+            out["allreduce_ms"] = round(max(r[2] for r in rank_ms), 4)   # the all-reduce of the count tables alone, slowest rank
+            out["per_rank_ms"] = {"columns": ["ms_per_step", "kernel_ms_per_step", "allreduce_ms"], "ranks": rank_ms}
         if world == 1 and not use_dist and args.other_configs and args.kind == "illumina":
             del batches[:]
             try:

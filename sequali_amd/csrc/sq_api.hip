@@ -27,6 +27,7 @@ static void knobs_load()
     auto num = [](const char *name, int unset) { const char *v = getenv(name); return v ? atoi(v) : unset; };
     k.span = num("SQ_SPAN", 1) != 0;
     k.span_split = num("SQ_SPAN_SPLIT", 1) != 0;
+    k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);

@@ -51,7 +51,7 @@ void sq_set_error(const char *fmt, ...);
  *   SQ_NO_PTQ, SQ_PT_SORT, SQ_PT_STORED, SQ_NO_SEGMENTS, SQ_LDS_PAD, SQ_DEDUP_SEQUENTIAL,
  *   SQ_DEDUP_DEBUG, SQ_LONG=0 (no k_long: k_read_sums + k_seg)  experiment switches */
 struct SqKnobs {
-    bool span = true, span_split = true;
+    bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
     bool span_stamps = false;
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */

@@ -84,6 +84,7 @@ struct sq_feeder {
     size_t read_in = 0, block_bytes = 0;
     std::vector<FeedBlock *> blocks;   /* the open one last; sealed ones until they are released */
     uint64_t next_id = 1;
+    size_t blocks_made = 0;
     bool file_eof = false;
     size_t pos = 0;           /* start of the next array in the open block */
     size_t logical_end = 0;   /* where the reference's buffer of the previous array ended */
@@ -100,10 +101,10 @@ FeedBlock *open_block(sq_feeder *f) { return f->blocks.empty() || f->blocks.back
 
 FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
 {
-    /* blocks grow with the file: a parser over a few records should not lock 64 MiB of pages */
-    size_t cap = std::max<size_t>(1u << 20, 4 * f->read_in);
-    for (const FeedBlock *b : f->blocks) cap = std::max(cap, std::min(f->block_bytes, b->cap * 8));
+    /* the first block is small: a parser over a few records should not lock 64 MiB of pages */
+    size_t cap = f->blocks_made == 0 ? std::max<size_t>((size_t)8 << 20, 4 * f->read_in) : f->block_bytes;
     cap = std::max(std::min(cap, std::max(f->block_bytes, (size_t)1 << 20)), min_bytes);
+    f->blocks_made++;
     FeedBlock *b = new FeedBlock();
     b->text = pool_get(cap + 64, f->ctx != nullptr);
     b->cap = b->text.p ? cap : 0;

@@ -7,16 +7,8 @@
 #include <vector>
 
 constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
-#ifndef SPAN_PAIR
-#define SPAN_PAIR 1
-#endif
-#if SPAN_PAIR
 constexpr uint32_t SPAN_DFA_ROW = 216;          /* bytes three states of the two-character automaton share: 36 entries each */
 constexpr uint32_t SPAN_DFA_MAX_STATES = 336;   /* 24 KB of LDS */
-#else
-constexpr uint32_t SPAN_DFA_ROW = 36;
-constexpr uint32_t SPAN_DFA_MAX_STATES = 1024;
-#endif
 constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass (one wave for both streams) */
 constexpr int SPAN_NW_AD_SPLIT = 8;   /* the same with a wave per stream: the whole range */
 constexpr uint32_t SPAN_ERR_N = 264;      /* error rates by raw quality byte, NaN for what is no phred character ... */
@@ -43,7 +35,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.gc = o; o += 104 * 4;
     L.ps = o; o += 96 * 4;
     L.dfa = o; o += ((states + 2) / 3 * SPAN_DFA_ROW + 15u) & ~15u; /* three states to a row */
-    L.out = o; o += states * (SPAN_PAIR ? 16 : 8);
+    L.out = o; o += states * 16;   /* adapters ending on the second / the first character of a step */
     L.adlen = o; o += states ? 64 : 0;
     L.hist = o; o += hs * (5 + 12 + (seg ? 1 : 0)) * 4 + ad_lds * hs * 4; /* seg: a 13th phred row takes the qualities of filler rows */
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;

@@ -44,14 +44,7 @@ namespace {
 constexpr uint32_t SPAN_R = 16;              /* records per span */
 constexpr uint32_t CLS6_PAD4 = 0x1E1E1E1Eu;  /* code 30 */
 constexpr int SPAN_W4 = 3;  /* dwords an automaton is restarted in front of its piece: adapters of up to 13 characters */
-#ifndef SPAN_PAIR
-#define SPAN_PAIR 1   /* the automaton takes two characters per step (half the dependent table reads) */
-#endif
-#if SPAN_PAIR
-#define SPAN_STATES(P) ((P).dfa2_states)
-#else
-#define SPAN_STATES(P) ((P).dfa_states)
-#endif
+#define SPAN_STATES(P) ((P).dfa2_states)   /* k_span walks the two-character automaton (build_pair_dfa) */
 #ifndef SPAN_S
 #define SPAN_S 1   /* pieces a lane cuts its quarter into, one automaton each (more pieces: shorter chains, more table reads; the reads cost more) */
 #endif
@@ -246,13 +239,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
        nearly every lane sits in (numbered first, build_dfa) in banks of their own: in rows of 32
        bytes, four to the 32 banks, a table read took 5 extra LDS cycles on average
        (SQ_LDS_BANK_CONFLICT, profiles/r2b). */
-    /* SPAN_PAIR: the automaton takes TWO characters per step (build_pair_dfa, sq_qc.hip): the entry
+    /* The automaton takes TWO characters per step (build_pair_dfa, sq_qc.hip): the entry
        of state n for the classes with codes (k1, k2) lives at address(n) + k1 + 6 k2 (multiples of
        6 up to 210: three states share 216 bytes), half as many dependent reads per read; a state
        that reports (>= dfa_hit) names the adapters that end on the step's second character
        (l_out[.][0]) and on its first (l_out[.][1]) */
     uint16_t *l_dfa = (uint16_t *)(smem + L.dfa);
-    unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states] adapters ending there (SPAN_PAIR: [states][2]) */
+    unsigned long long *l_out = (unsigned long long *)(smem + L.out); /* [states][2] adapters ending on the second / on the first character of the step into that state */
     uint8_t *l_adlen = smem + L.adlen;                     /* [64] */
     uint32_t *l_hist_base = (uint32_t *)(smem + L.hist);   /* [5][hs] */
     constexpr uint32_t PROWS = PHRED_COLS + (SEG ? 1 : 0);   /* SEG: one more row takes the qualities of filler rows */
@@ -277,20 +270,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
     if (AD) {
-#if SPAN_PAIR
         for (uint32_t i = tid; i < P.dfa2_states * 36; i += T) {
             const uint32_t st = i / 36, k = i % 36;   /* k = first class + 6 * second class */
             l_dfa[(span_dfa_offset(st) + 6 * k) >> 1] = (uint16_t)(dfa_root + span_dfa_offset(P.dfa2[i]));
         }
         for (uint32_t i = tid; i < 2 * P.dfa2_states; i += T) l_out[i] = P.dfa2_out[i];
-#else
-        for (uint32_t i = tid; i < P.dfa_states * 6; i += T) {
-            const uint32_t st = i / 6, c = i % 6;   /* class 5: padding, back to the root */
-            const uint32_t next = c < 5 ? span_dfa_offset((uint32_t)(P.dfa[st * 8 + c] >> 4)) : 0;
-            l_dfa[(span_dfa_offset(st) + 6 * c) >> 1] = (uint16_t)(dfa_root + next);
-        }
-        for (uint32_t i = tid; i < P.dfa_states; i += T) l_out[i] = P.dfa_out[i];
-#endif
         for (uint32_t i = tid; i < 64; i += T) l_adlen[i] = P.ad_len[i];
         for (uint32_t i = tid; i < P.ad_lds * hs; i += T) l_adf[i] = 0;
         for (uint32_t i = lane; i < SPAN_R * n_ad; i += 64) l_first[i] = 0xFFFFFFFFu;
@@ -335,8 +319,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                       __builtin_amdgcn_readfirstlane(maddr));
             }
         } else {
-            if (lane < 2 * (int)SPAN_R)   /* bytes 0 .. 31 of every meta: record_start, sequence_offset, qualities_offset */
-                dma16((const uint8_t *)(P.metas + sp * SPAN_R + ((uint32_t)lane >> 1)) + 16 * (lane & 1), __builtin_amdgcn_readfirstlane(maddr));
+            uint32_t lv = (uint32_t)lane;   /* opaque: the lane's part of the address is made here, not kept in two registers across the span */
+            asm volatile("" : "+v"(lv));
+            if (lv < 2 * SPAN_R)   /* bytes 0 .. 31 of every meta: record_start, sequence_offset, qualities_offset */
+                dma16((const uint8_t *)(P.metas + sp * SPAN_R) + 40 * (lv >> 1) + 16 * (lv & 1), __builtin_amdgcn_readfirstlane(maddr));
         }
     };
     uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
@@ -550,11 +536,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             }
             static_for<0, S>([&](auto sc) { tie(cl[decltype(sc)::value]); });
 
-#if SPAN_PAIR
             static_for<0, NR>([&](auto tc) {
-                /* one round = one dword of the lane's quarter = two steps of the two-character
-                   automaton; the schedule is the one of the one-character rounds (#else) with the
-                   second and fourth step gone */
+                /* one round = one dword of the lane's quarter = two steps of the two-character automaton */
                 constexpr int t = decltype(tc)::value;
                 constexpr bool proper = t >= WT;
                 constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
@@ -668,149 +651,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                     }
                 });
             });
-#else
-            static_for<0, NR>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr bool proper = t >= WT;
-                constexpr auto cap = [](int n) { return n < 15 ? n : 15; };
-                constexpr auto items_of = [](int round) { return ITEMS - round * HI < 0 ? 0 : ITEMS - round * HI < HI ? ITEMS - round * HI : HI; };
-                constexpr auto groups_of = [](int round) { return KRG - round * CG < 0 ? 0 : KRG - round * CG < CG ? KRG - round * CG : CG; };
-                constexpr int n_l = items_of(t), n_lq = DQ ? n_l : 0;   /* phase H items of the round; those that touch LDS (qualities) */
-                /* windows whose first cell the next round takes: their transposing reads go out in this one */
-                constexpr auto windows_through = [](int round) { /* windows the rounds up to `round` have touched */
-                    const int cells = (round + 1) * HI;
-                    return ((cells < ITEMS ? cells : ITEMS) + HALF - 1) / HALF;
-                };
-                constexpr int w_lo = windows_through(t), w_hi = t + 1 < NR ? windows_through(t + 1) : w_lo;
-                constexpr int n_nx = w_hi - w_lo;   /* windows */
-                constexpr int g_now = DQ ? groups_of(t) : 0, g_nx = DQ && t + 1 < NR ? groups_of(t + 1) : 0;
-                constexpr int nC1 = g_now >= 1 ? 4 : 0, nC2 = g_now >= 2 ? 4 : 0, SA = ADr ? S : 0;
-                static_assert(CG <= 2, "a round carries at most two groups of chain steps");
-                uint32_t e0[S], e1[S], e2[S], e3[S];
-                /* the class dwords of this round: padding in front of the read, behind the row's
-                   sequence, and (pieces may reach past the quarter) behind the lane's quarter */
-                if constexpr (ADr) {
-                    if (t == WT) st0 = st[0];
-                    static_for<0, S>([&](auto sc) {
-                        constexpr int sI = decltype(sc)::value, idx = sI * D + t - WT;   /* dword of the quarter, < 0: in front of it */
-                        if constexpr (proper && idx >= (int)Q4) cl[sI] = CLS6_PAD4;
-                        else {
-                            if constexpr (idx < 0) cl[sI] = co == 0 ? CLS6_PAD4 : cl[sI];
-                            if constexpr (3 * (int)Q4 + idx >= (int)DW) cl[sI] = Q4 * co + idx < DW ? cl[sI] : CLS6_PAD4;
-                        }
-                        e0[sI] = rd_u16<0>(add_byte<0>(st[sI], cl[sI]));
-                    });
-                }
-                /* rows of the phred histogram of this round's items, error rates of its chain steps */
-                uint32_t l[HI];
-                if constexpr (DQ)
-                    static_for<0, HI>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
-                        if constexpr (m < n_l) l[m] = rd_u16<SPAN_BIN_OFF>(shl1_byte<k % 4>(k < 4 ? tq[w].x : tq[w].y, one));
-                    });
-                double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if constexpr (nC1 && t > 0) { /* the quality bytes the round before asked for */
-                    wait_lgkm<cap(SA + n_lq)>();
-                    static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
-                }
-                if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
-                /* base counts of this round's items: one shift-add per base into the window's register */
-                if constexpr (DS)
-                    static_for<0, HI>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
-                        if constexpr (m < n_l) cnt[w] = add_one_shl_byte<k % 4>(k < 4 ? ts[w].x : ts[w].y, one, cnt[w]);
-                    });
-                if constexpr (ADr) {
-                    wait_lgkm<cap(n_lq + nC1)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e0[sI]); e1[sI] = rd_u16<0>(add_byte<1>(e0[sI], cl[sI])); });
-                }
-                if constexpr (n_lq > 0) {
-                    wait_lgkm<cap(nC1 + SA)>();
-                    static_for<0, HI>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value;
-                        if constexpr (m < n_l) { tie(l[m]); inc_u32<128 * ((t * HI + m) / HALF)>(hpp + l[m], one); }
-                    });
-                }
-                if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
-                if constexpr (ADr) {
-                    wait_lgkm<cap(n_lq + nC2)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e1[sI]); e2[sI] = rd_u16<0>(add_byte<2>(e1[sI], cl[sI])); });
-                } else if constexpr (nC1) {
-                    wait_lgkm<cap(n_lq + nC2)>();
-                }
-                if constexpr (nC1) { tie_f64(d[0]); tie_f64(d[1]); tie_f64(d[2]); tie_f64(d[3]); acc += d[0]; acc += d[1]; acc += d[2]; acc += d[3]; }
-                /* what the next round consumes: the bytes of its phase H items ... */
-                static_for<0, NW>([&](auto wc) {
-                    constexpr int w = decltype(wc)::value;
-                    if constexpr (w >= w_lo && w < w_hi) {
-                        if constexpr (DS) ts[w] = rd_tr8<32 * w>(trb);
-                        if constexpr (DQ) tq[w] = rd_tr8<32 * w + (int)QOFF>(trb);
-                    }
-                });
-                if constexpr (ADr) {
-                    wait_lgkm<cap(TRN * n_nx)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e2[sI]); e3[sI] = rd_u16<0>(add_byte<3>(e2[sI], cl[sI])); });
-                } else if constexpr (nC2) {
-                    wait_lgkm<cap(TRN * n_nx)>();
-                }
-                if constexpr (nC2) { tie_f64(d[4]); tie_f64(d[5]); tie_f64(d[6]); tie_f64(d[7]); acc += d[4]; acc += d[5]; acc += d[6]; acc += d[7]; }
-                /* ... its class dwords and the quality bytes of its chain steps */
-                uint32_t cln[S];
-                static_for<0, S>([&](auto sc) {
-                    constexpr int sI = decltype(sc)::value;
-                    cln[sI] = 0;
-                    if constexpr (ADr && t + 1 < NR) cln[sI] = rd_b32<4 * (sI * D + t + 1)>(abase);
-                });
-                if constexpr (DQ)
-                    static_for<0, 4 * CG>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
-                    });
-                constexpr int n_cln = ADr && t + 1 < NR ? S : 0;
-                if constexpr (ADr) {
-                    wait_lgkm<cap(n_cln + 4 * g_nx)>();
-                    static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(e3[sI]); st[sI] = e3[sI]; });
-                    if constexpr (proper) {
-                        uint32_t mx = 0;
-                        static_for<0, S>([&](auto sc) {
-                            constexpr int sI = decltype(sc)::value;
-                            mx = max(mx, max(max(e0[sI], e1[sI]), max(e2[sI], e3[sI])));
-                        });
-                        if (mx >= dfa_hit) {
-                            static_for<0, S>([&](auto sc) {
-                                constexpr int sI = decltype(sc)::value, idx = sI * D + t - WT;
-                                const uint32_t ee[4] = {e0[sI], e1[sI], e2[sI], e3[sI]};
-#pragma unroll
-                                for (uint32_t j = 0; j < 4; j++) {
-                                    if (ee[j] < dfa_hit) continue;
-                                    const uint32_t v = 0x80000000u | ((4 * (Q4 * co + (uint32_t)idx) + j) << 12) | span_dfa_state(ee[j] - dfa_root);
-                                    if (!rec) rec = v;
-                                    else if (!rec2) rec2 = v;
-                                    else multi = true;
-                                }
-                            });
-                        }
-                    }
-                }
-                /* the loads for the next round have arrived by the time they are used: those of
-                   phase H are older than the last automaton step; the class dwords are waited for
-                   here, the quality bytes (younger) with the next round's first wait */
-                wait_lgkm<cap(4 * g_nx)>();
-                static_for<0, S>([&](auto sc) { constexpr int sI = decltype(sc)::value; tie(cln[sI]); cl[sI] = cln[sI]; });
-                static_for<0, NW>([&](auto wc) {
-                    constexpr int w = decltype(wc)::value;
-                    if constexpr (w >= w_lo && w < w_hi) {
-                        if constexpr (DS) tie2(ts[w]);
-                        if constexpr (DQ) tie2(tq[w]);
-                    }
-                });
-            });
-#endif
             wait_lgkm<0>();
             SPAN_PHASE(1);   /* the rounds */
             if (ADr && __builtin_amdgcn_ballot_w64(rec != 0 || multi)) { /* update_adapter_count_array, :2643-2672 */
                 any_hit = true;
-#if SPAN_PAIR
                 auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton: on the step's second character (pos), on its first */
 #pragma unroll
                     for (uint32_t back = 0; back < 2; back++) {
@@ -822,16 +666,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                         }
                     }
                 };
-#else
-                auto matches = [&](uint32_t row, uint32_t pos) { /* the adapters that end in that row of the automaton */
-                    unsigned long long hits = l_out[row];
-                    while (hits) {
-                        const int a = __ffsll((long long)hits) - 1;
-                        hits &= hits - 1;
-                        lds_min(lds_addr(l_first + q * n_ad + a), pos);
-                    }
-                };
-#endif
                 if (__builtin_amdgcn_ballot_w64(multi)) {
                     uint32_t s2 = st0;
 #pragma unroll 1
@@ -839,20 +673,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                         const uint32_t dw = Q4 * c + tt;
                         uint32_t cl2 = lds_u32(seq_row + 4 * dw);
                         cl2 = dw < DW ? cl2 : CLS6_PAD4;
-#if SPAN_PAIR
                         const uint32_t pc2 = __umul24(cl2 >> 8, 6u) + cl2;
 #pragma unroll 1
                         for (uint32_t j = 0; j < 2; j++) {
                             s2 = lds_u16(s2 + ((pc2 >> (16 * j)) & 0xFFu));
                             if (s2 >= dfa_hit) matches(span_dfa_state(s2 - dfa_root), 4 * dw + 2 * j + 1);
                         }
-#else
-#pragma unroll 1
-                        for (uint32_t j = 0; j < 4; j++) {
-                            s2 = lds_u16(s2 + ((cl2 >> (8 * j)) & 0xFFu));
-                            if (s2 >= dfa_hit) matches(span_dfa_state(s2 - dfa_root), 4 * dw + j);
-                        }
-#endif
                     }
                 } else if (rec) {
                     matches(rec & 0xFFFu, (rec >> 12) & 0xFFFu);
@@ -1099,11 +925,46 @@ int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad,
 #endif
 }
 
+/* A register spilled inside the loop is reloaded behind an `s_waitcnt vmcnt(0)`, which also waits for
+   the span in flight (the LDS-DMA counts in vmcnt): a build of the kernel with a wave per stream
+   that spills is not used (the one with a wave for both streams has 168 registers) */
+template <int NW, bool SEG>
+bool split_build_spills(bool ad)
+{
+    static int spills[2] = {-1, -1};
+    if (spills[ad] < 0) {
+        hipFuncAttributes fa{};
+        const void *fn = (const void *)k_span<NW, false, SEG, SPAN_W4, true>;
+        if constexpr (NW <= SPAN_NW_AD_SPLIT) if (ad) fn = (const void *)k_span<NW, true, SEG, SPAN_W4, true>;
+        spills[ad] = hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.localSizeBytes > 0 ? 1 : 0;
+    }
+    return spills[ad] != 0;
+}
+template <bool SEG>
+bool split_build_spills_any(int nw, bool ad)
+{
+#ifdef SQ_SPAN_ONLY_NW
+    return nw == SQ_SPAN_ONLY_NW ? split_build_spills<SQ_SPAN_ONLY_NW, SEG>(ad) : true;
+#else
+    switch (nw) {
+        case 1: return split_build_spills<1, SEG>(ad);
+        case 2: return split_build_spills<2, SEG>(ad);
+        case 3: return split_build_spills<3, SEG>(ad);
+        case 4: return split_build_spills<4, SEG>(ad);
+        case 5: return split_build_spills<5, SEG>(ad);
+        case 6: return split_build_spills<6, SEG>(ad);
+        case 7: return split_build_spills<7, SEG>(ad);
+        default: return split_build_spills<8, SEG>(ad);
+    }
+#endif
+}
+
 /* does k_span take this pass at all, and with how many waves per workgroup (split: an even number) */
 int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg, bool split)
 {
     if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > (split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD))) return 0; /* unsplit: the automaton's rounds spill registers from 161 positions on */
     if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
+    if (split && !sq_knobs().span_spills_ok && (seg ? split_build_spills_any<true>(nw, ad) : split_build_spills_any<false>(nw, ad))) return 0;
     const int step = split ? 2 : 1;
     int waves = span_max_waves(nw, split, seg);   /* as many as LDS takes */
     while (waves >= 4 && span_lds_layout(nw, U, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;

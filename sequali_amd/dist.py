@@ -186,6 +186,7 @@ def merge_overrepresented(shards: Sequence, device, group=None) -> None:
         n = check(L.sq_overrep_shard_candidates(o._h, None, None, 0))
         h = torch.zeros(max(n, 1), dtype=torch.int64, device=device)
         r = torch.zeros(max(n, 1), dtype=torch.int64, device=device)
+        torch.cuda.synchronize()   # torch fills on ITS stream; the library writes on its own: the fill must not come second
         if n:
             check(L.sq_overrep_shard_candidates(o._h, h.data_ptr(), r.data_ptr(), n))
         hs.append(h[:n])
@@ -195,15 +196,18 @@ def merge_overrepresented(shards: Sequence, device, group=None) -> None:
     torch.cuda.synchronize()
     first = shards[0]
     sel = torch.zeros(max(min(h_all.numel(), first.max_unique_fragments), 1), dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
     m = check(L.sq_overrep_shard_select(first._h, h_all.data_ptr(), r_all.data_ptr(), h_all.numel(),
                                         sel.data_ptr(), sel.numel())) if h_all.numel() else 0
     sel = sel[:m].contiguous()
     counts = torch.zeros(max(m, 1), dtype=torch.int64, device=device)
     one = torch.zeros_like(counts)
+    torch.cuda.synchronize()       # as above: `one` is written by the library's stream
     for o in shards:
         if m:
-            check(L.sq_overrep_shard_lookup(o._h, sel.data_ptr(), m, one.data_ptr()))
+            check(L.sq_overrep_shard_lookup(o._h, sel.data_ptr(), m, one.data_ptr()))   # synchronises its stream
             counts += one
+            torch.cuda.synchronize()   # the next lookup overwrites `one`
     sums = torch.tensor([[o.number_of_sequences, o.sampled_sequences, o.total_fragments,
                           L.sq_overrep_warning_count(o._h)] for o in shards],
                         dtype=torch.int64, device=device).sum(0)

@@ -9,20 +9,25 @@ from the getters, under the reference's key names:
     per_position_base_content[_read2], per_position_n_content[_read2], per_sequence_gc_content[_read2],
     adapter_content, duplication_fractions, overrepresented_sequences[_read2], insert_size_metrics
 
+    per_position_mean_quality_and_spread[_read2], per_position_quality_distribution[_read2],
+    per_tile_quality[_read2], nanopore_metrics, adapter_content_from_overlap
+
 Not restated: the sequence identification against the contaminant database (out of
-scope; the three fields it fills are None), per_position_mean_quality_and_spread,
-per_position_quality_distribution, per_tile_quality, nanopore_metrics and
-adapter_content_from_overlap (their inputs are in driver.raw_outputs).
+scope; the fields it fills -- most_matches, max_matches, best_match, longest_adapter_read*_match
+-- are None).
 
 Pinned only by the expectations of the reference's integration tests (tests/test_integration.py:
-29-42, 97-124, 203-211), re-expressed in tests/test_gpu_driver.py: `report_modules` itself cannot
-be imported here (pygal), so no golden vectors exist for this layer -- parity unpinned beyond
-those expectations.
+29-42, 97-124, 203-211), re-expressed in tests/test_gpu_driver.py, and by recomputing every module
+from the oracle's getter outputs with an independent numpy formulation there: `report_modules`
+itself cannot be imported here (pygal), so no golden vectors exist for this layer -- parity
+unpinned beyond that.
 """
 from __future__ import annotations
 
 import collections
+import math
 import os
+import sys
 from typing import Dict, List, Optional, Sequence, Tuple
 
 NUMBER_OF_NUCS, NUMBER_OF_PHREDS = 5, 12
@@ -277,12 +282,204 @@ def overrepresented_sequences(seqdup, fraction_threshold=DEFAULT_FRACTION_THRESH
                 read_pair_info=read_pair_info)
 
 
+# PHRED_INDEX_TO_ERROR_RATE, report_modules.py:64-67: the mean error rate of the four phreds of a bin
+PHRED_INDEX_TO_ERROR_RATE = [sum(10 ** (-p / 10) for p in range(start * 4, start * 4 + 4)) / 4
+                             for start in range(NUMBER_OF_PHREDS)]
+
+
+def quality_distribution_table(phred: Sequence[int]) -> List[List[float]]:
+    """PerBaseQualityScoreDistribution.quality_distribution_table, report_modules.py:852-870"""
+    n = len(phred) // NUMBER_OF_PHREDS
+    out = [[0.0] * n for _ in range(NUMBER_OF_PHREDS)]
+    for i in range(n):
+        t = phred[i * NUMBER_OF_PHREDS:(i + 1) * NUMBER_OF_PHREDS]
+        total = sum(t)
+        if total == 0:
+            continue
+        for k, c in enumerate(t):
+            if c:
+                out[k][i] = c / total
+    return out
+
+
+def phred_tables_to_percentiles(phred: Sequence[int]) -> List[list]:
+    """PerPositionMeanQualityAndSpread.phred_tables_to_percentiles, report_modules.py:761-826: the mean
+    phred of the lowest / highest 1, 5, 10, 25, 50 % of the bases of every column, from the binned counts"""
+    fractions = [i / 100 for i in (1, 5, 10, 25, 50, 75, 90, 95, 99)]
+    n = len(phred) // NUMBER_OF_PHREDS
+    low = [[0.0] * n for _ in fractions]
+    high = [[0.0] * n for _ in fractions]
+    mean = [0.0] * n
+    for col in range(n):
+        table = phred[col * NUMBER_OF_PHREDS:(col + 1) * NUMBER_OF_PHREDS]
+        total = sum(table)
+        if total == 0:
+            continue
+        total_error = sum(PHRED_INDEX_TO_ERROR_RATE[i] * x for i, x in enumerate(table))
+        thresholds = [int(f * total) for f in fractions]
+        mean[col] = -10 * math.log10(total_error / total)
+        acc_count, acc_err, ti = 0, 0.0, 0
+        current = thresholds[0]
+        for k, count in enumerate(table):
+            while count > 0:
+                remaining = current - acc_count
+                if count > remaining:
+                    acc_err += remaining * PHRED_INDEX_TO_ERROR_RATE[k]
+                    acc_count += remaining
+                    if acc_count > 0:
+                        low[ti][col] = -10 * math.log10(acc_err / acc_count)
+                        high[ti][col] = -10 * math.log10((total_error - acc_err) / (total - acc_count))
+                    count -= remaining
+                    ti += 1
+                    if ti < len(thresholds):
+                        current = thresholds[ti]
+                    else:
+                        ti, current = sys.maxsize, 2 ** 65
+                    continue
+                break
+            acc_count += count
+            acc_err += PHRED_INDEX_TO_ERROR_RATE[k] * count
+    return [["bottom 1%", low[0]], ["bottom 5%", low[1]], ["bottom 10%", low[2]], ["bottom 25%", low[3]],
+            ["bottom 50%", low[4]], ["mean", mean], ["top 50%", high[-5]], ["top 25%", high[-4]],
+            ["top 10%", high[-3]], ["top 5%", high[-2]], ["top 1%", high[-1]]]
+
+
+def _phred_inputs(metrics, ranges):
+    phred = list(metrics.phred_count_table())
+    return (aggregate_count_matrix(phred, ranges, NUMBER_OF_PHREDS), phred[:metrics.end_anchor_length * NUMBER_OF_PHREDS],
+            list(metrics.end_anchored_phred_count_table()))
+
+
+def per_position_quality_distribution(metrics, ranges, read_pair_info=None) -> dict:
+    """PerBaseQualityScoreDistribution.from_phred_count_table_and_labels, report_modules.py:872-893"""
+    ag, front, end = _phred_inputs(metrics, ranges)
+    return dict(x_labels=stringify_ranges(ranges), series=quality_distribution_table(ag),
+                front_anchored_series=quality_distribution_table(front),
+                end_anchored_series=quality_distribution_table(end), read_pair_info=read_pair_info)
+
+
+def per_position_mean_quality_and_spread(metrics, ranges, read_pair_info=None) -> dict:
+    """PerPositionMeanQualityAndSpread.from_phred_table_and_labels, report_modules.py:828-842"""
+    ag, front, end = _phred_inputs(metrics, ranges)
+    return dict(x_labels=stringify_ranges(ranges), percentiles=phred_tables_to_percentiles(ag),
+                front_percentiles=phred_tables_to_percentiles(front), end_percentiles=phred_tables_to_percentiles(end),
+                read_pair_info=read_pair_info)
+
+
+def per_tile_quality(ptq, ranges, read_pair_info=None) -> dict:
+    """PerTileQualityReport.from_per_tile_quality_and_ranges, report_modules.py:1494-1544"""
+    if ptq.skipped_reason:
+        return dict(x_labels=[], normalized_per_tile_averages=[], tiles_2x_errors=[], tiles_10x_errors=[],
+                    skipped_reason=ptq.skipped_reason, read_pair_info=None)
+    per_category = [0.0] * len(ranges)
+    phreds = []
+    tiles = ptq.get_tile_counts()
+    for tile, errors, counts in tiles:
+        row = []
+        for i, (a, b) in enumerate(ranges):
+            average = sum(errors[a:b]) / max(sum(counts[a:b]), 1)
+            ph = -10 * math.log10(average) if average != 0 else 0
+            row.append(ph)
+            per_category[i] += ph      # averaging phreds takes the geometric mean of the error rates
+        phreds.append((tile, row))
+    averages = [t / len(tiles) for t in per_category]
+    normalized, x2, x10 = [], [], []
+    for tile, row in phreds:
+        if not row:
+            continue
+        norm = [p - a for p, a in zip(row, averages)]
+        lowest = min(norm)
+        if lowest <= -10.0:
+            x10.append(str(tile))
+        elif lowest <= -3.0:
+            x2.append(str(tile))
+        normalized.append([str(tile), norm])
+    return dict(x_labels=stringify_ranges(ranges), normalized_per_tile_averages=normalized, tiles_2x_errors=x2,
+                tiles_10x_errors=x10, skipped_reason=ptq.skipped_reason, read_pair_info=read_pair_info)
+
+
+def select_relevant_adapters(adapter_list):
+    """AdapterFromOverlapReport.select_relevant_adapters, report_modules.py:2295-2310: the most frequent
+    adapter of every length, by length"""
+    out, want = [], set(range(1, 32))
+    for adapter, count in sorted(adapter_list, reverse=True, key=lambda x: x[1]):
+        if len(adapter) in want:
+            want.remove(len(adapter))
+            out.append([adapter, count])
+    out.sort(key=lambda x: len(x[0]))
+    return out
+
+
+def adapter_content_from_overlap(isz) -> dict:
+    """AdapterFromOverlapReport.from_insert_size_metrics, report_modules.py:2312-2335, without the
+    identification of the longest adapters (out of scope)"""
+    a1, a2 = select_relevant_adapters(isz.adapters_read1()), select_relevant_adapters(isz.adapters_read2())
+    return dict(total_reads=isz.total_reads, number_of_adapters_read1=isz.number_of_adapters_read1,
+                number_of_adapters_read2=isz.number_of_adapters_read2, adapters_read1=a1, adapters_read2=a2,
+                longest_adapter_read1=a1[-1][0] if a1 else "", longest_adapter_read2=a2[-1][0] if a2 else "",
+                longest_adapter_read1_match=None, longest_adapter_read2_match=None)
+
+
+def nanopore_metrics(nanostats) -> dict:
+    """NanoStatsReport.from_nanostats, report_modules.py:1951-2041, over the NanoInfo array"""
+    empty = dict(x_labels=[], time_bases=[], time_reads=[], time_active_channels=[], qual_percentages_over_time=[],
+                 per_channel_bases={}, per_channel_quality={}, translocation_speed=[], reads_with_parent=None,
+                 total_reads=None, skipped_reason=nanostats.skipped_reason)
+    if nanostats.skipped_reason:
+        return empty
+    start, duration = nanostats.minimum_time, nanostats.maximum_time - nanostats.minimum_time
+    per_slot = duration / 200
+    interval = max(((math.ceil(per_slot) + 59) // 60) * 60, 1)
+    time_ranges = [(s0, s0 + interval) for s0 in range(0, duration + 1, interval)]
+    slots = len(time_ranges)
+    active = [set() for _ in range(slots)]
+    time_bases, time_reads = [0] * slots, [0] * slots
+    time_quals = [[0] * 12 for _ in range(slots)]
+    channel_bases, channel_error = collections.defaultdict(int), collections.defaultdict(float)
+    speeds = [0] * 81
+    with_parent = 0
+    for info in nanostats.nano_info_iterator():
+        if info.parent_id_hash:
+            with_parent += 1
+        length, err, channel = info.length, info.cumulative_error_rate, info.channel_id
+        phred = round(-10 * math.log10(err / length)) if length else 0
+        index = min(phred, 47) >> 2
+        if info.start_time:
+            slot = (info.start_time - start) // interval
+            active[slot].add(channel)
+            time_bases[slot] += length
+            time_reads[slot] += 1
+            time_quals[slot][index] += 1
+        channel_bases[channel] += length
+        channel_error[channel] += err
+        if info.duration:
+            speeds[min(round(length / info.duration), 800) // 10] += 1
+    quality = {ch: (-10 * math.log10(e / channel_bases[ch]) if channel_bases[ch] else 0) for ch, e in channel_error.items()}
+    over_time = [[] for _ in range(12)]
+    for quals in time_quals:
+        total = sum(quals)
+        for i, qv in enumerate(quals):
+            over_time[i].append(qv / max(total, 1))
+
+    def hm(seconds):
+        minutes = seconds // 60
+        return f"{minutes // 60:02}:{minutes % 60:02}"
+
+    return dict(x_labels=[f"{hm(a)}-{hm(b)}" for a, b in time_ranges], time_bases=time_bases, time_reads=time_reads,
+                time_active_channels=[len(x) for x in active], qual_percentages_over_time=over_time,
+                per_channel_bases=dict(sorted(channel_bases.items())), per_channel_quality=dict(sorted(quality.items())),
+                translocation_speed=speeds, reads_with_parent=with_parent if with_parent > 0 else None,
+                total_reads=nanostats.number_of_reads, skipped_reason=nanostats.skipped_reason)
+
+
 def qc_modules(metrics, ranges, read_pair_info=None) -> Dict[str, dict]:
     suffix = "_read2" if read_pair_info == READ2 else ""
     base = list(metrics.base_count_table())
     return {
         "summary" + suffix: summary(metrics, ranges, read_pair_info),
         "sequence_length_distribution" + suffix: sequence_length_distribution(base, metrics.number_of_reads, ranges, read_pair_info),
+        "per_position_quality_distribution" + suffix: per_position_quality_distribution(metrics, ranges, read_pair_info),
+        "per_position_mean_quality_and_spread" + suffix: per_position_mean_quality_and_spread(metrics, ranges, read_pair_info),
         "per_sequence_quality_scores" + suffix: per_sequence_quality_scores(metrics, read_pair_info),
         "per_position_base_content" + suffix: per_position_base_content(metrics, ranges, read_pair_info),
         "per_position_n_content" + suffix: per_position_n_content(metrics, ranges, read_pair_info),
@@ -308,14 +505,22 @@ def report(modules: Dict[str, object], filename: str, filename_reverse: Optional
                                          filename_read2=os.path.basename(filename_reverse) if filename_reverse else None,
                                          filesize_read2=size(filename_reverse) if filename_reverse else None)}
     out.update(qc_modules(m1, ranges, info1))
+    if modules.get("per_tile_quality") is not None:
+        out["per_tile_quality"] = per_tile_quality(modules["per_tile_quality"], ranges, info1)
     out["overrepresented_sequences"] = overrepresented_sequences(modules["sequence_duplication"], read_pair_info=info1)
     out["duplication_fractions"] = duplication_fractions(modules["dedup_estimator"])
+    if modules.get("nanostats") is not None:
+        out["nanopore_metrics"] = nanopore_metrics(modules["nanostats"])
     if modules.get("adapter_counter") is not None:
         out["adapter_content"] = adapter_content(modules["adapter_counter"], modules["adapters"], ranges, read_pair_info=info1)
     if modules.get("insert_size_metrics") is not None:
+        out["adapter_content_from_overlap"] = adapter_content_from_overlap(modules["insert_size_metrics"])
         out["insert_size_metrics"] = dict(insert_sizes=[int(x) for x in modules["insert_size_metrics"].insert_sizes()])
     m2 = modules.get("metrics_reverse")
     if m2 is not None and modules.get("sequence_duplication_reverse") is not None:
-        out.update(qc_modules(m2, data_ranges_of(m2.max_length, graph_resolution), READ2))
+        ranges2 = data_ranges_of(m2.max_length, graph_resolution)
+        out.update(qc_modules(m2, ranges2, READ2))
+        if modules.get("per_tile_quality_reverse") is not None:
+            out["per_tile_quality_read2"] = per_tile_quality(modules["per_tile_quality_reverse"], ranges2, READ2)
         out["overrepresented_sequences_read2"] = overrepresented_sequences(modules["sequence_duplication_reverse"], read_pair_info=READ2)
     return out

@@ -192,3 +192,74 @@ def test_report_paired_end(tmp_path):
     assert r["summary"]["total_reads"] == r["summary_read2"]["total_reads"] == 1000
     assert r["summary"]["read_pair_info"] == "Read 1" and r["summary_read2"]["read_pair_info"] == "Read 2"
     assert sum(r["insert_size_metrics"]["insert_sizes"]) == 1000
+
+
+REFERENCE_KEYS = {   # report_modules.py:2412-2427 (NAME_TO_CLASS) + the _read2 variants a paired run adds
+    "meta", "summary", "per_position_mean_quality_and_spread", "per_position_quality_distribution",
+    "sequence_length_distribution", "per_position_base_content", "per_position_n_content",
+    "per_sequence_gc_content", "per_sequence_quality_scores", "adapter_content", "per_tile_quality",
+    "duplication_fractions", "overrepresented_sequences", "nanopore_metrics"}
+
+
+def test_report_has_the_reference_key_set_and_the_quality_modules_agree_with_numpy(tmp_path):
+    """all sixteen keys of the reference's JSON (report_modules.py:2412-2427) on a paired run, and the
+    modules added in round 3 recomputed here with numpy from the same getters: the quality
+    distribution is a column-normalised table, the 'mean' series is -10 log10 of the count-weighted
+    bin error rates (:64-67, :776-779), bottom-50 % <= mean <= top-50 %; per-tile rows are phreds
+    minus the column mean over tiles (:1507-1533); the overlap adapters are the most frequent one of
+    every length (:2295-2310)"""
+    r = _report_of(tmp_path, ("ref_LTB_paired", "fastq1"), ("ref_LTB_paired", "fastq2"))
+    assert set(r) >= REFERENCE_KEYS | {"insert_size_metrics", "adapter_content_from_overlap"}
+    for suffix in ("", "_read2"):
+        for key in ("summary", "per_position_mean_quality_and_spread", "per_position_quality_distribution",
+                    "per_tile_quality", "sequence_length_distribution", "per_position_base_content"):
+            assert key + suffix in r, key + suffix
+    from sequali_amd import driver
+    from tests.helpers import golden_text
+    g = golden("ref_LTB_paired")
+    p1, p2 = tmp_path / "a.fastq", tmp_path / "b.fastq"
+    p1.write_bytes(golden_text(g, "fastq1")); p2.write_bytes(golden_text(g, "fastq2"))
+    m = driver.run(str(p1), str(p2))
+    qc = m["metrics"]
+    phred = np.array(qc.phred_count_table(), dtype=np.float64).reshape(-1, 12)   # 125 positions: one per range
+    dist = np.array(r["per_position_quality_distribution"]["series"])            # [12][ranges]
+    assert dist.shape == (12, len(phred))
+    np.testing.assert_allclose(dist.T, phred / phred.sum(axis=1, keepdims=True), rtol=1e-12)
+    np.testing.assert_allclose(dist.sum(axis=0), 1.0, rtol=1e-12)
+    err = np.array([sum(10 ** (-q / 10) for q in range(4 * b, 4 * b + 4)) / 4 for b in range(12)])
+    series = dict((k, np.array(v)) for k, v in r["per_position_mean_quality_and_spread"]["percentiles"])
+    np.testing.assert_allclose(series["mean"], -10 * np.log10((phred * err).sum(axis=1) / phred.sum(axis=1)), rtol=1e-12)
+    assert (series["bottom 50%"] <= series["mean"] + 1e-9).all() and (series["mean"] <= series["top 50%"] + 1e-9).all()
+    assert (series["bottom 1%"] <= series["bottom 25%"] + 1e-9).all() and (series["top 25%"] <= series["top 1%"] + 1e-9).all()
+    assert len(r["per_position_mean_quality_and_spread"]["front_percentiles"][0][1]) == 100
+    # per tile: phred of the mean error per tile and position, minus the mean over the tiles
+    tiles = m["per_tile_quality"].get_tile_counts()
+    ph = np.array([-10 * np.log10(np.array(e) / np.maximum(np.array(c, dtype=np.float64), 1)) for _, e, c in tiles])
+    rows = r["per_tile_quality"]["normalized_per_tile_averages"]
+    assert [t for t, _ in rows] == [str(t) for t, _, _ in tiles]
+    np.testing.assert_allclose(np.array([v for _, v in rows]), ph - ph.mean(axis=0), rtol=1e-9, atol=1e-9)
+    assert r["per_tile_quality"]["skipped_reason"] is None
+    # adapters from the overlap: one per length, the most frequent one
+    isz = m["insert_size_metrics"]
+    best = {}
+    for a, c in isz.adapters_read1():
+        if len(a) not in best or c > best[len(a)][1]:
+            best[len(a)] = (a, c)
+    got = r["adapter_content_from_overlap"]["adapters_read1"]
+    assert [len(a) for a, _ in got] == sorted(best) and all(best[len(a)][1] == c for a, c in got)
+    assert r["adapter_content_from_overlap"]["total_reads"] == 1000
+    assert r["nanopore_metrics"]["skipped_reason"] is not None and r["nanopore_metrics"]["time_reads"] == []
+
+
+def test_report_nanopore_metrics(tmp_path):
+    """NanoStatsReport.from_nanostats (report_modules.py:1951-2041) on the reference's nanopore reads:
+    every read lands in one time slot and one translocation-speed bin, the per-channel bases add
+    up to the bases of the file"""
+    r = _report_of(tmp_path, ("ref_100_nanopore", "fastq"))
+    n = r["nanopore_metrics"]
+    assert n["skipped_reason"] is None and n["total_reads"] == 100
+    assert sum(n["time_reads"]) == 100 and sum(n["translocation_speed"]) <= 100
+    assert sum(n["time_bases"]) == sum(n["per_channel_bases"].values()) == r["summary"]["total_bases"]
+    assert len(n["x_labels"]) == len(n["time_reads"]) == len(n["time_active_channels"])
+    assert all(len(s) == len(n["time_reads"]) for s in n["qual_percentages_over_time"])
+    assert r["per_tile_quality"]["skipped_reason"] is not None

@@ -385,3 +385,6 @@ def test_bench_step_with_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert all(d["checks"].values()), d["checks"]
     assert "reduced_base_table_sum_ok" in d["checks"]
+    # where the time goes on every rank, and the collective alone
+    assert d["allreduce_ms"] > 0 and len(d["per_rank_ms"]["ranks"]) == 2
+    assert all(r[0] >= r[1] > 0 for r in d["per_rank_ms"]["ranks"])

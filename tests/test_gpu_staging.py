@@ -64,10 +64,11 @@ def test_default_buffer_single_end_all_modules_few_launches():
     assert ov.sequence_counts() == ro.sequence_counts() and ov.total_fragments == ro.total_fragments
     np.testing.assert_array_equal(u64(dd.duplication_counts()), rd.duplication_counts())
     assert ns.skipped_reason is not None and ns.number_of_reads == 0      # no nanopore header: off at the first read
-    # 70 MB of text: two staging blocks, at most one launch per block and module (NanoStats stops at its first)
+    # 70 MB of text: an 8 MiB block (a parser starts small) and one or two of 64 MiB, at most one launch per block
+    # and module (NanoStats stops at its first)
     blocks = _qc.staging_stats["blocks"] - before["blocks"]
     runs = _qc.staging_stats["runs"] - before["runs"]
-    assert blocks == 2 and runs <= 6 * blocks, (blocks, runs)
+    assert 2 <= blocks <= 3 and runs <= 6 * blocks, (blocks, runs)
 
 
 def test_default_buffer_paired_reference_files():

@@ -809,3 +809,52 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
             np.testing.assert_array_equal(u64(f), fr)
             np.testing.assert_array_equal(u64(r), rr)
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 10   # chance matches only: the generator plants no probes
+
+
+def test_config3_one_million_pairs():
+    """BASELINE config 3 at a size the oracle finishes in seconds: 1 M device-generated pairs
+    (96 random tiles), (QCMetrics + PerTileQuality) x 2 through FusedPass, InsertSizeMetrics and a
+    paired DedupEstimator: every getter against the oracle -- k_span<QC> + k_ptspan (the 116 KB
+    tile table that leaves it 7 waves) + k_tile_parse / k_tile_assign per side, k_isz_span +
+    k_isz_adapters, k_dedup_hash -- and once more with SQ_SPAN=0 (the round-1 kernels) as the
+    cross-check.  Reference: _qcmodule.c:3088-3121, :3189-3220, :5668-5707, :4488-4517."""
+    from sequali_amd import DedupEstimator, FusedPass, InsertSizeMetrics, PerTileQuality, QCMetrics, synth
+    n, first = 1_000_000, 7_000_000
+    d1 = synth.device_array(synth.ILLUMINA, first, n)
+    d2 = synth.device_array(synth.ILLUMINA_R2, first, n)
+    b1, m1 = d1._batch.download()
+    b2, m2 = d2._batch.download()
+    rq1, rq2, rp1, rp2 = oracle.QCMetrics(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.PerTileQuality()
+    rz, rd = oracle.InsertSizeMetrics(), oracle.DedupEstimator(front_sequence_offset=0, back_sequence_offset=0)
+    rq1.add(b1, m1); rq2.add(b2, m2); rp1.add(b1, m1); rp2.add(b2, m2)
+    rz.add_pair(b1, m1, b2, m2)
+    rd.add_pair(b1, m1, b2, m2)
+    assert len(rp1.get_tile_counts()) == 96
+
+    def run():
+        q1, q2, p1, p2 = QCMetrics(), QCMetrics(), PerTileQuality(), PerTileQuality()
+        z, d = InsertSizeMetrics(), DedupEstimator(front_sequence_offset=0, back_sequence_offset=0)
+        FusedPass(q1, None, p1).add_record_array(d1)
+        FusedPass(q2, None, p2).add_record_array(d2)
+        z.add_record_array_pair(d1, d2)
+        d.add_record_array_pair(d1, d2)
+        q1.flush(); q2.flush()
+        return q1, q2, p1, p2, z, d
+
+    for env in ({}, {"SQ_SPAN": "0"}):
+        q1, q2, p1, p2, z, d = _with_env(env, run)
+        for g, r, dev, metas in ((q1, rq1, d1, m1), (q2, rq2, d2, m2)):
+            compare_qc(r, g, metas, dev)
+        for g, r in ((p1, rp1), (p2, rp2)):
+            assert g.number_of_reads == r.number_of_reads == n
+            gt, rt = g.get_tile_counts(), r.get_tile_counts()
+            assert [t for t, _, _ in gt] == [t for t, _, _ in rt]
+            for (t, e, c), (_, er, cr) in zip(gt, rt):
+                np.testing.assert_allclose(np.array(e), er, rtol=1e-6, err_msg=f"tile {t}")
+                np.testing.assert_array_equal(u64(c), cr, err_msg=f"tile {t}")
+        assert z.total_reads == rz.total_reads and z.number_of_adapters_read1 == rz.number_of_adapters_read1
+        assert z.number_of_adapters_read2 == rz.number_of_adapters_read2
+        np.testing.assert_array_equal(u64(z.insert_sizes()), rz.insert_sizes())
+        assert z.adapters_read1() == rz.adapters_read1() and z.adapters_read2() == rz.adapters_read2()
+        np.testing.assert_array_equal(u64(d.duplication_counts()), rd.duplication_counts())
+        assert d._modulo_bits == rd._modulo_bits and d.tracked_sequences == rd.tracked_sequences
