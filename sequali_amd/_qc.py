@@ -562,6 +562,15 @@ class _FedArray(FastqRecordArrayView):
     def _metas(self, v):
         self._m = v
 
+    def accumulated_error_rates(self) -> np.ndarray:
+        """FastqMeta.accumulated_error_rate of the array's records (:2126): the QCMetrics objects that
+        were handed arrays of the block count what they owe first"""
+        for w in list(self._blk.writers):
+            q = w()
+            if q is not None:
+                q.flush()
+        return self._metas["accumulated_error_rate"].copy()
+
 
 def _stage(arr: "FastqRecordArrayView"):
     """(block, slot) of an array; an array is staged once, whoever sees it first"""
@@ -603,11 +612,19 @@ class _Deferring:
 
     def _enqueue(self, arr) -> bool:
         """True: the array is staged and will be counted later"""
-        if not self._small(arr):
+        t = self._todo
+        if type(arr) is _FedArray:      # the driver loop's case: the next array of the parser's open block
+            blk, slot = arr._staged
+            if t:
+                last = t[-1]
+                if last[0] is blk and last[2] == slot and len(last) == 3:
+                    last[2] = slot + 1   # the block's writers are known, nothing has been sealed since the last call
+                    return True
+        elif not self._small(arr):
             self._drain()
             return False
-        blk, slot = _stage(arr)
-        t = self._todo
+        else:
+            blk, slot = _stage(arr)
         if t and len(t[-1]) == 3 and t[-1][0] is blk and t[-1][2] == slot:
             t[-1][2] = slot + 1
         else:

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsqgpu.so")
-SOURCES = ["sq_api.hip", "sq_qc.hip", "sq_span.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip"]
+SOURCES = ["sq_api.hip", "sq_qc.hip", "sq_span.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip", "sq_hostsimd.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -49,8 +49,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         tag = f".{os.getpid()}.tmp"
 
         def compile_one(src: str) -> str:
-            obj = os.path.join(objdir, src.replace(".hip", ".o"))
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj + tag]
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            flags = FLAGS if src.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]   # .cpp: host only
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj + tag]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -59,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.replace(obj + tag, obj)
             return obj
 
-        with ThreadPoolExecutor(max_workers=6) as pool:
+        with ThreadPoolExecutor(max_workers=7) as pool:
             objs = list(pool.map(compile_one, SOURCES))
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag, *objs],
                            capture_output=True, text=True)

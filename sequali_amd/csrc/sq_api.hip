@@ -42,6 +42,7 @@ static void knobs_load()
     k.pt_stored = flag("SQ_PT_STORED");
     k.no_segments = flag("SQ_NO_SEGMENTS");
     k.long_spans = num("SQ_LONG", 1) != 0;
+    k.long_nw = num("SQ_LONG_NW", 8);
     k.lds_pad = num("SQ_LDS_PAD", 0);
     k.probe_mode = num("SQ_PROBE_MODE", -1);
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
@@ -74,6 +75,8 @@ SQ_EXPORT sq_ctx *sq_init(int device)
     SQ_HIP_NULL(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    SQ_HIP_NULL(hipEventCreateWithFlags(&ctx->copied, hipEventDisableTiming));
     SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
     return ctx;
 }
@@ -86,6 +89,8 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->copied) (void)hipEventDestroy(ctx->copied);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (void *p : ctx->scratch)
         if (p) (void)hipFree(p);
@@ -102,46 +107,124 @@ SQ_EXPORT void *sq_stream_handle(sq_ctx *ctx) { return (void *)ctx->stream; }
 
 /* ---- host-side record boundary ------------------------------------------- */
 
+size_t sq_scan_newlines(const uint8_t *p, size_t n, uint32_t base, uint32_t *out, size_t cap, size_t *scanned, uint32_t *high);   /* sq_hostsimd.cpp */
+int64_t sq_first_non_ascii_fast(const uint8_t *p, size_t n);
+int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii);
+static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                          uint64_t stats[5], size_t ascii_from, int64_t *first_high);
+
 /* FastqParser_create_record_array, the record loop _qcmodule.c:1093-1171, over bytes
  * [start, end) of `base`; record_start is relative to `base`.  stats (may be NULL): bases,
- * longest read, longest name, longest record span, ~(shortest read) of the records so far */
+ * longest read, longest name, longest record span, ~(shortest read) of the records so far.
+ * The reference finds the four line ends of a record with four memchr calls; here the newline
+ * positions of the range come from one vectorised scan (sq_scan_newlines), 1 K of them at a time,
+ * and the record loop takes them as it needs them: same records, same errors in the same order. */
 int64_t sq_split_range(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
                        uint64_t stats[5])
 {
+    return sq_split_range_ascii(base, start, end_off, metas, cap, consumed, stats, (size_t)-1, nullptr);
+}
+
+/* ascii_from (offset in base, or (size_t)-1: no check): the bytes from there to the end of the range
+ * are new (FastqParser_create_record_array checks what it has just read for ASCII before it looks
+ * at records, :1055-1067): *non_ascii = offset of the first byte >= 0x80 among them, or -1.  The
+ * check rides on the newline scan; bytes the scan did not reach (the record loop ended early)
+ * are looked at separately.  When *non_ascii >= 0 the return value and the metas are to be
+ * ignored: the reference raises before it parses. */
+int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii)
+{
+    int64_t first_high = -1;
+    const int64_t n = split_core(base, start, end_off, metas, cap, consumed, stats, ascii_from, &first_high);
+    if (non_ascii) *non_ascii = first_high;
+    return n;
+}
+
+static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                          uint64_t stats[5], size_t ascii_from, int64_t *first_high)
+{
     const uint8_t *end = base + end_off;
     const uint8_t *rec = base + start;
+    /* the newlines of the range, in order: every call hands out the next one (NULL: there is none).
+       The record loop asks for them strictly left to right -- `from` is always one behind the
+       newline it got last -- so no position has to be compared */
+    uint32_t nl[2048];
+    size_t nl_count = 0, nl_next = 0;
+    const uint8_t *scan = rec;    /* everything in front of it has been scanned */
+    const uint8_t *chunk0 = rec;  /* nl[] holds offsets from here */
+    const uint8_t *ascii_lo = ascii_from == (size_t)-1 ? nullptr : base + ascii_from;
+    const uint8_t *high_at = nullptr;   /* the first byte >= 0x80 at or behind ascii_lo met so far */
+    auto refill = [&]() -> bool {       /* false: the range has no more newlines */
+        while (scan < end) {
+            size_t scanned = 0;
+            uint32_t high = UINT32_MAX;
+            chunk0 = scan;
+            nl_next = 0;
+            nl_count = sq_scan_newlines(scan, std::min<size_t>((size_t)(end - scan), (size_t)1 << 30), 0, nl, 2048, &scanned, &high);
+            if (high != UINT32_MAX && high_at == nullptr && ascii_lo) {
+                const uint8_t *h = scan + high;
+                if (h < ascii_lo) {   /* in front of the new bytes (checked by an earlier call): look again from there */
+                    const int64_t again = ascii_lo < scan + scanned ? sq_first_non_ascii_fast(ascii_lo, (size_t)(scan + scanned - ascii_lo)) : -1;
+                    h = again >= 0 ? ascii_lo + again : nullptr;
+                }
+                if (h) high_at = h;
+            }
+            scan += scanned;
+            if (nl_count) return true;
+        }
+        return false;
+    };
+    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
+        if (nl_next == nl_count && !refill()) return nullptr;
+        return chunk0 + nl[nl_next++];
+    };
+    /* what of the new bytes the scan has not seen (the loop ended on max_records, or on an error) */
+    auto finish_ascii = [&]() {
+        if (!ascii_lo || !first_high) return;
+        if (!high_at) {
+            const uint8_t *from = std::max(scan, ascii_lo);
+            if (from < end) {
+                const int64_t r = sq_first_non_ascii_fast(from, (size_t)(end - from));
+                if (r >= 0) high_at = from + r;
+            }
+        }
+        *first_high = high_at ? (int64_t)(high_at - base) : -1;
+    };
     int64_t n = 0;
     while ((size_t)n < cap) {
         if (rec + 2 >= end) break; /* :1094 */
         if (rec[0] != '@') {
             sq_set_error("Record does not start with @ but with %c", rec[0]);
+            finish_ascii();
             return SQ_ERR_VALUE;
         }
         const uint8_t *name = rec + 1;
-        /* the reference searches (end - rec) bytes from name, one past the end;
-           the buffer is a bytes object there so the extra byte is its NUL */
-        const uint8_t *name_end = (const uint8_t *)memchr(name, '\n', end - name);
+        const uint8_t *name_end = next_newline(name);
         if (!name_end) break;
         const uint8_t *seq = name_end + 1;
-        const uint8_t *seq_end = (const uint8_t *)memchr(seq, '\n', end - seq);
+        const uint8_t *seq_end = next_newline(seq);
         if (!seq_end) break;
         const uint8_t *plus = seq_end + 1;
         if (plus < end && plus[0] != '+') {
             sq_set_error("Record second header does not start with + but with %c", plus[0]);
+            finish_ascii();
             return SQ_ERR_VALUE;
         }
-        const uint8_t *plus_end = (const uint8_t *)memchr(plus, '\n', end - plus);
+        const uint8_t *plus_end = next_newline(plus);
         if (!plus_end) break;
         const uint8_t *qual = plus_end + 1;
-        const uint8_t *qual_end = (const uint8_t *)memchr(qual, '\n', end - qual);
+        const uint8_t *qual_end = next_newline(qual);
         if (!qual_end) break;
         if (seq_end - seq != qual_end - qual) {
             std::string nm((const char *)name, name_end - name);
             sq_set_error("Record sequence and qualities do not have equal length, '%s'", nm.c_str());
+            finish_ascii();
             return SQ_ERR_VALUE;
         }
         if ((uint64_t)(qual_end - name) > UINT32_MAX) {
             sq_set_error("Total length of FASTQ record exceeds 4 GiB");
+            finish_ascii();
             return SQ_ERR_OVERFLOW;
         }
         sq_meta *m = &metas[n++];
@@ -164,6 +247,7 @@ int64_t sq_split_range(const uint8_t *base, size_t start, size_t end_off, sq_met
         rec = qual_end + 1;
     }
     if (consumed) *consumed = (size_t)(rec - (base + start));
+    finish_ascii();
     return n;
 }
 
@@ -175,15 +259,7 @@ SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas,
 
 SQ_EXPORT int64_t sq_first_non_ascii(const uint8_t *buf, size_t len)
 {
-    size_t i = 0;
-    for (; i + 8 <= len; i += 8) {
-        uint64_t w;
-        memcpy(&w, buf + i, 8);
-        if (w & 0x8080808080808080ULL) break;
-    }
-    for (; i < len; i++)
-        if (buf[i] & 0x80) return (int64_t)i;
-    return -1;
+    return sq_first_non_ascii_fast(buf, len);
 }
 
 /* fastq_names_are_mates, _qcmodule.c:777-800 */
@@ -619,8 +695,13 @@ SQ_EXPORT sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t
         sq_set_error("sq_batch_from_fastq: out of device memory");
         return nullptr;
     }
-    if (len) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->stream));
-    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->stream));
+    /* the upload runs on a stream of its own: the passes over the batch before (queued on
+       ctx->stream by the caller, who is back here for the next buffer) go on beside it; the split
+       waits for it */
+    if (len) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->copy_stream));
+    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->copy_stream));
+    SQ_HIP_NULL(hipEventRecord(ctx->copied, ctx->copy_stream));
+    SQ_HIP_NULL(hipStreamWaitEvent(ctx->stream, ctx->copied, 0));
     return split_on_device(ctx, d_text, true, text, len, consumed);
 }
 

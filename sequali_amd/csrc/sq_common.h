@@ -58,6 +58,7 @@ struct SqKnobs {
     bool no_wide = false, ring = false, no_ring = false, no_split = false;
     bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
     bool long_spans = true;
+    int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;
 };
@@ -66,6 +67,8 @@ const SqKnobs &sq_knobs();
 struct sq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   /* uploads of FASTQ text (sq_batch_from_fastq): they run beside the counting of the batch before */
+    hipEvent_t copied = nullptr;
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */

@@ -26,8 +26,8 @@
 
 #include "sq_common.h"
 
-int64_t sq_split_range(const uint8_t *base, size_t start, size_t end, sq_meta *metas, size_t cap, size_t *consumed,
-                       uint64_t stats[5]);
+int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end, sq_meta *metas, size_t cap, size_t *consumed,
+                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii);
 
 namespace {
 
@@ -228,7 +228,14 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         f->arr_len = f->logical_end - f->pos;   /* the leftover of the previous array */
         f->arr_first_record = b->n_records;
     }
+    auto non_ascii_error = [&](int64_t at) {   /* at: offset in the block of a byte >= 0x80 among the new bytes, < 0: none */
+        if (at < 0 || (size_t)at < f->pos) return false;
+        sq_set_error("Found non-ASCII character in file: %c", b->pin()[at]);
+        f->in_array = false;
+        return true;
+    };
     for (;;) {
+        size_t fresh_from = (size_t)-1;   /* offset in the block of the bytes this round has read */
         /* one readinto of the reference: the free part of a new buffer of read_in bytes, later read_in more */
         const size_t want = f->first ? (f->read_in > f->arr_len ? f->read_in - f->arr_len : 0) : f->read_in;
         if (want > 0) {
@@ -252,13 +259,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             }
             const size_t got = std::min(want, have);
             if (got == 0) f->arr_eof = true;
-            const uint8_t *fresh = b->pin() + f->pos + f->arr_len;
-            const int64_t bad = sq_first_non_ascii(fresh, got);   /* :1055-1067, the new bytes only */
-            if (bad >= 0) {
-                sq_set_error("Found non-ASCII character in file: %c", fresh[bad]);
-                f->in_array = false;
-                return SQ_ERR_VALUE;
-            }
+            /* :1055-1067: the bytes just read are checked for ASCII before anything else is looked at.
+               The check rides on the newline scan of the record split below (fresh_from) */
+            fresh_from = got ? f->pos + f->arr_len : (size_t)-1;
             f->arr_len += got;
         }
         f->first = false;
@@ -266,6 +269,10 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         const uint8_t *buf = b->pin() + f->pos;
         if (f->arr_len == 0) break;   /* :1069 the entire file is read */
         if (f->arr_eof && count_newlines(buf, f->arr_len, 4) < 4) {   /* :1073-1081 buffer_contains_fastq */
+            if (fresh_from != (size_t)-1) {
+                const int64_t at = sq_first_non_ascii(b->pin() + fresh_from, f->pos + f->arr_len - fresh_from);
+                if (at >= 0 && non_ascii_error(at + (int64_t)fresh_from)) return SQ_ERR_VALUE;
+            }
             std::string s((const char *)buf, f->arr_len);
             sq_set_error("Incomplete record at the end of file %s", s.c_str());
             f->in_array = false;
@@ -280,7 +287,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         for (;;) {
             const size_t cap = std::min(b->meta_cap - b->n_records, max_records);
             memcpy(stats, b->stats, sizeof stats);
-            n = sq_split_range(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats);
+            int64_t bad = -1;
+            n = sq_split_range_ascii(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats, fresh_from, &bad);
+            if (non_ascii_error(bad)) return SQ_ERR_VALUE;
             if (n < 0) { f->in_array = false; return (int)n; }
             if ((size_t)n < cap || (size_t)n == max_records) break;
             /* the meta area is full: a bigger one (the block keeps its text) */

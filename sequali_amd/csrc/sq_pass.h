@@ -55,6 +55,7 @@ struct PassParams {
     uint32_t span_nsegs;
     uint32_t span_total;       /* spans of the launch */
     const struct SpanRow *span_rows; /* the batch's reads sorted by length, longest first */
+    unsigned int *long_first;  /* k_span<LONG>: [records][n_adapters] start of the first occurrence found so far, ~0: none */
 };
 
 namespace {

@@ -3118,7 +3118,35 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             /* (1) what is sequential per read */
             hipLaunchKernelGGL(k_read_sums, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
                                ctx->stream, P);
-            /* (2) every segment of every read: workgroups of up to 64 groups inside one segment */
+            /* (2) everything per position.  k_span<LONG> (sq_span.hip) streams segments of 128 positions
+               through LDS; it sends the padding behind a read's end to a histogram row of its own, where a
+               quality byte 0x80 would land too: a batch k_read_sums has flagged (an invalid phred byte,
+               one 8-byte read-back) keeps k_seg, whose counts k_qc_uncount knows how to take back.
+               SQ_LONG=0: k_seg for all */
+            const uint32_t n_ad_long = ad ? (uint32_t)a->groups[0].count : 0;
+            if (K.long_spans && K.span && b->owns && (!ad || gi == 0)) {
+                SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+                SQ_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->pinned[9] == UINT64_MAX) {
+                    PassParams Lp = P;
+                    if (ad) {
+                        Lp.long_first = (unsigned int *)sq_scratch(ctx, 5, b->n * n_ad_long * 4);
+                        if (!Lp.long_first) { sq_set_error("out of device memory for the adapter candidates"); return SQ_ERR_MEMORY; }
+                        SQ_HIP(hipMemsetAsync(Lp.long_first, 0xFF, b->n * n_ad_long * 4, ctx->stream));
+                    }
+                    uint64_t covered = 0;
+                    int rc = sq_span_launch_long(ctx, Lp, ad, n_ad_long, (uint32_t)b->max_length, &covered);
+                    if (rc) return rc;
+                    if (covered == b->n) {
+                        if (ad)
+                            hipLaunchKernelGGL(k_adapter_first, dim3((unsigned)std::min<uint64_t>((b->n * n_ad_long + 255) / 256, 8192)),
+                                               dim3(256), 0, ctx->stream, Lp.long_first, b->d_metas, (uint64_t)b->n, n_ad_long, P.ad_len,
+                                               P.ad_fwd, P.ad_rev, P.ad_cap);
+                        SQ_HIP(hipGetLastError());
+                        continue;
+                    }
+                }
+            }
             std::vector<uint32_t> table;
             for (uint32_t w = 0; w < stripes && stripe_reads[w]; w++) {
                 const uint64_t groups = (stripe_reads[w] + 63) / 64;

@@ -25,7 +25,7 @@ struct SpanLds {
 /* nw: 32-position windows per read; U: read length; states / n_ad / ad_lds: the automaton, its
  * adapters, how many of them are counted in LDS (0 without AdapterCounter); waves per workgroup */
 __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t states, uint32_t n_ad,
-                                                   uint32_t ad_lds, int waves, bool seg = false, bool split = false)
+                                                   uint32_t ad_lds, int waves, bool seg = false, bool split = false, bool lng = false)
 {
     SpanLds L;
     const uint32_t hs = (U + 31u) & ~31u;
@@ -41,7 +41,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.first = o; o += (uint32_t)waves * 16 * n_ad * 4;
     L.rows = o; o += (uint32_t)waves * (seg ? 64 : 32) * 4;
     /* split: a wave holds one stream of a span at a time (sequence or qualities): rows of 2 nw + 1 pieces */
-    const uint32_t pr = (split ? 2 : 4) * (uint32_t)nw + 1;
+    const uint32_t pr = (split ? 2 : 4) * (uint32_t)nw + 1 + (lng ? 2 : 0);   /* long: a piece in front of the segment (and one to stay odd) */
     L.dma = o; o += ((16u * pr + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
     L.meta = o; o += (uint32_t)waves * (seg ? 256 : SPAN_META_LDS);   /* one buffer: the metas of span k + 2 land where those of k + 1 were read */
@@ -59,7 +59,8 @@ struct SpanSeg {           /* one read length */
     uint32_t U;            /* the length */
     uint32_t last_rows;    /* reads in its last span (1 .. 16) */
     uint32_t first;        /* its first read among the sorted rows */
-    uint32_t pad[3];
+    uint32_t pos_base;     /* k_span<LONG>: where the segment starts in its reads */
+    uint32_t pad[2];
 };
 struct SpanRow {           /* one row of a span: 16 bytes */
     uint64_t seq;          /* offset of the sequence in the batch's buffer */
@@ -87,5 +88,6 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
 int sq_isz_span_launch(sq_ctx *ctx, const IszSpanParams &P, uint64_t *done);
 int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done);
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
+int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 
 #endif

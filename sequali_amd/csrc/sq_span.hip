@@ -209,9 +209,18 @@ __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves
    pairs on one sequence of spans: wave 2 j takes the bases of the pair's spans 0, 2, 4 .. and the
    qualities of 1, 3, 5 .., wave 2 j + 1 the other halves -- every wave alternates between the two
    roles, so the two kinds of work need no balancing. */
-template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false>
+/* LONG (with SEG and SPLIT): the rows are SEGMENTS of long reads -- positions [pos_base, pos_base +
+   32 NW) of the reads that are longer than pos_base, pos_base a per-stretch scalar like U -- for what
+   can be counted segment by segment: the positional histograms and the automaton (restarted in
+   front of the segment like in front of a lane's quarter, the 12 bases in front of the segment
+   come along in a piece of their own; a match is a candidate for the read's first occurrence,
+   P.long_first).  The rows of a span may end inside the segment (the read's last one): what lies
+   behind a row's end is turned into padding in LDS.  Nothing per read is done here (the f64
+   chains, the bins, GC: k_read_sums) nor the end-anchored tables (k_long_ea). */
+template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false>
 __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(PassParams P, uint32_t n_ad)
 {
+    static_assert(!LONG || (SEG && SPLIT), "segments of long reads come as sorted rows, a wave per stream");
 #ifdef SQ_SPAN_PROBE
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0, a_compq = 0, a_spansq = 0, ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp = 0, tq_ = 0;
 #endif
@@ -219,14 +228,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
        one of the two streams, at r * ROWB).  A row is an odd number of 16-byte pieces (the last one
        is never loaded) and a lane's quarter an odd number of dwords, so that the 32 lanes of an LDS
        instruction of phase S (8 rows x 4 quarters) fall into 32 different banks */
-    constexpr uint32_t SB = 32 * NW, PR = (SPLIT ? 2 : 4) * NW + 1, ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
+    constexpr uint32_t PRE = LONG ? 16 : 0;   /* LONG: the row's piece 0 holds the 16 bytes in front of the segment */
+    constexpr uint32_t SB = 32 * NW, PR = (SPLIT ? 2 : 4) * NW + 1 + (LONG ? 2 : 0), ROWB = 16 * PR, SLOT = SPAN_R * ROWB;
     constexpr uint32_t QOFF = SPLIT ? 0 : SB;
     constexpr uint32_t DW = 8 * NW, Q4 = 2 * NW + 1, ND = (SPAN_R * PR + 63) / 64;
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
     const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const SpanLds L = span_lds_layout(NW, U, AD ? SPAN_STATES(P) : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT);
+    const SpanLds L = span_lds_layout(NW, U, AD ? SPAN_STATES(P) : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT, LONG);
     double *l_err = (double *)smem;                        /* [SPAN_ERR_N] by raw quality byte; [SPAN_ERR_PAD]: +0.0 */
     uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
@@ -292,8 +302,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
 #pragma unroll
         for (int k = 0; k < (int)ND; k++) {
             const uint32_t i = 64 * k + lane, row = i / PR, pir = i % PR, stream = !SPLIT && pir >= 2 * NW;
-            const bool on = i < SPAN_R * PR && pir < PR - 1;
-            l_dma[64 * k + lane] = on ? (row * (SEG ? 16 : 8) + stream * (SEG ? 8 : 4)) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u : 0;
+            const bool on = i < SPAN_R * PR && pir < (LONG ? 2 * NW + 1 : PR - 1);
+            /* LONG: the row starts 16 bytes in front of the segment (l_rows points there); bit 30: that piece */
+            l_dma[64 * k + lane] = on ? (row * (SEG ? 16 : 8) + stream * (SEG ? 8 : 4)) | (((pir - stream * 2 * NW) * 16) << 8) | 0x80000000u |
+                                        (LONG && pir == 0 ? 0x40000000u : 0u) : 0;
         }
     }
     __syncthreads();
@@ -326,13 +338,19 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         }
     };
     uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
+    uint32_t urow_next = 0, urow_cur = 0, pos_base = 0;   /* LONG: positions of row q inside the segment (0: a filler row); where the segment starts */
     /* rl: SPLIT: the stream to fetch (the role the wave has in that span) */
     auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint32_t rl) {
         if constexpr (SEG) {
             const uint32_t ma = maddr + 16 * q;
-            const unsigned long long seq = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
+            unsigned long long seq = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
             const uint32_t qd = lds_u32(ma + 8);
             rec_next = lds_u32(ma + 12);
+            if constexpr (LONG) {   /* the row: sequence start | read length << 40; the segment starts pos_base behind it */
+                const uint32_t Lr = (uint32_t)(seq >> 40);
+                urow_next = Lr > pos_base ? min(U, Lr - pos_base) : 0;
+                seq = (seq & ((1ull << 40) - 1)) + pos_base - PRE;
+            }
             if (c == 0) {
                 *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q) = seq;
                 *(SQ_LDS unsigned long long *)(uintptr_t)(lds_addr(l_rows) + 16 * q + 8) = seq + qd;
@@ -346,7 +364,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             for (int k = 0; k < (int)ND; k++) rr[k] = *(SQ_LDS const unsigned long long *)(uintptr_t)(roff + (pk[k] & 0xFFu));
 #pragma unroll
             for (int k = 0; k < (int)ND; k++)
-                if ((int32_t)pk[k] < 0)
+                if ((int32_t)pk[k] < 0 && !(LONG && (pk[k] & 0x40000000u) && pos_base == 0))   /* nothing lies in front of a read's first segment */
                     dma16(P.buf + rr[k] + ((pk[k] >> 8) & 0xFFFu), __builtin_amdgcn_readfirstlane(slot_addr + 1024 * k));
             return;
         }
@@ -407,12 +425,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 atomicAdd(&P.ad_fwd[a * P.ad_cap + start], (unsigned long long)v);
                 atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
             }
-        const uint32_t ean = min(P.ea_len, U);
+        const uint32_t ean = LONG ? 0 : min(P.ea_len, U);   /* LONG: the end-anchored tables are k_long_ea's */
         for (uint32_t i = tid; i < hs * BASE_COLS; i += T) {
             const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
             if (zero) l_hist_base[i] = 0;
             if (!v || pos >= U) continue;
-            atomicAdd(&P.qc_base[(uint64_t)pos * 5 + cc], (unsigned long long)v);
+            atomicAdd(&P.qc_base[(uint64_t)(pos_base + pos) * 5 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
         for (uint32_t i = tid; i < hs * PROWS; i += T) {
@@ -420,9 +438,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             const uint32_t pos = i % hs;
             if (zero) l_hist_phred[i] = 0;
             if (pos >= U) continue;
-            if (cc >= PHRED_COLS) { v -= fill; cc = PHRED_COLS - 1; }
+            if (cc >= PHRED_COLS) {   /* the row of the padding: LONG: nothing else is there (the host sends batches with an invalid byte elsewhere) */
+                if (LONG) continue;
+                v -= fill;
+                cc = PHRED_COLS - 1;
+            }
             if (!v) continue;
-            atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + cc], (unsigned long long)v);
+            atomicAdd(&P.qc_phred[(uint64_t)(pos_base + pos) * 12 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
         }
     };
@@ -435,7 +457,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         const uint32_t sa = slot_base + cur * SLOT;
         const uint64_t r = SEG ? (uint64_t)rec_cur : s * SPAN_R + q;
         const uint32_t nv = SEG && s == s_last ? last_rows : SPAN_R;   /* rows q >= nv are filler */
-        const uint32_t seq_row = sa + q * ROWB, qual_row = seq_row + QOFF;
+        const uint32_t seq_row = sa + q * ROWB + PRE, qual_row = seq_row + QOFF;
+        const uint32_t urow = LONG ? (q < nv ? urow_cur : 0u) : 0u;   /* LONG: positions of this row inside the segment */
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(tp);
 #endif
@@ -448,14 +471,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         if constexpr (DS) {
             const uint32_t cb = seq_row + 4 * c;
             uint32_t Uv = U, cv = c; /* opaque: hipcc would keep the padding masks of all 2 NW dwords in registers across spans */
-            asm volatile("" : "+s"(Uv), "+v"(cv));
+            if constexpr (LONG) asm volatile("" : "+v"(cv)); else asm volatile("" : "+s"(Uv), "+v"(cv));
             uint32_t raw[2 * NW];
 #pragma unroll
             for (int t = 0; t < 2 * NW; t++) raw[t] = lds_u32(cb + 16 * t);
 #pragma unroll
             for (int t = 0; t < 2 * NW; t++) {
                 uint32_t cl = cls6_of_dword(raw[t]);
-                if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
+                if constexpr (LONG) {   /* every row has an end of its own */
+                    const uint32_t p0 = 16 * t + 4 * cv;
+                    cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
+                } else if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
                     const uint32_t p0 = 16 * t + 4 * cv;
                     cl = pad_tail(cl, p0 < Uv ? (int)min(4u, Uv - p0) : 0, CLS6_PAD4);
                 }
@@ -463,7 +489,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 gacc += cl & 0x04040404u;                 /* C, G and padding */
                 nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
             }
-            if (SEG && nv < SPAN_R) {   /* the last span of a length: filler rows become padding */
+            if constexpr (LONG && AD) {   /* the 12 bases in front of the segment: lanes 1 .. 3 of the quad, a dword each */
+                if (cv > 0) {
+                    const uint32_t a = seq_row - 16 + 4 * cv;
+                    lds_store_u32(a, pos_base && urow ? cls6_of_dword(lds_u32(a)) : CLS6_PAD4);
+                }
+            }
+            if (!LONG && SEG && nv < SPAN_R) {   /* the last span of a length: filler rows become padding */
                 if (q >= nv) {
 #pragma unroll
                     for (int t = 0; t < 2 * NW; t++) lds_store_u32(cb + 16 * t, CLS6_PAD4);
@@ -472,10 +504,19 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                 }
             }
         }
-        if constexpr (DQ && SEG) {
+        if constexpr (DQ && SEG && !LONG) {
             if (nv < SPAN_R && q >= nv) {
 #pragma unroll
                 for (int t = 0; t < 2 * NW; t++) lds_store_u32(qual_row + 4 * c + 16 * t, PAD4);
+            }
+        }
+        if constexpr (DQ && LONG) {   /* rows that end inside the segment (and filler rows): padding behind the end */
+            if (__builtin_amdgcn_ballot_w64(urow < U)) {
+#pragma unroll
+                for (int t = 0; t < 2 * NW; t++) {
+                    const uint32_t a = qual_row + 4 * c + 16 * t, p0 = 16 * t + 4 * c;
+                    if (p0 + 4 > urow) lds_store_u32(a, pad_tail(lds_u32(a), p0 < urow ? (int)(urow - p0) : 0, PAD4));
+                }
             }
         }
         SPAN_PHASE(0);   /* class codes */
@@ -497,7 +538,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             constexpr int NR = ADr ? WT + D : NW;   /* without the automaton: rounds of eight items and two groups */
             constexpr int HALF = (int)SPAN_R / 2, ITEMS = NW * HALF, HI = (ITEMS + NR - 1) / NR;
             static_assert(HI <= HALF, "a round stays inside two windows");
-            constexpr int KRG = 2 * (NW - 1), CG = (KRG + NR - 1) / NR;   /* groups of four chain steps that exist whatever U is */
+            constexpr int KRG = LONG ? 0 : 2 * (NW - 1), CG = (KRG + NR - 1) / NR;   /* groups of four chain steps that exist whatever U is (LONG: the chains are k_read_sums' work) */
             constexpr int KR4 = 4 * KRG;                                  /* chain steps the rounds carry */
             constexpr int TRN = (DS ? 1 : 0) + (DQ ? 1 : 0);              /* transposing reads per window */
             uint32_t co = c;   /* opaque: the padding masks of the rounds are made per span, not kept across spans */
@@ -506,7 +547,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
             const uint32_t qp = qual_row + c;
             /* transposing reads: lane 2 q + p of a group of 16 hands in row 8 h + q, bytes 8 p .. 8 p + 7 of
                the group's 16 positions; window w and the quality stream by immediate offset */
-            const uint32_t trb = sa + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
+            const uint32_t trb = sa + PRE + (8 * h + (((uint32_t)lane & 15) >> 1)) * ROWB + 16 * (((uint32_t)lane >> 4) & 1) + 8 * ((uint32_t)lane & 1);
             const uint32_t hpp = lds_addr(l_hist_phred + pl);
             const uint32_t one = 1;
             uint32_t rec = 0, rec2 = 0, st0 = dfa_root; /* a lane's first two matches of the span: row of the automaton | end position << 12 | 1 << 31 */
@@ -560,7 +601,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                     constexpr int idx = t - WT;   /* dword of the quarter, < 0: in front of it */
                     if constexpr (proper && idx >= (int)Q4) cl[0] = CLS6_PAD4;
                     else {
-                        if constexpr (idx < 0) cl[0] = co == 0 ? CLS6_PAD4 : cl[0];
+                        if constexpr (idx < 0 && !LONG) cl[0] = co == 0 ? CLS6_PAD4 : cl[0];   /* LONG: the bases in front of the segment are in the row (padding in front of a read) */
                         if constexpr (3 * (int)Q4 + idx >= (int)DW) cl[0] = Q4 * co + idx < DW ? cl[0] : CLS6_PAD4;
                     }
                     pc = __umul24(cl[0] >> 8, 6u) + cl[0];
@@ -689,7 +730,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
                behind the chains (:2100-2112): all their bytes first, then all their error rates --
                two round trips to LDS instead of two per step; what does not exist reads the
                padding entry of the table, +0.0 */
-            if constexpr (DQ) {
+            if constexpr (DQ && !LONG) {
                 uint32_t lb[8], tb[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) lb[j] = lds_u8(qp + 4 * (KR4 + j));
@@ -711,17 +752,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         }
         SPAN_PHASE(2);   /* matches; the chain steps and qualities behind the rounds */
         double total = 0.0;
-        if constexpr (DQ) {
+        if constexpr (DQ && !LONG) {
             total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
             total += tail0; total += tail1; total += tail2; total += tail3; /* :2100-2112 */
         }
         uint32_t gsum = 0, nsum = 0;
-        if constexpr (DS) {
+        if constexpr (DS && !LONG) {
             gsum = sum_bytes(gacc, 0); nsum = sum_bytes(nacc, 0);
             gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
             gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
         }
-        if (c == 0 && q < nv) {
+        if (!LONG && c == 0 && q < nv) {
             if constexpr (DS) {
                 const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
                 if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
@@ -756,6 +797,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         }
         SPAN_PHASE(3);   /* per read: bins, the error rate */
         if (ADr && __builtin_amdgcn_ballot_w64(any_hit)) { /* update_adapter_count_array, :2643-2672 */
+            if constexpr (LONG) {   /* the rows' records, where issue() keeps the row offsets between two calls */
+                if (c == 0) l_rows[q] = rec_cur;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             for (uint32_t i = lane; i < SPAN_R * n_ad; i += 64) {
                 const uint32_t v = l_first[i];
                 if (v == 0xFFFFFFFFu) continue;
@@ -764,7 +809,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
 #ifdef SQ_SPAN_DEBUG
                 if (start >= U) { printf("k_span: span %llu row %u adapter %u pos %u start %u\n", (unsigned long long)s, i / n_ad, a, v, start); continue; }
 #endif
-                if (P.ad_lds) {
+                if constexpr (LONG) {   /* a candidate for the read's first occurrence of the adapter (k_adapter_first) */
+                    const uint32_t record = l_rows[i / n_ad];   /* put there below; `start` may lie in front of the segment (mod 2^32) */
+                    atomicMin(&P.long_first[(uint64_t)record * n_ad + a], pos_base + start);
+                } else if (P.ad_lds) {
                     atomicAdd(&l_adf[a * hs + start], 1u);
                 } else {
                     atomicAdd(&P.ad_fwd[a * P.ad_cap + start], 1ULL);
@@ -803,6 +851,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         last_rows = g.last_rows;
         seg_first = g.first;
         seg_span0 = g.span0;
+        if constexpr (LONG) pos_base = g.pos_base;
         if (s_last >= c_lo && s_last < s_end) fill = SPAN_R - last_rows;
         if constexpr (SPLIT) role = (uint32_t)wave & 1;
     }
@@ -813,6 +862,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         issue(slot_base, meta_base, role);
         rec_cur = rec_next;
+        urow_cur = urow_next;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
         if (s + stride < s_end) issue_meta(s + stride, meta_base);
     }
@@ -848,6 +898,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(Pa
         cur ^= 1;
         s += stride;
         rec_cur = rec_next;
+        urow_cur = urow_next;
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t3);
         a_wait += t1 - t0; a_issue += t2 - t1;
@@ -1414,6 +1465,161 @@ int launch_isz_span(sq_ctx *ctx, const IszSpanParams &P, int waves, size_t lds, 
 }
 
 } // namespace
+
+namespace {
+
+/* ---- long reads (longer than k_span's rows): segments of 128 positions through k_span<LONG> ----
+ * The reads of the batch come sorted by length, longest first (P.order).  What a read needs as a
+ * whole -- the four f64 chains of its error sum in the reference's order, its GC and phred_scores
+ * bins (:2051-2137) -- is k_read_sums' work (sq_qc.hip); everything per position runs here, over
+ * ROWS that are segments of reads: segment j of the sorted reads 0 .. n_j - 1 (the ones longer than
+ * 128 j) is a stretch of spans of one positional window, so that a workgroup's LDS histograms are
+ * those of positions [128 j, 128 j + 128) and go to the device tables when j changes.  The
+ * automaton is restarted in front of every segment (the bases in front come along), its matches
+ * are candidates for the first occurrence per read and adapter (P.long_first, k_adapter_first).
+ * The end-anchored tables (the last `end_anchor_length` positions of every read, :1971-1972,
+ * :2115-2124) have a small kernel of their own.  Reference: QCMetrics_add_meta :1966-2139,
+ * AdapterCounter_add_meta :2786-2823. */
+
+
+__global__ void k_long_rows(const sq_meta *metas, const uint32_t *order, uint64_t n, SpanRow *rows)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t rec = order[i];
+        const sq_meta m = metas[rec];
+        SpanRow r;
+        r.seq = (m.record_start + m.sequence_offset) | ((uint64_t)m.sequence_length << 40);
+        r.qual_delta = m.qualities_offset - m.sequence_offset;
+        r.record = rec;
+        rows[i] = r;
+    }
+}
+/* rows sorted by length, longest first: counts[j] = how many are longer than j * seg */
+__global__ void k_long_counts(const SpanRow *rows, uint64_t n, uint32_t seg, uint32_t n_segs, unsigned long long *counts)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_segs) return;
+    const uint64_t limit = (uint64_t)j * seg;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if ((rows[mid].seq >> 40) > limit) lo = mid + 1; else hi = mid;
+    }
+    counts[j] = lo;
+}
+/* the end-anchored tables of a batch: item i = (read i / ea_len, slot i % ea_len of the tables) */
+__global__ void __launch_bounds__(256) k_long_ea(const uint8_t *buf, const sq_meta *metas, uint64_t n, uint32_t ea_len,
+                                                 unsigned long long *ea_base, unsigned long long *ea_phred)
+{
+    extern __shared__ uint32_t l_ea[];   /* [5 + 12][ea_len] */
+    for (uint32_t i = threadIdx.x; i < 17 * ea_len; i += blockDim.x) l_ea[i] = 0;
+    __syncthreads();
+    const uint64_t items = n * ea_len;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < items; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ea_len;
+        const uint32_t e = (uint32_t)(i % ea_len);
+        const sq_meta m = metas[r];
+        const uint32_t L = m.sequence_length, ean = min(ea_len, L);   /* :1971-1972: right aligned */
+        if (e < ea_len - ean) continue;
+        const uint64_t p = (uint64_t)L - ea_len + e;
+        const uint32_t cls = sq_base_class(buf[m.record_start + m.sequence_offset + p]);
+        const uint32_t bin = min((uint32_t)buf[m.record_start + m.qualities_offset + p] - 33u, 47u) >> 2;
+        atomicAdd(&l_ea[cls * ea_len + e], 1u);
+        atomicAdd(&l_ea[(5 + bin) * ea_len + e], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 17 * ea_len; i += blockDim.x) {
+        const uint32_t v = l_ea[i], row = i / ea_len, e = i % ea_len;
+        if (!v) continue;
+        if (row < 5) atomicAdd(&ea_base[(uint64_t)e * 5 + row], (unsigned long long)v);
+        else atomicAdd(&ea_phred[(uint64_t)e * 12 + (row - 5)], (unsigned long long)v);
+    }
+}
+
+} // namespace
+
+
+/* QCMetrics' positional tables, its end-anchored tables and AdapterCounter's candidates (P.long_first,
+ * [records][n_ad], preset to ~0) for a batch of long reads sorted by length (P.order).  *done = records
+ * covered: all or none (0: the kernel does not take this pass; nothing has been counted). */
+template <int NW>
+int launch_long(sq_ctx *ctx, const PassParams &C, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
+{
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, true, SPAN_W4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, true, SPAN_W4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (ad) hipLaunchKernelGGL((k_span<NW, true, true, SPAN_W4, true, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, C, n_ad);
+    else hipLaunchKernelGGL((k_span<NW, false, true, SPAN_W4, true, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, C, n_ad);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
+int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done)
+{
+    *done = 0;
+    const uint64_t n = P.n;
+    const int nw = sq_knobs().long_nw == 4 ? 4 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
+    const uint32_t LSEG = 32 * (uint32_t)nw;
+    if (!P.order || n < SPAN_R || n >= (1ull << 31) || !max_len || max_len >= (1u << 24) || P.buf_len >= (1ull << 40) || P.ea_len > 512) return SQ_OK;
+    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return SQ_OK;
+    int waves = span_max_waves(nw, true, true);
+    while (waves >= 4 && span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total > 160 * 1024) waves -= 2;
+    if (waves < 4) return SQ_OK;
+    if (sq_knobs().span_waves > 0) waves = std::max(2, std::min(waves, sq_knobs().span_waves / 2 * 2));
+    const uint32_t n_segs = (max_len + LSEG - 1) / LSEG;
+    SpanRow *rows = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
+    unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 3, (size_t)n_segs * 8);
+    if (!rows || !d_counts) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
+    hipLaunchKernelGGL(k_long_rows, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, P.metas, P.order, n, rows);
+    hipLaunchKernelGGL(k_long_counts, dim3((n_segs + 255) / 256), dim3(256), 0, ctx->stream, rows, n, LSEG, n_segs, d_counts);
+    std::vector<uint64_t> counts(n_segs);
+    SQ_HIP(hipMemcpyAsync(counts.data(), d_counts, (size_t)n_segs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<SpanSeg> segs;
+    uint64_t spans = 0;
+    for (uint32_t j = 0; j < n_segs && counts[j]; j++) {
+        SpanSeg g{};
+        g.span0 = (uint32_t)spans;
+        g.nspans = (uint32_t)((counts[j] + SPAN_R - 1) / SPAN_R);
+        g.U = LSEG;
+        g.last_rows = (uint32_t)(counts[j] - (uint64_t)(g.nspans - 1) * SPAN_R);
+        g.first = 0;
+        g.pos_base = j * LSEG;
+        segs.push_back(g);
+        spans += g.nspans;
+        if (spans >= (1ull << 32)) return SQ_OK;
+    }
+    if (segs.empty()) return SQ_OK;
+    SpanSeg *d_segs = (SpanSeg *)sq_scratch(ctx, 14, segs.size() * sizeof(SpanSeg));
+    if (!d_segs) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
+    PassParams C = P;
+    C.uniform_len = 0;
+    C.ad_lds = 0;
+    C.span_segs = d_segs;
+    C.span_nsegs = (uint32_t)segs.size();
+    C.span_total = (uint32_t)spans;
+    C.span_rows = rows;
+    const size_t lds = span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((spans + waves / 2 - 1) / (waves / 2), (uint64_t)ctx->num_cus));
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP(hipFuncSetAttribute((const void *)k_long_ea, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
+    if (rc) return rc;
+    if (P.ea_len)
+        hipLaunchKernelGGL(k_long_ea, dim3((unsigned)std::min<uint64_t>((n * P.ea_len + 255) / 256, (uint64_t)ctx->num_cus * 8)), dim3(256),
+                           (size_t)17 * P.ea_len * 4, ctx->stream, P.buf, P.metas, n, P.ea_len, P.qc_ea_base, P.qc_ea_phred);
+    SQ_HIP(hipGetLastError());
+    SQ_HIP(hipStreamSynchronize(ctx->stream));   /* the host vector of the segments goes out of scope */
+    *done = n;
+    return SQ_OK;
+}
 
 /* Runs k_span over the first 16 * (n / 16) records of the pass described by P (QCMetrics, with
  * AdapterCounter when `ad`).  *done = records covered, 0 when the kernel does not take this

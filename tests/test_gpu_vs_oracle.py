@@ -701,13 +701,14 @@ def test_long_reads_in_segments(which):
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(adapters)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
-    gq, ga = QCMetrics(), AdapterCounter(adapters)
-    FusedPass(gq, ga).add_record_array(arr)
-    compare_qc(rq, gq, metas, arr)
-    for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
-        np.testing.assert_array_equal(u64(f), fr)
-        np.testing.assert_array_equal(u64(r), rr)
+    for env in ({}, {"SQ_LONG": "0"}):   # k_span<LONG> where the adapters allow it (<= 13 characters), k_seg
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(), AdapterCounter(adapters)
+        _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
+        compare_qc(rq, gq, metas, arr)
+        for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+            np.testing.assert_array_equal(u64(f), fr)
+            np.testing.assert_array_equal(u64(r), rr)
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 500
     gq2 = QCMetrics()   # QCMetrics alone: k_seg without the automaton
     arr2 = FastqRecordArrayView._from_buffer(buf, metas.copy())
@@ -792,7 +793,7 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({}, {"SQ_NO_SEGMENTS": "1"}):
+    for env in ({}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}):   # k_span<LONG>; k_seg; stripes of k_pass
         dev = synth.device_array(synth.NANOPORE, first, n)
         gq, ga = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(dev), gq.flush()))
