@@ -186,7 +186,7 @@ template <int CTRL> __device__ __forceinline__ double quad_bcast_f64(double v)
  * positions per read on, which is 168 registers per lane instead of 128.  SPLIT (a wave holds one
  * stream of a span at a time): 16 waves of 128 registers up to 160 positions (128 when the batch
  * holds many lengths), 12 beyond */
-constexpr int span_max_waves(int nw, bool split = false, bool seg = false) { return nw <= (split ? (seg ? 4 : 5) : 3) ? 16 : 12; }
+constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool lng = false) { return nw <= (lng ? 6 : split ? (seg ? 4 : 5) : 3) ? 16 : 12; }
 
 #ifdef SQ_SPAN_PROBE
 __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
@@ -218,7 +218,7 @@ __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves
    behind a row's end is turned into padding in LDS.  Nothing per read is done here (the f64
    chains, the bins, GC: k_read_sums) nor the end-anchored tables (k_long_ea). */
 template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false>
-__global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG)) k_span(PassParams P, uint32_t n_ad)
+__global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_span(PassParams P, uint32_t n_ad)
 {
     static_assert(!LONG || (SEG && SPLIT), "segments of long reads come as sorted rows, a wave per stream");
 #ifdef SQ_SPAN_PROBE
@@ -1561,11 +1561,11 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
 {
     *done = 0;
     const uint64_t n = P.n;
-    const int nw = sq_knobs().long_nw == 4 ? 4 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
+    const int nw = sq_knobs().long_nw == 4 ? 4 : sq_knobs().long_nw == 6 ? 6 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
     const uint32_t LSEG = 32 * (uint32_t)nw;
     if (!P.order || n < SPAN_R || n >= (1ull << 31) || !max_len || max_len >= (1u << 24) || P.buf_len >= (1ull << 40) || P.ea_len > 512) return SQ_OK;
     if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return SQ_OK;
-    int waves = span_max_waves(nw, true, true);
+    int waves = span_max_waves(nw, true, true, true);
     while (waves >= 4 && span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total > 160 * 1024) waves -= 2;
     if (waves < 4) return SQ_OK;
     if (sq_knobs().span_waves > 0) waves = std::max(2, std::min(waves, sq_knobs().span_waves / 2 * 2));
@@ -1610,7 +1610,8 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
         SQ_HIP(hipFuncSetAttribute((const void *)k_long_ea, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
-    int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
+    int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : nw == 6 ? launch_long<6>(ctx, C, ad, n_ad, waves, lds, grid)
+                                                                       : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
     if (P.ea_len)
         hipLaunchKernelGGL(k_long_ea, dim3((unsigned)std::min<uint64_t>((n * P.ea_len + 255) / 256, (uint64_t)ctx->num_cus * 8)), dim3(256),
@@ -1630,7 +1631,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
-    bool split = sq_knobs().span_split;
+    bool split = sq_knobs().span_split && ad;   /* QCMetrics alone: one wave for both streams is 2-3 % ahead (and fetches less) */
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
     if (!waves) return SQ_OK;
