@@ -10,11 +10,19 @@ static thread_local std::string g_last_error;
 void sq_set_error(const char *fmt, ...)
 {
     char tmp[1024];
-    va_list ap;
+    va_list ap, ap2;
     va_start(ap, fmt);
-    vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_copy(ap2, ap);
+    const int need = vsnprintf(tmp, sizeof(tmp), fmt, ap);
     va_end(ap);
-    g_last_error = tmp;
+    if (need >= 0 && (size_t)need < sizeof(tmp)) {
+        g_last_error = tmp;
+    } else if (need > 0) {   /* the reference puts whole buffers into its messages (:1076): no cut */
+        g_last_error.resize((size_t)need + 1);
+        vsnprintf(&g_last_error[0], (size_t)need + 1, fmt, ap2);
+        g_last_error.resize((size_t)need);
+    }
+    va_end(ap2);
 }
 
 /* the switches of SqKnobs (sq_common.h) */
@@ -810,7 +818,15 @@ __global__ void k_bam_decode(const uint8_t *bam, const unsigned long long *offse
         o += f.l_seq;
         /* :1642-1650: missing qualities (0xff) become phred 0 */
         const bool missing = f.l_seq && bam[f.qual] == 0xff;
-        for (uint32_t i = lane; i < f.l_seq; i += 64) o[i] = missing ? (uint8_t)33 : (uint8_t)(bam[f.qual + i] + 33);
+        /* A quality of 95 .. 222 would become a byte >= 128: no phred character in the reference either
+           (`q > PHRED_MAX`, :2073-2075), but the round-1 kernels index 136-entry tables with the raw byte.
+           Such a byte is stored as 0x7F, the smallest character that is none too: same ValueError, same
+           tables behind it (every invalid character counts in bin 11); only the character the
+           message prints differs. */
+        for (uint32_t i = lane; i < f.l_seq; i += 64) {
+            const uint8_t v = (uint8_t)(bam[f.qual + i] + 33);
+            o[i] = missing ? (uint8_t)33 : v >= 128 ? (uint8_t)0x7F : v;
+        }
         o += f.l_seq;
         for (uint32_t i = lane; i < f.tags_len; i += 64) o[i] = bam[f.tags + i];
         if (lane == 0) {

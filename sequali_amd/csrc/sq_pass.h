@@ -56,6 +56,7 @@ struct PassParams {
     uint32_t span_total;       /* spans of the launch */
     const struct SpanRow *span_rows; /* the batch's reads sorted by length, longest first */
     unsigned int *long_first;  /* k_span<LONG>: [records][n_adapters] start of the first occurrence found so far, ~0: none */
+    unsigned int *long_gc;     /* k_span<LONG>: [records][2] G/C bases and A/C/G/T bases of the read, summed segment by segment */
 };
 
 namespace {

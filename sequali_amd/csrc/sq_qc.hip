@@ -653,23 +653,23 @@ struct SegParams {
 };
 
 /* Four lanes per read (16 reads per wave): per step the quad loads 64 consecutive bytes of
- * the read's sequence and of its qualities (whole sectors, where a lane-private stream would
- * fetch 16-byte pieces), every lane turns its 16 qualities into error rates and puts them in
- * LDS, and lane c of the quad then adds the ones at positions = c (mod 4), in position order,
- * to chain c: the four interleaved f64 chains of the reference (:2062-2097), one per lane. */
+ * the read's qualities (and, GC, of its sequence: whole sectors, where a lane-private stream would
+ * fetch 16-byte pieces); lane c of the quad then adds the error rates of positions = c (mod 4), in
+ * position order, to chain c -- the four interleaved f64 chains of the reference (:2062-2097), one per
+ * lane -- taking byte c of the quad's sixteen quality dwords as the other lanes hand them round by DPP
+ * (round 3; through an LDS buffer of error rates before: three LDS operations per position instead of one). */
 constexpr uint32_t SUMS_QUAD_STRIDE = 66; /* doubles per quad in LDS: 64 + padding against bank conflicts */
 
+/* GC = false: the sequences are not read at all (k_span<LONG> counts G/C per read on its way) */
+template <bool GC>
 __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
 {
-    __shared__ double l_err[136], l_thr[96];
+    __shared__ double l_err[256], l_thr[96];   /* by raw quality byte: NaN for what is no phred character (also >= 128: BAM qualities + 33) */
     __shared__ uint32_t l_gc[104], l_ps[96];
-    __shared__ double l_e[4 * 16 * SUMS_QUAD_STRIDE];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 136; i += 256) {
-        double e;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 256; i += 256) {
+        double e = __longlong_as_double(0x7FF8000000000000LL);
         if (i >= 33 && i <= 33 + SQ_PHRED_MAX) e = __longlong_as_double((long long)c_error_rate_bits[i - 33]);
-        else if (i >= 128) e = 0.0;
-        else e = __longlong_as_double(0x7FF8000000000000LL);
         l_err[i] = e;
     }
     for (int i = tid; i < 96; i += 256) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
@@ -677,8 +677,7 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
     for (int i = tid; i < 96; i += 256) l_ps[i] = 0;
     __syncthreads();
     const uint32_t quad = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
-    double *qe = l_e + (wave * 16 + quad) * SUMS_QUAD_STRIDE;
-    const uint64_t n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + (tid >> 6);
     for (uint64_t first = wave_id * 16; first < P.n; first += n_waves * 16) {
         const uint64_t slot = first + quad;
         const bool valid = slot < P.n;
@@ -697,7 +696,7 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
             sv = make_uint4(0, 0, 0, 0);
             qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
             if (pos < L) {
-                sv = load16(P.buf, soff + pos, P.buf_len);
+                if constexpr (GC) sv = load16(P.buf, soff + pos, P.buf_len);
                 qv = load16(P.buf, qoff + pos, P.buf_len);
             }
         };
@@ -706,29 +705,31 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
             const uint32_t p0 = base + 16 * c;
             if (base + 64 < maxL) load_piece(p0 + 64, ns, nq);
             const uint32_t qw[4] = {cq.x, cq.y, cq.z, cq.w}, sw[4] = {cs.x, cs.y, cs.z, cs.w};
+            if constexpr (GC) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t at = p0 + 4 * d;
-                /* positions behind Lmain (a multiple of four) add +0.0: the chains stop there */
-                const uint32_t w = at < Lmain ? qw[d] : PAD4;
-#pragma unroll
-                for (int j = 0; j < 4; j++) /* position 16 c + 4 d + j of the step -> slot (4 d + j) * 4 + c */
-                    qe[(4 * d + j) * 4 + c] = l_err[min((w >> (8 * j)) & 0xFFu, 128u)];
-                if (at < L) {
-                    const uint32_t sd = pad_tail(cls2_of_dword(sw[d]), (int)(L - at), CLS2_PAD4);
-                    gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
-                    acgt_cnt += __popc(~sd & 0x08080808u);
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t at = p0 + 4 * d;
+                    if (at < L) {
+                        const uint32_t sd = pad_tail(cls2_of_dword(sw[d]), (int)(L - at), CLS2_PAD4);
+                        gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                        acgt_cnt += __popc(~sd & 0x08080808u);
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            /* chain c: positions c, c + 4, ..., c + 60 of the step = lane cc's value 4 mm + c */
+            /* chain c: positions c, c + 4, ..., c + 60 of the step, in that order: byte c of the quad's 16
+               quality dwords (lane cc holds dwords 4 cc .. 4 cc + 3), handed round by DPP; positions behind
+               Lmain (a multiple of four, like a dword's first position) add +0.0: the chains stop there */
+            double e[16];
 #pragma unroll
             for (int cc = 0; cc < 4; cc++)
 #pragma unroll
-                for (int mm = 0; mm < 4; mm++) acc += qe[(4 * mm + c) * 4 + cc];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+                for (int mm = 0; mm < 4; mm++) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_mov_dpp((int)qw[mm], cc * 0x55, 0xF, 0xF, true);
+                    const bool inside = base + 16 * cc + 4 * mm < Lmain;
+                    e[4 * cc + mm] = inside ? l_err[(w >> (8 * c)) & 0xFFu] : 0.0;
+                }
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc += e[i];
             cs = ns;
             cq = nq;
         }
@@ -741,11 +742,11 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
             double total = a0 + a1 + a2 + a3; /* :2098-2099, left to right */
             for (uint32_t pos = Lmain; pos < L; pos++) { /* :2100-2112 */
                 const uint32_t qb = P.buf[qoff + pos];
-                total += l_err[qb < 128 ? qb : 0];
+                total += l_err[qb];
             }
             P.metas[r].accumulated_error_rate = total; /* :2126 */
             if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
-            if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+            if (GC && acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
             if (L > 0) {
                 const double avg = total / (double)L;
                 uint32_t lo = 0, hi = 93;
@@ -762,6 +763,35 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
     for (uint32_t i = tid; i < 94; i += 256)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+}
+
+/* QCMetrics' GC histogram alone (:1997-2060), a wave per read: the error path behind k_read_sums<false>
+ * (a batch with an invalid phred byte keeps k_seg, which counts no G/C) */
+__global__ void __launch_bounds__(256) k_read_gc(PassParams P)
+{
+    __shared__ uint32_t l_gc[104];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 104; i += 256) l_gc[i] = 0;
+    __syncthreads();
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (tid >> 6); r < P.n; r += n_waves) {
+        const sq_meta m = P.metas[r];
+        const uint32_t L = m.sequence_length;
+        const uint64_t soff = m.record_start + m.sequence_offset;
+        uint32_t gc_cnt = 0, acgt_cnt = 0;
+        for (uint32_t pos = 4 * lane; pos < L; pos += 256) {
+            uint32_t w = 0;
+            for (uint32_t k = 0; k < 4 && pos + k < L; k++) w |= (uint32_t)P.buf[soff + pos + k] << (8 * k);
+            const uint32_t sd = pad_tail(cls2_of_dword(w), (int)(L - pos), CLS2_PAD4);
+            gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+            acgt_cnt += __popc(~sd & 0x08080808u);
+        }
+        for (int off = 32; off > 0; off >>= 1) { gc_cnt += __shfl_xor(gc_cnt, off); acgt_cnt += __shfl_xor(acgt_cnt, off); }
+        if (lane == 0 && acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 101; i += 256)
+        if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
 }
 
 constexpr int SEG_DEPTH = 2; /* chunks of loads in flight per wave (3: -2 %, 4 costs a wave per SIMD: -15 %) */
@@ -3115,16 +3145,23 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         lds += (size_t)K.lds_pad; /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         if (qc && segments) {
-            /* (1) what is sequential per read */
-            hipLaunchKernelGGL(k_read_sums, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
-                               ctx->stream, P);
+            /* (1) what is sequential per read; where k_span<LONG> takes the per-position pass it counts G/C per
+               read on its way and this pass reads the qualities only */
+            const bool try_long = K.long_spans && K.span && b->owns &&
+                                  sq_span_long_takes(P, ad, ad ? (uint32_t)a->groups[0].count : 0, (uint32_t)b->max_length);
+            if (try_long)
+                hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
+                                   ctx->stream, P);
+            else
+                hipLaunchKernelGGL(k_read_sums<true>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
+                                   ctx->stream, P);
             /* (2) everything per position.  k_span<LONG> (sq_span.hip) streams segments of 128 positions
                through LDS; it sends the padding behind a read's end to a histogram row of its own, where a
                quality byte 0x80 would land too: a batch k_read_sums has flagged (an invalid phred byte,
                one 8-byte read-back) keeps k_seg, whose counts k_qc_uncount knows how to take back.
                SQ_LONG=0: k_seg for all */
             const uint32_t n_ad_long = ad ? (uint32_t)a->groups[0].count : 0;
-            if (K.long_spans && K.span && b->owns && (!ad || gi == 0)) {
+            if (try_long) {
                 SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
                 SQ_HIP(hipStreamSynchronize(ctx->stream));
                 if (ctx->pinned[9] == UINT64_MAX) {
@@ -3146,6 +3183,9 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                         continue;
                     }
                 }
+                /* not taken after all (a flagged batch, or no memory for its tables): the G/C histogram the
+                   pass above left out */
+                hipLaunchKernelGGL(k_read_gc, dim3((unsigned)std::min<uint64_t>((b->n + 3) / 4, 4096)), dim3(256), 0, ctx->stream, P);
             }
             std::vector<uint32_t> table;
             for (uint32_t w = 0; w < stripes && stripe_reads[w]; w++) {

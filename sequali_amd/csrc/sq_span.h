@@ -89,5 +89,6 @@ int sq_isz_span_launch(sq_ctx *ctx, const IszSpanParams &P, uint64_t *done);
 int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done);
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
+bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len);
 
 #endif

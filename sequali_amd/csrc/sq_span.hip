@@ -504,6 +504,16 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
                 }
             }
         }
+        if constexpr (DS && LONG) {   /* the read's G/C and A/C/G/T counts, a segment at a time (:1997-2049; the bin: k_long_gc_bins) */
+            uint32_t gs = sum_bytes(gacc, 0), ns = sum_bytes(nacc, 0);
+            gs += quad_bcast<0xB1>(gs); ns += quad_bcast<0xB1>(ns);
+            gs += quad_bcast<0x4E>(gs); ns += quad_bcast<0x4E>(ns);
+            if (c == 0 && urow) {
+                const uint32_t gc_cnt = (gs >> 2) - (SB - urow), acgt_cnt = SB - (ns >> 3);
+                unsigned int *dst = P.long_gc + 2 * (uint64_t)rec_cur;
+                asm volatile("global_atomic_add %0, %1, off\n\tglobal_atomic_add %0, %2, off offset:4" :: "v"(dst), "v"(gc_cnt), "v"(acgt_cnt) : "memory");
+            }
+        }
         if constexpr (DQ && SEG && !LONG) {
             if (nv < SPAN_R && q >= nv) {
 #pragma unroll
@@ -1536,10 +1546,24 @@ __global__ void __launch_bounds__(256) k_long_ea(const uint8_t *buf, const sq_me
     }
 }
 
+/* QCMetrics' GC histogram from the counts k_span<LONG> summed per read (:2051-2060: reads without any A/C/G/T have no bin) */
+__global__ void __launch_bounds__(256) k_long_gc_bins(const unsigned int *gc, uint64_t n, unsigned long long *qc_gc)
+{
+    __shared__ uint32_t l_gc[104];
+    for (int i = threadIdx.x; i < 104; i += 256) l_gc[i] = 0;
+    __syncthreads();
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t g = gc[2 * r], a = gc[2 * r + 1];
+        if (a > 0) atomicAdd(&l_gc[(uint32_t)round((double)g * 100.0 / (double)a)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 101; i += 256)
+        if (l_gc[i]) atomicAdd(&qc_gc[i], (unsigned long long)l_gc[i]);
+}
+
 } // namespace
 
-
-/* QCMetrics' positional tables, its end-anchored tables and AdapterCounter's candidates (P.long_first,
+/* QCMetrics' positional tables, its end-anchored tables, its GC histogram and AdapterCounter's candidates (P.long_first,
  * [records][n_ad], preset to ~0) for a batch of long reads sorted by length (P.order).  *done = records
  * covered: all or none (0: the kernel does not take this pass; nothing has been counted). */
 template <int NW>
@@ -1557,18 +1581,36 @@ int launch_long(sq_ctx *ctx, const PassParams &C, bool ad, uint32_t n_ad, int wa
     return SQ_OK;
 }
 
+static int long_waves(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, int *nw_out)
+{
+    const uint64_t n = P.n;
+    const int nw = sq_knobs().long_nw == 4 ? 4 : sq_knobs().long_nw == 6 ? 6 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
+    const uint32_t LSEG = 32 * (uint32_t)nw;
+    *nw_out = nw;
+    if (!P.order || n < SPAN_R || n >= (1ull << 31) || !max_len || max_len >= (1u << 24) || P.buf_len >= (1ull << 40) || P.ea_len > 512) return 0;
+    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0;
+    int waves = span_max_waves(nw, true, true, true);
+    while (waves >= 4 && span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total > 160 * 1024) waves -= 2;
+    if (waves < 4) return 0;
+    if (sq_knobs().span_waves > 0) waves = std::max(2, std::min(waves, sq_knobs().span_waves / 2 * 2));
+    return waves;
+}
+
+/* does k_span<LONG> take this batch (sq_span_launch_long may still decline: memory) */
+bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len)
+{
+    int nw;
+    return long_waves(P, ad, n_ad, max_len, &nw) > 0;
+}
+
 int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done)
 {
     *done = 0;
     const uint64_t n = P.n;
-    const int nw = sq_knobs().long_nw == 4 ? 4 : sq_knobs().long_nw == 6 ? 6 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
+    int nw = 8;
+    const int waves = long_waves(P, ad, n_ad, max_len, &nw);
+    if (!waves) return SQ_OK;
     const uint32_t LSEG = 32 * (uint32_t)nw;
-    if (!P.order || n < SPAN_R || n >= (1ull << 31) || !max_len || max_len >= (1u << 24) || P.buf_len >= (1ull << 40) || P.ea_len > 512) return SQ_OK;
-    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return SQ_OK;
-    int waves = span_max_waves(nw, true, true, true);
-    while (waves >= 4 && span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total > 160 * 1024) waves -= 2;
-    if (waves < 4) return SQ_OK;
-    if (sq_knobs().span_waves > 0) waves = std::max(2, std::min(waves, sq_knobs().span_waves / 2 * 2));
     const uint32_t n_segs = (max_len + LSEG - 1) / LSEG;
     SpanRow *rows = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 3, (size_t)n_segs * 8);
@@ -1610,9 +1652,14 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
         SQ_HIP(hipFuncSetAttribute((const void *)k_long_ea, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
+    C.long_gc = (unsigned int *)sq_scratch(ctx, 16, n * 8);
+    if (!C.long_gc) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemsetAsync(C.long_gc, 0, n * 8, ctx->stream));
     int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : nw == 6 ? launch_long<6>(ctx, C, ad, n_ad, waves, lds, grid)
                                                                        : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_long_gc_bins, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->num_cus * 4)), dim3(256), 0, ctx->stream,
+                       C.long_gc, n, P.qc_gc);
     if (P.ea_len)
         hipLaunchKernelGGL(k_long_ea, dim3((unsigned)std::min<uint64_t>((n * P.ea_len + 255) / 256, (uint64_t)ctx->num_cus * 8)), dim3(256),
                            (size_t)17 * P.ea_len * 4, ctx->stream, P.buf, P.metas, n, P.ea_len, P.qc_ea_base, P.qc_ea_phred);

@@ -272,3 +272,83 @@ def test_pair_automaton_reports_what_the_single_step_one_reports(adapters):
                 ev2 += [(a, pos - 1) for a in range(len(adapters)) if int(out2[s, 1]) >> a & 1]
                 assert (s >= accept) == bool(out2[s, 0] or out2[s, 1])
             assert first_hits(ev2) == want, (text, phase)
+
+
+# ---- the parser's buffer logic in the C ABI (sq_feeder) against the Python restatement -----------
+def _parse_all(text, buffersize, reads=None):
+    """(sizes, buffer lengths, metas, error) of a FastqParser run over `text`"""
+    from sequali_amd import FastqParser
+    p = FastqParser(io.BytesIO(text), buffersize)
+    sizes, lens, metas, err = [], [], [], None
+    try:
+        if reads is None:
+            arrays = list(p)
+        else:
+            arrays = []
+            for n in reads:
+                a = p.read(n) if n else next(p, None)
+                if a is None or len(a) == 0:
+                    break
+                arrays.append(a)
+        for a in arrays:
+            sizes.append(len(a))
+            lens.append(len(a.obj))
+            m = a._host_metas()
+            metas.append(np.stack([m[f].astype(np.int64) for f in ("record_start", "name_length", "sequence_offset",
+                                                                    "sequence_length", "qualities_offset", "tags_offset")], axis=1))
+            for i in (0, len(a) - 1):
+                r = a[i]
+                assert len(r.sequence()) == len(r.qualities())
+    except (ValueError, EOFError) as e:
+        err = (type(e).__name__, str(e))
+    return sizes, lens, (np.concatenate(metas).tolist() if metas else []), err
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_feeder_equals_the_python_parser_on_random_texts(seed):
+    """sq_feeder (pinned staging blocks, vectorised split, read-ahead) and the Python restatement of
+    FastqParser_create_record_array (_qcmodule.c:964-1184) that the golden parser cases pinned in
+    round 2: same arrays, same buffer lengths, same metas, same exception -- records of very
+    different sizes (some larger than the buffer: it is enlarged), buffer sizes from 1 byte up,
+    truncated tails, a broken record, a non-ASCII byte, iteration mixed with read(n)"""
+    from sequali_amd import _qc
+    rng = np.random.default_rng(900 + seed)
+    recs = []
+    for i in range(int(rng.integers(1, 60))):
+        L = int(rng.choice([0, 1, 5, 40, 150, 700, 5000], p=[.05, .1, .2, .25, .25, .1, .05]))
+        name = "r%d %s" % (i, "x" * int(rng.integers(0, 30)))
+        seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L).tobytes()
+        qual = (rng.integers(0, 94, size=L) + 33).astype(np.uint8).tobytes()
+        recs.append(b"@" + name.encode() + b"\n" + seq + b"\n+\n" + qual + b"\n")
+    text = b"".join(recs)
+    variants = [text, text[:max(1, len(text) - int(rng.integers(1, 40)))]]
+    if len(recs) > 2:
+        bad = list(recs)
+        k = int(rng.integers(1, len(bad)))
+        bad[k] = bad[k].replace(b"\n+\n", b"\n-\n", 1) if seed % 2 else b"X" + bad[k][1:]
+        variants.append(b"".join(bad))
+        hi = bytearray(text)
+        hi[int(rng.integers(0, len(hi)))] = 0xC3
+        variants.append(bytes(hi))
+    for t in variants:
+        for bs in (1, 7, 64, 333, 4096, 128 * 1024):
+            for reads in (None, [3, 0, 1, 0, 0, 5, 2, 0] * 20):
+                got = _parse_all(t, bs, reads)
+                _qc._USE_FEEDER = False
+                try:
+                    want = _parse_all(t, bs, reads)
+                finally:
+                    _qc._USE_FEEDER = True
+                assert got == want, (seed, bs, reads is not None, got[3], want[3])
+
+
+def test_pinned_reader_is_a_file_object():
+    from sequali_amd import FastqParser, PinnedReader
+    text = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(1000))
+    r = PinnedReader(text)
+    assert r.read(5) == text[:5]
+    buf = bytearray(11)
+    assert r.readinto(buf) == 11 and bytes(buf) == text[5:16]
+    assert r.read() == text[16:] and r.read(3) == b"" and r.readinto(bytearray(4)) == 0
+    arrays = list(FastqParser(PinnedReader(text), 300))        # through the host parser like any file
+    assert sum(len(a) for a in arrays) == 1000 and arrays[0][0].name() == "r0"

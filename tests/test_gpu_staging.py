@@ -97,3 +97,41 @@ def test_default_buffer_paired_reference_files():
     np.testing.assert_array_equal(u64(isz.insert_sizes()), g["is_insert_sizes"])
     np.testing.assert_array_equal(u64(dd.duplication_counts()), g["dd_counts_slot_order"])
     assert dd._modulo_bits == int(g["dd_modulo_bits"]) and isz.total_reads == int(g["is_total_reads"])
+
+
+def test_getter_in_the_middle_of_a_block_seals_it_and_the_parser_goes_on():
+    """a getter between two arrays needs the state of everything handed over so far: the parser's
+    open staging block is sealed behind its last array (sq_feeder_seal), uploaded and counted, and
+    the parser continues in a new block; arrays the caller still holds keep answering (their
+    bytes come from the pinned block while it is there, from HBM afterwards)"""
+    from sequali_amd import AdapterCounter, FastqParser, FusedPass, QCMetrics, synth
+    n = 60_000
+    text = synth.illumina_fastq(0, n)
+    buf, metas = split_fastq(text)
+    probes = list(synth.ILLUMINA_PROBES)
+    qc, ad = QCMetrics(), AdapterCounter(probes)
+    f = FusedPass(qc, ad)
+    seen, kept = 0, []
+    for k, arr in enumerate(FastqParser(io.BytesIO(text))):
+        f.add_record_array(arr)
+        if k % 23 == 4:
+            kept.append((seen, arr))
+        seen += len(arr)
+        if k % 17 == 5:
+            assert qc.number_of_reads == seen and ad.number_of_sequences == seen     # seals the open block
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    assert seen == n and qc.number_of_reads == n
+    np.testing.assert_array_equal(u64(qc.base_count_table()), rq.base_count_table())
+    np.testing.assert_array_equal(u64(qc.phred_count_table()), rq.phred_count_table())
+    np.testing.assert_array_equal(u64(qc.phred_scores()), rq.phred_scores())
+    for (_, fw, rv), (_, fr, rr) in zip(ad.get_counts(), ra.get_counts()):
+        np.testing.assert_array_equal(u64(fw), fr)
+        np.testing.assert_array_equal(u64(rv), rr)
+    for first, arr in kept:       # long after their blocks were sealed, some after the pinned copy was recycled
+        m = metas[first:first + len(arr)]
+        np.testing.assert_array_equal(arr.accumulated_error_rates().view(np.uint64), m["accumulated_error_rate"].view(np.uint64))
+        i = len(arr) // 2
+        want = buf[int(m[i]["record_start"]) + int(m[i]["sequence_offset"]):][:int(m[i]["sequence_length"])]
+        assert arr[i].sequence().encode() == want

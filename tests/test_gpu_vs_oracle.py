@@ -859,3 +859,40 @@ def test_config3_one_million_pairs():
         assert z.adapters_read1() == rz.adapters_read1() and z.adapters_read2() == rz.adapters_read2()
         np.testing.assert_array_equal(u64(d.duplication_counts()), rd.duplication_counts())
         assert d._modulo_bits == rd._modulo_bits and d.tracked_sequences == rd.tracked_sequences
+
+
+@pytest.mark.parametrize("bad_byte", [0x20, 0x80])
+def test_long_reads_with_an_invalid_phred_byte(bad_byte):
+    """>= 4096 long reads, one of them with a byte that is no phred character (0x80: what BAM
+    quality 95 becomes, and the code k_span<LONG> pads with): k_read_sums flags the batch, the
+    per-position pass falls back to k_seg, the flush raises the reference's ValueError and leaves
+    the reference's state behind it (:2073-2075, :2102-2105)"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(bad_byte)
+    n, bad = 4200, 2777
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    lens = rng.integers(520, 1400, size=n)
+    parts, metas, pos = [], np.zeros(n, dtype=oracle.META_DTYPE), 0
+    for i in range(n):
+        L = int(lens[i])
+        q = (rng.integers(0, 94, size=L) + 33).astype(np.uint8)
+        if i == bad:
+            q[L // 3] = bad_byte
+        name = b"r%d" % i
+        rec = b"@" + name + b"\n" + rng.choice(letters, size=L).tobytes() + b"\n+\n" + q.tobytes() + b"\n"
+        metas[i] = (pos + 1, len(name), len(name) + 1, L, len(name) + 1 + L + 3, len(name) + 1 + 2 * L + 3, 0, 0.0)
+        parts.append(rec)
+        pos += len(rec)
+    buf = b"".join(parts)
+    ref, ref_metas = oracle.QCMetrics(), metas.copy()
+    with pytest.raises(ValueError):
+        ref.add(buf, ref_metas)
+    probes = ["ACGTACGTACGT", "GGGGGGGGGGGG"]
+    m, a = QCMetrics(), AdapterCounter(probes)
+    FusedPass(m, a).add_record_array(FastqRecordArrayView._from_buffer(buf, metas.copy()))
+    with pytest.raises(ValueError, match="Not a valid phred character"):
+        m.flush()
+    assert m.number_of_reads == ref.number_of_reads and m.max_length == ref.max_length
+    for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                 "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+        np.testing.assert_array_equal(u64(getattr(m, name)()), getattr(ref, name)(), err_msg=name)
