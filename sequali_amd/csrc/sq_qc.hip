@@ -660,6 +660,17 @@ struct SegParams {
  * (round 3; through an LDS buffer of error rates before: three LDS operations per position instead of one). */
 constexpr uint32_t SUMS_QUAD_STRIDE = 66; /* doubles per quad in LDS: 64 + padding against bank conflicts */
 
+/* the value lane `from` (0..3, a constant after unrolling) of each quad holds: DPP quad_perm broadcast */
+__device__ __forceinline__ uint32_t quad_lane_u32(uint32_t v, int from)
+{
+    switch (from) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xF, 0xF, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xF, 0xF, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);
+    }
+}
+
 /* GC = false: the sequences are not read at all (k_span<LONG> counts G/C per read on its way) */
 template <bool GC>
 __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
@@ -724,7 +735,7 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
             for (int cc = 0; cc < 4; cc++)
 #pragma unroll
                 for (int mm = 0; mm < 4; mm++) {
-                    const uint32_t w = (uint32_t)__builtin_amdgcn_mov_dpp((int)qw[mm], cc * 0x55, 0xF, 0xF, true);
+                    const uint32_t w = quad_lane_u32(qw[mm], cc);
                     const bool inside = base + 16 * cc + 4 * mm < Lmain;
                     e[4 * cc + mm] = inside ? l_err[(w >> (8 * c)) & 0xFFu] : 0.0;
                 }
