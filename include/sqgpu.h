@@ -154,6 +154,14 @@ sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len, v
  * or borrowed (device variant). */
 sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed);
 sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len, size_t *consumed);
+/* sq_batch_from_fastq for a caller who knows the bytes of its NEXT buffer already (text that lies in
+ * page-locked memory as a whole: `ahead` must stay valid and unchanged until a later call has covered it):
+ * their upload is started behind this buffer's and runs while this buffer is split and counted; a later
+ * call whose text contains `ahead` finds them in HBM and uploads only what lies in front of them (the
+ * leftover of the buffer before) and behind them; bytes sent ahead that the next call does not cover are
+ * dropped. */
+sq_batch *sq_batch_from_fastq_ahead(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed,
+                                    const uint8_t *ahead, size_t ahead_len);
 /* BAM input.  sq_bam_scan is the record walk of BamParser__next__
  * (_qcmodule.c:1601-1681) on the host: offsets of the complete records of an uncompressed
  * BAM record stream that are not secondary / supplementary (:1262,1611), the bytes they

@@ -866,7 +866,14 @@ class FastqParser:
             if eof and C.string_at(addr, have).count(b"\n") < 4:  # :1073-1081
                 raise EOFError("Incomplete record at the end of file " + C.string_at(addr, have).decode("latin-1"))
             consumed = C.c_size_t(0)
-            h = lib().sq_batch_from_fastq(context(), addr, have, C.byref(consumed))
+            if src is not None:    # the pages of the next buffer are known already: their upload starts now
+                # (with the end of this buffer: the leftover of this call will be in front of the next one)
+                back = min(src._pos, have, 64 << 10)
+                nxt = min(self._read_in_size, src._size - src._pos) if os.environ.get("SQ_AHEAD", "1") != "0" else 0
+                h = lib().sq_batch_from_fastq_ahead(context(), addr, have, C.byref(consumed),
+                                                    src._address + src._pos - back if nxt > 0 else None, nxt + back if nxt > 0 else 0)
+            else:
+                h = lib().sq_batch_from_fastq(context(), addr, have, C.byref(consumed))
             if not h:
                 raise ValueError(_lib.last_error())
             batch = _DeviceBatch(h)

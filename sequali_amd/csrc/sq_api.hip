@@ -102,6 +102,9 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (void *p : ctx->scratch)
         if (p) (void)hipFree(p);
+    if (ctx->ahead.dev) sq_dev_put(ctx, ctx->ahead.dev);
+    for (auto &f : ctx->pool_free) (void)hipFree(f.p);
+    for (auto &f : ctx->pool_live) (void)hipFree(f.p);   /* batches that outlive their context hold dangling blocks: as before */
     delete ctx;
 }
 
@@ -548,8 +551,11 @@ __global__ void k_split_metas(const uint8_t *text, const unsigned long long *nl,
 sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const uint8_t *h_text, size_t len,
                           size_t *consumed)
 {
+    /* d_text (when owned) and the metas are blocks of the context's pool, the temporaries live in its
+       scratch slots: no hipMalloc / hipFree per buffer (round 3; a 64 MiB buffer spent more time in those
+       than in its kernels) */
     auto fail = [&](sq_batch *b) -> sq_batch * {
-        if (owns_text && d_text && !b) (void)hipFree(d_text);
+        if (owns_text && d_text && !b) sq_dev_put(ctx, d_text);
         if (b) sq_batch_free(b);
         return nullptr;
     };
@@ -561,25 +567,27 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
     b->d_buf = d_text;
     b->buf_len = len;
     b->owns = owns_text;
+    b->pooled = true;
     if (len == 0 || n_blocks == 0) {
-        if (hipMalloc((void **)&b->d_metas, sizeof(sq_meta)) != hipSuccess) return fail(b);
+        if (!(b->d_metas = (sq_meta *)sq_dev_get(ctx, sizeof(sq_meta)))) return fail(b);
         b->owns_metas = true;
         return b;
     }
-    if (hipMalloc((void **)&d_counts, (n_blocks + 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&d_prefix, (n_blocks + 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&d_flags, 16) != hipSuccess) {
+    d_counts = (unsigned long long *)sq_scratch(ctx, 18, (2 * (n_blocks + 1) + 2) * 8);
+    if (!d_counts) {
         sq_set_error("sq_batch_from_fastq: out of device memory");
         return fail(b);
     }
+    d_prefix = d_counts + n_blocks + 1;
+    d_flags = d_prefix + n_blocks + 1;
     (void)hipMemsetAsync(d_flags, 0xFF, 16, ctx->stream);
     (void)hipMemsetAsync(d_counts + n_blocks, 0, 8, ctx->stream);
     hipLaunchKernelGGL(k_split_count, dim3((unsigned)n_blocks), dim3(SPLIT_THREADS), 0, ctx->stream, d_text,
                        (uint64_t)len, d_counts, d_flags);
     size_t temp_bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_counts, d_prefix, (int)(n_blocks + 1), ctx->stream);
-    void *d_temp = nullptr;
-    (void)hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8);
+    void *d_temp = sq_scratch(ctx, 19, temp_bytes ? temp_bytes : 8);
+    if (!d_temp) { sq_set_error("sq_batch_from_fastq: out of device memory"); return fail(b); }
     (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_prefix, (int)(n_blocks + 1), ctx->stream);
     unsigned long long h[3] = {0, 0, 0};
     (void)hipMemcpyAsync(&ctx->pinned[40], d_prefix + n_blocks, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -587,22 +595,20 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { sq_set_error("FASTQ split failed on the device"); return fail(b); }
     h[0] = ctx->pinned[40];
     h[1] = ctx->pinned[41];
-    (void)hipFree(d_temp);
     if (h[1] != ~0ULL) { /* :1055-1067 */
         uint8_t c = 0;
         if (h_text) c = h_text[h[1]];
         else (void)hipMemcpy(&c, d_text + h[1], 1, hipMemcpyDeviceToHost);
         sq_set_error("Found non-ASCII character in file: %c", (char)c);
-        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags);
         return fail(b);
     }
     const uint64_t n_newlines = h[0], n_records = n_newlines / 4;
     b->n = n_records;
     b->owns_metas = true;
-    if (hipMalloc((void **)&b->d_metas, (n_records ? n_records : 1) * sizeof(sq_meta)) != hipSuccess ||
-        hipMalloc((void **)&d_nl, (n_newlines ? n_newlines : 1) * 8) != hipSuccess) {
+    b->d_metas = (sq_meta *)sq_dev_get(ctx, (n_records ? n_records : 1) * sizeof(sq_meta));
+    d_nl = (unsigned long long *)sq_scratch(ctx, 20, (n_newlines ? n_newlines : 1) * 8);
+    if (!b->d_metas || !d_nl) {
         sq_set_error("sq_batch_from_fastq: out of device memory");
-        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags);
         return fail(b);
     }
     auto byte_at = [&](uint64_t at) -> uint8_t {
@@ -610,9 +616,6 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
         if (h_text) return h_text[at];
         (void)hipMemcpy(&c, d_text + at, 1, hipMemcpyDeviceToHost);
         return c;
-    };
-    auto release = [&]() {
-        (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags); (void)hipFree(d_nl);
     };
     if (n_newlines)
         hipLaunchKernelGGL(k_split_positions, dim3((unsigned)n_blocks), dim3(SPLIT_THREADS), 0, ctx->stream,
@@ -623,7 +626,7 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
         hipLaunchKernelGGL(k_split_metas, dim3(blocks), dim3(256), 0, ctx->stream, d_text, d_nl, n_records,
                            b->d_metas, d_flags + 1);
         unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 5, 64);
-        if (!d_out) { sq_set_error("sq_batch_from_fastq: out of device memory"); release(); return fail(b); }
+        if (!d_out) { sq_set_error("sq_batch_from_fastq: out of device memory"); return fail(b); }
         (void)hipMemsetAsync(d_out, 0, 64, ctx->stream);
         const int sb = (int)((n_records + 255) / 256 > 4096 ? 4096 : (n_records + 255) / 256);
         hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, (size_t)n_records, d_out);
@@ -632,7 +635,6 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
         (void)hipMemcpyAsync(&ctx->pinned[43], d_nl + 4 * n_records - 1, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
             sq_set_error("FASTQ split failed on the device");
-            release();
             return fail(b);
         }
         b->total_bases = ctx->pinned[0];
@@ -664,7 +666,6 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
                 default:
                     sq_set_error("Total length of FASTQ record exceeds 4 GiB");
             }
-            release();
             return fail(b);
         }
     }
@@ -675,7 +676,6 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
         const uint8_t c = byte_at(tail_start);
         if (c != '@') {
             sq_set_error("Record does not start with @ but with %c", (char)c);
-            release();
             return fail(b);
         }
         if (n_newlines % 4 >= 2) {
@@ -684,33 +684,89 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
             (void)hipStreamSynchronize(ctx->stream);
             if (second + 1 < len && byte_at(second + 1) != '+') {
                 sq_set_error("Record second header does not start with + but with %c", (char)byte_at(second + 1));
-                release();
                 return fail(b);
             }
         }
     }
     if (consumed) *consumed = (size_t)tail_start;
-    (void)hipFree(d_counts); (void)hipFree(d_prefix); (void)hipFree(d_flags); (void)hipFree(d_nl);
     return b;
 }
 
 } // namespace
 
-SQ_EXPORT sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed)
+namespace {
+/* dst[0, n) = src[0, n), both anywhere: 16 bytes per thread and step where dst is aligned */
+__global__ void __launch_bounds__(256) k_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
 {
-    uint8_t *d_text = nullptr;
-    if (hipMalloc((void **)&d_text, len + 64) != hipSuccess) {
+    const uint64_t lead = (16 - ((uintptr_t)dst & 15)) & 15, first = lead < n ? lead : n;
+    const uint64_t chunks = (n - first) / 16, rest = first + 16 * chunks;
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = tid; i < chunks; i += stride) {
+        uint4 v;
+        __builtin_memcpy(&v, src + first + 16 * i, 16);
+        *(uint4 *)(dst + first + 16 * i) = v;
+    }
+    if (tid < first) dst[tid] = src[tid];
+    if (tid < n - rest) dst[rest + tid] = src[rest + tid];
+}
+} // namespace
+
+SQ_EXPORT sq_batch *sq_batch_from_fastq_ahead(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed,
+                                              const uint8_t *ahead, size_t ahead_len)
+{
+    uint8_t *d_text = (uint8_t *)sq_dev_get(ctx, len + 64);
+    if (!d_text) {
         sq_set_error("sq_batch_from_fastq: out of device memory");
         return nullptr;
     }
     /* the upload runs on a stream of its own: the passes over the batch before (queued on
        ctx->stream by the caller, who is back here for the next buffer) go on beside it; the split
-       waits for it */
-    if (len) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->copy_stream));
-    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->copy_stream));
+       waits for it.  What an earlier call has sent ahead is already in HBM: a copy within the device. */
+    sq_ctx::Ahead &A = ctx->ahead;
+    /* what was sent ahead may begin in front of this buffer and reach beyond it (the caller did not know
+       its leftover then): the overlap is copied inside the device, the rest comes from the host */
+    const uint8_t *lo = A.dev ? std::max(A.host, text) : nullptr, *hi = A.dev ? std::min(A.host + A.len, text + len) : nullptr;
+    const bool covered = A.dev && lo < hi;
+    if (covered) {
+        const size_t head = (size_t)(lo - text), tail = (size_t)(text + len - hi);
+        if (head) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, head, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (tail) SQ_HIP_NULL(hipMemcpyAsync(d_text + (hi - text), hi, tail, hipMemcpyHostToDevice, ctx->copy_stream));
+    } else if (len) {
+        SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->copy_stream));
+    }
     SQ_HIP_NULL(hipEventRecord(ctx->copied, ctx->copy_stream));
-    SQ_HIP_NULL(hipStreamWaitEvent(ctx->stream, ctx->copied, 0));
-    return split_on_device(ctx, d_text, true, text, len, consumed);
+    SQ_HIP_NULL(hipStreamWaitEvent(ctx->stream, ctx->copied, 0));   /* behind the upload sent ahead too: same stream */
+    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->stream));
+    if (covered)   /* a kernel, not hipMemcpyDeviceToDevice: that one goes through the copy engines at ~60 GB/s */
+        hipLaunchKernelGGL(k_copy_bytes, dim3(2048), dim3(256), 0, ctx->stream, d_text + (lo - text),
+                           (const uint8_t *)A.dev + (lo - A.host), (uint64_t)(hi - lo));
+    uint8_t *spent = A.dev;   /* used, or sent for a buffer that never came: back to the pool when the copy kernel has read it */
+    A = sq_ctx::Ahead();
+    if (ahead && ahead_len) {
+        /* the caller's next buffer: on its way while this one is split and counted (into a block of its
+           own, so the upload depends on nothing that is queued) */
+        A.dev = (uint8_t *)sq_dev_get(ctx, ahead_len);
+        if (A.dev) {
+            if (hipMemcpyAsync(A.dev, ahead, ahead_len, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess) {
+                A.host = ahead;
+                A.len = ahead_len;
+            } else {
+                sq_dev_put(ctx, A.dev);
+                A = sq_ctx::Ahead();
+            }
+        }
+    }
+    sq_batch *b = split_on_device(ctx, d_text, true, text, len, consumed);
+    if (spent) {
+        (void)hipStreamSynchronize(ctx->stream);   /* the split has done that already unless it failed early */
+        sq_dev_put(ctx, spent);
+    }
+    return b;
+}
+
+SQ_EXPORT sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed)
+{
+    return sq_batch_from_fastq_ahead(ctx, text, len, consumed, nullptr, 0);
 }
 
 SQ_EXPORT sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len, size_t *consumed)
@@ -908,8 +964,13 @@ SQ_EXPORT void sq_batch_free(sq_batch *b)
 {
     if (!b) return;
     if (b->owns || b->owns_metas) (void)hipStreamSynchronize(b->ctx->stream);
-    if (b->owns && b->d_buf) (void)hipFree(b->d_buf);
-    if ((b->owns || b->owns_metas) && b->d_metas) (void)hipFree(b->d_metas);
+    if (b->pooled) {
+        if (b->owns && b->d_buf) sq_dev_put(b->ctx, b->d_buf);
+        if ((b->owns || b->owns_metas) && b->d_metas) sq_dev_put(b->ctx, b->d_metas);
+    } else {
+        if (b->owns && b->d_buf) (void)hipFree(b->d_buf);
+        if ((b->owns || b->owns_metas) && b->d_metas) (void)hipFree(b->d_metas);
+    }
     delete b;
 }
 

@@ -74,9 +74,62 @@ struct sq_ctx {
     uint64_t *pinned = nullptr; /* 64 words */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
-    void *scratch[18] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span */
-    size_t scratch_bytes[18] = {};
+    void *scratch[24] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split */
+    size_t scratch_bytes[24] = {};
+    /* device blocks of batches made by sq_batch_from_fastq (text, metas): kept for the next buffer of the
+       same size instead of a hipFree + hipMalloc per buffer (hipFree waits for the whole device) */
+    struct DevBlock { void *p; size_t cap; };
+    std::vector<DevBlock> pool_free, pool_live;
+    size_t pool_free_bytes = 0;
+    /* FASTQ text uploaded ahead of the call that will split it (sq_batch_from_fastq_ahead) */
+    struct Ahead { const uint8_t *host = nullptr; size_t len = 0; uint8_t *dev = nullptr; };
+    Ahead ahead;
 };
+
+/* a device block of at least `bytes` from the context's pool (sq_dev_put hands it back) */
+inline void *sq_dev_get(sq_ctx *ctx, size_t bytes)
+{
+    size_t best = ctx->pool_free.size();
+    for (size_t i = 0; i < ctx->pool_free.size(); i++)
+        if (ctx->pool_free[i].cap >= bytes && ctx->pool_free[i].cap <= 2 * bytes + (1 << 20) &&
+            (best == ctx->pool_free.size() || ctx->pool_free[i].cap < ctx->pool_free[best].cap))
+            best = i;
+    sq_ctx::DevBlock blk{nullptr, 0};
+    if (best < ctx->pool_free.size()) {
+        blk = ctx->pool_free[best];
+        ctx->pool_free.erase(ctx->pool_free.begin() + (long)best);
+        ctx->pool_free_bytes -= blk.cap;
+    } else {
+        blk.cap = (bytes + (bytes >> 4) + 0xFFFFF) & ~(size_t)0xFFFFF;   /* buffers of one parser differ by a leftover */
+        if (hipMalloc(&blk.p, blk.cap) != hipSuccess) {
+            /* give the pool's idle blocks back and try once more */
+            for (auto &f : ctx->pool_free) (void)hipFree(f.p);
+            ctx->pool_free.clear();
+            ctx->pool_free_bytes = 0;
+            if (hipMalloc(&blk.p, blk.cap) != hipSuccess) return nullptr;
+        }
+    }
+    ctx->pool_live.push_back(blk);
+    return blk.p;
+}
+
+inline void sq_dev_put(sq_ctx *ctx, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < ctx->pool_live.size(); i++)
+        if (ctx->pool_live[i].p == p) {
+            const sq_ctx::DevBlock blk = ctx->pool_live[i];
+            ctx->pool_live.erase(ctx->pool_live.begin() + (long)i);
+            if (ctx->pool_free.size() >= 8 || ctx->pool_free_bytes + blk.cap > ((size_t)2 << 30)) {
+                (void)hipFree(blk.p);
+            } else {
+                ctx->pool_free.push_back(blk);
+                ctx->pool_free_bytes += blk.cap;
+            }
+            return;
+        }
+    (void)hipFree(p);   /* not from the pool */
+}
 
 inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)
 {
@@ -105,6 +158,7 @@ struct sq_batch {
     sq_meta *d_metas = nullptr;
     size_t buf_len = 0;
     size_t n = 0;
+    bool pooled = false;     /* d_buf and d_metas are blocks of the context's pool (sq_dev_get) */
     bool owns = false;       /* frees d_buf (and d_metas) */
     bool owns_metas = false; /* frees d_metas although d_buf is borrowed */
     uint64_t total_bases = 0;

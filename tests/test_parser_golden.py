@@ -23,11 +23,11 @@ def metas_matrix(metas) -> np.ndarray:
     return np.stack([metas[f].astype(np.int64) for f in FIELDS], axis=1) if len(metas) else np.zeros((0, 7), np.int64)
 
 
-def check_case(key: str, **parser_kwargs):
+def check_case(key: str, source=io.BytesIO, **parser_kwargs):
     from sequali_amd import FastqParser
     text = CASES[key.rsplit("_", 1)[0] + "_text"].tobytes()
     bs = int(CASES[key + "_buffersize"])
-    arrays = list(FastqParser(io.BytesIO(text), bs, **parser_kwargs))
+    arrays = list(FastqParser(source(text), bs, **parser_kwargs))
     assert [len(a) for a in arrays] == CASES[key + "_sizes"].tolist()
     assert [len(a.obj) for a in arrays] == CASES[key + "_objlens"].tolist()
     got = [metas_matrix(a._host_metas()) for a in arrays]
@@ -35,10 +35,10 @@ def check_case(key: str, **parser_kwargs):
     assert np.array_equal(got, CASES[key + "_metas"])
 
 
-def check_error(case, **parser_kwargs):
+def check_error(case, source=io.BytesIO, **parser_kwargs):
     from sequali_amd import FastqParser
     text = case["text"].encode("latin-1")
-    parser = FastqParser(io.BytesIO(text), case["buffersize"], **parser_kwargs)
+    parser = FastqParser(source(text), case["buffersize"], **parser_kwargs)
     if "error" not in case:
         assert [len(a) for a in parser] == case["sizes"]
         return
@@ -68,6 +68,58 @@ def test_device_split_matches_reference_chunking(key):
 @pytest.mark.parametrize("i", range(len(ERRORS)))
 def test_device_split_errors_match_reference(i):
     check_error(ERRORS[i], split_on_device=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", NAMES)
+def test_device_split_from_pinned_pages_matches_reference_chunking(key):
+    """the text in page-locked memory: every buffer but the first was sent ahead by the call before
+    (sq_batch_from_fastq_ahead) and is joined with its leftover inside the device"""
+    from sequali_amd import PinnedReader
+    check_case(key, source=PinnedReader, split_on_device=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(0, len(ERRORS), 3))
+def test_device_split_from_pinned_pages_errors_match_reference(i):
+    from sequali_amd import PinnedReader
+    check_error(ERRORS[i], source=PinnedReader, split_on_device=True)
+
+
+@pytest.mark.gpu
+def test_upload_ahead_through_the_c_abi():
+    """sq_batch_from_fastq_ahead: a buffer that contains what was sent ahead (leftover in front, more text
+    behind), one that does not (the bytes sent ahead are dropped), and the tables of the records"""
+    import ctypes as C
+    from sequali_amd import PinnedReader, QCMetrics, synth
+    from sequali_amd._lib import context, lib
+    from sequali_amd._qc import FastqRecordArrayView, _DeviceBatch
+    text, metas = synth.host_records(0, 0, 30_000)
+    pages = PinnedReader(text)
+    base, n = pages._address, len(text)
+    ends = [n // 4 + 7, n // 2 + 1, 3 * n // 4, n]     # four buffers; the split leaves a leftover in front of 2, 3 and 4
+    # sent ahead by call k: from in front of the next buffer (its leftover included) to the middle of it /
+    # from behind the leftover to beyond the end of the next buffer / nothing
+    ahead = [(base + ends[0] - 5000, 5000 + (ends[1] - ends[0]) // 2), (base + ends[1], n - ends[1]), (None, 0), (None, 0)]
+    consumed = C.c_size_t(0)
+    got, start = QCMetrics(), 0
+    for k in range(4):
+        h = lib().sq_batch_from_fastq_ahead(context(), base + start, ends[k] - start, C.byref(consumed), *ahead[k])
+        assert h
+        got.add_record_array(FastqRecordArrayView._from_device(_DeviceBatch(h)))
+        start += consumed.value
+    assert start == n
+    # sent ahead but never asked for: the next call takes its whole text from the host
+    h = lib().sq_batch_from_fastq_ahead(context(), base, n // 4, C.byref(consumed), base + n // 2, 1000)
+    assert h
+    first = _DeviceBatch(h)
+    h = lib().sq_batch_from_fastq(context(), base, n // 4, C.byref(consumed))
+    assert _DeviceBatch(h).number_of_records == first.number_of_records
+    want = QCMetrics()
+    want.add_record_array(FastqRecordArrayView._from_buffer(text, metas))
+    assert got.number_of_reads == 30_000
+    assert got.base_count_table() == want.base_count_table()
+    assert got.phred_count_table() == want.phred_count_table()
 
 
 @pytest.mark.gpu
