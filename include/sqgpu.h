@@ -228,6 +228,12 @@ int64_t sq_adapter_automaton_tables(const char *const *adapters, const size_t *l
                                     uint16_t *dfa, uint64_t *out, size_t cap, uint32_t *accept_first,
                                     uint16_t *dfa2, uint64_t *out2, size_t cap2, uint32_t *states2);
 
+/* Test hook (host only): thresholds[k] = the largest average error rate whose phred_scores bin
+ * (floor(-10 log10(avg)), _qcmodule.c:2127-2136, host libm) is >= k, and what k_span compares the SUM of a
+ * read's error rates with instead of dividing it by the length (1..256): sums[k] = the largest double S with
+ * S / length <= thresholds[k] in IEEE double division.  94 entries each. */
+void sq_phred_sum_thresholds(uint32_t length, double *thresholds, double *sums);
+
 /* AdapterCounter__new__ :2464: n ASCII adapters, each at most 64 bytes. */
 sq_adaptercounter *sq_adaptercounter_new(sq_ctx *ctx, const char *const *adapters,
                                          const size_t *lengths, size_t n);

@@ -29,6 +29,7 @@ struct PassParams {
     uint32_t ea_in_lds;
     uint32_t uniform_len;     /* != 0: every record of the batch has this length (<= lds_len) */
     const double *thresholds; /* [94], see phred_thresholds() */
+    const double *thr_sum;    /* [257][96]: row U = the same thresholds for the SUM of the error rates of a read of U bases (phred_sum_thresholds()) */
     unsigned long long *qc_first_bad;
     /* AdapterCounter */
     const uint16_t *dfa;      /* [states][8] */

@@ -2170,6 +2170,38 @@ const double *phred_thresholds()
     return thr;
 }
 
+/* k_span bins a read by the SUM of its error rates (no f64 division per read): row U of this table holds,
+ * for every k, the largest double S with fl(S / U) <= thr[k] -- x -> fl(x / U) does not fall when x grows, so
+ * total <= S says exactly what total / U <= thr[k] says (NaN: neither).  [257][96], entries 94, 95 of a row 0. */
+const double *phred_sum_thresholds()
+{
+    static std::vector<double> t;
+    if (!t.empty()) return t.data();
+    const double *thr = phred_thresholds();
+    t.assign(257 * 96, 0.0);
+    for (int U = 1; U <= 256; U++) {
+        double *row = &t[(size_t)U * 96];
+        const double d = (double)U;
+        row[0] = INFINITY;
+        for (int k = 1; k < 94; k++) {
+            double c = thr[k] * d;
+            while (c / d > thr[k]) c = nextafter(c, 0.0);
+            for (;;) {
+                const double n = nextafter(c, INFINITY);
+                if (n / d <= thr[k]) c = n; else break;
+            }
+            row[k] = c;
+        }
+    }
+    return t.data();
+}
+
+SQ_EXPORT void sq_phred_sum_thresholds(uint32_t length, double *thresholds, double *sums)
+{
+    memcpy(thresholds, phred_thresholds(), 94 * sizeof(double));
+    if (length >= 1 && length <= 256) memcpy(sums, phred_sum_thresholds() + (size_t)length * 96, 94 * sizeof(double));
+}
+
 /* ---- processing order --------------------------------------------------------
  * The tables are sums over records, so the pass may visit the records in any
  * order.  Two orders pay: by length when a batch is ragged (a wave's 64 reads
@@ -2308,7 +2340,7 @@ struct sq_qcmetrics {
     unsigned long long *d_base = nullptr, *d_phred = nullptr;
     size_t cap_phred = 0;
     unsigned long long *d_ea_base = nullptr, *d_ea_phred = nullptr, *d_gc = nullptr, *d_ps = nullptr;
-    double *d_thr = nullptr;
+    double *d_thr = nullptr, *d_thr_sum = nullptr;
     unsigned long long *d_first_bad = nullptr;
     uint64_t records_seen = 0;
     /* batches since the last flush (by id: a freed batch's address may be handed out again) and
@@ -2377,6 +2409,8 @@ SQ_EXPORT sq_qcmetrics *sq_qcmetrics_new(sq_ctx *ctx, uint64_t end_anchor_length
     SQ_HIP_NULL(hipMalloc((void **)&m->d_gc, 101 * 8));
     SQ_HIP_NULL(hipMalloc((void **)&m->d_ps, 94 * 8));
     SQ_HIP_NULL(hipMalloc((void **)&m->d_thr, 94 * 8));
+    SQ_HIP_NULL(hipMalloc((void **)&m->d_thr_sum, 257 * 96 * 8));
+    SQ_HIP_NULL(hipMemcpyAsync(m->d_thr_sum, phred_sum_thresholds(), 257 * 96 * 8, hipMemcpyHostToDevice, ctx->stream));
     SQ_HIP_NULL(hipMalloc((void **)&m->d_first_bad, 8));
     SQ_HIP_NULL(hipMemsetAsync(m->d_ea_base, 0, ea * 5 * 8, ctx->stream));
     SQ_HIP_NULL(hipMemsetAsync(m->d_ea_phred, 0, ea * 12 * 8, ctx->stream));
@@ -2393,7 +2427,7 @@ SQ_EXPORT void sq_qcmetrics_free(sq_qcmetrics *m)
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
     for (void *p : {(void *)m->d_base, (void *)m->d_phred, (void *)m->d_ea_base, (void *)m->d_ea_phred,
-                    (void *)m->d_gc, (void *)m->d_ps, (void *)m->d_thr, (void *)m->d_first_bad})
+                    (void *)m->d_gc, (void *)m->d_ps, (void *)m->d_thr, (void *)m->d_thr_sum, (void *)m->d_first_bad})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -2896,6 +2930,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         P.ea_len = (uint32_t)m->end_anchor;
         P.ea_in_lds = m->end_anchor <= LDS_EA_MAX;
         P.thresholds = m->d_thr;
+        P.thr_sum = m->d_thr_sum;
         P.qc_first_bad = m->d_first_bad;
     }
     if (p) {
@@ -3317,7 +3352,7 @@ SQ_EXPORT int sq_qcmetrics_uncount_tail(sq_qcmetrics *m, sq_batch *b, uint64_t f
     PassParams P{};
     P.buf = b->d_buf; P.buf_len = b->buf_len; P.metas = b->d_metas; P.n = end;
     P.qc_base = m->d_base; P.qc_phred = m->d_phred; P.qc_ea_base = m->d_ea_base; P.qc_ea_phred = m->d_ea_phred;
-    P.qc_gc = m->d_gc; P.qc_ps = m->d_ps; P.ea_len = (uint32_t)m->end_anchor; P.thresholds = m->d_thr;
+    P.qc_gc = m->d_gc; P.qc_ps = m->d_ps; P.ea_len = (uint32_t)m->end_anchor; P.thresholds = m->d_thr; P.thr_sum = m->d_thr_sum;
     const uint64_t tail = end - first;
     hipLaunchKernelGGL(k_qc_uncount, dim3((unsigned)std::min<uint64_t>((tail + 255) / 256, 4096)), dim3(256), 0, ctx->stream, P, first);
     SQ_HIP(hipGetLastError());

@@ -217,6 +217,20 @@ __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves
    P.long_first).  The rows of a span may end inside the segment (the read's last one): what lies
    behind a row's end is turned into padding in LDS.  Nothing per read is done here (the f64
    chains, the bins, GC: k_read_sums) nor the end-anchored tables (k_long_ea). */
+/* round(gc * 100.0 / acgt) of _qcmodule.c:2058 (C round: halves away from zero) for 0 <= gc <= acgt <= 4096 in
+ * integers: the quotient is a multiple of 1 / (2 acgt) away from every half unless it IS one, far more than the
+ * rounding of the f64 division moves it, so floor((200 gc + acgt) / (2 acgt)) is the same number.  The
+ * division by a float reciprocal, corrected by the remainder. */
+__device__ __forceinline__ uint32_t gc_percent(uint32_t gc, uint32_t acgt)
+{
+    const uint32_t n = 200u * gc + acgt, d = 2u * acgt;
+    uint32_t q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int32_t r = (int32_t)(n - q * d);
+    if (r < 0) { q--; r += (int32_t)d; }
+    if (r >= (int32_t)d) q++;
+    return q;
+}
+
 template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false>
 __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_span(PassParams P, uint32_t n_ad)
 {
@@ -275,7 +289,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
     }
     /* SEG: filler rows hold quality 0x80, which goes to a row of its own (a real 0x80 too: the merge tells them apart) */
     for (int i = tid; i < 256; i += T) l_bin[i] = (uint16_t)((SEG && i == 0x80 ? PHRED_COLS : min((uint32_t)i - 33u, 47u) >> 2) * hs * 4);
-    for (int i = tid; i < 96; i += T) l_thr[i] = i < 94 ? P.thresholds[i] : 0.0;
+    /* thresholds for the SUM of a read's error rates (phred_sum_thresholds(), sq_qc.hip): row U of the table */
+    if constexpr (!SEG) for (int i = tid; i < 96; i += T) l_thr[i] = P.thr_sum[U * 96 + i];
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
@@ -775,7 +790,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         if (!LONG && c == 0 && q < nv) {
             if constexpr (DS) {
                 const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
-                if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
+                if (acgt_cnt > 0) atomicAdd(&l_gc[gc_percent(gc_cnt, acgt_cnt)], 1u);
             }
             if constexpr (DQ) {
                 {   /* :2126; a store hipcc does not count either */
@@ -783,23 +798,25 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
                     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(total) : "memory");
                 }
                 if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
-                /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i).  A float
-                   logarithm names a candidate, the three thresholds around it (one round trip to LDS)
-                   decide; the bisection of the other kernels only when they do not (NaN: bin 0) */
-                const double avg = total / (double)U;
-                const int guess = (int)floorf(-10.0f * log10f((float)avg));
+                /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i), avg = total / U.
+                   l_thr holds the thresholds of the SUM for this U (total <= l_thr[i] exactly when total / U
+                   <= thresholds[i]: no f64 division).  A hardware log2 names a candidate, the three thresholds
+                   around it (one round trip to LDS) decide; the bisection of the other kernels only when
+                   they do not (NaN: bin 0) */
+                const float lg = __builtin_amdgcn_logf((float)total) - __builtin_amdgcn_logf((float)U);   /* log2 of the average */
+                const int guess = (int)floorf(-3.0103f * lg);
                 const uint32_t b0 = (uint32_t)min(max(guess, 1), 92);
                 const double t_lo = l_thr[b0 - 1], t_mid = l_thr[b0], t_hi = l_thr[b0 + 1];
                 uint32_t lo;
-                if (avg <= t_lo && !(avg <= t_mid)) lo = b0 - 1;
-                else if (avg <= t_mid && !(avg <= t_hi)) lo = b0;
-                else if (avg <= t_hi && (b0 + 1 == 93 || !(avg <= l_thr[b0 + 2]))) lo = b0 + 1;
+                if (total <= t_lo && !(total <= t_mid)) lo = b0 - 1;
+                else if (total <= t_mid && !(total <= t_hi)) lo = b0;
+                else if (total <= t_hi && (b0 + 1 == 93 || !(total <= l_thr[b0 + 2]))) lo = b0 + 1;
                 else {
                     uint32_t hi = 93;
                     lo = 0;
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi + 1) >> 1;
-                        if (avg <= l_thr[mid]) lo = mid; else hi = mid - 1;
+                        if (total <= l_thr[mid]) lo = mid; else hi = mid - 1;
                     }
                 }
                 atomicAdd(&l_ps[lo], 1u);
@@ -862,6 +879,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         seg_first = g.first;
         seg_span0 = g.span0;
         if constexpr (LONG) pos_base = g.pos_base;
+        if constexpr (!LONG) {   /* the bins of the per-read average: thresholds of this length (everybody is behind the barrier of the stretch before) */
+            for (int i = tid; i < 96; i += T) l_thr[i] = P.thr_sum[U * 96 + i];
+            __syncthreads();
+        }
         if (s_last >= c_lo && s_last < s_end) fill = SPAN_R - last_rows;
         if constexpr (SPLIT) role = (uint32_t)wave & 1;
     }

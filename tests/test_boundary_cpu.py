@@ -352,3 +352,29 @@ def test_pinned_reader_is_a_file_object():
     assert r.read() == text[16:] and r.read(3) == b"" and r.readinto(bytearray(4)) == 0
     arrays = list(FastqParser(PinnedReader(text), 300))        # through the host parser like any file
     assert sum(len(a) for a in arrays) == 1000 and arrays[0][0].name() == "r0"
+
+
+def test_sum_thresholds_say_what_the_division_says():
+    """k_span compares a read's SUM of error rates with sums[k] instead of sum / length with thresholds[k]
+    (DESIGN 4.1b): sums[k] must be the largest double whose quotient is still <= thresholds[k], for every length"""
+    import ctypes as C
+    import math
+    import numpy as np
+    from sequali_amd._lib import lib
+    thr = (C.c_double * 94)()
+    sums = (C.c_double * 94)()
+    for length in list(range(1, 257)):
+        lib().sq_phred_sum_thresholds(length, thr, sums)
+        t, s = np.array(thr[:]), np.array(sums[:])
+        assert math.isinf(t[0]) and math.isinf(s[0])
+        d = np.float64(length)
+        assert np.all(s[1:] / d <= t[1:]), length
+        assert np.all(np.nextafter(s[1:], np.inf) / d > t[1:]), length
+        assert np.all(np.diff(s[1:]) < 0)          # falls with k like the thresholds
+    # the bins of sums around every threshold, by the reference's formula (floor(-10 log10(avg)), :2127-2136)
+    lib().sq_phred_sum_thresholds(150, thr, sums)
+    for k in range(1, 94):
+        for x in (sums[k], float(np.nextafter(sums[k], np.inf))):
+            want = int(math.floor(-10.0 * math.log10(x / 150.0)))
+            got = max(i for i in range(94) if x <= sums[i])
+            assert got == min(want, 93), (k, x)
