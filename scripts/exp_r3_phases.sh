@@ -14,7 +14,7 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o sequali_amd/libsqgpu.so sequali_amd
 B="python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-other-configs"
 for sp in 0 1; do
   echo "== split $sp"
-  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B 2>&1 | grep -A1 "k_span stamps" | tail -2
+  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B 2>&1 | grep -A1 "stamps per span" | tail -2
   echo "== split $sp, QCMetrics alone"
-  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B --modules qc 2>&1 | grep -A1 "k_span stamps" | tail -2
+  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B --modules qc 2>&1 | grep -A1 "stamps per span" | tail -2
 done | tee $OUT/summary.txt

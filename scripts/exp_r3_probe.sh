@@ -36,5 +36,5 @@ for sp in 0 1; do
     SQ_SPAN_SPLIT=$sp SQ_SPAN_PROBE=$m $B 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('split $sp probe $m (1: no DMA, 2: no counting, 3: neither, 4: DMA into a slot nobody reads, 8: bases not counted, 16: qualities not counted): %.3f ms per launch' % d['roofline']['avg_launch_ms'])"
   done
-  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B --steps 1 --warmup 0 2>&1 | grep "k_span stamps" | tail -1
+  SQ_SPAN_SPLIT=$sp SQ_SPAN_STAMPS=1 $B --steps 1 --warmup 0 2>&1 | grep "stamps per span" | tail -1
 done | tee $OUT/summary.txt

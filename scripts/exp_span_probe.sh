@@ -16,4 +16,4 @@ for m in 0 1 2 3 4; do
   SQ_SPAN=1 SQ_SPAN_PROBE=$m python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-configs 2>/dev/null | tail -1 | \
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('probe $m (1: no DMA, 2: no counting, 3: neither, 4: DMA into a slot nobody reads + counting on stale slots): %.3f ms per launch' % d['roofline']['avg_launch_ms'])"
 done | tee $OUT/summary.txt
-SQ_SPAN=1 SQ_SPAN_STAMPS=1 python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-other-configs 2>&1 | grep "k_span stamps" | tail -2 | tee -a $OUT/summary.txt
+SQ_SPAN=1 SQ_SPAN_STAMPS=1 python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-other-configs 2>&1 | grep "stamps per span" | tail -2 | tee -a $OUT/summary.txt

@@ -193,6 +193,8 @@ __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves
 #define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
 /* phases inside a span: cycles since the stamp before go to ph[5 * (quality role) + k] */
 #define SPAN_PHASE(k) do { SPAN_STAMP(tq_); ph[(DS ? 0 : 5) + (k)] += tq_ - tp; tp = tq_; } while (0)
+#elif defined(SQ_SPAN_MARK)   /* comments in the ISA listing (hipcc -S): instructions per phase can be counted */
+#define SPAN_PHASE(k) do { asm volatile("; SPAN_PHASE " #k ::: "memory"); } while (0)
 #else
 #define SPAN_PHASE(k) do { } while (0)
 #endif
@@ -1690,6 +1692,27 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     return SQ_OK;
 }
 
+/* probe builds (-DSQ_SPAN_PROBE, SQ_SPAN_STAMPS=1): what the launch just issued spent per span and wave */
+static void span_print_stamps(sq_ctx *ctx, int nw)
+{
+#ifdef SQ_SPAN_PROBE
+    if (!sq_knobs().span_stamps) return;
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
+    const double all = (double)(h[3] + h[5]);
+    fprintf(stderr, "k_span<%d> stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
+            nw, (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+    fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
+            h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
+            h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
+#else
+    (void)ctx; (void)nw;
+#endif
+}
+
 /* Runs k_span over the first 16 * (n / 16) records of the pass described by P (QCMetrics, with
  * AdapterCounter when `ad`).  *done = records covered, 0 when the kernel does not take this
  * pass (read length, automaton size, LDS). */
@@ -1711,21 +1734,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
     int rc = split ? launch_any<false, true>(nw, ctx, C, ad, n_ad, waves, lds, grid) : launch_any<false, false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
-#ifdef SQ_SPAN_PROBE
-    if (sq_knobs().span_stamps) {
-        unsigned long long h[16];
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
-        const double all = (double)(h[3] + h[5]);
-        fprintf(stderr, "k_span stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
-                (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
-        fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
-                h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
-                h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
-    }
-#endif
+    span_print_stamps(ctx, nw);
     *done = C.n;
     return SQ_OK;
 }
@@ -1808,6 +1817,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
         int rc = split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
         if (rc) return rc;
+        span_print_stamps(ctx, l.nw);
         seg_off += l.segs.size();
     }
     *done = n;
