@@ -492,20 +492,28 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
             uint32_t raw[2 * NW];
 #pragma unroll
             for (int t = 0; t < 2 * NW; t++) raw[t] = lds_u32(cb + 16 * t);
+            /* LONG: every row has an end of its own, but the rows that end inside their segment are the
+               last ones of a stretch (the reads are sorted by length): most spans hold full rows only */
+            const bool ragged_rows = LONG && __builtin_amdgcn_ballot_w64(urow < U) != 0;
+            auto classes = [&](auto ragged_c) {
 #pragma unroll
-            for (int t = 0; t < 2 * NW; t++) {
-                uint32_t cl = cls6_of_dword(raw[t]);
-                if constexpr (LONG) {   /* every row has an end of its own */
-                    const uint32_t p0 = 16 * t + 4 * cv;
-                    cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
-                } else if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
-                    const uint32_t p0 = 16 * t + 4 * cv;
-                    cl = pad_tail(cl, p0 < Uv ? (int)min(4u, Uv - p0) : 0, CLS6_PAD4);
+                for (int t = 0; t < 2 * NW; t++) {
+                    uint32_t cl = cls6_of_dword(raw[t]);
+                    if constexpr (LONG) {
+                        if constexpr (decltype(ragged_c)::value) {
+                            const uint32_t p0 = 16 * t + 4 * cv;
+                            cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
+                        }
+                    } else if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
+                        const uint32_t p0 = 16 * t + 4 * cv;
+                        cl = pad_tail(cl, p0 < Uv ? (int)min(4u, Uv - p0) : 0, CLS6_PAD4);
+                    }
+                    lds_store_u32(cb + 16 * t, cl);
+                    gacc += cl & 0x04040404u;                 /* C, G and padding */
+                    nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
                 }
-                lds_store_u32(cb + 16 * t, cl);
-                gacc += cl & 0x04040404u;                 /* C, G and padding */
-                nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
-            }
+            };
+            if (ragged_rows) classes(std::true_type{}); else classes(std::false_type{});
             if constexpr (LONG && AD) {   /* the 12 bases in front of the segment: lanes 1 .. 3 of the quad, a dword each */
                 if (cv > 0) {
                     const uint32_t a = seq_row - 16 + 4 * cv;
@@ -965,6 +973,27 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
     for (uint32_t i = tid; i < 94; i += T)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+}
+
+/* probe builds (-DSQ_SPAN_PROBE, SQ_SPAN_STAMPS=1): what the launch just issued spent per span and wave */
+static void span_print_stamps(sq_ctx *ctx, int nw)
+{
+#ifdef SQ_SPAN_PROBE
+    if (!sq_knobs().span_stamps) return;
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
+    const double all = (double)(h[3] + h[5]);
+    fprintf(stderr, "k_span<%d> stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
+            nw, (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+    fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
+            h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
+            h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
+#else
+    (void)ctx; (void)nw;
+#endif
 }
 
 template <int NW, bool SEG, bool SPLIT>
@@ -1681,6 +1710,7 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : nw == 6 ? launch_long<6>(ctx, C, ad, n_ad, waves, lds, grid)
                                                                        : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
+    span_print_stamps(ctx, nw);
     hipLaunchKernelGGL(k_long_gc_bins, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->num_cus * 4)), dim3(256), 0, ctx->stream,
                        C.long_gc, n, P.qc_gc);
     if (P.ea_len)
@@ -1690,27 +1720,6 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     SQ_HIP(hipStreamSynchronize(ctx->stream));   /* the host vector of the segments goes out of scope */
     *done = n;
     return SQ_OK;
-}
-
-/* probe builds (-DSQ_SPAN_PROBE, SQ_SPAN_STAMPS=1): what the launch just issued spent per span and wave */
-static void span_print_stamps(sq_ctx *ctx, int nw)
-{
-#ifdef SQ_SPAN_PROBE
-    if (!sq_knobs().span_stamps) return;
-    unsigned long long h[16];
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
-    const double all = (double)(h[3] + h[5]);
-    fprintf(stderr, "k_span<%d> stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
-            nw, (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
-    fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
-            h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
-            h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
-#else
-    (void)ctx; (void)nw;
-#endif
 }
 
 /* Runs k_span over the first 16 * (n / 16) records of the pass described by P (QCMetrics, with
