@@ -310,24 +310,34 @@ def other_configs(lib, ctx, steps, warmup):
         return dt, arrays, ok
 
     first_dt, _, _ = e2e(lambda: io.BytesIO(text))       # first pass: page-locks its 64 MiB staging blocks (they go to a pool)
-    dt, arrays, ok = e2e(lambda: io.BytesIO(text))       # the reference's call pattern: default initial_buffersize
+    runs = [e2e(lambda: io.BytesIO(text)) for _ in range(3)]   # the reference's call pattern: default initial_buffersize
+    dt, arrays, ok = sorted(runs)[1]                     # host bound, ~0.1 s a pass: the median of three
+    ok = all(r[2] for r in runs)
     out["e2e_host_fastq_default_buffer"] = {
         "workload": f"{n} x 150 bp FASTQ text in host memory (io.BytesIO) through FastqParser at its default 128 KiB ({arrays} arrays, "
                     "~380 reads each), QCMetrics + AdapterCounter called once per array as __main__.py:279-306 does; the parser's buffer logic "
                     "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), one upload and one launch per block; file read, record "
                     "split, upload and counting included",
         "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
-        "first_pass_seconds": round(first_dt, 3),
+        "first_pass_seconds": round(first_dt, 3), "seconds_of_three_passes": [round(r[0], 3) for r in runs],
         "checks": {"base_table_sum_ok": ok}}
     big = dict(initial_buffersize=64 << 20, split_on_device=True)
-    e2e(lambda: PinnedReader(text), **big)
     reader = PinnedReader(text)                            # the text in page-locked memory, as a file object
-    dt, arrays, ok = e2e(lambda: reader, **big)
+
+    def rewound():
+        reader.seek(0)
+        return reader
+
+    e2e(rewound, **big)
+    runs = [e2e(rewound, **big) for _ in range(3)]
+    dt, arrays, ok = sorted(runs)[1]
+    ok = all(r[2] for r in runs)
     out["e2e_pinned_64MiB_device_split"] = {
         "workload": f"the same {n} reads as text in page-locked host memory (PinnedReader) through FastqParser(initial_buffersize=64 MiB, "
                     f"split_on_device=True): {arrays} arrays, uploaded from where they lie, records split on the GPU (k_split_*), "
                     "QCMetrics + AdapterCounter; upload, split and counting included",
         "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+        "seconds_of_three_passes": [round(r[0], 3) for r in runs],
         "checks": {"base_table_sum_ok": ok}}
     return out
 

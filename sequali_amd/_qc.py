@@ -747,6 +747,20 @@ class PinnedReader:
         n = self._skip(self._size - self._pos if n is None or n < 0 else n)
         return C.string_at(self._address + at, n)
 
+    def seek(self, offset: int, whence: int = 0) -> int:
+        base = {0: 0, 1: self._pos, 2: self._size}[whence]
+        self._pos = min(max(base + offset, 0), self._size)
+        return self._pos
+
+    def tell(self) -> int:
+        return self._pos
+
+    def readable(self) -> bool:
+        return True
+
+    def seekable(self) -> bool:
+        return True
+
 
 class _DeviceSplitArray(FastqRecordArrayView):
     """an array whose records were split on the device.  `obj` (the buffer the reference's array

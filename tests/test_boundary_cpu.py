@@ -350,6 +350,8 @@ def test_pinned_reader_is_a_file_object():
     buf = bytearray(11)
     assert r.readinto(buf) == 11 and bytes(buf) == text[5:16]
     assert r.read() == text[16:] and r.read(3) == b"" and r.readinto(bytearray(4)) == 0
+    assert r.tell() == len(text) and r.seek(7) == 7 and r.read(4) == text[7:11] and r.seek(-3, 2) == len(text) - 3
+    assert r.read() == text[-3:] and r.seek(0) == 0
     arrays = list(FastqParser(PinnedReader(text), 300))        # through the host parser like any file
     assert sum(len(a) for a in arrays) == 1000 and arrays[0][0].name() == "r0"
 
