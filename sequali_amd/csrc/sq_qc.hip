@@ -700,9 +700,12 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
         const uint64_t qoff = valid ? m.record_start + m.qualities_offset : 0;
         const uint32_t Lmain = L > 0 ? 4 * ((L - 1) / 4) : 0; /* :2062,2068 */
         const uint32_t maxL = wave_max_u32(L);
+        const uint32_t minLmain = ~wave_max_u32(valid ? ~Lmain : 0u);
         double acc = 0.0;                   /* chain c of this read */
         uint32_t gc_cnt = 0, acgt_cnt = 0;  /* this lane's share, :1997-2049 */
-        uint4 cs, cq, ns = make_uint4(0, 0, 0, 0), nq = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        /* a step = 128 bytes of every read of the wave: whole lines, each asked for once (64 bytes per step left
+           the second half of a line to the caches, which 24 waves x 16 reads per CU do not hold) */
+        uint4 cs[2], cq[2], ns[2], nq[2];
         auto load_piece = [&](uint32_t pos, uint4 &sv, uint4 &qv) {
             sv = make_uint4(0, 0, 0, 0);
             qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
@@ -711,38 +714,54 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
                 qv = load16(P.buf, qoff + pos, P.buf_len);
             }
         };
-        load_piece(16 * c, cs, cq);
-        for (uint32_t base = 0; base < maxL; base += 64) {
-            const uint32_t p0 = base + 16 * c;
-            if (base + 64 < maxL) load_piece(p0 + 64, ns, nq);
-            const uint32_t qw[4] = {cq.x, cq.y, cq.z, cq.w}, sw[4] = {cs.x, cs.y, cs.z, cs.w};
-            if constexpr (GC) {
+        load_piece(16 * c, cs[0], cq[0]);
+        load_piece(16 * c + 64, cs[1], cq[1]);
+        for (uint32_t base0 = 0; base0 < maxL; base0 += 128) {
+            if (base0 + 128 < maxL) {
+                load_piece(base0 + 128 + 16 * c, ns[0], nq[0]);
+                load_piece(base0 + 192 + 16 * c, ns[1], nq[1]);
+            }
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const uint32_t at = p0 + 4 * d;
-                    if (at < L) {
-                        const uint32_t sd = pad_tail(cls2_of_dword(sw[d]), (int)(L - at), CLS2_PAD4);
-                        gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
-                        acgt_cnt += __popc(~sd & 0x08080808u);
+            for (int half = 0; half < 2; half++) {
+                const uint32_t base = base0 + 64 * half, p0 = base + 16 * c;
+                const uint32_t qw[4] = {cq[half].x, cq[half].y, cq[half].z, cq[half].w};
+                if constexpr (GC) {
+                    const uint32_t sw[4] = {cs[half].x, cs[half].y, cs[half].z, cs[half].w};
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t at = p0 + 4 * d;
+                        if (at < L) {
+                            const uint32_t sd = pad_tail(cls2_of_dword(sw[d]), (int)(L - at), CLS2_PAD4);
+                            gc_cnt += __popc(((sd >> 1) ^ sd) & 0x02020202u);
+                            acgt_cnt += __popc(~sd & 0x08080808u);
+                        }
                     }
                 }
-            }
-            /* chain c: positions c, c + 4, ..., c + 60 of the step, in that order: byte c of the quad's 16
-               quality dwords (lane cc holds dwords 4 cc .. 4 cc + 3), handed round by DPP; positions behind
-               Lmain (a multiple of four, like a dword's first position) add +0.0: the chains stop there */
-            double e[16];
+                /* chain c: positions c, c + 4, ..., c + 60 of the 64, in that order: byte c of the quad's 16
+                   quality dwords (lane cc holds dwords 4 cc .. 4 cc + 3), handed round by DPP; positions behind
+                   Lmain (a multiple of four, like a dword's first position) add +0.0: the chains stop there */
+                double e[16];
+                if (base + 64 <= minLmain) {   /* no read of the wave ends here (sorted by length: all but the last step or two) */
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++)
+                    for (int cc = 0; cc < 4; cc++)
 #pragma unroll
-                for (int mm = 0; mm < 4; mm++) {
-                    const uint32_t w = quad_lane_u32(qw[mm], cc);
-                    const bool inside = base + 16 * cc + 4 * mm < Lmain;
-                    e[4 * cc + mm] = inside ? l_err[(w >> (8 * c)) & 0xFFu] : 0.0;
+                        for (int mm = 0; mm < 4; mm++)
+                            e[4 * cc + mm] = l_err[__builtin_amdgcn_ubfe(quad_lane_u32(qw[mm], cc), 8 * c, 8)];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                        for (int mm = 0; mm < 4; mm++) {
+                            const uint32_t w = quad_lane_u32(qw[mm], cc);
+                            const bool inside = base + 16 * cc + 4 * mm < Lmain;
+                            e[4 * cc + mm] = inside ? l_err[(w >> (8 * c)) & 0xFFu] : 0.0;
+                        }
                 }
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc += e[i];
-            cs = ns;
-            cq = nq;
+                for (int i = 0; i < 16; i++) acc += e[i];
+            }
+            cs[0] = ns[0]; cs[1] = ns[1];
+            cq[0] = nq[0]; cq[1] = nq[1];
         }
         /* the quad's four chains and counts */
         const double a0 = __shfl(acc, (lane & ~3) + 0), a1 = __shfl(acc, (lane & ~3) + 1);

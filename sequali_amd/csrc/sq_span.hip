@@ -1576,18 +1576,31 @@ __global__ void __launch_bounds__(256) k_long_ea(const uint8_t *buf, const sq_me
     extern __shared__ uint32_t l_ea[];   /* [5 + 12][ea_len] */
     for (uint32_t i = threadIdx.x; i < 17 * ea_len; i += blockDim.x) l_ea[i] = 0;
     __syncthreads();
-    const uint64_t items = n * ea_len;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < items; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i / ea_len;
-        const uint32_t e = (uint32_t)(i % ea_len);
-        const sq_meta m = metas[r];
-        const uint32_t L = m.sequence_length, ean = min(ea_len, L);   /* :1971-1972: right aligned */
-        if (e < ea_len - ean) continue;
-        const uint64_t p = (uint64_t)L - ea_len + e;
-        const uint32_t cls = sq_base_class(buf[m.record_start + m.sequence_offset + p]);
-        const uint32_t bin = min((uint32_t)buf[m.record_start + m.qualities_offset + p] - 33u, 47u) >> 2;
-        atomicAdd(&l_ea[cls * ea_len + e], 1u);
-        atomicAdd(&l_ea[(5 + bin) * ea_len + e], 1u);
+    /* 64 reads per wave and round: lane j fetches the meta of read j, then the wave walks the reads, a lane per slot
+       (round 3: an item per thread paid a 64-bit division and a dependent meta load per slot) */
+    const uint32_t lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    for (uint64_t r0 = ((uint64_t)blockIdx.x * waves + (threadIdx.x >> 6)) * 64; r0 < n; r0 += (uint64_t)gridDim.x * waves * 64) {
+        unsigned long long so = 0, qo = 0;   /* where slot 0 would lie (in front of the read when it is shorter than ea_len: never touched) */
+        uint32_t first = ea_len;
+        if (r0 + lane < n) {
+            const sq_meta m = metas[r0 + lane];
+            const uint32_t L = m.sequence_length;
+            first = ea_len - min(ea_len, L);   /* :1971-1972: right aligned */
+            so = m.record_start + m.sequence_offset + L - ea_len;
+            qo = m.record_start + m.qualities_offset + L - ea_len;
+        }
+        const uint32_t cnt = (uint32_t)min((uint64_t)64, n - r0);
+#pragma unroll 4
+        for (uint32_t j = 0; j < cnt; j++) {
+            const unsigned long long sj = __shfl(so, (int)j), qj = __shfl(qo, (int)j);
+            const uint32_t fj = __shfl(first, (int)j);
+            for (uint32_t e = fj + lane; e < ea_len; e += 64) {
+                const uint32_t cls = sq_base_class(buf[sj + e]);
+                const uint32_t bin = min((uint32_t)buf[qj + e] - 33u, 47u) >> 2;
+                atomicAdd(&l_ea[cls * ea_len + e], 1u);
+                atomicAdd(&l_ea[(5 + bin) * ea_len + e], 1u);
+            }
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 17 * ea_len; i += blockDim.x) {
@@ -1714,7 +1727,7 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     hipLaunchKernelGGL(k_long_gc_bins, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->num_cus * 4)), dim3(256), 0, ctx->stream,
                        C.long_gc, n, P.qc_gc);
     if (P.ea_len)
-        hipLaunchKernelGGL(k_long_ea, dim3((unsigned)std::min<uint64_t>((n * P.ea_len + 255) / 256, (uint64_t)ctx->num_cus * 8)), dim3(256),
+        hipLaunchKernelGGL(k_long_ea, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->num_cus * 8)), dim3(256),
                            (size_t)17 * P.ea_len * 4, ctx->stream, P.buf, P.metas, n, P.ea_len, P.qc_ea_base, P.qc_ea_phred);
     SQ_HIP(hipGetLastError());
     SQ_HIP(hipStreamSynchronize(ctx->stream));   /* the host vector of the segments goes out of scope */
