@@ -176,6 +176,10 @@ void sq_batch_free(sq_batch *b);
 uint64_t sq_batch_size(const sq_batch *b);
 uint64_t sq_batch_total_bases(const sq_batch *b);
 uint64_t sq_batch_max_length(const sq_batch *b);
+/* counts[L] = records of L bases for L < 256, counts[256] = records of 256 and more (257 entries): counted when
+ * the batch is made (with its number of bases and longest read); k_span over a batch of many read lengths puts
+ * its rows in order with them instead of sorting.  Returns 0 when the batch has none. */
+int sq_batch_length_counts(const sq_batch *b, uint32_t *counts);
 uint64_t sq_batch_bytes(const sq_batch *b);
 /* Device addresses of the batch's text and of its 40-byte metas (interop: torch, RCCL). */
 void *sq_batch_device_text(const sq_batch *b);

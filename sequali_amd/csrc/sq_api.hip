@@ -37,6 +37,7 @@ static void knobs_load()
     k.span_split = num("SQ_SPAN_SPLIT", 1) != 0;
     k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
+    k.span_radix = flag("SQ_SPAN_RADIX");
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);
     k.span_stamps = flag("SQ_SPAN_STAMPS");
@@ -86,6 +87,7 @@ SQ_EXPORT sq_ctx *sq_init(int device)
     SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     SQ_HIP_NULL(hipEventCreateWithFlags(&ctx->copied, hipEventDisableTiming));
     SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
+    SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned_stats, SQ_STATS_N * sizeof(uint64_t), hipHostMallocDefault));
     return ctx;
 }
 
@@ -100,6 +102,7 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copied) (void)hipEventDestroy(ctx->copied);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_stats) (void)hipHostFree(ctx->pinned_stats);
     for (void *p : ctx->scratch)
         if (p) (void)hipFree(p);
     if (ctx->ahead.dev) sq_dev_put(ctx, ctx->ahead.dev);
@@ -121,9 +124,9 @@ SQ_EXPORT void *sq_stream_handle(sq_ctx *ctx) { return (void *)ctx->stream; }
 size_t sq_scan_newlines(const uint8_t *p, size_t n, uint32_t base, uint32_t *out, size_t cap, size_t *scanned, uint32_t *high);   /* sq_hostsimd.cpp */
 int64_t sq_first_non_ascii_fast(const uint8_t *p, size_t n);
 int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii);
+                             uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii);
 static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                          uint64_t stats[5], size_t ascii_from, int64_t *first_high);
+                          uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *first_high);
 
 /* FastqParser_create_record_array, the record loop _qcmodule.c:1093-1171, over bytes
  * [start, end) of `base`; record_start is relative to `base`.  stats (may be NULL): bases,
@@ -132,7 +135,7 @@ static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_
  * positions of the range come from one vectorised scan (sq_scan_newlines), 1 K of them at a time,
  * and the record loop takes them as it needs them: same records, same errors in the same order. */
 int64_t sq_split_range(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                       uint64_t stats[5])
+                       uint64_t stats[SQ_STATS_N])
 {
     return sq_split_range_ascii(base, start, end_off, metas, cap, consumed, stats, (size_t)-1, nullptr);
 }
@@ -144,7 +147,7 @@ int64_t sq_split_range(const uint8_t *base, size_t start, size_t end_off, sq_met
  * are looked at separately.  When *non_ascii >= 0 the return value and the metas are to be
  * ignored: the reference raises before it parses. */
 int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii)
+                             uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii)
 {
     int64_t first_high = -1;
     const int64_t n = split_core(base, start, end_off, metas, cap, consumed, stats, ascii_from, &first_high);
@@ -153,7 +156,7 @@ int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, 
 }
 
 static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                          uint64_t stats[5], size_t ascii_from, int64_t *first_high)
+                          uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *first_high)
 {
     const uint8_t *end = base + end_off;
     const uint8_t *rec = base + start;
@@ -254,6 +257,7 @@ static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_
             if (m->name_length > stats[2]) stats[2] = m->name_length;
             if (span > stats[3]) stats[3] = span;
             if (~L > stats[4]) stats[4] = ~L;
+            stats[5 + (L < SQ_LEN_BINS - 1 ? L : SQ_LEN_BINS - 1)]++;
         }
         rec = qual_end + 1;
     }
@@ -304,6 +308,9 @@ SQ_EXPORT int sq_names_are_mates(const uint8_t *buf1, const sq_meta *metas1, con
  * [4] ~min length (kept as a max so that one memset(0) initialises all) */
 __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long *out)
 {
+    __shared__ uint32_t l_len[SQ_LEN_BINS];   /* reads per length (out[5 ..]) */
+    for (int i = threadIdx.x; i < SQ_LEN_BINS; i += blockDim.x) l_len[i] = 0;
+    __syncthreads();
     unsigned long long bases = 0, maxlen = 0, maxname = 0, maxspan = 0, minlen_inv = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -315,6 +322,7 @@ __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long
         if (span > maxspan) maxspan = span;
         unsigned long long inv = ~(unsigned long long)m.sequence_length;
         if (inv > minlen_inv) minlen_inv = inv;
+        atomicAdd(&l_len[m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1], 1u);
     }
     for (int off = 32; off > 0; off >>= 1) {
         bases += __shfl_down(bases, off);
@@ -347,6 +355,33 @@ __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long
         atomicMax(&out[3], maxspan);
         atomicMax(&out[4], minlen_inv);
     }
+    for (int i = threadIdx.x; i < SQ_LEN_BINS; i += blockDim.x)
+        if (l_len[i]) atomicAdd(&out[5 + i], (unsigned long long)l_len[i]);
+}
+
+/* k_batch_stats over a batch's metas, queued on the context's stream; stats_take() behind the next
+ * synchronisation of that stream puts the numbers into the batch */
+static int stats_issue(sq_ctx *ctx, const sq_meta *d_metas, size_t n)
+{
+    unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 21, SQ_STATS_N * 8);
+    if (!d_out) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemsetAsync(d_out, 0, SQ_STATS_N * 8, ctx->stream));
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_batch_stats, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, d_metas, n, d_out);
+    SQ_HIP(hipMemcpyAsync(ctx->pinned_stats, d_out, SQ_STATS_N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return SQ_OK;
+}
+
+static void stats_take(sq_ctx *ctx, sq_batch *b)
+{
+    const uint64_t *h = ctx->pinned_stats;
+    b->total_bases = h[0];
+    b->max_length = h[1];
+    b->max_name_length = h[2];
+    b->max_record_span = h[3];
+    b->min_length = ~h[4];
+    b->len_hist.resize(SQ_LEN_BINS);
+    for (int i = 0; i < SQ_LEN_BINS; i++) b->len_hist[i] = (uint32_t)h[5 + i];
 }
 
 SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_len,
@@ -357,6 +392,7 @@ SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_
     b->buf_len = buf_len;
     b->n = n;
     b->owns = true;
+    b->len_hist.assign(SQ_LEN_BINS, 0);
     for (size_t i = 0; i < n; i++) {
         const sq_meta &m = metas[i];
         uint64_t span = (uint64_t)m.qualities_offset + m.sequence_length;
@@ -368,6 +404,7 @@ SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_
             return nullptr;
         }
         b->total_bases += m.sequence_length;
+        b->len_hist[m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1]++;
         if (m.sequence_length > b->max_length) b->max_length = m.sequence_length;
         if (i == 0 || m.sequence_length < b->min_length) b->min_length = m.sequence_length;
         if (m.name_length > b->max_name_length) b->max_name_length = m.name_length;
@@ -400,20 +437,9 @@ SQ_EXPORT sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t 
     b->n = n;
     b->owns = false;
     if (n) {
-        unsigned long long *d_out = nullptr;
-        SQ_HIP_NULL(hipMalloc((void **)&d_out, 8 * sizeof(unsigned long long)));
-        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 8 * sizeof(unsigned long long), ctx->stream));
-        int blocks = (int)((n + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_batch_stats, dim3(blocks), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
-        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+        if (stats_issue(ctx, b->d_metas, n) != SQ_OK) { delete b; return nullptr; }
         SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_out);
-        b->total_bases = ctx->pinned[0];
-        b->max_length = ctx->pinned[1];
-        b->max_name_length = ctx->pinned[2];
-        b->max_record_span = ctx->pinned[3];
-        b->min_length = ~ctx->pinned[4];
+        stats_take(ctx, b);
     }
     return b;
 }
@@ -625,23 +651,14 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
         const int blocks = (int)((n_records + 255) / 256 > 65535 ? 65535 : (n_records + 255) / 256);
         hipLaunchKernelGGL(k_split_metas, dim3(blocks), dim3(256), 0, ctx->stream, d_text, d_nl, n_records,
                            b->d_metas, d_flags + 1);
-        unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 5, 64);
-        if (!d_out) { sq_set_error("sq_batch_from_fastq: out of device memory"); return fail(b); }
-        (void)hipMemsetAsync(d_out, 0, 64, ctx->stream);
-        const int sb = (int)((n_records + 255) / 256 > 4096 ? 4096 : (n_records + 255) / 256);
-        hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, (size_t)n_records, d_out);
-        (void)hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream);
+        if (stats_issue(ctx, b->d_metas, (size_t)n_records) != SQ_OK) return fail(b);
         (void)hipMemcpyAsync(&ctx->pinned[42], d_flags + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
         (void)hipMemcpyAsync(&ctx->pinned[43], d_nl + 4 * n_records - 1, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
             sq_set_error("FASTQ split failed on the device");
             return fail(b);
         }
-        b->total_bases = ctx->pinned[0];
-        b->max_length = ctx->pinned[1];
-        b->max_name_length = ctx->pinned[2];
-        b->max_record_span = ctx->pinned[3];
-        b->min_length = ~ctx->pinned[4];
+        stats_take(ctx, b);
         tail_start = ctx->pinned[43] + 1;
         const unsigned long long bad = ctx->pinned[42];
         if (bad != ~0ULL) {
@@ -944,18 +961,9 @@ SQ_EXPORT sq_batch *sq_batch_from_bam(sq_ctx *ctx, const uint8_t *bam, size_t le
     const int wblocks = (int)std::min<uint64_t>((n + 3) / 4, 16384);
     hipLaunchKernelGGL(k_bam_decode, dim3(wblocks), dim3(256), 0, ctx->stream, d_bam, d_off, d_starts, (uint64_t)n,
                        b->d_buf, b->d_metas);
-    unsigned long long *d_out = (unsigned long long *)sq_scratch(ctx, 5, 64);
-    if (!d_out) return fail("out of device memory");
-    (void)hipMemsetAsync(d_out, 0, 64, ctx->stream);
-    const int sb = (int)std::min<uint64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, (size_t)n, d_out);
-    (void)hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream);
+    if (stats_issue(ctx, b->d_metas, (size_t)n) != SQ_OK) return fail("out of device memory");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("BAM decode failed on the device");
-    b->total_bases = ctx->pinned[0];
-    b->max_length = ctx->pinned[1];
-    b->max_name_length = ctx->pinned[2];
-    b->max_record_span = ctx->pinned[3];
-    b->min_length = ~ctx->pinned[4];
+    stats_take(ctx, b);
     (void)hipFree(d_bam); (void)hipFree(d_off); (void)hipFree(d_sizes); (void)hipFree(d_starts); (void)hipFree(d_temp);
     return b;
 }
@@ -976,6 +984,12 @@ SQ_EXPORT void sq_batch_free(sq_batch *b)
 
 SQ_EXPORT uint64_t sq_batch_size(const sq_batch *b) { return b->n; }
 SQ_EXPORT uint64_t sq_batch_total_bases(const sq_batch *b) { return b->total_bases; }
+SQ_EXPORT int sq_batch_length_counts(const sq_batch *b, uint32_t *counts)
+{
+    if (b->len_hist.size() != SQ_LEN_BINS) return 0;
+    memcpy(counts, b->len_hist.data(), SQ_LEN_BINS * sizeof(uint32_t));
+    return 1;
+}
 SQ_EXPORT uint64_t sq_batch_max_length(const sq_batch *b) { return b->max_length; }
 
 SQ_EXPORT uint64_t sq_batch_bytes(const sq_batch *b) { return b->buf_len; }
@@ -1149,20 +1163,9 @@ SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64
         unsigned blocks = (unsigned)((waves + 3) / 4);
         hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, ctx->stream, kind, seed, first,
                            n, d_offs, fixed, b->d_buf, b->d_metas);
-        unsigned long long *d_out = nullptr;
-        SQ_HIP_NULL(hipMalloc((void **)&d_out, 64));
-        SQ_HIP_NULL(hipMemsetAsync(d_out, 0, 64, ctx->stream));
-        int sb = (int)((n + 255) / 256);
-        if (sb > 4096) sb = 4096;
-        hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, n, d_out);
-        SQ_HIP_NULL(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+        if (stats_issue(ctx, b->d_metas, n) != SQ_OK) return nullptr;
         SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_out);
-        b->total_bases = ctx->pinned[0];
-        b->max_length = ctx->pinned[1];
-        b->max_name_length = ctx->pinned[2];
-        b->max_record_span = ctx->pinned[3];
-        b->min_length = ~ctx->pinned[4];
+        stats_take(ctx, b);
     }
     if (d_offs) (void)hipFree(d_offs);
     return b;
@@ -1187,20 +1190,10 @@ SQ_EXPORT int sq_synth_trim(sq_batch *b, uint64_t seed, uint32_t lo)
     sq_ctx *ctx = b->ctx;
     hipLaunchKernelGGL(k_synth_trim, dim3((unsigned)std::min<uint64_t>((b->n + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
                        b->d_metas, (uint64_t)b->n, seed, lo);
-    unsigned long long *d_out = nullptr;
-    SQ_HIP(hipMalloc((void **)&d_out, 64));
-    SQ_HIP(hipMemsetAsync(d_out, 0, 64, ctx->stream));
-    int sb = (int)((b->n + 255) / 256);
-    if (sb > 4096) sb = 4096;
-    hipLaunchKernelGGL(k_batch_stats, dim3(sb), dim3(256), 0, ctx->stream, b->d_metas, b->n, d_out);
-    SQ_HIP(hipMemcpyAsync(ctx->pinned, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = stats_issue(ctx, b->d_metas, b->n);
+    if (rc != SQ_OK) return rc;
     SQ_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_out);
-    b->total_bases = ctx->pinned[0];
-    b->max_length = ctx->pinned[1];
-    b->max_name_length = ctx->pinned[2];
-    b->max_record_span = ctx->pinned[3];
-    b->min_length = ~ctx->pinned[4];
+    stats_take(ctx, b);
     b->h_metas.clear(); /* the host copy, if any, no longer describes the batch */
     b->h_buf.clear();
     return SQ_OK;

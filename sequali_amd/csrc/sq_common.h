@@ -53,6 +53,7 @@ void sq_set_error(const char *fmt, ...);
 struct SqKnobs {
     bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */
     bool span_stamps = false;
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
     bool no_wide = false, ring = false, no_ring = false, no_split = false;
@@ -72,6 +73,7 @@ struct sq_ctx {
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */
+    uint64_t *pinned_stats = nullptr; /* SQ_STATS_N words: k_batch_stats' read-back */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
     void *scratch[24] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split */
@@ -149,6 +151,12 @@ inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)
     return ctx->scratch[i];
 }
 
+/* what is known of a batch's records without reading them again: bases, longest read, longest name, longest
+ * record span, ~(shortest read), then how many reads have 0, 1, ..., 255 and 256 or more bases (k_span over a
+ * batch of many lengths puts its rows in order with these counts instead of sorting keys) */
+constexpr int SQ_LEN_BINS = 257;
+constexpr int SQ_STATS_N = 5 + SQ_LEN_BINS;
+
 inline uint64_t sq_next_batch_id() { static uint64_t next = 0; return ++next; }   /* objects are used from one thread (sqgpu.h) */
 
 struct sq_batch {
@@ -161,6 +169,7 @@ struct sq_batch {
     bool pooled = false;     /* d_buf and d_metas are blocks of the context's pool (sq_dev_get) */
     bool owns = false;       /* frees d_buf (and d_metas) */
     bool owns_metas = false; /* frees d_metas although d_buf is borrowed */
+    std::vector<uint32_t> len_hist;   /* [SQ_LEN_BINS] reads per length (the last bin: 256 and more); empty: not counted */
     uint64_t total_bases = 0;
     uint64_t max_length = 0;
     uint64_t min_length = 0;

@@ -27,7 +27,7 @@
 #include "sq_common.h"
 
 int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end, sq_meta *metas, size_t cap, size_t *consumed,
-                             uint64_t stats[5], size_t ascii_from, int64_t *non_ascii);
+                             uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii);
 
 namespace {
 
@@ -72,7 +72,7 @@ struct FeedBlock {
     bool sealed = false;
     hipEvent_t copied = nullptr;   /* the upload of the block has left pinned memory */
     bool in_flight = false;
-    uint64_t stats[5] = {0, 0, 0, 0, 0};   /* bases, longest read, longest name, longest record span, ~(shortest read) */
+    uint64_t stats[SQ_STATS_N] = {};   /* bases, longest read, longest name, longest record span, ~(shortest read) */
     uint8_t *pin() const { return (uint8_t *)text.p; }
     sq_meta *metas() const { return (sq_meta *)meta.p; }
 };
@@ -283,7 +283,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         b->n_records = f->arr_first_record;
         size_t consumed = 0;
         int64_t n;
-        uint64_t stats[5];
+        uint64_t stats[SQ_STATS_N];
         for (;;) {
             const size_t cap = std::min(b->meta_cap - b->n_records, max_records);
             memcpy(stats, b->stats, sizeof stats);
@@ -390,6 +390,8 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     b->max_name_length = fb->stats[2];
     b->max_record_span = fb->stats[3];
     b->min_length = fb->n_records ? ~fb->stats[4] : 0;
+    b->len_hist.resize(SQ_LEN_BINS);
+    for (int i = 0; i < SQ_LEN_BINS; i++) b->len_hist[i] = (uint32_t)fb->stats[5 + i];
     if (hipMalloc((void **)&b->d_buf, b->buf_len + 64) != hipSuccess ||
         hipMalloc((void **)&b->d_metas, (b->n ? b->n : 1) * sizeof(sq_meta)) != hipSuccess) {
         sq_set_error("sq_feeder_upload: out of device memory");

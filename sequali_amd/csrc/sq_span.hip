@@ -1099,6 +1099,44 @@ __global__ void k_span_keys(const sq_meta *metas, uint64_t n, uint32_t max_len, 
         rows[i] = r;
     }
 }
+/* The rows of a batch in order of length (longest first) without a sort: how many reads have each length is
+ * known since the batch was made (sq_batch::len_hist), so where the rows of a length start is too (start[L]).  A
+ * workgroup takes 8 K records at a time: ranks them by length in LDS, reserves its share of every length's rows
+ * with one atomic per length, and writes its rows there.  The order inside a length is whatever the atomics make
+ * it: every table is a sum over reads. */
+constexpr int SCATTER_THREADS = 512, SCATTER_PER = 16;
+__global__ void __launch_bounds__(SCATTER_THREADS) k_span_scatter(const sq_meta *metas, uint64_t n, const uint32_t *start, uint32_t *cursor, SpanRow *rows)
+{
+    __shared__ uint32_t l_cnt[SQ_LEN_BINS], l_base[SQ_LEN_BINS];
+    const uint64_t chunk = (uint64_t)SCATTER_THREADS * SCATTER_PER;
+    for (uint64_t c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk) {
+        for (int i = threadIdx.x; i < SQ_LEN_BINS; i += SCATTER_THREADS) l_cnt[i] = 0;
+        __syncthreads();
+        uint32_t len[SCATTER_PER], rank[SCATTER_PER];
+        SpanRow r[SCATTER_PER];
+#pragma unroll
+        for (int k = 0; k < SCATTER_PER; k++) {
+            const uint64_t i = c0 + (uint64_t)k * SCATTER_THREADS + threadIdx.x;
+            len[k] = 0xFFFFFFFFu;
+            if (i < n) {
+                const sq_meta m = metas[i];
+                len[k] = m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1;
+                r[k].seq = m.record_start + m.sequence_offset;
+                r[k].qual_delta = m.qualities_offset - m.sequence_offset;
+                r[k].record = (uint32_t)i;
+                rank[k] = atomicAdd(&l_cnt[len[k]], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SQ_LEN_BINS; i += SCATTER_THREADS)
+            if (l_cnt[i]) l_base[i] = start[i] + atomicAdd(&cursor[i], l_cnt[i]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCATTER_PER; k++)
+            if (len[k] != 0xFFFFFFFFu) rows[l_base[len[k]] + rank[k]] = r[k];
+        __syncthreads();
+    }
+}
 /* keys sorted ascending: longer[w] = how many reads are longer than w (w = 0 .. max_len) */
 __global__ void k_span_longer(const uint32_t *keys, uint64_t n, uint32_t max_len, unsigned long long *longer)
 {
@@ -1767,7 +1805,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
  * and the reads of the lengths that share a window count go through one launch of
  * k_span<NW, ., SEG>, cut into spans of 16 reads of one length.  *done = records covered: all of
  * them or none. */
-int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done)
+int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, const uint32_t *len_hist, uint64_t *done)
 {
     *done = 0;
     const uint64_t n = P.n;
@@ -1781,8 +1819,26 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         if (!split || pass == 1) return SQ_OK;
         split = false;
     }
+    SpanRow *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
+    std::vector<uint64_t> longer((size_t)max_len + 1);   /* longer[w] = how many reads are longer than w */
+    if (len_hist && !sq_knobs().span_radix) {
+        /* the counts per length came with the batch: the rows go to their places in one pass (k_span_scatter) */
+        uint64_t sum = 0;
+        for (uint32_t w = max_len; w > 0; w--) { longer[w] = sum; sum += len_hist[w]; }
+        longer[0] = sum;
+        if (sum != n) return SQ_OK;   /* a read without bases (or the counts are not those of these records): the general pass */
+        uint32_t start[SQ_LEN_BINS] = {};
+        for (uint32_t w = 1; w <= max_len; w++) start[w] = (uint32_t)longer[w];
+        uint32_t *d_start = (uint32_t *)sq_scratch(ctx, 3, 2 * SQ_LEN_BINS * 4), *d_cursor = d_start ? d_start + SQ_LEN_BINS : nullptr;
+        if (!rows_out || !d_start) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemcpyAsync(d_start, start, sizeof start, hipMemcpyHostToDevice, ctx->stream));   /* pageable: copied when the call returns */
+        SQ_HIP(hipMemsetAsync(d_cursor, 0, SQ_LEN_BINS * 4, ctx->stream));
+        const uint64_t chunk = (uint64_t)SCATTER_THREADS * SCATTER_PER;
+        hipLaunchKernelGGL(k_span_scatter, dim3((unsigned)std::min<uint64_t>((n + chunk - 1) / chunk, (uint64_t)ctx->num_cus * 4)), dim3(SCATTER_THREADS), 0,
+                           ctx->stream, P.metas, n, d_start, d_cursor, rows_out);
+    } else {
     uint32_t *keys_in = (uint32_t *)sq_scratch(ctx, 0, n * 4), *keys_out = (uint32_t *)sq_scratch(ctx, 1, n * 4);
-    SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow)), *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
+    SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow));
     unsigned long long *d_longer = (unsigned long long *)sq_scratch(ctx, 3, ((size_t)max_len + 1) * 8);
     if (!keys_in || !keys_out || !rows_in || !rows_out || !d_longer) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
     hipLaunchKernelGGL(k_span_keys, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
@@ -1799,9 +1855,9 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         return SQ_ERR_HIP;
     }
     hipLaunchKernelGGL(k_span_longer, dim3((max_len + 256) / 256), dim3(256), 0, ctx->stream, keys_out, n, max_len, d_longer);
-    std::vector<uint64_t> longer((size_t)max_len + 1);
     SQ_HIP(hipMemcpyAsync(longer.data(), d_longer, longer.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     SQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
     if (longer[0] != n) return SQ_OK;   /* a read without bases: the general pass knows what to do with it */
     struct Launch { int nw, waves; std::vector<SpanSeg> segs; uint32_t spans; };
     std::vector<Launch> launches;

@@ -557,6 +557,49 @@ def test_sorted_spans_every_length(max_len, with_adapters, ea):
                 np.testing.assert_array_equal(u64(r), rr)
 
 
+def test_batches_know_their_length_counts():
+    """sq_batch_length_counts (what k_span_scatter orders a ragged batch with) for every way a batch is made:
+    generated on the device and trimmed, uploaded from host arrays, split on the device, a sealed feeder block"""
+    import ctypes as C
+    import io
+    from sequali_amd import FastqParser, QCMetrics, _lib, synth
+    from sequali_amd._lib import context, lib
+    from sequali_amd._qc import FastqRecordArrayView, _DeviceBatch
+
+    def counts_of(handle):
+        out = (C.c_uint32 * 257)()
+        assert lib().sq_batch_length_counts(handle, out) == 1
+        return np.array(out[:], dtype=np.int64)
+
+    def want(metas):
+        return np.bincount(np.minimum(metas["sequence_length"].astype(np.int64), 256), minlength=257)
+
+    dev = synth.device_array(synth.ILLUMINA, 5, 30_000)
+    np.testing.assert_array_equal(counts_of(dev._batch.handle), want(dev._batch.download()[1]))
+    _lib.check(lib().sq_synth_trim(dev._batch.handle, 3, 20))
+    buf, metas = dev._batch.download()
+    assert len(set(metas["sequence_length"].tolist())) > 100
+    np.testing.assert_array_equal(counts_of(dev._batch.handle), want(metas))
+    long_reads = synth.device_array(synth.NANOPORE, 0, 300)
+    np.testing.assert_array_equal(counts_of(long_reads._batch.handle), want(long_reads._batch.download()[1]))
+    text, hm = synth.host_records(synth.ILLUMINA, 0, 5000)
+    uploaded = _DeviceBatch(lib().sq_batch_upload(context(), text, len(text), hm.ctypes.data, len(hm)))
+    np.testing.assert_array_equal(counts_of(uploaded.handle), want(hm))
+    consumed = C.c_size_t(0)
+    split = _DeviceBatch(lib().sq_batch_from_fastq(context(), text, len(text), C.byref(consumed)))
+    np.testing.assert_array_equal(counts_of(split.handle), want(hm))
+    # through the default parser: arrays of a feeder block, counted by a module (the block is sealed and uploaded at the flush)
+    ragged = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"A" * (1 + i % 97), b"I" * (1 + i % 97)) for i in range(4000))
+    q = QCMetrics()
+    arrays = list(FastqParser(io.BytesIO(ragged), 4096))
+    for a in arrays:
+        q.add_record_array(a)
+    q.flush()
+    assert q.number_of_reads == 4000
+    blk = arrays[0]._blk
+    np.testing.assert_array_equal(counts_of(blk.array._batch.handle), np.bincount(1 + np.arange(4000) % 97, minlength=257))
+
+
 def test_sorted_spans_two_million_trimmed_reads():
     """the ragged variant of the bench workload at a size the oracle finishes in seconds: 2 M
     device-generated 150 bp records cut to 50..150 bases, QCMetrics + AdapterCounter; the default
@@ -571,7 +614,8 @@ def test_sorted_spans_two_million_trimmed_reads():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     gq, ga = QCMetrics(), AdapterCounter(probes)
     f = FusedPass(gq, ga)
-    for env in ({}, {"SQ_SPAN": "0"}):
+    # rows in order by the batch's length counts (k_span_scatter) / by a radix sort of keys / the general k_pass
+    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}):
         rq.add(buf, metas)
         ra.add(buf, metas)
         _with_env(env, lambda: (f.add_record_array(dev), gq.flush()))
