@@ -322,7 +322,15 @@ __global__ void k_batch_stats(const sq_meta *metas, size_t n, unsigned long long
         if (span > maxspan) maxspan = span;
         unsigned long long inv = ~(unsigned long long)m.sequence_length;
         if (inv > minlen_inv) minlen_inv = inv;
-        atomicAdd(&l_len[m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1], 1u);
+        /* one read length in the whole wave (a file of untrimmed reads): one lane counts for all, 64 atomics on
+           one LDS address would take their turns */
+        const uint32_t bin = m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1;
+        const unsigned long long active = __ballot(1), same = __ballot(bin == (uint32_t)__shfl(bin, __ffsll((long long)active) - 1));
+        if (same == active) {
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)active) - 1) atomicAdd(&l_len[bin], (uint32_t)__popcll(active));
+        } else {
+            atomicAdd(&l_len[bin], 1u);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         bases += __shfl_down(bases, off);
