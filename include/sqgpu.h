@@ -131,6 +131,10 @@ sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
 /* the host copy of a sealed block is no longer needed */
 void sq_feeder_release(sq_feeder *f, uint64_t block_id);
 
+/* Diagnostics: seconds the process's feeders have spent moving to a new block, in the record split and in fresh
+ * allocations of the page-locked pool, and the number of those allocations (out[0..3]); reset != 0: start again. */
+void sq_feeder_debug_times(double *out, int reset);
+
 /* page-locked host memory (uploads from it run at the bus rate); plain memory without a device */
 void *sq_host_alloc(size_t bytes, int *pinned);
 void sq_host_free(void *p, int pinned);

@@ -58,7 +58,11 @@ for rep in range(4):
     _lib.synchronize()
     t3 = time.perf_counter()
     _lib.lib().sq_feeder_next = real_next
+    import ctypes as C
+    dbg = (C.c_double * 4)()
+    _lib.lib().sq_feeder_debug_times(dbg, 1)
     dt = t3 - t0
+    print(f"   inside the feeder: new blocks {dbg[0] * 1e3:.1f} ms, record split {dbg[1] * 1e3:.1f} ms, fresh pinned allocations {dbg[2] * 1e3:.1f} ms ({int(dbg[3])} of them)")
     print(f"pass {rep}: {150 * n / dt / 1e9:.2f} Gbases/s, {dt * 1e3:.1f} ms for {len(text) / 1e6:.0f} MB in {arrays} arrays: readinto {Timed.spent * 1e3:.1f} ms, "
           f"sq_feeder_next {split[0] * 1e3:.1f} ms, add_record_array {add * 1e3:.1f} ms, final flush {1e3 * (t3 - t2):.1f} ms, "
           f"rest (iteration, objects) {1e3 * (dt - Timed.spent - split[0] - add - (t3 - t2)):.1f} ms", flush=True)

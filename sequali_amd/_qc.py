@@ -415,7 +415,7 @@ class _Block:
             v.obj = self.array.obj
             v._metas = self.array._metas[r0:r1] if self.array._metas is not None else None
             v._parent = parent          # the memory belongs to the block's batch
-            v._blk, v._blk_r0 = getattr(self.array, "_blk", None), r0
+            v._blk, v._blk_r0 = getattr(self.array, "_blk", None), r0    # (a weak reference: see seal)
         v._children = self._children_of(s0, s1)
         return v
 
@@ -486,7 +486,9 @@ class _FeedBlock(_Block):
             if not h:
                 raise MemoryError(_lib.last_error())
             self.array = FastqRecordArrayView._from_device(_DeviceBatch(h))
-            self.array._blk = self
+            # weak: block -> array -> block would keep both (and the feeder's page-locked blocks) until the
+            # cycle collector comes by, long after the parser is gone
+            self.array._blk = weakref.ref(self)
             staging_stats["blocks"] += 1
             if self.source.open_block is self:
                 self.source.open_block = None
@@ -1145,6 +1147,7 @@ class QCMetrics(_Deferring):
             check(lib().sq_qcmetrics_flush(self._handle))    # the log of the handled batches ends here
         for arr in pending:
             blk = getattr(arr, "_blk", None)
+            blk = blk() if blk is not None else None
             if blk is not None:
                 blk.rates_version += 1      # its arrays fetch the rates from HBM when somebody asks for them
             if arr._metas is not None and arr._batch is not None and len(arr._metas):

@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "sq_common.h"
+#include <time.h>
 
 int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end, sq_meta *metas, size_t cap, size_t *consumed,
                              uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii);
@@ -35,19 +36,36 @@ struct PinBuf { void *p; size_t bytes; bool pinned; };
 /* pinned buffers are expensive to make (the pages are locked): parsers hand them back to a
    process-wide list instead of freeing them */
 std::vector<PinBuf> g_pool;
+/* where the feeder's time goes (scripts/exp_e2e_default_timeline.py): seconds in roll_block, in the record split,
+   in fresh allocations of the pool; fresh allocations */
+double g_feed_times[4] = {0, 0, 0, 0};
+inline double feed_now()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 PinBuf pool_get(size_t bytes, bool want_pinned)
 {
+    /* the smallest buffer that is big enough (a parser's first, small block may sit in a big one: it is locked
+       already; locking 64 MiB of pages takes 6-9 ms) */
+    size_t best = g_pool.size();
     for (size_t i = 0; i < g_pool.size(); i++)
-        if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 && g_pool[i].pinned == want_pinned) {
-            PinBuf b = g_pool[i];
-            g_pool.erase(g_pool.begin() + i);
-            return b;
-        }
+        if (g_pool[i].bytes >= bytes && g_pool[i].pinned == want_pinned && (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes))
+            best = i;
+    if (best < g_pool.size()) {
+        PinBuf b = g_pool[best];
+        g_pool.erase(g_pool.begin() + (long)best);
+        return b;
+    }
     PinBuf b{nullptr, bytes, false};
-    if (want_pinned && hipHostMalloc(&b.p, bytes, hipHostMallocDefault) == hipSuccess) { b.pinned = true; return b; }
+    const double t0 = feed_now();
+    g_feed_times[3] += 1;
+    if (want_pinned && hipHostMalloc(&b.p, bytes, hipHostMallocDefault) == hipSuccess) { b.pinned = true; g_feed_times[2] += feed_now() - t0; return b; }
     (void)hipGetLastError();
     b.p = malloc(bytes);
+    g_feed_times[2] += feed_now() - t0;
     return b;
 }
 void pool_put(PinBuf b)
@@ -55,7 +73,7 @@ void pool_put(PinBuf b)
     if (!b.p) return;
     size_t held = 0;
     for (const PinBuf &x : g_pool) held += x.bytes;
-    if (held + b.bytes > (512u << 20)) {
+    if (held + b.bytes > (1u << 30)) {   /* two parsers' worth of 64 MiB blocks: the blocks of one that has just ended often come back after the next one has started */
         if (b.pinned) (void)hipHostFree(b.p); else free(b.p);
         return;
     }
@@ -247,7 +265,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                         b->n_records = f->arr_first_record;
                     }
                     const size_t keep_len = f->arr_len;
+                    const double t_roll = feed_now();
                     int rc = roll_block(f, keep_len + want + f->read_in);
+                    g_feed_times[0] += feed_now() - t_roll;
                     if (rc) return rc;
                     b = open_block(f);
                     f->arr_first_record = 0;
@@ -288,7 +308,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             const size_t cap = std::min(b->meta_cap - b->n_records, max_records);
             memcpy(stats, b->stats, sizeof stats);
             int64_t bad = -1;
+            const double t_split = feed_now();
             n = sq_split_range_ascii(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats, fresh_from, &bad);
+            g_feed_times[1] += feed_now() - t_split;
             if (non_ascii_error(bad)) return SQ_ERR_VALUE;
             if (n < 0) { f->in_array = false; return (int)n; }
             if ((size_t)n < cap || (size_t)n == max_records) break;
@@ -410,6 +432,11 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
 
 /* The caller no longer needs the host copy of a sealed block (its pinned memory goes back to the
  * pool once the upload has left it). */
+SQ_EXPORT void sq_feeder_debug_times(double *out, int reset)
+{
+    for (int i = 0; i < 4; i++) { out[i] = g_feed_times[i]; if (reset) g_feed_times[i] = 0; }
+}
+
 SQ_EXPORT void sq_feeder_release(sq_feeder *f, uint64_t block_id)
 {
     for (size_t i = 0; i < f->blocks.size(); i++)
