@@ -38,6 +38,7 @@ static void knobs_load()
     k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
     k.span_radix = flag("SQ_SPAN_RADIX");
+    k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);
     k.span_stamps = flag("SQ_SPAN_STAMPS");
@@ -85,6 +86,7 @@ SQ_EXPORT sq_ctx *sq_init(int device)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    SQ_HIP_NULL(hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
     SQ_HIP_NULL(hipEventCreateWithFlags(&ctx->copied, hipEventDisableTiming));
     SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
     SQ_HIP_NULL(hipHostMalloc((void **)&ctx->pinned_stats, SQ_STATS_N * sizeof(uint64_t), hipHostMallocDefault));
@@ -100,6 +102,7 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
     if (ctx->copied) (void)hipEventDestroy(ctx->copied);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_stats) (void)hipHostFree(ctx->pinned_stats);
@@ -431,6 +434,8 @@ SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_
     if (buf_len) SQ_HIP_NULL(hipMemcpyAsync(b->d_buf, b->h_buf.data(), buf_len, hipMemcpyHostToDevice, ctx->stream));
     SQ_HIP_NULL(hipMemsetAsync(b->d_buf + buf_len, 0, 64, ctx->stream));
     if (n) SQ_HIP_NULL(hipMemcpyAsync(b->d_metas, b->h_metas.data(), n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream));
+    SQ_HIP_NULL(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    SQ_HIP_NULL(hipEventRecord(b->ready, ctx->stream));
     return b;
 }
 
@@ -980,6 +985,7 @@ SQ_EXPORT void sq_batch_free(sq_batch *b)
 {
     if (!b) return;
     if (b->owns || b->owns_metas) (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->ready) (void)hipEventDestroy(b->ready);
     if (b->pooled) {
         if (b->owns && b->d_buf) sq_dev_put(b->ctx, b->d_buf);
         if ((b->owns || b->owns_metas) && b->d_metas) sq_dev_put(b->ctx, b->d_metas);

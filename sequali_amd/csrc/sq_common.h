@@ -58,6 +58,7 @@ struct SqKnobs {
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
     bool no_wide = false, ring = false, no_ring = false, no_split = false;
     bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
+    bool pt_prep_inline = false;   /* SQ_PT_PREP_INLINE: PerTileQuality's pass over the headers on the work stream (round 2) */
     bool long_spans = true;
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
     int lds_pad = 0, probe_mode = -1;
@@ -70,6 +71,7 @@ struct sq_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   /* uploads of FASTQ text (sq_batch_from_fastq): they run beside the counting of the batch before */
     hipEvent_t copied = nullptr;
+    hipStream_t prep_stream = nullptr;   /* PerTileQuality's pass over the headers (tile ids, table slots): it runs beside the counting of the batch before */
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */
@@ -166,6 +168,7 @@ struct sq_batch {
     sq_meta *d_metas = nullptr;
     size_t buf_len = 0;
     size_t n = 0;
+    hipEvent_t ready = nullptr;   /* recorded behind an upload that was still running when the batch was handed out (a kernel on another stream waits for it) */
     bool pooled = false;     /* d_buf and d_metas are blocks of the context's pool (sq_dev_get) */
     bool owns = false;       /* frees d_buf (and d_metas) */
     bool owns_metas = false; /* frees d_metas although d_buf is borrowed */

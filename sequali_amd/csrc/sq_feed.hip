@@ -427,6 +427,8 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     if (!fb->copied) SQ_HIP_NULL(hipEventCreateWithFlags(&fb->copied, hipEventDisableTiming));
     SQ_HIP_NULL(hipEventRecord(fb->copied, ctx->stream));
     fb->in_flight = true;
+    SQ_HIP_NULL(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    SQ_HIP_NULL(hipEventRecord(b->ready, ctx->stream));
     return b;
 }
 

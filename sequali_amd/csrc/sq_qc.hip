@@ -2408,6 +2408,7 @@ struct sq_pertile {
     unsigned long long *d_first_bad = nullptr;
     int *d_overflow = nullptr;
     uint64_t first_bad = UINT64_MAX;
+    hipEvent_t used = nullptr;   /* behind the kernels of the last call that read d_slots: the next call's pass over the headers, on another stream, overwrites them */
 };
 
 /* ---- QCMetrics ------------------------------------------------------------------ */
@@ -2771,6 +2772,8 @@ SQ_EXPORT void sq_pertile_free(sq_pertile *p)
 {
     if (!p) return;
     (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipStreamSynchronize(p->ctx->prep_stream);
+    if (p->used) (void)hipEventDestroy(p->used);
     for (void *q : {(void *)p->map.keys, (void *)p->map.vals, (void *)p->map.n_slots,
                     (void *)p->d_first_bad, (void *)p->d_overflow, (void *)p->d_len_counts,
                     (void *)p->d_errors, (void *)p->d_slots, (void *)p->d_tiles})
@@ -2813,18 +2816,27 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
         p->slots_cap = b->n;
     }
     int blocks = (int)std::min<uint64_t>((b->n + 255) / 256, 8192);
-    SQ_HIP(hipMemsetAsync(p->d_overflow + 1, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, ctx->stream, b->d_buf, (uint64_t)b->buf_len,
+    /* The pass over the headers runs on a stream of its own: it reads the batch and writes this object's tile
+       and slot arrays, nothing the kernels queued on ctx->stream for OTHER batches touch, so it goes beside
+       them (the read-back below used to wait for all of them too).  It waits for the kernels of this
+       object's call before (they read the slots) and for the batch's upload if that is still on its way. */
+    hipStream_t S = sq_knobs().pt_prep_inline ? ctx->stream : ctx->prep_stream;
+    if (S != ctx->stream) {
+        if (p->used) SQ_HIP(hipStreamWaitEvent(S, p->used, 0));
+        if (b->ready) SQ_HIP(hipStreamWaitEvent(S, b->ready, 0));
+    }
+    SQ_HIP(hipMemsetAsync(p->d_overflow + 1, 0, 4, S));
+    hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, S, b->d_buf, (uint64_t)b->buf_len,
                        b->d_metas, (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
     /* a workgroup sets up a 12 KB LDS cache of resolved tiles first: fewer, longer-lived ones */
     const int ablocks = (int)std::min<uint64_t>((b->n + 255) / 256, (uint64_t)ctx->num_cus * 4);
-    hipLaunchKernelGGL(k_tile_assign, dim3(ablocks), dim3(256), 0, ctx->stream, p->d_tiles,
+    hipLaunchKernelGGL(k_tile_assign, dim3(ablocks), dim3(256), 0, S, p->d_tiles,
                        (uint64_t)b->n, p->records_seen, p->map, p->d_slots, p->d_first_bad,
                        p->d_overflow);
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[1], p->map.n_slots, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[2], p->d_overflow, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[0], p->d_first_bad, 8, hipMemcpyDeviceToHost, S));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[1], p->map.n_slots, 4, hipMemcpyDeviceToHost, S));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[2], p->d_overflow, 8, hipMemcpyDeviceToHost, S));
+    SQ_HIP(hipStreamSynchronize(S));
     p->first_bad = ctx->pinned[0];
     p->n_slots = (int)(uint32_t)ctx->pinned[1];
     p->tile_changes = (uint32_t)(ctx->pinned[2] >> 32);
@@ -2930,6 +2942,17 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         int rc = pertile_prepare(p, b, &pt_active);
         if (rc) return rc;
     }
+    /* wherever this call ends: the kernels it has queued are the last readers of p's slots (pertile_prepare) */
+    struct SlotsUsed {
+        sq_pertile *p;
+        sq_ctx *ctx;
+        ~SlotsUsed()
+        {
+            if (!p) return;
+            if (!p->used && hipEventCreateWithFlags(&p->used, hipEventDisableTiming) != hipSuccess) { p->used = nullptr; return; }
+            (void)hipEventRecord(p->used, ctx->stream);
+        }
+    } slots_used{pt_active ? p : nullptr, ctx};
     if (b->n == 0) return SQ_OK;
     PassParams P{};
     P.buf = b->d_buf;
