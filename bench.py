@@ -101,7 +101,7 @@ class HipEvents:
 def dominant_kernel(kind, mods):
     """the kernel sq_fused_add_batch launches for the synthetic batch of this run"""
     if kind != "illumina":
-        return "k_span<LONG> (long reads: k_read_sums + k_span<4,AD,LONG> + k_long_ea + k_adapter_first)"
+        return "k_span<LONG> (long reads: k_read_sums + k_span<8,AD,LONG> + k_long_gc_bins + k_long_ea + k_adapter_first)"
     if "pertile" in mods:
         return "k_pass (fused per-base pass, tile-sorted order)"
     if "adapter" in mods and "qc" in mods:
@@ -238,7 +238,7 @@ def other_configs(lib, ctx, steps, warmup):
     out["ragged_50_150"] = run(
         "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
         "QCMetrics + AdapterCounter fused, records resident in HBM",
-        "k_span<NW,AD,SEG> x 4 window counts (reads sorted by length, spans of 16 reads of one length; radix sort of 16-byte rows in front)", (bases, n, 2 * bases + 48 * n),
+        "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
         lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
         lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
@@ -283,7 +283,7 @@ def other_configs(lib, ctx, steps, warmup):
 
     out["config4_nanopore"] = run(
         "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
-        "k_span<4,AD,LONG> (segments of 128 positions streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
+        "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
         lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
         lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})

@@ -135,3 +135,32 @@ def test_getter_in_the_middle_of_a_block_seals_it_and_the_parser_goes_on():
         i = len(arr) // 2
         want = buf[int(m[i]["record_start"]) + int(m[i]["sequence_offset"]):][:int(m[i]["sequence_length"])]
         assert arr[i].sequence().encode() == want
+
+
+@pytest.mark.gpu
+def test_sealed_blocks_return_to_the_pinned_pool_without_the_cycle_collector():
+    """a block that has been sealed and uploaded (a module counted its arrays) must not be kept alive by its own
+    device array: with the cycle collector off, the second and third parser over the same text lock no new
+    memory (sq_feeder_debug_times counts the pool's fresh allocations)"""
+    import ctypes as C
+    import gc
+    import io
+    from sequali_amd import FastqParser, QCMetrics
+    from sequali_amd._lib import lib
+    text = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(50000))
+    out = (C.c_double * 4)()
+    gc.collect()
+    gc.disable()
+    try:
+        for rep in range(3):
+            lib().sq_feeder_debug_times(out, 1)
+            q = QCMetrics()
+            for a in FastqParser(io.BytesIO(text), 8192):
+                q.add_record_array(a)
+            assert q.number_of_reads == 50000
+            del q, a
+            lib().sq_feeder_debug_times(out, 0)
+            if rep:
+                assert out[3] == 0, "a later parser had to lock staging memory afresh"
+    finally:
+        gc.enable()

@@ -886,7 +886,9 @@ def test_config3_one_million_pairs():
         q1.flush(); q2.flush()
         return q1, q2, p1, p2, z, d
 
-    for env in ({}, {"SQ_SPAN": "0"}):
+    # the default (the pass over the headers on a stream of its own, beside the counting) / that pass on the
+    # work stream / the round-1 kernels
+    for env in ({}, {"SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
         q1, q2, p1, p2, z, d = _with_env(env, run)
         for g, r, dev, metas in ((q1, rq1, d1, m1), (q2, rq2, d2, m2)):
             compare_qc(r, g, metas, dev)
