@@ -38,6 +38,7 @@ static void knobs_load()
     k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
     k.span_radix = flag("SQ_SPAN_RADIX");
+    k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);

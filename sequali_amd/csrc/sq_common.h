@@ -44,6 +44,7 @@ void sq_set_error(const char *fmt, ...);
  * dispatchers consult this struct, never getenv().  Defaults = what production runs.
  *   SQ_SPAN=0         no k_span / k_ptspan / k_isz_span: the round-1 kernels (cross-checks)
  *   SQ_SPAN_SPLIT=0   k_span with one wave for both streams of a span (round 2)
+ *   SQ_SPAN_SYNC=0    a wave per stream without the tie between the two waves of a pair
  *   SQ_SPAN_SORTED    1 / 0: force / forbid the length-sorted k_span route for ragged batches
  *   SQ_SPAN_WAVES     cap on k_span's waves per workgroup (occupancy experiments)
  *   SQ_WIDE / SQ_NO_WIDE / SQ_RING / SQ_NO_RING   force / forbid k_wide, k_ring
@@ -53,6 +54,7 @@ void sq_set_error(const char *fmt, ...);
 struct SqKnobs {
     bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
     bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */
     bool span_stamps = false;
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */

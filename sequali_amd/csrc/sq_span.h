@@ -18,7 +18,7 @@ constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
 constexpr uint32_t SPAN_META_LDS = 16 * 32;     /* what k_span keeps of them: the first 32 bytes of each (SEG: 16 bytes per row) */
 
 struct SpanLds {
-    uint32_t thr, gc, ps, dfa, out, adlen, hist, first, rows, dma, meta, slots;
+    uint32_t thr, gc, ps, prog, dfa, out, adlen, hist, first, rows, dma, meta, slots;
     size_t total;
 };
 
@@ -34,6 +34,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.thr = o; o += 96 * 8;
     L.gc = o; o += 104 * 4;
     L.ps = o; o += 96 * 4;
+    L.prog = o; o += 64;                 /* spans done, per wave (a wave per stream: the two waves of a pair stay within a span of each other) */
     L.dfa = o; o += ((states + 2) / 3 * SPAN_DFA_ROW + 15u) & ~15u; /* three states to a row */
     L.out = o; o += states * 16;   /* adapters ending on the second / the first character of a step */
     L.adlen = o; o += states ? 64 : 0;
