@@ -39,6 +39,7 @@ static void knobs_load()
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
     k.span_radix = flag("SQ_SPAN_RADIX");
     k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
+    k.span_split_qc = num("SQ_SPAN_SPLIT_QC", 0) != 0;
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);

@@ -54,6 +54,7 @@ void sq_set_error(const char *fmt, ...);
 struct SqKnobs {
     bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span_split_qc = false;   /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream too */
     bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
     bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */
     bool span_stamps = false;

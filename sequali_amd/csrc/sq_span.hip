@@ -866,6 +866,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
     };
 
     uint32_t spans_done = 0;   /* by this wave, over all stretches */
+    /* scalars: nothing of the tie between the waves of a pair may cost a vector register (the builds of 128 have none to spare) */
+    const uint32_t prog_mine = __builtin_amdgcn_readfirstlane(lds_addr(l_prog) + 4 * (uint32_t)wave);
+    const uint32_t prog_partner = __builtin_amdgcn_readfirstlane(lds_addr(l_prog) + 4 * ((uint32_t)wave ^ 1));
     /* SEG: the workgroup's stretch of the launch's spans, one length after the other */
     uint64_t c_lo = 0, c_hi = 0;
     uint32_t seg_i = 0;
@@ -925,7 +928,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
                span's metas) comes from memory twice -- 1.69 x the algorithmic bytes instead of 1.2 x.  A wave
                does not start a span while its partner is more than one span behind. */
             if (P.span_sync)
-                while (*(volatile SQ_LDS uint32_t *)(uintptr_t)lds_addr(l_prog + (wave ^ 1)) + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
+                while (*(volatile SQ_LDS uint32_t *)(uintptr_t)prog_partner + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
         }
         if (s + stride < s_end) {
 #ifdef SQ_SPAN_PROBE
@@ -953,7 +956,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         urow_cur = urow_next;
         if constexpr (SPLIT) {
             spans_done++;
-            if (P.span_sync && lane == 0) *(volatile SQ_LDS uint32_t *)(uintptr_t)lds_addr(l_prog + wave) = spans_done;
+            if (P.span_sync) *(volatile SQ_LDS uint32_t *)(uintptr_t)prog_mine = spans_done;   /* every lane the same word */
         }
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t3);
@@ -1801,7 +1804,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
-    bool split = sq_knobs().span_split && ad;   /* QCMetrics alone: one wave for both streams is 2-3 % ahead (and fetches less) */
+    bool split = sq_knobs().span_split && (ad || sq_knobs().span_split_qc);   /* QCMetrics alone: one wave for both streams was 2-3 % ahead (SQ_SPAN_SPLIT_QC=1: a wave per stream there too) */
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
     if (!waves) return SQ_OK;
