@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
     if constexpr (!SEG) for (int i = tid; i < 96; i += T) l_thr[i] = P.thr_sum[U * 96 + i];
     for (int i = tid; i < 104; i += T) l_gc[i] = 0;
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
-    uint32_t *l_prog = (uint32_t *)(smem + L.prog);   /* [16] spans done by each wave */
+    uint32_t *l_prog = (uint32_t *)(smem + L.prog);   /* [16] spans started by each wave */
     if (tid < 16) l_prog[tid] = 0;
     for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
     if (AD) {
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         SPAN_PHASE(4);   /* first hits to the tables, base counts to LDS */
     };
 
-    uint32_t spans_done = 0;   /* by this wave, over all stretches */
+    uint32_t spans_done = 0;   /* spans this wave has started, over all stretches */
     /* scalars: nothing of the tie between the waves of a pair may cost a vector register (the builds of 128 have none to spare) */
     const uint32_t prog_mine = __builtin_amdgcn_readfirstlane(lds_addr(l_prog) + 4 * (uint32_t)wave);
     const uint32_t prog_partner = __builtin_amdgcn_readfirstlane(lds_addr(l_prog) + 4 * ((uint32_t)wave ^ 1));
@@ -926,9 +926,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
             /* The two waves of a pair fetch the two streams of the same records: nothing else ties them, and
                once they have drifted apart the line a record's sequence ends and its qualities begin in (and the
                span's metas) comes from memory twice -- 1.69 x the algorithmic bytes instead of 1.2 x.  A wave
-               does not start a span while its partner is more than one span behind. */
-            if (P.span_sync)
+               does not start span number k of its sequence before its partner has started number k - 1. */
+            if (P.span_sync) {
+                spans_done++;
+                *(volatile SQ_LDS uint32_t *)(uintptr_t)prog_mine = spans_done;   /* every lane the same word */
                 while (*(volatile SQ_LDS uint32_t *)(uintptr_t)prog_partner + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
+            }
         }
         if (s + stride < s_end) {
 #ifdef SQ_SPAN_PROBE
@@ -954,10 +957,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         s += stride;
         rec_cur = rec_next;
         urow_cur = urow_next;
-        if constexpr (SPLIT) {
-            spans_done++;
-            if (P.span_sync) *(volatile SQ_LDS uint32_t *)(uintptr_t)prog_mine = spans_done;   /* every lane the same word */
-        }
 #ifdef SQ_SPAN_PROBE
         SPAN_STAMP(t3);
         a_wait += t1 - t0; a_issue += t2 - t1;
