@@ -6,6 +6,8 @@
 //   rows      chunks, but only 300 of every 341 bytes (the sequence and quality lines of a record, not its name)
 //   meta      40-byte structs, a lane per struct, three loads (16 + 16 + 8 bytes) as the compiler does for `sq_meta m = metas[i]`
 //   dma x2    every KB by LDS-DMA twice, the second time GAP steps later (does the L2 keep what an LDS-DMA brought?)
+//   gather    rows of 208 bytes (13 pieces: a read of 100 bases, its sequence and its qualities) from random records by
+//             LDS-DMA, four rows per wave instruction: what k_span over length-sorted rows asks memory for
 // with 4 / 8 / 16 waves per CU.   hipcc --offload-arch=gfx950 -O3 -o scripts/build/ubench_stream scripts/ubench_stream.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -55,6 +57,18 @@ __global__ void __launch_bounds__(1024) k_stream(const uint8_t *buf, uint64_t by
                     __builtin_memcpy(&v, src + off, 16);
                     acc += v.x + v.y + v.z + v.w;
                 }
+            } else if (MODE == 8) {
+                /* `steps` x 4 rows per chunk; row number -> a record somewhere in the buffer */
+                const uint64_t n_rec = bytes / 341;
+                const uint32_t row_in = lane / 13, piece = lane % 13;
+                for (uint32_t s = 0; s < steps; s++) {
+                    const uint64_t rowno = (c * steps + s) * 4 + row_in;
+                    const uint64_t rec = (rowno * 0x9E3779B97F4A7C15ULL >> 20) % n_rec;
+                    if (lane < 52) dma16(buf + rec * 341 + 37 + 16 * piece, __builtin_amdgcn_readfirstlane(slot + 1024 * (s & 1)));
+                    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                acc += *(const uint32_t *)(smem + wave * 2048 + 4 * lane);
             } else if (MODE >= 6) {
                 const uint32_t gap = MODE == 6 ? 1 : 4;
                 for (uint32_t s = 0; s < steps + gap; s++) {
@@ -95,7 +109,8 @@ template <int MODE> void run(const char *name, const uint8_t *buf, uint64_t byte
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;
     }
-    const double useful = MODE == 4 ? bytes * (300.0 / 341.0) : (double)bytes;
+    /* gather: every KB step asks for 4 rows of 208 bytes = 832 bytes (they touch 2.6 lines of 128 bytes each: 1333 bytes) */
+    const double useful = MODE == 4 ? bytes * (300.0 / 341.0) : MODE == 8 ? bytes * (832.0 / 1024.0) : (double)bytes;
     printf("%-8s chunk %6u B, %2d waves per workgroup: %7.3f ms = %5.2f TB/s of the bytes asked for\n", name, chunk, waves, best, useful / best / 1e9);
 }
 
@@ -116,6 +131,7 @@ int main()
             run<4>("rows", buf, bytes, chunk, waves, sink);
             run<6>("dma x2/1", buf, bytes, chunk, waves, sink);
             run<7>("dma x2/4", buf, bytes, chunk, waves, sink);
+            run<8>("gather", buf, bytes, chunk, waves, sink);
         }
     }
     return 0;

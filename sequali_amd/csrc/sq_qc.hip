@@ -3154,6 +3154,9 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             if (ad && dfa_lds && a->groups[gi].count * hist_stride(32u * (((uint32_t)b->max_length + 31) / 32)) * 4 <= 8192)
                 S.ad_lds = (uint32_t)a->groups[gi].count;
             uint64_t covered = 0;
+#ifdef SQ_SPAN_PROBE
+            if (K.span_probe >= 0) S.blocked = (uint32_t)K.span_probe;   /* timing builds: DMA alone, counting alone (wrong tables) */
+#endif
             int rc = sq_span_launch_sorted(ctx, S, ad, ad ? (uint32_t)a->groups[gi].count : 0, (uint32_t)b->max_length,
                                            S.n == b->n && S.metas == b->d_metas && b->len_hist.size() == SQ_LEN_BINS ? b->len_hist.data() : nullptr, &covered);
             if (rc) return rc;
