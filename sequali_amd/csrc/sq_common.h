@@ -63,6 +63,7 @@ struct SqKnobs {
     bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
     bool pt_prep_inline = false;   /* SQ_PT_PREP_INLINE: PerTileQuality's pass over the headers on the work stream (round 2) */
     bool long_spans = true;
+    int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;
@@ -81,7 +82,7 @@ struct sq_ctx {
     uint64_t *pinned_stats = nullptr; /* SQ_STATS_N words: k_batch_stats' read-back */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
-    void *scratch[24] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split */
+    void *scratch[24] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split; 21: k_batch_stats; 22: workgroup shares of k_span<LONG> */
     size_t scratch_bytes[24] = {};
     /* device blocks of batches made by sq_batch_from_fastq (text, metas): kept for the next buffer of the
        same size instead of a hipFree + hipMalloc per buffer (hipFree waits for the whole device) */

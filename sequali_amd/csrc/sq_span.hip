@@ -876,6 +876,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG)) k_s
         const uint64_t chunk = ((uint64_t)P.span_total + gridDim.x - 1) / gridDim.x;
         c_lo = min((uint64_t)P.span_total, blockIdx.x * chunk);
         c_hi = min((uint64_t)P.span_total, c_lo + chunk);
+        if (P.span_bounds) { c_lo = P.span_bounds[blockIdx.x]; c_hi = P.span_bounds[blockIdx.x + 1]; }   /* shares of equal cost (sq_span_launch_long) */
         while (seg_i < P.span_nsegs && (uint64_t)P.span_segs[seg_i].span0 + P.span_segs[seg_i].nspans <= c_lo) seg_i++;
     }
     for (;;) {
@@ -1771,6 +1772,43 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     C.span_rows = rows;
     const size_t lds = span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total;
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((spans + waves / 2 - 1) / (waves / 2), (uint64_t)ctx->num_cus));
+    /* Where every workgroup's stretch of the spans begins.  Equal numbers of spans are not equal work: a
+       workgroup that meets a new segment flushes, merges its histograms and restarts its DMA pipeline (what a
+       dozen spans cost it), and the segments far into the reads hold a few spans each -- with equal shares
+       the last workgroup of config 4 went through 155 of them, the others through 1-18, and the launch waited
+       for it: 9.65 ms, 7.85 with shares of equal COST (spans + SQ_LONG_STRETCH_COST per segment met; 12 and
+       more all measure the same). */
+    std::vector<uint32_t> bounds((size_t)grid + 1, (uint32_t)spans);
+    {
+        const double K = (double)sq_knobs().long_stretch_cost;
+        double total = 0;
+        for (const SpanSeg &g : segs) total += (double)g.nspans + K;
+        total += K * grid;   /* a share that ends inside a segment makes the next workgroup meet it too */
+        const double share = total / grid;
+        bounds[0] = 0;
+        int wg = 1;
+        double acc = 0;   /* cost of the spans handed out so far */
+        for (const SpanSeg &g : segs) {
+            double left = (double)g.nspans;   /* spans of this segment not handed out yet */
+            uint32_t at = g.span0;
+            acc += K;
+            while (wg < grid && acc + left > share * wg) {
+                const double take = std::max(0.0, share * wg - acc);
+                const uint32_t t = (uint32_t)std::min<double>(left, std::floor(take));
+                at += t; left -= t; acc += t;
+                bounds[wg++] = at;
+                acc += K;   /* the next workgroup meets this segment too */
+                if (left <= 0) break;
+            }
+            acc += left;
+        }
+        for (size_t i = 1; i < bounds.size(); i++) bounds[i] = std::max(bounds[i], bounds[i - 1]);
+        bounds[grid] = (uint32_t)spans;
+    }
+    uint32_t *d_bounds = (uint32_t *)sq_scratch(ctx, 22, bounds.size() * 4);
+    if (!d_bounds) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    C.span_bounds = sq_knobs().long_stretch_cost > 0 ? d_bounds : nullptr;
     static bool attr = false;
     if (!attr) {
         SQ_HIP(hipFuncSetAttribute((const void *)k_long_ea, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
