@@ -86,7 +86,7 @@ def total(kernel_filter):
 uni = lambda k: k.startswith(HEAD + "k_span<5, true, false")
 cfg = {
     "headline": (uni, 2 * 2),   # per LAUNCH: the headline run holds 50 M reads = 2 launches per pass
-    "ragged_50_150": (lambda k: ("k_span<" in k and ", true, true, 3, true, false>" in k) or "k_span_keys" in k or "k_span_longer" in k or "DeviceRadixSort" in k, 2),
+    "ragged_50_150": (lambda k: ("k_span<" in k and (", true, true, 3, true, false>" in k or ", true, true, 3, false, false>" in k)) or "k_span_scatter" in k or "k_span_keys" in k or "k_span_longer" in k or "DeviceRadixSort" in k, 2),
     "config3_paired": (lambda k: k.startswith("k_span<5, false, false") or any(x in k for x in ("k_ptspan", "k_tile_parse", "k_tile_assign", "k_isz_span", "k_isz_adapters", "k_tile_")), 2),
     "config4_nanopore": (lambda k: ", true, true>" in k or any(x in k for x in ("k_read_sums", "k_long_", "k_adapter_first", "k_stripe_counts")), 2),
 }

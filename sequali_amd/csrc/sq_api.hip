@@ -38,6 +38,7 @@ static void knobs_load()
     k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
     k.span_radix = flag("SQ_SPAN_RADIX");
+    k.span_sorted_split = num("SQ_SPAN_SORTED_SPLIT", 0) != 0;
     k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
     k.span_split_qc = num("SQ_SPAN_SPLIT_QC", 0) != 0;
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");

@@ -56,6 +56,7 @@ struct SqKnobs {
     int span_sorted = -1, span_waves = 0, span_probe = -1;
     bool span_split_qc = false;   /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream too */
     bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
+    bool span_sorted_split = false;   /* SQ_SPAN_SORTED_SPLIT: the length-sorted route with a wave per stream */
     bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */
     bool span_stamps = false;
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */

@@ -1868,15 +1868,18 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
 {
     *done = 0;
     const uint64_t n = P.n;
-    bool split = sq_knobs().span_split;
+    /* one wave for both streams: with rows gathered from all over the buffer a wave per stream measures the same
+       (676-707 against 699-715 Gbases/s), and its 4-window build sits at exactly 128 registers -- a spill there
+       sent the whole route to the other build without a word (SQ_SPAN_SORTED_SPLIT=1: a wave per stream) */
+    bool split = sq_knobs().span_split && sq_knobs().span_sorted_split;
     if (!max_len || max_len > 32u * SPAN_NW_MAX || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
     for (int pass = 0; pass < 2; pass++) {   /* every window count of the batch must be one the kernel takes */
         bool all = true;
         for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
             if (!span_waves(P, nw, 32 * nw, ad, n_ad, true, split)) all = false;
         if (all) break;
-        if (!split || pass == 1) return SQ_OK;
-        split = false;
+        if (pass == 1 || (!split && !sq_knobs().span_split)) return SQ_OK;
+        split = !split;   /* the other build (reads of 161-256 bases with adapters exist as a wave per stream only) */
     }
     SpanRow *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     std::vector<uint64_t> longer((size_t)max_len + 1);   /* longer[w] = how many reads are longer than w */
