@@ -707,17 +707,28 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
            the second half of a line to the caches, which 24 waves x 16 reads per CU do not hold) */
         uint4 cs[2], cq[2], ns[2], nq[2];
         auto load_piece = [&](uint32_t pos, uint4 &sv, uint4 &qv) {
-            sv = make_uint4(0, 0, 0, 0);
-            qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
-            if (pos < L) {
-                if constexpr (GC) sv = load16(P.buf, soff + pos, P.buf_len);
-                qv = load16(P.buf, qoff + pos, P.buf_len);
+            if constexpr (GC) {
+                sv = make_uint4(0, 0, 0, 0);
+                qv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (pos < L) {
+                    sv = load16(P.buf, soff + pos, P.buf_len);
+                    qv = load16(P.buf, qoff + pos, P.buf_len);
+                }
+            } else {
+                /* no branch around the load: hipcc waits for a load it cannot count with vmcnt(0), and that drained
+                   the loads of the NEXT step in front of every step.  Behind a read's end the 16 bytes are whatever
+                   follows (the batch owns 64 spare bytes behind its text: sq_fused_add_batch sends only such
+                   batches here); nothing looks at them (`inside`, Lmain). */
+                sv = make_uint4(0, 0, 0, 0);
+                __builtin_memcpy(&qv, P.buf + qoff + min(pos, L), 16);
             }
         };
         load_piece(16 * c, cs[0], cq[0]);
         load_piece(16 * c + 64, cs[1], cq[1]);
-        for (uint32_t base0 = 0; base0 < maxL; base0 += 128) {
-            if (base0 + 128 < maxL) {
+        /* two steps per turn of the loop, the buffers swapping roles: a copy `current = next` at the end of a step
+           would have to wait for the loads of the next step there */
+        auto step = [&](uint4 (&cs)[2], uint4 (&cq)[2], uint4 (&ns)[2], uint4 (&nq)[2], uint32_t base0) {
+            if (!GC || base0 + 128 < maxL) {   /* without a condition where the load has none (behind the end it reads the clamped address again): a load on one path only cannot be waited for by count */
                 load_piece(base0 + 128 + 16 * c, ns[0], nq[0]);
                 load_piece(base0 + 192 + 16 * c, ns[1], nq[1]);
             }
@@ -760,8 +771,10 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc += e[i];
             }
-            cs[0] = ns[0]; cs[1] = ns[1];
-            cq[0] = nq[0]; cq[1] = nq[1];
+        };
+        for (uint32_t base0 = 0; base0 < maxL; base0 += 256) {
+            step(cs, cq, ns, nq, base0);
+            if (base0 + 128 < maxL) step(ns, nq, cs, cq, base0 + 128);
         }
         /* the quad's four chains and counts */
         const double a0 = __shfl(acc, (lane & ~3) + 0), a1 = __shfl(acc, (lane & ~3) + 1);
