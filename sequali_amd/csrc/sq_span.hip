@@ -1628,6 +1628,7 @@ __global__ void k_long_counts(const SpanRow *rows, uint64_t n, uint32_t seg, uin
     counts[j] = lo;
 }
 /* the end-anchored tables of a batch: item i = (read i / ea_len, slot i % ea_len of the tables) */
+constexpr uint32_t EA_READS = 4;   /* reads whose loads a wave of k_long_ea has in flight */
 __global__ void __launch_bounds__(256) k_long_ea(const uint8_t *buf, const sq_meta *metas, uint64_t n, uint32_t ea_len,
                                                  unsigned long long *ea_base, unsigned long long *ea_phred)
 {
@@ -1648,17 +1649,36 @@ __global__ void __launch_bounds__(256) k_long_ea(const uint8_t *buf, const sq_me
             qo = m.record_start + m.qualities_offset + L - ea_len;
         }
         const uint32_t cnt = (uint32_t)min((uint64_t)64, n - r0);
-#pragma unroll 4
-        for (uint32_t j = 0; j < cnt; j++) {
-            const unsigned long long sj = __shfl(so, (int)j), qj = __shfl(qo, (int)j);
-            const uint32_t fj = __shfl(first, (int)j);
-            for (uint32_t e = fj + lane; e < ea_len; e += 64) {
-                const uint32_t cls = sq_base_class(buf[sj + e]);
-                const uint32_t bin = min((uint32_t)buf[qj + e] - 33u, 47u) >> 2;
-                atomicAdd(&l_ea[cls * ea_len + e], 1u);
-                atomicAdd(&l_ea[(5 + bin) * ea_len + e], 1u);
+        /* four reads at a time, 128 slots each, every load without a condition (a slot that does not exist reads
+           the read's last byte again and counts nothing): hipcc issues the 16 loads and waits for them by count;
+           behind `if (e < ea_len)` it waited for every read's loads with vmcnt(0), one memory latency per read */
+        for (uint32_t e0 = 0; e0 < ea_len; e0 += 128)
+            for (uint32_t j0 = 0; j0 < cnt; j0 += EA_READS) {
+                uint32_t sb[EA_READS][2], qb[EA_READS][2], at[EA_READS][2];
+#pragma unroll
+                for (uint32_t u = 0; u < EA_READS; u++) {
+                    const uint32_t j = min(j0 + u, cnt - 1);
+                    const unsigned long long sj = __shfl(so, (int)j), qj = __shfl(qo, (int)j);
+                    const uint32_t fj = j0 + u < cnt ? __shfl(first, (int)j) : ea_len;   /* (a repeated read counts nothing) */
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        const uint32_t e = e0 + 64 * h + lane;
+                        const bool on = e >= fj && e < ea_len;
+                        const uint32_t ec = on ? e : ea_len - 1;
+                        sb[u][h] = buf[sj + ec];
+                        qb[u][h] = buf[qj + ec];
+                        at[u][h] = on ? e : 0xFFFFFFFFu;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < EA_READS; u++)
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++)
+                        if (at[u][h] != 0xFFFFFFFFu) {
+                            atomicAdd(&l_ea[sq_base_class((uint8_t)sb[u][h]) * ea_len + at[u][h]], 1u);
+                            atomicAdd(&l_ea[(5 + (min(qb[u][h] - 33u, 47u) >> 2)) * ea_len + at[u][h]], 1u);
+                        }
             }
-        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 17 * ea_len; i += blockDim.x) {
