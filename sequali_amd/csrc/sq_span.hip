@@ -1136,17 +1136,18 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_span_scatter(const sq_meta 
         SpanRow r[SCATTER_PER];
 #pragma unroll
         for (int k = 0; k < SCATTER_PER; k++) {
+            /* the load has no condition (behind the end the last record is read again): 16 of them are in flight
+               together; behind `if (i < n)` hipcc waited for each with vmcnt(0) */
             const uint64_t i = c0 + (uint64_t)k * SCATTER_THREADS + threadIdx.x;
-            len[k] = 0xFFFFFFFFu;
-            if (i < n) {
-                const sq_meta m = metas[i];
-                len[k] = m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1;
-                r[k].seq = m.record_start + m.sequence_offset;
-                r[k].qual_delta = m.qualities_offset - m.sequence_offset;
-                r[k].record = (uint32_t)i;
-                rank[k] = atomicAdd(&l_cnt[len[k]], 1u);
-            }
+            const sq_meta m = metas[i < n ? i : n - 1];
+            len[k] = i < n ? (m.sequence_length < SQ_LEN_BINS - 1 ? m.sequence_length : SQ_LEN_BINS - 1) : 0xFFFFFFFFu;
+            r[k].seq = m.record_start + m.sequence_offset;
+            r[k].qual_delta = m.qualities_offset - m.sequence_offset;
+            r[k].record = (uint32_t)i;
         }
+#pragma unroll
+        for (int k = 0; k < SCATTER_PER; k++)
+            if (len[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&l_cnt[len[k]], 1u);
         __syncthreads();
         for (int i = threadIdx.x; i < SQ_LEN_BINS; i += SCATTER_THREADS)
             if (l_cnt[i]) l_base[i] = start[i] + atomicAdd(&cursor[i], l_cnt[i]);
