@@ -131,6 +131,13 @@ sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
 /* the host copy of a sealed block is no longer needed */
 void sq_feeder_release(sq_feeder *f, uint64_t block_id);
 
+/* Diagnostics: the counting kernels the dispatchers have launched on this context since sq_route_reset(), joined by
+ * '+' ("k_span<5,AD,split>+k_span_scatter+k_span<4,AD,sorted>+..."): which kernel takes a batch is decided per batch
+ * (DESIGN.md 4.1), and a build that no longer fits its registers makes a dispatcher take another one silently;
+ * tests/test_gpu_routes.py pins the routes of the benchmark's shapes. */
+const char *sq_last_route(sq_ctx *ctx);
+void sq_route_reset(sq_ctx *ctx);
+
 /* Diagnostics: seconds the process's feeders have spent moving to a new block, in the record split and in fresh
  * allocations of the page-locked pool, and the number of those allocations (out[0..3]); reset != 0: start again. */
 void sq_feeder_debug_times(double *out, int reset);

@@ -118,6 +118,9 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     delete ctx;
 }
 
+SQ_EXPORT const char *sq_last_route(sq_ctx *ctx) { return ctx->route.c_str(); }
+SQ_EXPORT void sq_route_reset(sq_ctx *ctx) { ctx->route.clear(); }
+
 SQ_EXPORT int sq_synchronize(sq_ctx *ctx)
 {
     SQ_HIP(hipStreamSynchronize(ctx->stream));

@@ -80,6 +80,7 @@ struct sq_ctx {
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */
+    std::string route;   /* the counting kernels launched since sq_route_reset(): "k_span<5,AD,split>+k_ptspan<5>+..." (sq_last_route) */
     uint64_t *pinned_stats = nullptr; /* SQ_STATS_N words: k_batch_stats' read-back */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
@@ -163,6 +164,20 @@ inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)
  * batch of many lengths puts its rows in order with these counts instead of sorting keys) */
 constexpr int SQ_LEN_BINS = 257;
 constexpr int SQ_STATS_N = 5 + SQ_LEN_BINS;
+
+/* names the kernel a dispatcher has just chosen (tests assert the routes: a build that spills makes a dispatcher
+ * fall back to another kernel without a word) */
+inline void sq_route(sq_ctx *ctx, const char *fmt, ...)
+{
+    if (ctx->route.size() > 2000) return;
+    char buf[96];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (!ctx->route.empty()) ctx->route += '+';
+    ctx->route += buf;
+}
 
 inline uint64_t sq_next_batch_id() { static uint64_t next = 0; return ++next; }   /* objects are used from one thread (sqgpu.h) */
 

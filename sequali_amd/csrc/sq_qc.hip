@@ -2903,6 +2903,7 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
 template <bool QC, bool AD, bool PT>
 void launch_pass(sq_ctx *ctx, const PassParams &P, bool dfa_lds, int grid, size_t lds)
 {
+    sq_route(ctx, "k_pass<%s%s%s>", QC ? "QC" : "", AD ? "AD" : "", PT ? "PT" : "");
     if (dfa_lds)
         hipLaunchKernelGGL((k_pass<QC, AD, PT, true>), dim3(grid), dim3(WG_THREADS), lds, ctx->stream, P);
     else
@@ -3112,6 +3113,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         }
         const uint64_t want = (C.n / 64 + PTQ_WAVES - 1) / PTQ_WAVES;
         const int pgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus * 2));
+        sq_route(ctx, "k_ptq");
         hipLaunchKernelGGL(k_ptq, dim3(pgrid), dim3(PTQ_THREADS), ptq_lds_bytes(P.uniform_len), ctx->stream, C);
         SQ_HIP(hipGetLastError());
         if (C.n == b->n) {
@@ -3218,6 +3220,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             }
             const uint64_t want = (C.n / 64 + WIDE_WAVES - 1) / WIDE_WAVES;
             const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus));
+            sq_route(ctx, "k_wide<%s>", ad ? "AD" : "QC");
             if (ad) hipLaunchKernelGGL((k_wide<true>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
             else hipLaunchKernelGGL((k_wide<false>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
             SQ_HIP(hipGetLastError());
@@ -3238,6 +3241,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                 SQ_HIP(hipFuncSetAttribute((const void *)k_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_set = true;
             }
+            sq_route(ctx, "k_ring<%s>", ad ? "AD" : "QC");
             if (ad) hipLaunchKernelGGL((k_ring<true>), dim3(rgrid), dim3(RING_THREADS), rlds, ctx->stream, C);
             else hipLaunchKernelGGL((k_ring<false>), dim3(rgrid), dim3(RING_THREADS), rlds, ctx->stream, C);
             SQ_HIP(hipGetLastError());
@@ -3254,6 +3258,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                read on its way and this pass reads the qualities only */
             const bool try_long = K.long_spans && K.span && b->owns &&
                                   sq_span_long_takes(P, ad, ad ? (uint32_t)a->groups[0].count : 0, (uint32_t)b->max_length);
+            sq_route(ctx, try_long ? "k_read_sums<qualities>" : "k_read_sums<GC>");
             if (try_long)
                 hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
                                    ctx->stream, P);
@@ -3316,6 +3321,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             }
             const size_t slds = seg_lds_bytes(ea_rows, ad, states);
             const unsigned sgrid = (unsigned)(table.size() / 3);
+            sq_route(ctx, "k_seg<%s>", ad ? "AD" : "QC");
             if (ad) hipLaunchKernelGGL((k_seg<true>), dim3(sgrid), dim3(WG_THREADS), slds, ctx->stream, P, S);
             else hipLaunchKernelGGL((k_seg<false>), dim3(sgrid), dim3(WG_THREADS), slds, ctx->stream, P, S);
             SQ_HIP(hipGetLastError());

@@ -186,7 +186,14 @@ template <int CTRL> __device__ __forceinline__ double quad_bcast_f64(double v)
  * positions per read on, which is 168 registers per lane instead of 128.  SPLIT (a wave holds one
  * stream of a span at a time): 16 waves of 128 registers up to 160 positions (128 when the batch
  * holds many lengths), 12 beyond */
-constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool lng = false) { return nw <= (lng ? 6 : split ? (seg ? 4 : 5) : 3) ? 16 : 12; }
+constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool lng = false)
+{
+    /* 225-256 positions (and 193-224 of the builds for sorted rows): 8 waves of up to 256 registers -- at 12
+       waves these builds spilled, and a build that spills is not used (span_waves): such reads went to the round-1
+       kernels without a word (tests/test_gpu_routes.py) */
+    if (!lng && (nw >= 8 || (nw == 7 && seg))) return 8;
+    return nw <= (lng ? 6 : split ? (seg ? 4 : 5) : 3) ? 16 : 12;
+}
 
 #ifdef SQ_SPAN_PROBE
 __device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
@@ -1027,6 +1034,7 @@ int launch_nw(sq_ctx *ctx, const PassParams &P0, bool ad, uint32_t n_ad, int wav
         SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, SEG, SPAN_W4, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    sq_route(ctx, "k_span<%d,%s,%s,%s>", NW, ad ? "AD" : "QC", SEG ? "sorted" : "uniform", SPLIT ? "split" : "both");
     if (ad) {
         if constexpr (HAS_AD)
             hipLaunchKernelGGL((k_span<NW, true, SEG, SPAN_W4, SPLIT>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, n_ad);
@@ -1366,6 +1374,7 @@ int launch_ptspan(sq_ctx *ctx, const PassParams &P, uint32_t nslots, int waves, 
         SQ_HIP(hipFuncSetAttribute((const void *)k_ptspan<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    sq_route(ctx, "k_ptspan<%d>", NW);
     hipLaunchKernelGGL((k_ptspan<NW>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, nslots);
     SQ_HIP(hipGetLastError());
     return SQ_OK;
@@ -1580,6 +1589,7 @@ int launch_isz_span(sq_ctx *ctx, const IszSpanParams &P, int waves, size_t lds, 
         SQ_HIP(hipFuncSetAttribute((const void *)k_isz_span<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    sq_route(ctx, "k_isz_span<%d>", NW);
     hipLaunchKernelGGL((k_isz_span<NW>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P);
     SQ_HIP(hipGetLastError());
     return SQ_OK;
@@ -1721,6 +1731,7 @@ int launch_long(sq_ctx *ctx, const PassParams &C0, bool ad, uint32_t n_ad, int w
         SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, true, SPAN_W4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    sq_route(ctx, "k_span<%d,%s,long>", NW, ad ? "AD" : "QC");
     if (ad) hipLaunchKernelGGL((k_span<NW, true, true, SPAN_W4, true, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, C, n_ad);
     else hipLaunchKernelGGL((k_span<NW, false, true, SPAN_W4, true, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, C, n_ad);
     SQ_HIP(hipGetLastError());
@@ -1917,6 +1928,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         SQ_HIP(hipMemcpyAsync(d_start, start, sizeof start, hipMemcpyHostToDevice, ctx->stream));   /* pageable: copied when the call returns */
         SQ_HIP(hipMemsetAsync(d_cursor, 0, SQ_LEN_BINS * 4, ctx->stream));
         const uint64_t chunk = (uint64_t)SCATTER_THREADS * SCATTER_PER;
+        sq_route(ctx, "k_span_scatter");
         hipLaunchKernelGGL(k_span_scatter, dim3((unsigned)std::min<uint64_t>((n + chunk - 1) / chunk, (uint64_t)ctx->num_cus * 4)), dim3(SCATTER_THREADS), 0,
                            ctx->stream, P.metas, n, d_start, d_cursor, rows_out);
     } else {
@@ -1924,6 +1936,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     SpanRow *rows_in = (SpanRow *)sq_scratch(ctx, 14, n * sizeof(SpanRow));
     unsigned long long *d_longer = (unsigned long long *)sq_scratch(ctx, 3, ((size_t)max_len + 1) * 8);
     if (!keys_in || !keys_out || !rows_in || !rows_out || !d_longer) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
+    sq_route(ctx, "k_span_keys+radix_sort");
     hipLaunchKernelGGL(k_span_keys, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
                        P.metas, n, max_len, keys_in, rows_in);
     int bits = 1;
