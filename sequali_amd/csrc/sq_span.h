@@ -10,7 +10,7 @@ constexpr int SPAN_NW_MAX = 8;               /* reads of up to 256 bases */
 constexpr uint32_t SPAN_DFA_ROW = 216;          /* bytes three states of the two-character automaton share: 36 entries each */
 constexpr uint32_t SPAN_DFA_MAX_STATES = 336;   /* 24 KB of LDS */
 constexpr int SPAN_NW_AD = 5;   /* windows of 32 positions with the automaton in the pass (one wave for both streams) */
-constexpr int SPAN_NW_AD_SPLIT = 7;   /* the same with a wave per stream: up to 224 positions (at 225-256 the build needs 8 waves of ~190 registers and k_wide is 9 % ahead: 954 against 877 Gbases/s at 250 bases, scripts/bench_len.py) */
+constexpr int SPAN_NW_AD_SPLIT = 8;   /* the same with a wave per stream: the whole range (batches of ONE read length of 225-256 bases go to k_wide all the same: sq_span_launch) */
 constexpr uint32_t SPAN_ERR_N = 264;      /* error rates by raw quality byte, NaN for what is no phred character ... */
 constexpr uint32_t SPAN_ERR_PAD = 256;    /* ... and one entry that no byte reaches: +0.0, for chain steps that do not exist */
 constexpr uint32_t SPAN_BIN_OFF = SPAN_ERR_N * 8;

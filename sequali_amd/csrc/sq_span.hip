@@ -1069,33 +1069,35 @@ int launch_any(int nw, sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad,
 /* A register spilled inside the loop is reloaded behind an `s_waitcnt vmcnt(0)`, which also waits for
    the span in flight (the LDS-DMA counts in vmcnt): a build of the kernel with a wave per stream
    that spills is not used (the one with a wave for both streams has 168 registers) */
-template <int NW, bool SEG>
-bool split_build_spills(bool ad)
+/* does the build <NW, ad, SEG, SPLIT> use scratch memory?  A register spilled inside the loop is reloaded behind an
+   s_waitcnt vmcnt(0), which also waits for the span in flight (the LDS-DMA counts in vmcnt): such a build is not used */
+template <int NW, bool SEG, bool SPLIT>
+bool span_build_spills(bool ad)
 {
     static int spills[2] = {-1, -1};
     if (spills[ad] < 0) {
         hipFuncAttributes fa{};
-        const void *fn = (const void *)k_span<NW, false, SEG, SPAN_W4, true>;
-        if constexpr (NW <= SPAN_NW_AD_SPLIT) if (ad) fn = (const void *)k_span<NW, true, SEG, SPAN_W4, true>;
+        const void *fn = (const void *)k_span<NW, false, SEG, SPAN_W4, SPLIT>;
+        if constexpr (NW <= (SPLIT ? SPAN_NW_AD_SPLIT : SPAN_NW_AD)) if (ad) fn = (const void *)k_span<NW, true, SEG, SPAN_W4, SPLIT>;
         spills[ad] = hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.localSizeBytes > 0 ? 1 : 0;
     }
     return spills[ad] != 0;
 }
-template <bool SEG>
-bool split_build_spills_any(int nw, bool ad)
+template <bool SEG, bool SPLIT>
+bool span_build_spills_any(int nw, bool ad)
 {
 #ifdef SQ_SPAN_ONLY_NW
-    return nw == SQ_SPAN_ONLY_NW ? split_build_spills<SQ_SPAN_ONLY_NW, SEG>(ad) : true;
+    return nw == SQ_SPAN_ONLY_NW ? span_build_spills<SQ_SPAN_ONLY_NW, SEG, SPLIT>(ad) : true;
 #else
     switch (nw) {
-        case 1: return split_build_spills<1, SEG>(ad);
-        case 2: return split_build_spills<2, SEG>(ad);
-        case 3: return split_build_spills<3, SEG>(ad);
-        case 4: return split_build_spills<4, SEG>(ad);
-        case 5: return split_build_spills<5, SEG>(ad);
-        case 6: return split_build_spills<6, SEG>(ad);
-        case 7: return split_build_spills<7, SEG>(ad);
-        default: return split_build_spills<8, SEG>(ad);
+        case 1: return span_build_spills<1, SEG, SPLIT>(ad);
+        case 2: return span_build_spills<2, SEG, SPLIT>(ad);
+        case 3: return span_build_spills<3, SEG, SPLIT>(ad);
+        case 4: return span_build_spills<4, SEG, SPLIT>(ad);
+        case 5: return span_build_spills<5, SEG, SPLIT>(ad);
+        case 6: return span_build_spills<6, SEG, SPLIT>(ad);
+        case 7: return span_build_spills<7, SEG, SPLIT>(ad);
+        default: return span_build_spills<8, SEG, SPLIT>(ad);
     }
 #endif
 }
@@ -1105,7 +1107,9 @@ int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, 
 {
     if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > (split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD))) return 0; /* unsplit: the automaton's rounds spill registers from 161 positions on */
     if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
-    if (split && !sq_knobs().span_spills_ok && (seg ? split_build_spills_any<true>(nw, ad) : split_build_spills_any<false>(nw, ad))) return 0;
+    if (!sq_knobs().span_spills_ok &&
+        (seg ? (split ? span_build_spills_any<true, true>(nw, ad) : span_build_spills_any<true, false>(nw, ad))
+             : (split ? span_build_spills_any<false, true>(nw, ad) : span_build_spills_any<false, false>(nw, ad)))) return 0;
     const int step = split ? 2 : 1;
     int waves = span_max_waves(nw, split, seg);   /* as many as LDS takes */
     while (waves >= 4 && span_lds_layout(nw, U, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;
@@ -1873,6 +1877,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
+    if (ad && nw >= 8) return SQ_OK;   /* 225-256 positions with adapters: k_wide is 9 % ahead of the 8-wave build (scripts/bench_len.py); that build serves the sorted route */
     bool split = sq_knobs().span_split && (ad || sq_knobs().span_split_qc);   /* QCMetrics alone: one wave for both streams was 2-3 % ahead (SQ_SPAN_SPLIT_QC=1: a wave per stream there too) */
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
@@ -1903,15 +1908,19 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     /* one wave for both streams: with rows gathered from all over the buffer a wave per stream measures the same
        (676-707 against 699-715 Gbases/s), and its 4-window build sits at exactly 128 registers -- a spill there
        sent the whole route to the other build without a word (SQ_SPAN_SORTED_SPLIT=1: a wave per stream) */
-    bool split = sq_knobs().span_split && sq_knobs().span_sorted_split;
+    const bool prefer_split = sq_knobs().span_split && sq_knobs().span_sorted_split;
     if (!max_len || max_len > 32u * SPAN_NW_MAX || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
-    for (int pass = 0; pass < 2; pass++) {   /* every window count of the batch must be one the kernel takes */
-        bool all = true;
-        for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++)
-            if (!span_waves(P, nw, 32 * nw, ad, n_ad, true, split)) all = false;
-        if (all) break;
-        if (pass == 1 || (!split && !sq_knobs().span_split)) return SQ_OK;
-        split = !split;   /* the other build (reads of 161-256 bases with adapters exist as a wave per stream only) */
+    /* every window count of the batch must be one the kernel takes, in one build or the other (each launch has its
+       own: reads of 161-224 bases with adapters exist as a wave per stream only, the 4-window build of a wave per
+       stream does not fit its registers) */
+    bool split_of[SPAN_NW_MAX + 1] = {};
+    for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++) {
+        bool found = false;
+        for (const bool sp : {prefer_split, !prefer_split}) {
+            if (found || (sp && !sq_knobs().span_split)) continue;
+            if (span_waves(P, nw, 32 * nw, ad, n_ad, true, sp)) { split_of[nw] = sp; found = true; }
+        }
+        if (!found) return SQ_OK;
     }
     SpanRow *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     std::vector<uint64_t> longer((size_t)max_len + 1);   /* longer[w] = how many reads are longer than w */
@@ -1962,7 +1971,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         if (!count) continue;
         const int nw = (int)((U + 31) / 32);
         if (launches.empty() || launches.back().nw != nw)
-            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad, true, split), {}, 0});
+            launches.push_back(Launch{nw, span_waves(P, nw, 32 * nw, ad, n_ad, true, split_of[nw]), {}, 0});
         Launch &l = launches.back();
         SpanSeg g{};
         g.span0 = l.spans;
@@ -1986,6 +1995,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         C.span_nsegs = (uint32_t)l.segs.size();
         C.span_total = l.spans;
         C.span_rows = rows_out;
+        const bool split = split_of[l.nw];
         const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
         const int seqs = split ? l.waves / 2 : l.waves;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
