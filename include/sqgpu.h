@@ -131,6 +131,11 @@ sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
 /* the host copy of a sealed block is no longer needed */
 void sq_feeder_release(sq_feeder *f, uint64_t block_id);
 
+/* Test hook (host only): how k_span over the segments of long reads shares its spans among `grid` workgroups -- bounds
+ * [grid + 1] = first span of every workgroup's stretch of consecutive spans -- when a span costs 1 and every segment a
+ * workgroup meets `cost` (nspans[j] = spans of segment j). */
+void sq_span_cost_shares(const uint32_t *nspans, size_t n, int grid, int cost, uint32_t *bounds);
+
 /* Diagnostics: the counting kernels the dispatchers have launched on this context since sq_route_reset(), joined by
  * '+' ("k_span<5,AD,split>+k_span_scatter+k_span<4,AD,sorted>+..."): which kernel takes a batch is decided per batch
  * (DESIGN.md 4.1), and a build that no longer fits its registers makes a dispatcher take another one silently;

@@ -1757,6 +1757,46 @@ static int long_waves(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_
     return waves;
 }
 
+/* Where every workgroup's stretch of consecutive spans begins ([grid + 1] span numbers): shares of equal cost, a span
+ * costing 1 and every segment a workgroup meets K (a share that ends inside a segment makes the next workgroup meet it
+ * too).  nspans[j] = spans of segment j, in span order. */
+std::vector<uint32_t> span_cost_shares(const std::vector<uint32_t> &nspans, int grid, double K)
+{
+    uint64_t spans = 0;
+    double total = K * grid;
+    for (uint32_t n : nspans) { spans += n; total += (double)n + K; }
+    std::vector<uint32_t> bounds((size_t)grid + 1, (uint32_t)spans);
+    const double share = total / grid;
+    bounds[0] = 0;
+    int wg = 1;
+    double acc = 0;   /* cost handed out so far */
+    uint32_t span0 = 0;
+    for (uint32_t n : nspans) {
+        double left = (double)n;   /* spans of this segment not handed out yet */
+        uint32_t at = span0;
+        acc += K;
+        while (wg < grid && acc + left > share * wg) {
+            const double take = std::max(0.0, share * wg - acc);
+            const uint32_t t = (uint32_t)std::min<double>(left, std::floor(take));
+            at += t; left -= t; acc += t;
+            bounds[wg++] = at;
+            acc += K;   /* the next workgroup meets this segment too */
+            if (left <= 0) break;
+        }
+        acc += left;
+        span0 += n;
+    }
+    for (size_t i = 1; i < bounds.size(); i++) bounds[i] = std::max(bounds[i], bounds[i - 1]);
+    bounds[grid] = (uint32_t)spans;
+    return bounds;
+}
+
+SQ_EXPORT void sq_span_cost_shares(const uint32_t *nspans, size_t n, int grid, int cost, uint32_t *bounds)
+{
+    const std::vector<uint32_t> b = span_cost_shares(std::vector<uint32_t>(nspans, nspans + n), grid, (double)cost);
+    memcpy(bounds, b.data(), b.size() * sizeof(uint32_t));
+}
+
 /* does k_span<LONG> take this batch (sq_span_launch_long may still decline: memory) */
 bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len)
 {
@@ -1814,33 +1854,9 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
        the last workgroup of config 4 went through 155 of them, the others through 1-18, and the launch waited
        for it: 9.65 ms, 7.85 with shares of equal COST (spans + SQ_LONG_STRETCH_COST per segment met; 12 and
        more all measure the same). */
-    std::vector<uint32_t> bounds((size_t)grid + 1, (uint32_t)spans);
-    {
-        const double K = (double)sq_knobs().long_stretch_cost;
-        double total = 0;
-        for (const SpanSeg &g : segs) total += (double)g.nspans + K;
-        total += K * grid;   /* a share that ends inside a segment makes the next workgroup meet it too */
-        const double share = total / grid;
-        bounds[0] = 0;
-        int wg = 1;
-        double acc = 0;   /* cost of the spans handed out so far */
-        for (const SpanSeg &g : segs) {
-            double left = (double)g.nspans;   /* spans of this segment not handed out yet */
-            uint32_t at = g.span0;
-            acc += K;
-            while (wg < grid && acc + left > share * wg) {
-                const double take = std::max(0.0, share * wg - acc);
-                const uint32_t t = (uint32_t)std::min<double>(left, std::floor(take));
-                at += t; left -= t; acc += t;
-                bounds[wg++] = at;
-                acc += K;   /* the next workgroup meets this segment too */
-                if (left <= 0) break;
-            }
-            acc += left;
-        }
-        for (size_t i = 1; i < bounds.size(); i++) bounds[i] = std::max(bounds[i], bounds[i - 1]);
-        bounds[grid] = (uint32_t)spans;
-    }
+    std::vector<uint32_t> nspans_of;
+    for (const SpanSeg &g : segs) nspans_of.push_back(g.nspans);
+    const std::vector<uint32_t> bounds = span_cost_shares(nspans_of, grid, (double)sq_knobs().long_stretch_cost);
     uint32_t *d_bounds = (uint32_t *)sq_scratch(ctx, 22, bounds.size() * 4);
     if (!d_bounds) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
     SQ_HIP(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, ctx->stream));

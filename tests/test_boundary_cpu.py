@@ -405,3 +405,33 @@ def test_a_parser_that_has_ended_gives_its_blocks_back():
                 assert out[3] == 0, "a later parser had to allocate staging memory afresh"
     finally:
         gc.enable()
+
+
+def test_workgroup_shares_of_equal_cost():
+    """k_span over the segments of long reads: every span belongs to exactly one workgroup, the shares
+    are consecutive, and no workgroup's cost (spans + 16 per segment it meets) is far from the mean -- with equal
+    numbers of spans the last workgroup of config 4 went through 155 segments"""
+    import ctypes as C
+    import numpy as np
+    from sequali_amd._lib import lib
+    rng = np.random.default_rng(4)
+    lengths = np.clip(rng.lognormal(np.log(8000), 0.75, 200_000), 200, 100_000).astype(np.int64)
+    nj = [(lengths > 256 * j).sum() for j in range(int((lengths.max() + 255) // 256))]
+    nspans = np.array([-(-int(n) // 16) for n in nj if n], dtype=np.uint32)
+    starts = np.concatenate([[0], np.cumsum(nspans)])
+    for grid, cost in ((256, 16), (256, 1), (7, 16), (1, 16), (300, 48)):
+        bounds = (C.c_uint32 * (grid + 1))()
+        lib().sq_span_cost_shares(nspans.ctypes.data, len(nspans), grid, cost, bounds)
+        b = np.array(bounds[:], dtype=np.int64)
+        assert b[0] == 0 and b[-1] == nspans.sum() and np.all(np.diff(b) >= 0)
+        costs = []
+        for w in range(grid):
+            lo, hi = b[w], b[w + 1]
+            met = int(np.searchsorted(starts, hi, "left") - np.searchsorted(starts, lo, "right") + 1) if hi > lo else 0
+            costs.append((hi - lo) + cost * met)
+        if grid >= 7:
+            assert max(costs) <= 1.05 * np.mean(costs) + 2 * cost, (grid, cost, max(costs), np.mean(costs))
+    # equal numbers of spans, for comparison: the last share meets most of the segments
+    per = -(-int(nspans.sum()) // 256)
+    last_lo = 255 * per
+    assert len(nspans) - np.searchsorted(starts, last_lo, "right") > 50
