@@ -117,6 +117,15 @@ def dominant_kernel(kind, mods):
     return "k_pass (fused per-base pass)"
 
 
+def compact_route(route: str) -> str:
+    """"a+b+a+b" -> "2 x (a+b)": the route of a step that walks several batches"""
+    parts = route.split("+") if route else []
+    for period in range(1, len(parts) // 2 + 1):
+        if len(parts) % period == 0 and parts == parts[:period] * (len(parts) // period):
+            return f"{len(parts) // period} x ({'+'.join(parts[:period])})"
+    return "+".join(parts)
+
+
 def host_cpu():
     """model name and core count of the box the CPU baseline ran on"""
     model = "unknown"
@@ -198,9 +207,11 @@ def other_configs(lib, ctx, steps, warmup):
     def run(name, workload, kernel, arrays_bases_reads, make, step, check):
         bases, reads, algo = arrays_bases_reads
         objs = make()
-        for _ in range(warmup):
+        lib.sq_route_reset(ctx)
+        for _ in range(max(warmup, 1)):
             step(objs)
         _lib.synchronize()
+        route = route_of_step()     # the kernels one step launched (sq_last_route): a silent fallback would show here
         ev = HipEvents(lib.sq_stream_handle(ctx))
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -213,7 +224,7 @@ def other_configs(lib, ctx, steps, warmup):
         avg = sum(ms) / len(ms)
         achieved = algo / (avg * 1e-3) / 1e9
         return {"workload": workload, "value": round(bases / dt / 1e9, 3), "unit": "Gbases/s",
-                "ms_per_step": round(dt * 1e3, 3),
+                "ms_per_step": round(dt * 1e3, 3), "route": route,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBPS, 5), "kernel": kernel,
                              "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_step": int(algo)},
@@ -222,7 +233,29 @@ def other_configs(lib, ctx, steps, warmup):
     def clear(f):
         f.qc_metrics._pending.clear()
 
+    def route_of_step():
+        return compact_route((lib.sq_last_route(ctx) or b"").decode())
+
     out = {}
+    # ---- batches of one read length other than 150: 200 and 250 bases (2 x 250 is a real Illumina length) ----
+    for L in (200, 250):
+        n, per = 50_000_000, 25_000_000
+        batches = [synth.device_array(synth.with_length(synth.ILLUMINA, L), k * per, per) for k in range(n // per)]
+        bases = sum(b._batch.total_bases for b in batches)
+
+        def uniform_step(f, batches=batches):
+            for b in batches:
+                f.add_record_array(b)
+                clear(f)
+
+        out[f"uniform_{L}bp"] = run(
+            f"uniform{L}", f"{n} x {L} bp synthetic single-end reads, QCMetrics + AdapterCounter fused, records resident in HBM",
+            "the kernel `route` names", (bases, n, 2 * bases + 48 * n),
+            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), uniform_step,
+            lambda f, passes, bases=bases, n=n: {
+                "base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+        del batches
     # ---- ragged: the config-2 records cut to 50 .. 150 bases (what adapter trimming leaves) ----
     n, per = 50_000_000, 25_000_000
     batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
@@ -429,8 +462,10 @@ def main():
             torch.cuda.synchronize()
         _lib.synchronize()
 
+    lib.sq_route_reset(ctx)
     for _ in range(args.warmup):
         step()
+    headline_route = compact_route((lib.sq_last_route(ctx) or b"").decode()) if args.warmup else None
     events = HipEvents(lib.sq_stream_handle(ctx))
     barrier()
     t0 = time.perf_counter()
@@ -510,6 +545,7 @@ def main():
                          "kernel": dominant_kernel(args.kind, mods),
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launch_ms)},
+            "route": headline_route,
             "checks": checks,
         }
         if rank_ms is not None:

@@ -125,6 +125,8 @@ int sq_feeder_seal(sq_feeder *f);
 const uint8_t *sq_feeder_block_text(sq_feeder *f, uint64_t block_id);
 const sq_meta *sq_feeder_block_metas(sq_feeder *f, uint64_t block_id);
 uint64_t sq_feeder_block_records(sq_feeder *f, uint64_t block_id);
+/* bytes of the block that hold text: every array window of the block lies inside [0, bytes) */
+uint64_t sq_feeder_block_bytes(sq_feeder *f, uint64_t block_id);
 int sq_feeder_block_is_open(sq_feeder *f, uint64_t block_id);
 /* a sealed block as a record array in HBM (one async copy from pinned memory); NULL on failure */
 sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
@@ -178,6 +180,9 @@ sq_batch *sq_batch_from_fastq_device(sq_ctx *ctx, const void *d_text, size_t len
  * dropped. */
 sq_batch *sq_batch_from_fastq_ahead(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed,
                                     const uint8_t *ahead, size_t ahead_len);
+/* forgets what was sent ahead (the parser has ended, failed or been rewound: the next buffer will not be the one
+ * it named; a later text at the same host address must not meet the stale copy) */
+void sq_ahead_drop(sq_ctx *ctx);
 /* BAM input.  sq_bam_scan is the record walk of BamParser__next__
  * (_qcmodule.c:1601-1681) on the host: offsets of the complete records of an uncompressed
  * BAM record stream that are not secondary / supplementary (:1262,1611), the bytes they
@@ -449,6 +454,9 @@ int sq_adaptercounter_set_row_length(sq_adaptercounter *a, uint64_t row_length);
 #define SQ_SYNTH_ILLUMINA_R2 1    /* the mate of read i              */
 #define SQ_SYNTH_NANOPORE 2       /* variable length, ~10 kb          */
 #define SQ_SYNTH_ILLUMINA_BY_TILE 3 /* kind 0 with the reads ordered by tile */
+#define SQ_SYNTH_ILLUMINA_R2_BY_TILE 4 /* kind 1 with the reads ordered by tile: the mates of kind 3 */
+/* Illumina kinds: `kind | (L << 8)` makes reads of L bases instead of 150 (1 <= L <= 65535) */
+#define SQ_SYNTH_KIND_LEN(kind, L) ((kind) | ((L) << 8))
 /* Size in bytes of records [first, first+n) and the generators themselves.
  * Host version writes FASTQ text + metas into caller memory; device version
  * allocates a batch in HBM and fills it with a kernel. */

@@ -443,11 +443,17 @@ class _Feeder:
             pass
         self.h = None
 
-    def retire(self, block_id: int) -> None:
-        """a block has been closed: the oldest host copies go back to the pool"""
-        self.sealed.append(block_id)
+    def retire(self, blk: "_FeedBlock") -> None:
+        """a block has been closed: the oldest pinned copies go back to the pool.  A block that somebody
+        still holds arrays of and that has no copy in HBM keeps its bytes: they move to pageable memory
+        (the reference's arrays own their buffer and stay valid for ever, _qcmodule.c:575-579)"""
+        self.sealed.append((blk.block_id, weakref.ref(blk)))
         while len(self.sealed) > self.KEEP:
-            lib().sq_feeder_release(self.h, self.sealed.pop(0))
+            block_id, ref = self.sealed.pop(0)
+            old = ref()
+            if old is not None and old.array is None:
+                old.detach()
+            lib().sq_feeder_release(self.h, block_id)
 
 
 class _FeedArrayInfo(C.Structure):
@@ -466,6 +472,21 @@ class _FeedBlock(_Block):
         self.rates_version = 0       # bumped when a QCMetrics pass has left error rates in the block's metas in HBM
         self._host_text = None
         self._host_metas = None
+        self.detached = False        # the pinned copy is gone and no copy in HBM was made: _host_text / _host_metas hold the block
+
+    def detach(self) -> None:
+        """the block's bytes and metas out of the pinned block (which is about to be handed back)"""
+        f = self.feeder
+        p = lib().sq_feeder_block_text(f.h, self.block_id)
+        pm = lib().sq_feeder_block_metas(f.h, self.block_id)
+        if not p or not pm:
+            return
+        nbytes = lib().sq_feeder_block_bytes(f.h, self.block_id)
+        nrec = lib().sq_feeder_block_records(f.h, self.block_id)
+        self._host_text = C.string_at(p, nbytes)
+        self._host_metas = (np.ctypeslib.as_array((C.c_uint8 * (40 * nrec)).from_address(pm)).view(META_DTYPE).copy()
+                            if nrec else np.zeros(0, dtype=META_DTYPE))
+        self.detached = True
 
     @property
     def sealed(self) -> bool:
@@ -481,11 +502,14 @@ class _FeedBlock(_Block):
             if not self.closed:
                 check(lib().sq_feeder_seal(f.h))     # the parser's next array opens a new block
                 self.closed = True
-                f.retire(self.block_id)
-            h = lib().sq_feeder_upload(f.h, self.block_id)
-            if not h:
-                raise MemoryError(_lib.last_error())
-            self.array = FastqRecordArrayView._from_device(_DeviceBatch(h))
+                f.retire(self)
+            if self.detached:    # the pinned block went back before anybody asked for a copy in HBM
+                self.array = FastqRecordArrayView._from_buffer(self._host_text, self._host_metas)
+            else:
+                h = lib().sq_feeder_upload(f.h, self.block_id)
+                if not h:
+                    raise MemoryError(_lib.last_error())
+                self.array = FastqRecordArrayView._from_device(_DeviceBatch(h))
             # weak: block -> array -> block would keep both (and the feeder's page-locked blocks) until the
             # cycle collector comes by, long after the parser is gone
             self.array._blk = weakref.ref(self)
@@ -720,6 +744,12 @@ class _HostBuffer:
         self.address = None
 
 
+def _ahead_drop() -> None:
+    """what sq_batch_from_fastq_ahead sent ahead is void: the buffer it named will not be asked for"""
+    if _lib._ctx is not None:
+        lib().sq_ahead_drop(_lib._ctx)
+
+
 class PinnedReader:
     """A binary file object over FASTQ text held in page-locked host memory (the text is copied
     there once, when the object is made).  Any parser can read() / readinto() it;
@@ -731,6 +761,12 @@ class PinnedReader:
         self._hold = _HostBuffer(len(view))
         self._address, self._size, self._pos = self._hold.address, len(view), 0
         C.memmove(self._address, _addr(np.frombuffer(view, dtype=np.uint8)) if len(view) else 0, len(view))
+
+    def __del__(self):
+        try:
+            _ahead_drop()      # before the pages go back: a block sent ahead from them must not be matched by address later
+        except Exception:
+            pass
 
     def _skip(self, n: int) -> int:
         n = min(n, self._size - self._pos)
@@ -752,6 +788,7 @@ class PinnedReader:
     def seek(self, offset: int, whence: int = 0) -> int:
         base = {0: 0, 1: self._pos, 2: self._size}[whence]
         self._pos = min(max(base + offset, 0), self._size)
+        _ahead_drop()          # the next buffer is no longer the one a parser named
         return self._pos
 
     def tell(self) -> int:
@@ -849,12 +886,22 @@ class FastqParser:
         if blk is None or blk.block_id != info.block_id:
             if blk is not None and not blk.closed:     # the feeder went on to a new block by itself: the old one is complete
                 blk.closed = True
-                f.retire(blk.block_id)
+                f.retire(blk)
             blk = self._blk = _FeedBlock(self._token, f, info.block_id)
         slot = blk.add(info.n_records)
         return _FedArray(blk, slot, info.byte_start, info.byte_len, info.first_record, info.n_records)
 
     def _create_on_device(self) -> FastqRecordArrayView:
+        try:
+            arr = self._create_on_device_inner()
+        except BaseException:
+            _ahead_drop()      # the parse is over: whatever was sent ahead has no taker
+            raise
+        if len(arr) == 0:
+            _ahead_drop()
+        return arr
+
+    def _create_on_device_inner(self) -> FastqRecordArrayView:
         """The loop of FastqParser_create_record_array (_qcmodule.c:964-1184) with the
         ASCII check and the record split done by sq_batch_from_fastq.  The buffer is page-locked
         (the upload runs at the bus rate); a PinnedReader hands its own pages over, no copy at all."""

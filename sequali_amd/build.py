@@ -16,6 +16,58 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+# Builds of k_span (sq_span.hip: <NW, AD, SEG, W4T, SPLIT, LONG>) that the DEFAULT dispatch launches (sq_span_launch,
+# sq_span_launch_sorted, sq_span_launch_long; tests/test_gpu_routes.py asserts the same routes on the GPU).  A register
+# spilled inside their loop is reloaded behind an `s_waitcnt vmcnt(0)`, which also waits for the span in flight: the
+# dispatcher would fall back to another kernel without a word (span_build_spills; round 2 lost a third of a route's
+# speed that way), so the build fails instead.  The run-time guard stays for experiment builds.
+def default_route_builds():
+    b = lambda x: "Lb1" if x else "Lb0"   # noqa: E731
+    out = []
+    for nw in range(1, 9):
+        out.append((nw, False, False, False, False))                   # QCMetrics alone, one read length: one wave for both streams
+        if nw <= 7:
+            out.append((nw, True, False, True, False))                 # + AdapterCounter: a wave per stream (8 windows: k_wide)
+        # reads of many lengths: one wave for both streams where that build exists, else a wave per stream
+        out.append((nw, False, True, nw == 6, False))
+        out.append((nw, True, True, nw >= 6, False))
+    for ad in (False, True):
+        out.append((8, ad, True, True, True))                          # segments of long reads
+    names = ["k_spanILi%dE%sE%sELi3E%sE%sEE" % (nw, b(ad), b(seg), b(split), b(lng)) for nw, ad, seg, split, lng in out]
+    names += ["k_ptspanILi%dEE" % nw for nw in range(1, 9)] + ["k_isz_spanILi%dEE" % nw for nw in range(1, 9)]
+    return names
+
+
+def parse_resource_remarks(stderr: str):
+    """{mangled kernel name: {"vgprs": .., "scratch": .., "spill": ..}} from -Rpass-analysis=kernel-resource-usage"""
+    import re
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[{"VGPRs": "vgprs", "VGPRs Spill": "spill", "SGPRs Spill": "sgpr_spill", "ScratchSize [bytes/lane]": "scratch",
+                 "Occupancy [waves/SIMD]": "occupancy"}[m.group(1)]] = int(m.group(2))
+    return out
+
+
+def check_default_routes(resources) -> None:
+    missing, spilling = [], []
+    for want in default_route_builds():
+        hit = [(k, v) for k, v in resources.items() if want in k]
+        if not hit:
+            missing.append(want)
+        for k, v in hit:
+            if v.get("spill", 0) or v.get("scratch", 0):
+                spilling.append(f"{k}: {v}")
+    if missing or spilling:
+        raise RuntimeError("kernels of a default route are missing from the build or use scratch memory:\n" +
+                           "\n".join(missing + spilling))
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -50,18 +102,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
         def compile_one(src: str) -> str:
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-            flags = FLAGS if src.endswith(".hip") else ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]   # .cpp: host only
+            flags = FLAGS + ["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else \
+                ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]   # .cpp: host only
             cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj + tag]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+            res = parse_resource_remarks(r.stderr)
             if verbose and r.stderr:
-                print(r.stderr, file=sys.stderr)
+                print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and l.strip() not in ("^", "")
+                                and not l.lstrip().split("|")[0].strip().isdigit()), file=sys.stderr)
             os.replace(obj + tag, obj)
-            return obj
+            return obj, res
 
-        with ThreadPoolExecutor(max_workers=7) as pool:
-            objs = list(pool.map(compile_one, SOURCES))
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            done = list(pool.map(compile_one, SOURCES))
+        objs = [o for o, _ in done]
+        resources = {}
+        for _, res in done:
+            resources.update(res)
+        import json
+        with open(os.path.join(objdir, "resources.json"), "w") as f:
+            json.dump(resources, f, indent=0, sort_keys=True)
+        check_default_routes(resources)   # before the link: a library with a spilling default route is not made
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag, *objs],
                            capture_output=True, text=True)
         if r.returncode != 0:

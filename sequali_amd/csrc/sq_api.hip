@@ -760,24 +760,35 @@ SQ_EXPORT sq_batch *sq_batch_from_fastq_ahead(sq_ctx *ctx, const uint8_t *text, 
        ctx->stream by the caller, who is back here for the next buffer) go on beside it; the split
        waits for it.  What an earlier call has sent ahead is already in HBM: a copy within the device. */
     sq_ctx::Ahead &A = ctx->ahead;
+    uint8_t *spent = nullptr;
+    /* wherever this call fails: the block of this buffer (and the one sent ahead, once taken off the context)
+       go back to the pool, behind whatever is still reading or writing them */
+    auto fail = [&]() -> sq_batch * {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        sq_dev_put(ctx, d_text);
+        if (spent) sq_dev_put(ctx, spent);
+        return nullptr;
+    };
+#define SQ_HIP_FAIL(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sq_set_error("%s: %s", #call, hipGetErrorString(e_)); return fail(); } } while (0)
     /* what was sent ahead may begin in front of this buffer and reach beyond it (the caller did not know
        its leftover then): the overlap is copied inside the device, the rest comes from the host */
     const uint8_t *lo = A.dev ? std::max(A.host, text) : nullptr, *hi = A.dev ? std::min(A.host + A.len, text + len) : nullptr;
     const bool covered = A.dev && lo < hi;
     if (covered) {
         const size_t head = (size_t)(lo - text), tail = (size_t)(text + len - hi);
-        if (head) SQ_HIP_NULL(hipMemcpyAsync(d_text, text, head, hipMemcpyHostToDevice, ctx->copy_stream));
-        if (tail) SQ_HIP_NULL(hipMemcpyAsync(d_text + (hi - text), hi, tail, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (head) SQ_HIP_FAIL(hipMemcpyAsync(d_text, text, head, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (tail) SQ_HIP_FAIL(hipMemcpyAsync(d_text + (hi - text), hi, tail, hipMemcpyHostToDevice, ctx->copy_stream));
     } else if (len) {
-        SQ_HIP_NULL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->copy_stream));
+        SQ_HIP_FAIL(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, ctx->copy_stream));
     }
-    SQ_HIP_NULL(hipEventRecord(ctx->copied, ctx->copy_stream));
-    SQ_HIP_NULL(hipStreamWaitEvent(ctx->stream, ctx->copied, 0));   /* behind the upload sent ahead too: same stream */
-    SQ_HIP_NULL(hipMemsetAsync(d_text + len, 0, 64, ctx->stream));
+    SQ_HIP_FAIL(hipEventRecord(ctx->copied, ctx->copy_stream));
+    SQ_HIP_FAIL(hipStreamWaitEvent(ctx->stream, ctx->copied, 0));   /* behind the upload sent ahead too: same stream */
+    SQ_HIP_FAIL(hipMemsetAsync(d_text + len, 0, 64, ctx->stream));
     if (covered)   /* a kernel, not hipMemcpyDeviceToDevice: that one goes through the copy engines at ~60 GB/s */
         hipLaunchKernelGGL(k_copy_bytes, dim3(2048), dim3(256), 0, ctx->stream, d_text + (lo - text),
                            (const uint8_t *)A.dev + (lo - A.host), (uint64_t)(hi - lo));
-    uint8_t *spent = A.dev;   /* used, or sent for a buffer that never came: back to the pool when the copy kernel has read it */
+    spent = A.dev;   /* used, or sent for a buffer that never came: back to the pool when the copy kernel has read it */
     A = sq_ctx::Ahead();
     if (ahead && ahead_len) {
         /* the caller's next buffer: on its way while this one is split and counted (into a block of its
@@ -799,6 +810,18 @@ SQ_EXPORT sq_batch *sq_batch_from_fastq_ahead(sq_ctx *ctx, const uint8_t *text, 
         sq_dev_put(ctx, spent);
     }
     return b;
+#undef SQ_HIP_FAIL
+}
+
+/* What sq_batch_from_fastq_ahead has sent ahead is forgotten: the caller's next buffer will not be the one it
+ * named (a parser that ends, fails or is rewound; its pages may be handed to somebody else).  Without this a later
+ * call whose text happens to lie at the same host address would be assembled from the stale copy in HBM. */
+SQ_EXPORT void sq_ahead_drop(sq_ctx *ctx)
+{
+    if (!ctx || !ctx->ahead.dev) return;
+    (void)hipStreamSynchronize(ctx->copy_stream);   /* the upload may still be writing the block */
+    sq_dev_put(ctx, ctx->ahead.dev);
+    ctx->ahead = sq_ctx::Ahead();
 }
 
 SQ_EXPORT sq_batch *sq_batch_from_fastq(sq_ctx *ctx, const uint8_t *text, size_t len, size_t *consumed)
@@ -1049,19 +1072,20 @@ __host__ __device__ static inline void synth_write_record(int kind, uint64_t see
                                                           uint32_t nlanes)
 {
     /* lanes stride over the bytes of one record */
-    int mate = kind == SQ_SYNTH_ILLUMINA_R2 ? 1 : 0;
+    const int mate = sqs_kind_mate(kind);
+    const bool nanopore = sqs_base_kind(kind) == SQ_SYNTH_NANOPORE;
     uint32_t nl = sqs_name_length(kind);
     uint32_t L = sqs_read_length(kind, seed, i);
     uint64_t src = 0;
     uint32_t flen = 0;
-    if (kind != SQ_SYNTH_NANOPORE) {
+    if (!nanopore) {
         src = sqs_source_pair(seed, i);
         flen = sqs_fragment_length(seed, src);
     }
     if (lane == 0) {
         dst[0] = '@';
-        if (kind == SQ_SYNTH_NANOPORE) sqs_nanopore_name(seed, i, dst + 1);
-        else sqs_illumina_name(seed, i, mate, dst + 1, kind == SQ_SYNTH_ILLUMINA_BY_TILE);
+        if (nanopore) sqs_nanopore_name(seed, i, dst + 1);
+        else sqs_illumina_name(seed, i, mate, dst + 1, sqs_kind_by_tile(kind));
         dst[1 + nl] = '\n';
         dst[2 + nl + L] = '\n';
         dst[3 + nl + L] = '+';
@@ -1071,12 +1095,12 @@ __host__ __device__ static inline void synth_write_record(int kind, uint64_t see
     uint8_t *seq = dst + 2 + nl;
     uint8_t *qual = dst + 5 + nl + L;
     for (uint32_t p = lane; p < L; p += nlanes) {
-        if (kind == SQ_SYNTH_NANOPORE) {
+        if (nanopore) {
             seq[p] = sqs_nanopore_base(seed, i, p);
             qual[p] = sqs_nanopore_qual(seed, i, p);
         } else {
             seq[p] = sqs_illumina_base(seed, i, src, flen, mate, p);
-            qual[p] = sqs_illumina_qual(seed, i, mate, p);
+            qual[p] = sqs_illumina_qual(seed, i, mate, p, L);
         }
     }
 }
@@ -1097,7 +1121,7 @@ __host__ __device__ static inline void synth_fill_meta(int kind, uint64_t seed, 
 
 SQ_EXPORT uint64_t sq_synth_bytes(int kind, uint64_t seed, uint64_t first, uint64_t n)
 {
-    if (kind != SQ_SYNTH_NANOPORE) return n * sqs_record_bytes(kind, seed, 0);
+    if (sqs_base_kind(kind) != SQ_SYNTH_NANOPORE) return n * sqs_record_bytes(kind, seed, 0);
     uint64_t t = 0;
     for (uint64_t i = 0; i < n; i++) t += sqs_record_bytes(kind, seed, first + i);
     return t;
@@ -1148,7 +1172,7 @@ SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64
     b->owns = true;
     uint64_t *d_offs = nullptr;
     uint64_t fixed = 0, total = 0;
-    if (kind == SQ_SYNTH_NANOPORE) {
+    if (sqs_base_kind(kind) == SQ_SYNTH_NANOPORE) {
         /* sizes on the device, exclusive scan on the host (n is ~1e6) */
         std::vector<uint64_t> sizes(n);
         SQ_HIP_NULL(hipMalloc((void **)&d_offs, (n ? n : 1) * sizeof(uint64_t)));

@@ -84,8 +84,12 @@ struct sq_ctx {
     uint64_t *pinned_stats = nullptr; /* SQ_STATS_N words: k_batch_stats' read-back */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
-    void *scratch[24] = {};       /* 0-5: the fused pass (sorting, carries); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split; 21: k_batch_stats; 22: workgroup shares of k_span<LONG> */
-    size_t scratch_bytes[24] = {};
+    void *scratch[32] = {};       /* 0-5: the fused pass (sorting, carries; 3 holds P.order while a pass runs); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split; 21: k_batch_stats; 22: workgroup shares of k_span<LONG>; 23: its reads per segment; 24-27: the paired pass (sq_pair.hip) */
+    size_t scratch_bytes[32] = {};
+    /* small host arrays an asynchronous copy reads from (segment tables, row starts): the last few calls' copies
+       stay alive here, whatever HIP does with pageable sources */
+    std::vector<uint8_t> host_keep[8];
+    unsigned host_keep_at = 0;
     /* device blocks of batches made by sq_batch_from_fastq (text, metas): kept for the next buffer of the
        same size instead of a hipFree + hipMalloc per buffer (hipFree waits for the whole device) */
     struct DevBlock { void *p; size_t cap; };
@@ -139,6 +143,14 @@ inline void sq_dev_put(sq_ctx *ctx, void *p)
             return;
         }
     (void)hipFree(p);   /* not from the pool */
+}
+
+/* a copy of `bytes` bytes at `src` that outlives the caller's frame (see sq_ctx::host_keep) */
+inline const void *sq_host_keep(sq_ctx *ctx, const void *src, size_t bytes)
+{
+    std::vector<uint8_t> &v = ctx->host_keep[ctx->host_keep_at++ % 8];
+    v.assign((const uint8_t *)src, (const uint8_t *)src + bytes);
+    return v.data();
 }
 
 inline void *sq_scratch(sq_ctx *ctx, int i, size_t bytes)

@@ -268,7 +268,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                     const double t_roll = feed_now();
                     int rc = roll_block(f, keep_len + want + f->read_in);
                     g_feed_times[0] += feed_now() - t_roll;
-                    if (rc) return rc;
+                    if (rc) { f->in_array = false; return rc; }
                     b = open_block(f);
                     f->arr_first_record = 0;
                     f->logical_end = 0;   /* of no use until this array is done */
@@ -316,7 +316,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             if ((size_t)n < cap || (size_t)n == max_records) break;
             /* the meta area is full: a bigger one (the block keeps its text) */
             PinBuf bigger = pool_get(2 * b->meta_cap * sizeof(sq_meta), f->ctx != nullptr);
-            if (!bigger.p) { sq_set_error("out of memory for the record table"); return SQ_ERR_MEMORY; }
+            if (!bigger.p) { sq_set_error("out of memory for the record table"); f->in_array = false; return SQ_ERR_MEMORY; }
             memcpy(bigger.p, b->meta.p, b->n_records * sizeof(sq_meta));
             pool_put(b->meta);
             b->meta = bigger;
@@ -386,6 +386,11 @@ SQ_EXPORT uint64_t sq_feeder_block_records(sq_feeder *f, uint64_t block_id)
     FeedBlock *b = find_block(f, block_id);
     return b ? b->n_records : 0;
 }
+SQ_EXPORT uint64_t sq_feeder_block_bytes(sq_feeder *f, uint64_t block_id)
+{
+    FeedBlock *b = find_block(f, block_id);
+    return b ? b->used : 0;
+}
 SQ_EXPORT int sq_feeder_block_is_open(sq_feeder *f, uint64_t block_id)
 {
     FeedBlock *b = find_block(f, block_id);
@@ -421,14 +426,24 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
         delete b;
         return nullptr;
     }
-    if (b->buf_len) SQ_HIP_NULL(hipMemcpyAsync(b->d_buf, fb->pin(), b->buf_len, hipMemcpyHostToDevice, ctx->stream));
-    SQ_HIP_NULL(hipMemsetAsync(b->d_buf + b->buf_len, 0, 64, ctx->stream));
-    if (b->n) SQ_HIP_NULL(hipMemcpyAsync(b->d_metas, fb->metas(), b->n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream));
-    if (!fb->copied) SQ_HIP_NULL(hipEventCreateWithFlags(&fb->copied, hipEventDisableTiming));
-    SQ_HIP_NULL(hipEventRecord(fb->copied, ctx->stream));
-    fb->in_flight = true;
-    SQ_HIP_NULL(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
-    SQ_HIP_NULL(hipEventRecord(b->ready, ctx->stream));
+    auto fail = [&](const char *what, hipError_t e) -> sq_batch * {
+        sq_set_error("sq_feeder_upload: %s: %s", what, hipGetErrorString(e));
+        (void)hipStreamSynchronize(ctx->stream);   /* nothing may still be writing the blocks that go back */
+        if (b->ready) (void)hipEventDestroy(b->ready);
+        (void)hipFree(b->d_buf);
+        (void)hipFree(b->d_metas);
+        delete b;
+        return nullptr;
+    };
+    hipError_t e = hipSuccess;
+    if (b->buf_len && (e = hipMemcpyAsync(b->d_buf, fb->pin(), b->buf_len, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("text upload", e);
+    if ((e = hipMemsetAsync(b->d_buf + b->buf_len, 0, 64, ctx->stream)) != hipSuccess) return fail("padding", e);
+    if (b->n && (e = hipMemcpyAsync(b->d_metas, fb->metas(), b->n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("meta upload", e);
+    fb->in_flight = true;   /* from here on the pinned block may be read by a copy: free_block waits (for the event, or the stream) */
+    if (!fb->copied && (e = hipEventCreateWithFlags(&fb->copied, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+    if ((e = hipEventRecord(fb->copied, ctx->stream)) != hipSuccess) return fail("event", e);
+    if ((e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
+    if ((e = hipEventRecord(b->ready, ctx->stream)) != hipSuccess) return fail("event", e);
     return b;
 }
 

@@ -1814,7 +1814,7 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     const uint32_t LSEG = 32 * (uint32_t)nw;
     const uint32_t n_segs = (max_len + LSEG - 1) / LSEG;
     SpanRow *rows = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
-    unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 3, (size_t)n_segs * 8);
+    unsigned long long *d_counts = (unsigned long long *)sq_scratch(ctx, 23, (size_t)n_segs * 8);   /* a slot of its own: 3 holds P.order, which further adapter groups still walk */
     if (!rows || !d_counts) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
     hipLaunchKernelGGL(k_long_rows, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, P.metas, P.order, n, rows);
     hipLaunchKernelGGL(k_long_counts, dim3((n_segs + 255) / 256), dim3(256), 0, ctx->stream, rows, n, LSEG, n_segs, d_counts);
@@ -1932,7 +1932,11 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     bool split_of[SPAN_NW_MAX + 1] = {};
     for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++) {
         bool found = false;
-        for (const bool sp : {prefer_split, !prefer_split}) {
+        /* the build the default dispatch names for this window count (sequali_amd/build.py::default_route_builds fails
+           the build when one of them spills): one wave for both streams, except where that build does not exist (the
+           automaton beyond 5 windows) or does not fit its registers (6 windows for sorted rows) */
+        const bool first = prefer_split || (ad ? nw > SPAN_NW_AD : nw == 6);
+        for (const bool sp : {first, !first}) {
             if (found || (sp && !sq_knobs().span_split)) continue;
             if (span_waves(P, nw, 32 * nw, ad, n_ad, true, sp)) { split_of[nw] = sp; found = true; }
         }
@@ -1950,7 +1954,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         for (uint32_t w = 1; w <= max_len; w++) start[w] = (uint32_t)longer[w];
         uint32_t *d_start = (uint32_t *)sq_scratch(ctx, 3, 2 * SQ_LEN_BINS * 4), *d_cursor = d_start ? d_start + SQ_LEN_BINS : nullptr;
         if (!rows_out || !d_start) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
-        SQ_HIP(hipMemcpyAsync(d_start, start, sizeof start, hipMemcpyHostToDevice, ctx->stream));   /* pageable: copied when the call returns */
+        SQ_HIP(hipMemcpyAsync(d_start, sq_host_keep(ctx, start, sizeof start), sizeof start, hipMemcpyHostToDevice, ctx->stream));
         SQ_HIP(hipMemsetAsync(d_cursor, 0, SQ_LEN_BINS * 4, ctx->stream));
         const uint64_t chunk = (uint64_t)SCATTER_THREADS * SCATTER_PER;
         sq_route(ctx, "k_span_scatter");
@@ -2003,8 +2007,10 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     SpanSeg *d_segs = (SpanSeg *)sq_scratch(ctx, 5, total_segs * sizeof(SpanSeg));
     if (!d_segs) { sq_set_error("out of device memory for the sorted spans"); return SQ_ERR_MEMORY; }
     size_t seg_off = 0;
-    for (const Launch &l : launches) {   /* pageable memory: the copy is done when the call returns */
-        SQ_HIP(hipMemcpyAsync(d_segs + seg_off, l.segs.data(), l.segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<SpanSeg> all_segs;
+    for (const Launch &l : launches) all_segs.insert(all_segs.end(), l.segs.begin(), l.segs.end());
+    SQ_HIP(hipMemcpyAsync(d_segs, sq_host_keep(ctx, all_segs.data(), all_segs.size() * sizeof(SpanSeg)), all_segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
+    for (const Launch &l : launches) {
         PassParams C = P;
         C.uniform_len = 0;
         C.span_segs = d_segs + seg_off;

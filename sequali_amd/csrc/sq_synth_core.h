@@ -120,12 +120,12 @@ SQ_HD uint8_t sqs_illumina_base(uint64_t seed, uint64_t i, uint64_t src, uint32_
     return c;
 }
 
-SQ_HD uint8_t sqs_illumina_qual(uint64_t seed, uint64_t i, int mate, uint32_t p)
+SQ_HD uint8_t sqs_illumina_qual(uint64_t seed, uint64_t i, int mate, uint32_t p, uint32_t L = SQ_SYNTH_READ_LEN)
 {
     uint64_t r = sqs_rand(seed, SQS_QUAL + 16 * (uint64_t)mate, i, p >> 2);
     uint32_t u = (uint32_t)(r >> (16 * (p & 3))) & 0xFFFF;
     /* Q37 weight 0.80 -> 0.55 over the read, in 1/65536 units */
-    uint32_t w37 = 52429 - (16384 * p) / (SQ_SYNTH_READ_LEN - 1);
+    uint32_t w37 = 52429 - (16384 * p) / (L > 1 ? L - 1 : 1);
     if (u < w37) return 'F';
     uint32_t v = ((u - w37) * 10) / (65536 - w37); /* 0..9 over the rest: 6:3:1 */
     return v < 6 ? ':' : v < 9 ? ',' : '#';
@@ -235,10 +235,16 @@ SQ_HD void sqs_nanopore_name(uint64_t seed, uint64_t i, uint8_t *dst)
 }
 
 /* ---- record geometry ---------------------------------------------------- */
-SQ_HD uint32_t sqs_name_length(int kind) { return kind == 2 ? SQ_SYNTH_NANOPORE_NAME : SQ_SYNTH_ILLUMINA_NAME; }
+/* kind: bits 0-7 the kind proper (0 R1, 1 R2, 2 nanopore, 3 R1 by tile, 4 R2 by tile), bits 8-23 the read length of
+   the Illumina kinds (0: SQ_SYNTH_READ_LEN) */
+SQ_HD int sqs_base_kind(int kind) { return kind & 0xFF; }
+SQ_HD int sqs_kind_mate(int kind) { return sqs_base_kind(kind) == 1 || sqs_base_kind(kind) == 4; }
+SQ_HD int sqs_kind_by_tile(int kind) { return sqs_base_kind(kind) == 3 || sqs_base_kind(kind) == 4; }
+SQ_HD uint32_t sqs_name_length(int kind) { return sqs_base_kind(kind) == 2 ? SQ_SYNTH_NANOPORE_NAME : SQ_SYNTH_ILLUMINA_NAME; }
 SQ_HD uint32_t sqs_read_length(int kind, uint64_t seed, uint64_t i)
 {
-    return kind == 2 ? sqs_nanopore_length(seed, i) : SQ_SYNTH_READ_LEN;
+    if (sqs_base_kind(kind) == 2) return sqs_nanopore_length(seed, i);
+    return (kind >> 8) ? (uint32_t)(kind >> 8) & 0xFFFF : SQ_SYNTH_READ_LEN;
 }
 /* '@' name '\n' seq '\n+\n' qual '\n' */
 SQ_HD uint64_t sqs_record_bytes(int kind, uint64_t seed, uint64_t i)

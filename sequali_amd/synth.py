@@ -11,7 +11,12 @@ from ._lib import check, context, lib
 from ._qc import META_DTYPE, FastqRecordArrayView, _DeviceBatch
 
 DEFAULT_SEED = 20250912
-ILLUMINA, ILLUMINA_R2, NANOPORE, ILLUMINA_BY_TILE = 0, 1, 2, 3
+ILLUMINA, ILLUMINA_R2, NANOPORE, ILLUMINA_BY_TILE, ILLUMINA_R2_BY_TILE = 0, 1, 2, 3, 4
+
+
+def with_length(kind: int, length: int) -> int:
+    """an Illumina kind with reads of `length` bases instead of 150 (SQ_SYNTH_KIND_LEN)"""
+    return kind | (int(length) << 8)
 
 ILLUMINA_PROBES = ("AGATCGGAAGAG", "TGGAATTCTCGG", "GATCGTCGGACT", "CTGTCTCTTATA",
                    "GGGGGGGGGGGG", "AAAAAAAAAAAA")  # adapters/adapter_list.tsv:8-15

@@ -31,7 +31,7 @@ def _quarter(U):
     return 4 * (2 * ((U + 31) // 32) + 1)
 
 
-@pytest.mark.parametrize("U", [150, 97, 160, 64])
+@pytest.mark.parametrize("U", [150, 97, 160, 64, 200, 224])
 @pytest.mark.parametrize("route", ["uniform", "sorted", "unsplit"])
 def test_adapter_ending_on_every_quarter_seam(U, route):
     """a 13-character adapter (the most SPAN_W4 = 3 dwords of restart in front of a quarter cover) and
@@ -80,7 +80,15 @@ def test_adapter_ending_on_every_quarter_seam(U, route):
     arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
     gq, ga = QCMetrics(), AdapterCounter(probes)
     env = {"uniform": {}, "sorted": {"SQ_SPAN_SORTED": "1"}, "unsplit": {"SQ_SPAN_SPLIT": "0"}}[route]
-    with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
+    from tests.test_gpu_vs_oracle import _route_of
+    r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush())))
+    nw = (U + 31) // 32
+    if route == "uniform":
+        assert r.split("+")[0] == f"k_span<{nw},AD,uniform,split>", r
+    elif route == "sorted":
+        assert any(p.startswith(f"k_span<{nw},AD,sorted,") for p in r.split("+")), r
+    elif nw <= 5:
+        assert r.split("+")[0] == f"k_span<{nw},AD,uniform,both>", r
     compare_qc(rq, gq, metas, arr)
     assert _compare_adapters(ga, ra) >= 3 * len(ends)
 
@@ -202,3 +210,54 @@ def test_quality_bytes_from_128_on_are_no_phred_characters(raw, ragged):
     with_env(env, lambda: (m.add_record_array(more), m.flush()))
     np.testing.assert_array_equal(u64(m.phred_count_table()), ref.phred_count_table())
     assert m.number_of_reads == ref.number_of_reads
+
+
+def test_fuzz_thirty_iterations():
+    """scripts/fuzz.py (random batches, module parameters and batch splits through every module against the
+    oracle) as part of the suite: 30 iterations of a fixed seed"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz.py"), "30", "4"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "failures: 0" in r.stdout
+
+
+def test_few_very_long_reads_with_more_than_64_adapters():
+    """k_span<LONG> with a second adapter group: the reads-per-segment table of the long route has a scratch slot of its
+    own (it used to share the one P.order lives in, which the passes of further adapter groups still walk) -- few
+    reads, one of them long enough for more segments than there are reads"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(99)
+    n = 4200
+    lens = rng.integers(300, 1500, size=n)
+    lens[17] = 1_300_000
+    lens[18] = 70_000
+    adapters = []
+    while len(adapters) < 70:
+        w = rng.choice(LETTERS, size=int(rng.integers(8, 13))).tobytes().decode()
+        if w not in adapters:
+            adapters.append(w)
+    names, seqs, quals = [], [], []
+    for i, L in enumerate(lens):
+        L = int(L)
+        s = rng.choice(LETTERS, size=L).tobytes().decode()
+        for _ in range(2):
+            w = adapters[int(rng.integers(0, len(adapters)))]
+            at = int(rng.integers(0, L - len(w) + 1))
+            s = s[:at] + w + s[at + len(w):]
+        names.append(f"n{i}")
+        seqs.append(s)
+        quals.append((rng.integers(0, 60, size=L) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(adapters)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq, ga = QCMetrics(), AdapterCounter(adapters)
+    from tests.test_gpu_vs_oracle import _route_of
+    r = _route_of(lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
+    assert "k_span<8,AD,long>" in r, r
+    compare_qc(rq, gq, metas, arr)
+    assert _compare_adapters(ga, ra) > n

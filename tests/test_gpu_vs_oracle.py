@@ -454,7 +454,26 @@ def test_two_million_reads_all_tables_equal_oracle():
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 50_000
 
 
-@pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 251, 512])
+def _route_of(run):
+    """the kernels a call launched (sq_last_route): a build that does not fit makes a dispatcher fall back to another
+    kernel without a word, and a sweep that thinks it covers k_span<7> would be covering k_wide"""
+    from sequali_amd._lib import context, lib
+    lib().sq_route_reset(context())
+    run()
+    return (lib().sq_last_route(context()) or b"").decode()
+
+
+def _uniform_route(U, with_adapters):
+    """the first kernel the default dispatch launches for a batch of one read length U"""
+    nw = (U + 31) // 32
+    if U > 256:
+        return "k_wide<AD>" if with_adapters else "k_ring<QC>"
+    if with_adapters:
+        return f"k_span<{nw},AD,uniform,split>"
+    return f"k_span<{nw},QC,uniform,both>"
+
+
+@pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 161, 176, 192, 193, 200, 224, 225, 250, 251, 256, 512])
 def test_uniform_length_kernels_every_alignment(U):
     """Batches of one read length have four kernels.  k_span streams 16 records at a time
     through LDS and counts them with four lanes per read, k_ring cuts a read into 32-byte aligned
@@ -500,7 +519,9 @@ def test_uniform_length_kernels_every_alignment(U):
             else:
                 gq.add_record_array(arr)
             gq.flush()
-        _with_env(env, run)
+        route = _route_of(lambda: _with_env(env, run))
+        if not env:      # the default dispatch: the kernel DESIGN 4.1b names for this length, not a silent fallback
+            assert route.split("+")[0] == _uniform_route(U, with_adapters), (U, with_adapters, route)
         compare_qc(rq, gq, metas, arr)
         if with_adapters:
             for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
@@ -509,7 +530,8 @@ def test_uniform_length_kernels_every_alignment(U):
 
 
 @pytest.mark.parametrize("max_len,with_adapters,ea", [(160, True, 100), (151, True, 20), (33, True, 100),
-                                                      (256, False, 100), (97, False, 300), (12, True, 5)])
+                                                      (256, False, 100), (97, False, 300), (12, True, 5),
+                                                      (224, True, 100), (256, True, 100), (200, False, 40)])
 def test_sorted_spans_every_length(max_len, with_adapters, ea):
     """reads of many lengths through k_span (sorted by length, spans of 16 reads of one length;
     SQ_SPAN_SORTED=1 takes the path at this size): every length from 1 to max_len with a number
@@ -548,7 +570,11 @@ def test_sorted_spans_every_length(max_len, with_adapters, ea):
             else:
                 gq.add_record_array(arr)
             gq.flush()
-        _with_env(env, run)
+        route = _route_of(lambda: _with_env(env, run))
+        if "SQ_SPAN_SORTED" in env:   # every window count of the batch went through a build of k_span<NW,.,sorted,.>
+            kinds = {p.split(",")[0] for p in route.split("+") if p.startswith("k_span<")}
+            assert kinds == {f"k_span<{nw}" for nw in range(1, (max_len + 31) // 32 + 1)}, route
+            assert all(",sorted," in p for p in route.split("+") if p.startswith("k_span<")), route
         compare_qc(rq, gq, metas, arr)
         assert gq.number_of_reads == len(lengths) and gq.max_length == max_len
         if with_adapters:

@@ -154,3 +154,53 @@ def test_device_split_of_synthetic_text_equals_generator_metas(kind, n):
     assert np.array_equal(arr.accumulated_error_rates().view(np.uint64),
                           FastqRecordArrayView._from_buffer(text, metas).accumulated_error_rates().view(np.uint64)) \
         or b.number_of_reads() == n
+
+
+def test_arrays_outlive_the_staging_blocks_they_came_from(monkeypatch):
+    """The reference's arrays own their buffer and stay valid however far the parser has moved on
+    (_qcmodule.c:575-579).  Arrays of sq_feeder are windows of pinned staging blocks that go back to a
+    pool: a block somebody still holds arrays of keeps its bytes (in pageable memory) when it does."""
+    from sequali_amd import FastqParser, _qc, synth
+    monkeypatch.setattr(_qc, "_STAGE_LIMIT", 1 << 20)     # 1 MiB staging blocks: 5 MB of text are several of them
+    n = 15_000
+    text = synth.host_records(synth.ILLUMINA, 0, n, 0)[0]
+    arrays = list(FastqParser(io.BytesIO(text)))           # every array held while the parser runs to the end
+    blocks = {id(a._blk) for a in arrays}
+    assert len(blocks) > _qc._Feeder.KEEP + 2
+    assert sum(len(a) for a in arrays) == n
+    from tests.helpers import split_fastq
+    buf, metas = split_fastq(text)
+    first = 0
+    for a in arrays:                                       # the oldest ones first: their blocks are long gone
+        assert a[0].name() == buf[int(metas["record_start"][first]):][:int(metas["name_length"][first])].decode()
+        last = first + len(a) - 1
+        r = a[len(a) - 1]
+        s0 = int(metas["record_start"][last]) + int(metas["sequence_offset"][last])
+        assert r.sequence() == buf[s0:s0 + int(metas["sequence_length"][last])].decode()
+        q0 = int(metas["record_start"][last]) + int(metas["qualities_offset"][last])
+        assert r.qualities() == buf[q0:q0 + int(metas["sequence_length"][last])].decode()
+        first += len(a)
+
+
+@pytest.mark.gpu
+def test_arrays_of_released_blocks_can_still_be_counted(monkeypatch):
+    """... and a module that is handed such an array later counts it (the block is uploaded from the
+    pageable copy)."""
+    from oracle import oracle
+    from sequali_amd import FastqParser, QCMetrics, _qc, synth
+    from tests.helpers import split_fastq
+    monkeypatch.setattr(_qc, "_STAGE_LIMIT", 1 << 20)
+    n = 15_000
+    text = synth.host_records(synth.ILLUMINA, 0, n, 0)[0]
+    arrays = list(FastqParser(io.BytesIO(text)))
+    qc = QCMetrics()
+    for a in arrays:
+        qc.add_record_array(a)
+    buf, metas = split_fastq(text)
+    ref = oracle.QCMetrics()
+    ref.add(buf, metas)
+    assert qc.number_of_reads == n
+    np.testing.assert_array_equal(np.array(qc.base_count_table(), np.uint64), ref.base_count_table())
+    np.testing.assert_array_equal(np.array(qc.phred_scores(), np.uint64), ref.phred_scores())
+    rates = np.concatenate([a.accumulated_error_rates() for a in arrays])
+    np.testing.assert_array_equal(rates.view(np.uint64), metas["accumulated_error_rate"].view(np.uint64))
