@@ -11,12 +11,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsqgpu.so")
-SOURCES = ["sq_api.hip", "sq_qc.hip", "sq_span.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip", "sq_hostsimd.cpp"]
+SOURCES = ["sq_span.hip", "sq_pair.hip", "sq_qc.hip", "sq_api.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip", "sq_hostsimd.cpp"]   # the slowest first
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
-# Builds of k_span (sq_span.hip: <NW, AD, SEG, W4T, SPLIT, LONG>) that the DEFAULT dispatch launches (sq_span_launch,
+# Builds of k_span (sq_span_kernel.h: <NW, AD, SEG, W4T, SPLIT, LONG, PT>) that the DEFAULT dispatch launches (sq_span_launch,
 # sq_span_launch_sorted, sq_span_launch_long; tests/test_gpu_routes.py asserts the same routes on the GPU).  A register
 # spilled inside their loop is reloaded behind an `s_waitcnt vmcnt(0)`, which also waits for the span in flight: the
 # dispatcher would fall back to another kernel without a word (span_build_spills; round 2 lost a third of a route's
@@ -33,7 +33,8 @@ def default_route_builds():
         out.append((nw, True, True, nw >= 6, False))
     for ad in (False, True):
         out.append((8, ad, True, True, True))                          # segments of long reads
-    names = ["k_spanILi%dE%sE%sELi3E%sE%sEE" % (nw, b(ad), b(seg), b(split), b(lng)) for nw, ad, seg, split, lng in out]
+    names = ["k_spanILi%dE%sE%sELi3E%sE%sELb0EE" % (nw, b(ad), b(seg), b(split), b(lng)) for nw, ad, seg, split, lng in out]
+    names += ["k_spanILi%dELb0ELb0ELi3ELb0ELb0ELb1EE" % nw for nw in range(1, 9)]   # QCMetrics with PerTileQuality riding along (sq_pair.hip)
     names += ["k_ptspanILi%dEE" % nw for nw in range(1, 9)] + ["k_isz_spanILi%dEE" % nw for nw in range(1, 9)]
     return names
 

@@ -60,7 +60,20 @@ struct PassParams {
     const struct SpanRow *span_rows; /* the batch's reads sorted by length, longest first */
     unsigned int *long_first;  /* k_span<LONG>: [records][n_adapters] start of the first occurrence found so far, ~0: none */
     unsigned int *long_gc;     /* k_span<LONG>: [records][2] G/C bases and A/C/G/T bases of the read, summed segment by segment */
+    /* k_span<PT> (sq_pair.hip): PerTileQuality rides in the QCMetrics pass.  The tile id is parsed from the header
+       bytes (the lines the pass fetches anyway); a wave sums the error rates of consecutive reads of ONE tile in
+       registers (a sequencer writes its reads tile by tile) and stages every such run -- tile, reads, a sum per
+       position -- for k_pt_fold, which knows the table rows.  Nothing reaches PerTileQuality's tables from the pass
+       itself: a batch with a header that does not parse, or with more runs than fit, is counted by the older route */
+    long long *pt_tiles;            /* [n] tile id of every record (< 0: the header does not parse); NULL: not wanted */
+    unsigned long long *pt_bad;     /* atomicMin: pt_first_index + index of the first record whose header does not parse */
+    uint64_t pt_first_index;
+    struct PtRun *pt_runs;          /* [pt_runs_cap]; NULL: tiles only */
+    double *pt_run_sums;            /* [pt_runs_cap][uniform_len] */
+    unsigned int *pt_nruns;         /* runs asked for so far (more than pt_runs_cap: the rest was not stored) */
+    uint32_t pt_runs_cap;
 };
+struct PtRun { long long tile; uint32_t reads; uint32_t pad; };
 
 namespace {
 
@@ -232,6 +245,85 @@ __device__ __forceinline__ uint32_t xor_add(uint32_t x, uint32_t s, uint32_t b)
     asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(s), "v"(b));
     return r;
 }
+
+/* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180): the decimal number
+ * between the 4th and the 5th ':' of the header.  Colons are found eight bytes at a
+ * time (headers are 7-bit ASCII, so x + 0x7F sets bit 7 of every non-zero byte). */
+__device__ long long tile_id_of(const uint8_t *name, uint32_t n)
+{
+    uint32_t colons = 0, c4 = n, c5 = n;
+    for (uint32_t off = 0; off < n && c5 == n; off += 8) {
+        /* the sequence follows the name inside the same buffer: reading 8 bytes is safe */
+        uint64_t w = sq_load_u64_unaligned(name + off);
+        if (n - off < 8) w |= ~0ULL << (8 * (n - off)); /* bytes past the name never match */
+        const uint64_t x = w ^ 0x3A3A3A3A3A3A3A3AULL;
+        uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
+        while (m) {
+            const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
+            m &= m - 1;
+            colons++;
+            if (colons == 4) c4 = at;
+            else if (colons == 5) { c5 = at; break; }
+        }
+    }
+    if (c5 == n) return -1;           /* fewer than five colons */
+    const uint32_t start = c4 + 1, len = c5 - start;
+    if (len < 1 || len > 18) return -1;
+    unsigned long long v = 0;
+    for (uint32_t k = start; k < c5; k++) {
+        const uint32_t d = (uint32_t)name[k] - '0';
+        if (d > 9) return -1;
+        v = v * 10 + d;
+    }
+    return (long long)v;
+}
+
+/* The same for a header of at most 8 NWORDS bytes whose bytes were fetched with independent
+ * 16-byte loads (tile_id_of asks memory for 8 bytes at a time, each load waiting for the scan
+ * of the one before: the slowest way to gather).  w[] holds the bytes little endian.  Returns
+ * -2 when the tile field is longer than 8 digits: the caller falls back to tile_id_of. */
+template <int NWORDS>
+__device__ long long tile_id_of_words(const uint64_t (&w)[NWORDS], uint32_t n)
+{
+    uint32_t colons = 0, c4 = n, c5 = n;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)NWORDS; k++) {
+        const uint32_t off = 8 * k;
+        if (off < n && c5 == n) {
+            uint64_t x = w[k];
+            if (n - off < 8) x |= ~0ULL << (8 * (n - off)); /* bytes past the name never match */
+            x ^= 0x3A3A3A3A3A3A3A3AULL;
+            uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
+            while (m) {
+                const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
+                m &= m - 1;
+                colons++;
+                if (colons == 4) c4 = at;
+                else if (colons == 5) { c5 = at; break; }
+            }
+        }
+    }
+    if (c5 == n) return -1;
+    const uint32_t start = c4 + 1, len = c5 - start;
+    if (len < 1 || len > 18) return -1;
+    if (len > 8) return -2;
+    /* the 8 bytes from `start` on: a funnel over two neighbouring words */
+    const uint32_t wi = start >> 3, sh = 8 * (start & 7);
+    uint64_t lo = w[0], hi = w[1];
+#pragma unroll
+    for (uint32_t k = 1; k < (uint32_t)NWORDS; k++) {
+        if (wi == k) { lo = w[k]; hi = k + 1 < (uint32_t)NWORDS ? w[k + 1] : 0; }
+    }
+    const uint64_t win = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    unsigned long long v = 0;
+    for (uint32_t k = 0; k < len; k++) {
+        const uint32_t d = (uint32_t)((win >> (8 * k)) & 0xFF) - '0';
+        if (d > 9) return -1;
+        v = v * 10 + d;
+    }
+    return (long long)v;
+}
+
 
 } // namespace
 

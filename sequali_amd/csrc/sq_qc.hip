@@ -1989,83 +1989,7 @@ struct TileMap {
     int *n_slots;
 };
 
-/* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180): the decimal number
- * between the 4th and the 5th ':' of the header.  Colons are found eight bytes at a
- * time (headers are 7-bit ASCII, so x + 0x7F sets bit 7 of every non-zero byte). */
-__device__ long long tile_id_of(const uint8_t *name, uint32_t n)
-{
-    uint32_t colons = 0, c4 = n, c5 = n;
-    for (uint32_t off = 0; off < n && c5 == n; off += 8) {
-        /* the sequence follows the name inside the same buffer: reading 8 bytes is safe */
-        uint64_t w = sq_load_u64_unaligned(name + off);
-        if (n - off < 8) w |= ~0ULL << (8 * (n - off)); /* bytes past the name never match */
-        const uint64_t x = w ^ 0x3A3A3A3A3A3A3A3AULL;
-        uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
-        while (m) {
-            const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
-            m &= m - 1;
-            colons++;
-            if (colons == 4) c4 = at;
-            else if (colons == 5) { c5 = at; break; }
-        }
-    }
-    if (c5 == n) return -1;           /* fewer than five colons */
-    const uint32_t start = c4 + 1, len = c5 - start;
-    if (len < 1 || len > 18) return -1;
-    unsigned long long v = 0;
-    for (uint32_t k = start; k < c5; k++) {
-        const uint32_t d = (uint32_t)name[k] - '0';
-        if (d > 9) return -1;
-        v = v * 10 + d;
-    }
-    return (long long)v;
-}
-
-/* The same for a header of at most 48 bytes whose 48 bytes were fetched with three independent
- * 16-byte loads (tile_id_of asks memory for 8 bytes at a time, each load waiting for the scan
- * of the one before: the slowest way to gather).  w[] holds the bytes little endian.  Returns
- * -2 when the tile field is longer than 8 digits: the caller falls back to tile_id_of. */
-__device__ long long tile_id_of_words(const uint64_t (&w)[6], uint32_t n)
-{
-    uint32_t colons = 0, c4 = n, c5 = n;
-#pragma unroll
-    for (uint32_t k = 0; k < 6; k++) {
-        const uint32_t off = 8 * k;
-        if (off < n && c5 == n) {
-            uint64_t x = w[k];
-            if (n - off < 8) x |= ~0ULL << (8 * (n - off)); /* bytes past the name never match */
-            x ^= 0x3A3A3A3A3A3A3A3AULL;
-            uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
-            while (m) {
-                const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
-                m &= m - 1;
-                colons++;
-                if (colons == 4) c4 = at;
-                else if (colons == 5) { c5 = at; break; }
-            }
-        }
-    }
-    if (c5 == n) return -1;
-    const uint32_t start = c4 + 1, len = c5 - start;
-    if (len < 1 || len > 18) return -1;
-    if (len > 8) return -2;
-    /* the 8 bytes from `start` on: a funnel over two neighbouring words */
-    const uint32_t wi = start >> 3, sh = 8 * (start & 7);
-    uint64_t lo = w[0], hi = w[1];
-#pragma unroll
-    for (uint32_t k = 1; k < 6; k++) {
-        if (wi == k) { lo = w[k]; hi = k + 1 < 6 ? w[k + 1] : 0; }
-    }
-    const uint64_t win = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-    unsigned long long v = 0;
-    for (uint32_t k = 0; k < len; k++) {
-        const uint32_t d = (uint32_t)((win >> (8 * k)) & 0xFF) - '0';
-        if (d > 9) return -1;
-        v = v * 10 + d;
-    }
-    return (long long)v;
-}
-
+/* tile_id_of, tile_id_of_words: sq_pass.h (k_span<PT> parses headers too) */
 /* pass 1: tile id of every record, first record whose header does not parse */
 __global__ void k_tile_parse(const uint8_t *buf, uint64_t buf_len, const sq_meta *metas, uint64_t n,
                              uint64_t first_read_index, long long *tiles,
@@ -2421,6 +2345,9 @@ struct sq_pertile {
     unsigned long long *d_first_bad = nullptr;
     int *d_overflow = nullptr;
     uint64_t first_bad = UINT64_MAX;
+    /* k_span<PT> (sq_pair.hip): PerTileQuality inside QCMetrics' pass */
+    bool runs_ok = true;       /* the batches so far came in runs of one tile (as a sequencer writes): sums per run are staged in the pass */
+    bool tiles_ready = false;  /* d_tiles holds the tile ids of the batch in hand (the pass wrote them): pertile_prepare skips k_tile_parse */
     hipEvent_t used = nullptr;   /* behind the kernels of the last call that read d_slots: the next call's pass over the headers, on another stream, overwrites them */
 };
 
@@ -2815,32 +2742,145 @@ int fetch_meta(sq_batch *b, uint64_t i, sq_meta *m)
     return SQ_OK;
 }
 
+/* room for the tile id and the table slot of every record of a batch */
+int pertile_reserve_records(sq_pertile *p, uint64_t n)
+{
+    if (n > p->slots_cap) {
+        SQ_HIP(hipStreamSynchronize(p->ctx->stream));
+        if (p->ctx->prep_stream) SQ_HIP(hipStreamSynchronize(p->ctx->prep_stream));
+        if (p->d_slots) SQ_HIP(hipFree(p->d_slots));
+        if (p->d_tiles) SQ_HIP(hipFree(p->d_tiles));
+        p->d_slots = nullptr;
+        p->d_tiles = nullptr;
+        p->slots_cap = 0;
+        SQ_HIP(hipMalloc((void **)&p->d_slots, n * 4));
+        SQ_HIP(hipMalloc((void **)&p->d_tiles, n * 8));
+        p->slots_cap = n;
+    }
+    return SQ_OK;
+}
+
+/* the tables [slot][len] grow to need_slots rows of need_len entries */
+int pertile_reserve_tables(sq_pertile *p, size_t need_slots, size_t need_len)
+{
+    if (need_slots > p->slot_cap || need_len > p->len_cap) {
+        size_t ns = std::max(need_slots, p->slot_cap), nl = std::max(need_len, p->len_cap);
+        if (need_slots > p->slot_cap) ns = std::max<size_t>(need_slots, p->slot_cap * 2);
+        int rc = regrow_rows(p->ctx, &p->d_len_counts, p->slot_cap, ns, p->len_cap, nl);
+        if (rc) return rc;
+        rc = regrow_rows(p->ctx, &p->d_errors, p->slot_cap, ns, p->len_cap, nl);
+        if (rc) return rc;
+        p->slot_cap = ns;
+        p->len_cap = nl;
+    }
+    return SQ_OK;
+}
+
+/* ---- PerTileQuality inside QCMetrics' pass (k_span<PT>, sq_pair.hip) ----
+ * pt_ride_setup fills P.pt_*; the pass parses every header (the first that does not parse lands in p->d_first_bad)
+ * and, while the batches come in runs of one tile, stages a sum per run and position.  pt_ride_finish reads back how
+ * that went: the runs are folded into the tables -- or dropped, and *done stays false: the caller counts the batch by
+ * the older route (a header that does not parse: that route knows where the reference stops, :3137-3148; more runs
+ * than the staging area holds: the reads do not come tile by tile, and the following batches only take their tile
+ * ids from the pass). */
+struct PtRide {
+    PtRun *runs = nullptr;
+    double *sums = nullptr;
+    unsigned int *nruns = nullptr;
+    uint32_t cap = 0;
+    bool launched = false;
+};
+
+int pt_ride_setup(sq_pertile *p, sq_batch *b, PassParams &P, PtRide &R)
+{
+    sq_ctx *ctx = p->ctx;
+    int rc = pertile_reserve_records(p, b->n);
+    if (rc) return rc;
+    P.pt_bad = p->d_first_bad;
+    P.pt_first_index = p->records_seen;
+    P.pt_tiles = nullptr;
+    P.pt_runs = nullptr;
+    if (p->runs_ok && sq_knobs().pt_fused == 1) {
+        const uint32_t U = (uint32_t)b->max_length;
+        R.cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, b->n / 64));
+        R.runs = (PtRun *)sq_scratch(ctx, 24, (size_t)R.cap * sizeof(PtRun));
+        R.sums = (double *)sq_scratch(ctx, 25, (size_t)R.cap * U * 8);
+        R.nruns = (unsigned int *)sq_scratch(ctx, 26, 16);
+        if (!R.runs || !R.sums || !R.nruns) { sq_set_error("out of device memory for PerTileQuality's runs"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemsetAsync(R.nruns, 0, 16, ctx->stream));
+        P.pt_runs = R.runs;
+        P.pt_run_sums = R.sums;
+        P.pt_nruns = R.nruns;
+        P.pt_runs_cap = R.cap;
+    } else {
+        P.pt_tiles = p->d_tiles;   /* the table by k_ptspan, from these tile ids */
+    }
+    /* the pass writes d_tiles / reads nothing of d_slots, but the kernels of this object's call before may still read them (on the work stream: in order) */
+    return SQ_OK;
+}
+
+int pt_ride_finish(sq_pertile *p, sq_batch *b, const PtRide &R, bool *done)
+{
+    *done = false;
+    sq_ctx *ctx = p->ctx;
+    if (!R.runs) {             /* tile ids only: the older route goes on from them */
+        p->tiles_ready = true;
+        return SQ_OK;
+    }
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[10], R.nruns, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[11], p->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t nruns = (uint32_t)ctx->pinned[10];
+    if (ctx->pinned[11] != UINT64_MAX) return SQ_OK;        /* a header that does not parse: the older route, from scratch */
+    if (nruns > R.cap) { p->runs_ok = false; return SQ_OK; } /* reads of mixed tiles */
+    const uint32_t U = (uint32_t)b->max_length;
+    int rc = sq_pt_runs_assign(ctx, R.runs, nruns, p->map.keys, p->map.vals, p->map.n_slots, p->d_overflow);
+    if (rc) return rc;
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[10], p->map.n_slots, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[11], p->d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    p->n_slots = (int)(uint32_t)ctx->pinned[10];
+    if ((uint32_t)ctx->pinned[11]) {
+        sq_set_error("PerTileQuality: more than %u distinct tile ids", TILE_MAP_SIZE / 2);
+        return SQ_ERR_MEMORY;
+    }
+    p->number_of_reads += b->n;
+    p->max_length = std::max<uint64_t>(p->max_length, U);
+    rc = pertile_reserve_tables(p, (size_t)p->n_slots, (size_t)std::max<uint64_t>(p->max_length, 1));
+    if (rc) return rc;
+    rc = sq_pt_fold(ctx, R.runs, R.sums, nruns, U, p->d_errors, p->d_len_counts, p->len_cap);
+    if (rc) return rc;
+    p->records_seen += b->n;
+    *done = true;
+    return SQ_OK;
+}
+
 /* stage 1 of a PerTileQuality add: tile ids, slots, first unparsable header */
 int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
 {
     *active = false;
     if (p->skipped || b->n == 0) return SQ_OK; /* :3126 */
     sq_ctx *ctx = p->ctx;
-    if (b->n > p->slots_cap) {
-        if (p->d_slots) SQ_HIP(hipFree(p->d_slots));
-        if (p->d_tiles) SQ_HIP(hipFree(p->d_tiles));
-        SQ_HIP(hipMalloc((void **)&p->d_slots, b->n * 4));
-        SQ_HIP(hipMalloc((void **)&p->d_tiles, b->n * 8));
-        p->slots_cap = b->n;
+    {
+        int rc = pertile_reserve_records(p, b->n);
+        if (rc) return rc;
     }
     int blocks = (int)std::min<uint64_t>((b->n + 255) / 256, 8192);
     /* The pass over the headers runs on a stream of its own: it reads the batch and writes this object's tile
        and slot arrays, nothing the kernels queued on ctx->stream for OTHER batches touch, so it goes beside
        them (the read-back below used to wait for all of them too).  It waits for the kernels of this
        object's call before (they read the slots) and for the batch's upload if that is still on its way. */
-    hipStream_t S = sq_knobs().pt_prep_inline ? ctx->stream : ctx->prep_stream;
+    const bool tiles_ready = p->tiles_ready;   /* QCMetrics' pass over this batch has parsed the headers (on ctx->stream) */
+    p->tiles_ready = false;
+    hipStream_t S = sq_knobs().pt_prep_inline || tiles_ready ? ctx->stream : ctx->prep_stream;
     if (S != ctx->stream) {
         if (p->used) SQ_HIP(hipStreamWaitEvent(S, p->used, 0));
         if (b->ready) SQ_HIP(hipStreamWaitEvent(S, b->ready, 0));
     }
     SQ_HIP(hipMemsetAsync(p->d_overflow + 1, 0, 4, S));
-    hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, S, b->d_buf, (uint64_t)b->buf_len,
-                       b->d_metas, (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
+    if (!tiles_ready)
+        hipLaunchKernelGGL(k_tile_parse, dim3(blocks), dim3(256), 0, S, b->d_buf, (uint64_t)b->buf_len,
+                           b->d_metas, (uint64_t)b->n, p->records_seen, p->d_tiles, p->d_first_bad);
     /* a workgroup sets up a 12 KB LDS cache of resolved tiles first: fewer, longer-lived ones */
     const int ablocks = (int)std::min<uint64_t>((b->n + 255) / 256, (uint64_t)ctx->num_cus * 4);
     hipLaunchKernelGGL(k_tile_assign, dim3(ablocks), dim3(256), 0, S, p->d_tiles,
@@ -2885,16 +2925,9 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
     p->max_length = std::max(p->max_length, maxlen);
     if (counted == 0) return SQ_OK;
     /* tables: [slot][len] */
-    size_t need_slots = (size_t)p->n_slots, need_len = (size_t)std::max<uint64_t>(p->max_length, 1);
-    if (need_slots > p->slot_cap || need_len > p->len_cap) {
-        size_t ns = std::max(need_slots, p->slot_cap), nl = std::max(need_len, p->len_cap);
-        if (need_slots > p->slot_cap) ns = std::max<size_t>(need_slots, p->slot_cap * 2);
-        int rc = regrow_rows(ctx, &p->d_len_counts, p->slot_cap, ns, p->len_cap, nl);
+    {
+        int rc = pertile_reserve_tables(p, (size_t)p->n_slots, (size_t)std::max<uint64_t>(p->max_length, 1));
         if (rc) return rc;
-        rc = regrow_rows(ctx, &p->d_errors, p->slot_cap, ns, p->len_cap, nl);
-        if (rc) return rc;
-        p->slot_cap = ns;
-        p->len_cap = nl;
     }
     *active = true;
     return SQ_OK;
@@ -2928,7 +2961,7 @@ void dispatch_pass(sq_ctx *ctx, const PassParams &P, bool qc, bool ad, bool pt, 
 
 } // namespace
 
-static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p);
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride = nullptr, bool *ride_done = nullptr);
 
 SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
 {
@@ -2941,17 +2974,23 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
     if (m && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
         b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !K.no_wide && !K.ring &&
         !K.no_split && (a || (b->max_length <= 32u * SPAN_NW_MAX && K.span))) {
-        int rc = fused_add_batch(b, m, a, nullptr);
-        return rc ? rc : fused_add_batch(b, nullptr, nullptr, p);
+        /* without the adapters: PerTileQuality rides in QCMetrics' pass (sq_pair.hip) -- the tile ids from the header
+           bytes the pass fetches anyway, and, while the reads come tile by tile, the table itself */
+        bool pt_done = false;
+        const bool ride = !a && K.pt_fused && K.span && b->max_length <= 32u * SPAN_NW_MAX;
+        int rc = fused_add_batch(b, m, a, nullptr, ride ? p : nullptr, &pt_done);
+        if (rc || pt_done) return rc;
+        return fused_add_batch(b, nullptr, nullptr, p);
     }
     return fused_add_batch(b, m, a, p);
 }
 
-static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride, bool *ride_done)
 {
     const SqKnobs &K = sq_knobs();
     sq_ctx *ctx = b->ctx;
     bool pt_active = false;
+    PtRide R;
     if (p) {
         int rc = pertile_prepare(p, b, &pt_active);
         if (rc) return rc;
@@ -3196,7 +3235,16 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
 #ifdef SQ_SPAN_PROBE
             if (K.span_probe >= 0) P.blocked = (uint32_t)K.span_probe;
 #endif
-            int rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
+            int rc = SQ_OK;
+            if (ride && !ad && !R.launched) {
+                PassParams C = P;
+                rc = pt_ride_setup(ride, b, C, R);
+                if (rc) return rc;
+                rc = sq_span_launch_pt(ctx, C, &covered);
+                R.launched = covered != 0;
+                if (!R.launched) R = PtRide();
+            }
+            if (!rc && !covered) rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
 #ifdef SQ_SPAN_PROBE
             P.blocked = 0;
 #endif
@@ -3359,6 +3407,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     }
     if (a) a->number_of_sequences += b->n;
     if (p) p->records_seen += b->n;
+    if (R.launched) return pt_ride_finish(ride, b, R, ride_done);
     return SQ_OK;
 }
 

@@ -91,5 +91,10 @@ int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, const uint32_t *len_hist, uint64_t *done);
 int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len);
+/* sq_pair.hip: QCMetrics' pass with PerTileQuality riding along (k_span<PT>), and what folds its staged runs into the tables */
+struct PtRun;
+int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, uint64_t *done);
+int sq_pt_runs_assign(sq_ctx *ctx, PtRun *runs, uint32_t n_runs, long long *keys, int *vals, int *n_slots, int *overflow);
+int sq_pt_fold(sq_ctx *ctx, const PtRun *runs, const double *sums, uint32_t n_runs, uint32_t U, double *errors, unsigned long long *len_counts, uint64_t cap);
 
 #endif

@@ -467,9 +467,9 @@ def _uniform_route(U, with_adapters):
     """the first kernel the default dispatch launches for a batch of one read length U"""
     nw = (U + 31) // 32
     if U > 256:
-        return "k_wide<AD>" if with_adapters else "k_ring<QC>"
-    if with_adapters:
-        return f"k_span<{nw},AD,uniform,split>"
+        return None      # the round-1 kernels, by what fits their LDS
+    if with_adapters:     # 225-256 bases with adapters: k_wide is ahead of the 8-window build (scripts/bench_len.py)
+        return f"k_span<{nw},AD,uniform,split>" if nw < 8 else "k_wide<AD>"
     return f"k_span<{nw},QC,uniform,both>"
 
 
@@ -520,7 +520,7 @@ def test_uniform_length_kernels_every_alignment(U):
                 gq.add_record_array(arr)
             gq.flush()
         route = _route_of(lambda: _with_env(env, run))
-        if not env:      # the default dispatch: the kernel DESIGN 4.1b names for this length, not a silent fallback
+        if not env and _uniform_route(U, with_adapters):   # the default dispatch: the kernel DESIGN 4.1b names for this length, not a silent fallback
             assert route.split("+")[0] == _uniform_route(U, with_adapters), (U, with_adapters, route)
         compare_qc(rq, gq, metas, arr)
         if with_adapters:
@@ -882,17 +882,20 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
     assert sum(int(f.sum()) for _, f, _ in ra.get_counts()) > 10   # chance matches only: the generator plants no probes
 
 
-def test_config3_one_million_pairs():
-    """BASELINE config 3 at a size the oracle finishes in seconds: 1 M device-generated pairs
-    (96 random tiles), (QCMetrics + PerTileQuality) x 2 through FusedPass, InsertSizeMetrics and a
-    paired DedupEstimator: every getter against the oracle -- k_span<QC> + k_ptspan (the 116 KB
-    tile table that leaves it 7 waves) + k_tile_parse / k_tile_assign per side, k_isz_span +
-    k_isz_adapters, k_dedup_hash -- and once more with SQ_SPAN=0 (the round-1 kernels) as the
-    cross-check.  Reference: _qcmodule.c:3088-3121, :3189-3220, :5668-5707, :4488-4517."""
+@pytest.mark.parametrize("by_tile", [True, False])
+def test_config3_one_million_pairs(by_tile):
+    """BASELINE config 3 at a size the oracle finishes in seconds: 1 M device-generated pairs (96 tiles: in the order a
+    sequencer writes, 65536 reads of a tile in a row, or a random tile per read), (QCMetrics + PerTileQuality) x 2
+    through FusedPass, InsertSizeMetrics and a paired DedupEstimator: every getter against the oracle.  By tile:
+    k_span<QC+PT> (PerTileQuality rides in QCMetrics' pass, sq_pair.hip) + k_pt_fold per side; random tiles: the same pass
+    for the tile ids and k_ptspan (the 116 KB tile table that leaves it 7 waves) for the table; k_isz_span +
+    k_isz_adapters, k_dedup_hash -- and once more with the passes of round 2 (SQ_PT_FUSED=0: k_tile_parse, k_span,
+    k_ptspan) and with SQ_SPAN=0 (the round-1 kernels) as the cross-checks.
+    Reference: _qcmodule.c:3088-3121, :3189-3220, :5668-5707, :4488-4517."""
     from sequali_amd import DedupEstimator, FusedPass, InsertSizeMetrics, PerTileQuality, QCMetrics, synth
     n, first = 1_000_000, 7_000_000
-    d1 = synth.device_array(synth.ILLUMINA, first, n)
-    d2 = synth.device_array(synth.ILLUMINA_R2, first, n)
+    d1 = synth.device_array(synth.ILLUMINA_BY_TILE if by_tile else synth.ILLUMINA, first, n)
+    d2 = synth.device_array(synth.ILLUMINA_R2_BY_TILE if by_tile else synth.ILLUMINA_R2, first, n)
     b1, m1 = d1._batch.download()
     b2, m2 = d2._batch.download()
     rq1, rq2, rp1, rp2 = oracle.QCMetrics(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.PerTileQuality()
@@ -900,7 +903,7 @@ def test_config3_one_million_pairs():
     rq1.add(b1, m1); rq2.add(b2, m2); rp1.add(b1, m1); rp2.add(b2, m2)
     rz.add_pair(b1, m1, b2, m2)
     rd.add_pair(b1, m1, b2, m2)
-    assert len(rp1.get_tile_counts()) == 96
+    assert len(rp1.get_tile_counts()) == (96 if not by_tile else len({(i >> 16) % 96 for i in range(first, first + n, 4096)}))
 
     def run():
         q1, q2, p1, p2 = QCMetrics(), QCMetrics(), PerTileQuality(), PerTileQuality()
@@ -914,7 +917,11 @@ def test_config3_one_million_pairs():
 
     # the default (the pass over the headers on a stream of its own, beside the counting) / that pass on the
     # work stream / the round-1 kernels
-    for env in ({}, {"SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
+    for env in ({}, {"SQ_PT_FUSED": "0"}, {"SQ_PT_FUSED": "0", "SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
+        route = _route_of(lambda: _with_env(env, run))
+        if not env:
+            want = "k_span<5,QC+PT,uniform,both>+k_pt_fold" if by_tile else "k_span<5,QC+PT,uniform,both>+k_ptspan<5>"
+            assert route.startswith(want + "+" + want + "+k_isz_span<5>"), route
         q1, q2, p1, p2, z, d = _with_env(env, run)
         for g, r, dev, metas in ((q1, rq1, d1, m1), (q2, rq2, d2, m2)):
             compare_qc(r, g, metas, dev)
