@@ -100,7 +100,7 @@ int launch_pt(sq_ctx *ctx, const PassParams &P, int waves, size_t lds, int grid)
         SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, false, SPAN_W4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    sq_route(ctx, "k_span<%d,QC+PT,uniform,both>", NW);
+    sq_route(ctx, "k_span<%d,QCPT,uniform,both>", NW);
     hipLaunchKernelGGL((k_span<NW, false, false, SPAN_W4, false, false, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, 0u);
     SQ_HIP(hipGetLastError());
     return SQ_OK;

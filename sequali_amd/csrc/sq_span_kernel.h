@@ -408,8 +408,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         const uint8_t *g0 = P.buf + base;
         if constexpr (PT) {   /* lane c: bytes 16 c .. 16 c + 15 of its read's header; used behind the wait at the top of the loop */
             nlen_next = lds_u32(ma + 8);
+            /* a load hipcc KNOWS of (unlike the DMA): it may move or spill the four registers only behind a wait of its
+               own, which it puts in front of their first use -- right behind the wait at the top of the loop, where
+               nothing is in flight any more.  (As inline asm the load was consumed early now and then: the compiler
+               takes the output of an asm statement for valid at once and is free to copy it.) */
             const uint8_t *np = g0 + (long long)(int32_t)rel + 16 * c;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(name_next) : "v"(np) : "memory");
+            __builtin_memcpy(&name_next, np, 16);
         }
         const uint32_t roff = lds_addr(l_rows) + (SPLIT ? 4 * rl : 0);
         uint32_t pk[ND];
@@ -489,6 +493,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
        is written out) */
     double pt_acc[PT ? NW : 1];
     uint32_t pt_lo = 0, pt_hi = 0, pt_reads = 0;   /* wave-uniform: the run's tile id, its reads so far */
+    bool pt_full = false;                          /* the staging area has overflowed (reads of mixed tiles): nothing more is staged, the host counts the batch by the older route */
     if constexpr (PT) {
 #pragma unroll
         for (int w = 0; w < NW; w++) pt_acc[w] = 0.0;
@@ -499,6 +504,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             uint32_t idx = 0;
             if (lane == 0) idx = atomicAdd(P.pt_nruns, 1u);
             idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= P.pt_runs_cap) pt_full = true;
             if (idx < P.pt_runs_cap) {
                 if (lane == 0) {
                     PtRun r;
@@ -818,7 +824,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             wait_lgkm<0>();
             SPAN_PHASE(1);   /* the rounds */
             if constexpr (PT && DQ) {
-                if (P.pt_runs) {
+                if (P.pt_runs && !pt_full) {
                     /* error rates of the eight qualities the lane holds per window (tq[w]: rows 8 h .. 8 h + 7 at position
                        32 w + pl); rows: bit 8 h + k set = row 8 h + k is added.  The lookups of window w + 1 are in flight
                        while those of window w are added */
@@ -860,7 +866,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                             uint32_t idx = 0;
                             if (lane == 0) idx = atomicAdd(P.pt_nruns, 1u);
                             idx = __builtin_amdgcn_readfirstlane(idx);
-                            if (idx >= P.pt_runs_cap) continue;
+                            if (idx >= P.pt_runs_cap) { pt_full = true; break; }
                             if (lane == 0) {
                                 PtRun run;
                                 run.tile = (long long)(((unsigned long long)rhi << 32) | rlo);

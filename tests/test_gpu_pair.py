@@ -60,7 +60,7 @@ def test_pertile_rides_in_the_qcmetrics_pass(U, n):
         rp.add(buf, metas)
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         r = _route_of(lambda: (f.add_record_array(arr), gq.flush(), gp.flush()))
-        assert r.split("+")[0] == f"k_span<{nw},QC+PT,uniform,both>" and "k_pt_fold" in r and "k_ptspan" not in r and "k_tile" not in r, r
+        assert r.split("+")[0] == f"k_span<{nw},QCPT,uniform,both>" and "k_pt_fold" in r and "k_ptspan" not in r and "k_tile" not in r, r
         compare_qc(rq, gq, metas, arr)
         _compare_pertile(gp, rp)
 
@@ -94,7 +94,7 @@ def test_pertile_ride_headers_of_every_shape():
     arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
     gq, gp = QCMetrics(), PerTileQuality()
     r = _route_of(lambda: (FusedPass(gq, None, gp).add_record_array(arr), gq.flush(), gp.flush()))
-    assert r.split("+")[0] == "k_span<4,QC+PT,uniform,both>" and "k_pt_fold" in r, r
+    assert r.split("+")[0] == "k_span<4,QCPT,uniform,both>" and "k_pt_fold" in r, r
     compare_qc(rq, gq, metas, arr)
     _compare_pertile(gp, rp)
     assert gp.skipped_reason is None
@@ -149,9 +149,9 @@ def test_pertile_ride_gives_way_to_reads_of_mixed_tiles():
         routes.append(_route_of(lambda: (f.add_record_array(arr), gq.flush(), gp.flush())))
         compare_qc(rq, gq, metas, arr)
         _compare_pertile(gp, rp)
-    assert routes[0].startswith("k_span<5,QC+PT,uniform,both>") and "k_ptspan<5>" in routes[0] and "k_pt_fold" not in routes[0], routes[0]
+    assert routes[0].startswith("k_span<5,QCPT,uniform,both>") and "k_ptspan<5>" in routes[0] and "k_pt_fold" not in routes[0], routes[0]
     for r in routes[1:]:
-        assert r == "k_span<5,QC+PT,uniform,both>+k_ptspan<5>", r
+        assert r == "k_span<5,QCPT,uniform,both>+k_ptspan<5>", r
 
 
 @pytest.mark.parametrize("fused", ["0", "2"])
@@ -172,7 +172,7 @@ def test_pertile_ride_switched_off_or_tile_ids_only(fused):
     if fused == "0":
         assert r.startswith("k_span<5,QC,uniform,both>") and "k_ptspan<5>" in r, r
     else:
-        assert r.startswith("k_span<5,QC+PT,uniform,both>") and "k_ptspan<5>" in r and "k_pt_fold" not in r, r
+        assert r.startswith("k_span<5,QCPT,uniform,both>") and "k_ptspan<5>" in r and "k_pt_fold" not in r, r
     compare_qc(rq, gq, metas, arr)
     _compare_pertile(gp, rp)
 
@@ -190,7 +190,7 @@ def test_pertile_ride_on_device_batches_by_tile():
         rp.add(buf, metas)
         gq, gp = QCMetrics(), PerTileQuality()
         r = _route_of(lambda: (FusedPass(gq, None, gp).add_record_array(dev), gq.flush(), gp.flush()))
-        assert r == "k_span<5,QC+PT,uniform,both>+k_pt_fold", r
+        assert r == "k_span<5,QCPT,uniform,both>+k_pt_fold", r
         compare_qc(rq, gq, metas, dev)
         _compare_pertile(gp, rp)
         assert len(rp.get_tile_counts()) >= 5

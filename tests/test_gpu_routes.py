@@ -59,11 +59,11 @@ def test_config3_route():
     d2 = synth.device_array(synth.ILLUMINA_R2_BY_TILE, 0, 100_000)
     fa, z = FusedPass(QCMetrics(), None, PerTileQuality()), InsertSizeMetrics()
     r = route_of(lambda: (fa.add_record_array(d1), fa.qc_metrics.flush()))
-    assert r == "k_span<5,QC+PT,uniform,both>+k_pt_fold", r
+    assert r == "k_span<5,QCPT,uniform,both>+k_pt_fold", r
     fr = FusedPass(QCMetrics(), None, PerTileQuality())
     dr = synth.device_array(synth.ILLUMINA, 0, 100_000)
     r = route_of(lambda: (fr.add_record_array(dr), fr.qc_metrics.flush()))
-    assert r == "k_span<5,QC+PT,uniform,both>+k_ptspan<5>", r
+    assert r == "k_span<5,QCPT,uniform,both>+k_ptspan<5>", r
     r = route_of(lambda: z.add_record_array_pair(d1, d2))
     assert r.startswith("k_isz_span<5>"), r
 
