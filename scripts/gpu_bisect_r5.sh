@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round 4 lost its GPU access to two boxes that died while `scripts/gpu_pair.sh` ran WITHOUT pytest's -x (the same script
+# with -x, which stopped at the first test, and two runs of scripts/gpu_probe_pt.sh in between were fine).  Some test of
+#   tests/test_gpu_pair.py  tests/test_gpu_routes.py
+#   tests/test_gpu_span_edges.py::test_few_very_long_reads_with_more_than_64_adapters
+#   tests/test_gpu_vs_oracle.py::test_config3_one_million_pairs
+# takes the machine down (or the pool did; the calls reported "run 0.0s").  Find it ONE test per gpurun call, each under
+# its own short timeout, the least suspicious first:
+#   gpurun --timeout 300 -- 'bash scripts/gpu_bisect_r5.sh 1'      (then 2, 3, ...)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/bisect
+case "$1" in
+  1) T="tests/test_gpu_routes.py" ;;
+  2) T="tests/test_gpu_pair.py::test_pertile_ride_on_device_batches_by_tile" ;;
+  3) T="tests/test_gpu_pair.py::test_pertile_rides_in_the_qcmetrics_pass" ;;
+  4) T="tests/test_gpu_pair.py::test_pertile_ride_headers_of_every_shape" ;;
+  5) T="tests/test_gpu_pair.py::test_pertile_ride_meets_a_header_that_does_not_parse" ;;
+  6) T="tests/test_gpu_pair.py::test_pertile_ride_gives_way_to_reads_of_mixed_tiles tests/test_gpu_pair.py::test_pertile_ride_switched_off_or_tile_ids_only" ;;
+  7) T="tests/test_gpu_vs_oracle.py::test_config3_one_million_pairs" ;;
+  8) T="tests/test_gpu_span_edges.py::test_few_very_long_reads_with_more_than_64_adapters" ;;
+  *) echo "usage: $0 1..8"; exit 2 ;;
+esac
+timeout 240 python -m pytest $T -q -x -p no:cacheprovider > gpurun_out/bisect/step$1.log 2>&1
+echo "step $1 rc=$?"; tail -5 gpurun_out/bisect/step$1.log

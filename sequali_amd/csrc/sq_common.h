@@ -62,7 +62,7 @@ struct SqKnobs {
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
     bool no_wide = false, ring = false, no_ring = false, no_split = false;
     bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
-    int pt_fused = 1;          /* SQ_PT_FUSED: 1: PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan */
+    int pt_fused = 0;          /* SQ_PT_FUSED: 1: PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan.  Default 0 until the new pass has met the oracle on a GPU (round 4 lost its GPU access before tests/test_gpu_pair.py had run: DESIGN 5.0) */
     bool pt_prep_inline = false;   /* SQ_PT_PREP_INLINE: PerTileQuality's pass over the headers on the work stream (round 2) */
     bool long_spans = true;
     int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */

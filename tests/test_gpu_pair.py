@@ -11,6 +11,8 @@ from tests.test_gpu_vs_oracle import _route_of, compare_qc, u64
 
 pytestmark = pytest.mark.gpu
 
+RIDE = {"SQ_PT_FUSED": "1"}    # the pass under test (not the default yet: csrc/sq_common.h, SqKnobs::pt_fused)
+
 LETTERS = np.frombuffer(b"ACGT", np.uint8)
 
 
@@ -59,7 +61,7 @@ def test_pertile_rides_in_the_qcmetrics_pass(U, n):
         rq.add(buf, metas)
         rp.add(buf, metas)
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
-        r = _route_of(lambda: (f.add_record_array(arr), gq.flush(), gp.flush()))
+        r = _route_of(lambda: with_env(RIDE, lambda: (f.add_record_array(arr), gq.flush(), gp.flush())))
         assert r.split("+")[0] == f"k_span<{nw},QCPT,uniform,both>" and "k_pt_fold" in r and "k_ptspan" not in r and "k_tile" not in r, r
         compare_qc(rq, gq, metas, arr)
         _compare_pertile(gp, rp)
@@ -93,7 +95,7 @@ def test_pertile_ride_headers_of_every_shape():
     rp.add(buf, metas)
     arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
     gq, gp = QCMetrics(), PerTileQuality()
-    r = _route_of(lambda: (FusedPass(gq, None, gp).add_record_array(arr), gq.flush(), gp.flush()))
+    r = _route_of(lambda: with_env(RIDE, lambda: (FusedPass(gq, None, gp).add_record_array(arr), gq.flush(), gp.flush())))
     assert r.split("+")[0] == "k_span<4,QCPT,uniform,both>" and "k_pt_fold" in r, r
     compare_qc(rq, gq, metas, arr)
     _compare_pertile(gp, rp)
@@ -121,8 +123,7 @@ def test_pertile_ride_meets_a_header_that_does_not_parse(bad_at):
         rq.add(b, m)
         rp.add(b, m)
         arr = FastqRecordArrayView._from_buffer(b, m.copy())
-        f.add_record_array(arr)
-        gq.flush()
+        with_env(RIDE, lambda: (f.add_record_array(arr), gq.flush()))
         compare_qc(rq, gq, m, arr)
     _compare_pertile(gp, rp)
     assert rp.skipped and gp.skipped_reason == "Can not parse header: 'no colons here'"
@@ -146,7 +147,7 @@ def test_pertile_ride_gives_way_to_reads_of_mixed_tiles():
         rq.add(buf, metas)
         rp.add(buf, metas)
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
-        routes.append(_route_of(lambda: (f.add_record_array(arr), gq.flush(), gp.flush())))
+        routes.append(_route_of(lambda: with_env(RIDE, lambda: (f.add_record_array(arr), gq.flush(), gp.flush()))))
         compare_qc(rq, gq, metas, arr)
         _compare_pertile(gp, rp)
     assert routes[0].startswith("k_span<5,QCPT,uniform,both>") and "k_ptspan<5>" in routes[0] and "k_pt_fold" not in routes[0], routes[0]
@@ -189,7 +190,7 @@ def test_pertile_ride_on_device_batches_by_tile():
         rq.add(buf, metas)
         rp.add(buf, metas)
         gq, gp = QCMetrics(), PerTileQuality()
-        r = _route_of(lambda: (FusedPass(gq, None, gp).add_record_array(dev), gq.flush(), gp.flush()))
+        r = _route_of(lambda: with_env(RIDE, lambda: (FusedPass(gq, None, gp).add_record_array(dev), gq.flush(), gp.flush())))
         assert r == "k_span<5,QCPT,uniform,both>+k_pt_fold", r
         compare_qc(rq, gq, metas, dev)
         _compare_pertile(gp, rp)

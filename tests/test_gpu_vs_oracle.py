@@ -917,11 +917,13 @@ def test_config3_one_million_pairs(by_tile):
 
     # the default (the pass over the headers on a stream of its own, beside the counting) / that pass on the
     # work stream / the round-1 kernels
-    for env in ({}, {"SQ_PT_FUSED": "0"}, {"SQ_PT_FUSED": "0", "SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
+    for env in ({"SQ_PT_FUSED": "1"}, {}, {"SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
         route = _route_of(lambda: _with_env(env, run))
-        if not env:
+        if env.get("SQ_PT_FUSED") == "1":
             want = "k_span<5,QCPT,uniform,both>+k_pt_fold" if by_tile else "k_span<5,QCPT,uniform,both>+k_ptspan<5>"
             assert route.startswith(want + "+" + want + "+k_isz_span<5>"), route
+        elif not env:
+            assert route.startswith("k_span<5,QC,uniform,both>+k_ptspan<5>+k_span<5,QC,uniform,both>+k_ptspan<5>+k_isz_span<5>"), route
         q1, q2, p1, p2, z, d = _with_env(env, run)
         for g, r, dev, metas in ((q1, rq1, d1, m1), (q2, rq2, d2, m2)):
             compare_qc(r, g, metas, dev)
