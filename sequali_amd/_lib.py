@@ -62,7 +62,8 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        path = _build.build()
+        # SQ_LIB: another build of the same sources (scripts/build_asan.sh: the host side under ASan + UBSan)
+        path = os.environ.get("SQ_LIB") or _build.build()
         _lib = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(_lib, name)  # AttributeError = header and library out of sync
