@@ -449,6 +449,24 @@ int sq_adaptercounter_set_totals(sq_adaptercounter *a, uint64_t number_of_sequen
 uint64_t sq_adaptercounter_row_length(sq_adaptercounter *a);
 int sq_adaptercounter_set_row_length(sq_adaptercounter *a, uint64_t row_length);
 
+/* ---- multi-GPU without torch: RCCL through the C ABI (csrc/sq_dist.hip) ---------- */
+/* The job's one exchange step (the reference has no counterpart: it is one process) for a host that binds
+ * this library directly.  One process per GPU; librccl.so is opened on first use.  Rank 0: sq_rccl_unique_id, hand
+ * the 128 bytes to every rank; all ranks: comm = sq_rccl_comm_init(ctx, n_ranks, id, rank); after the pass over the
+ * rank's shard: sq_qcmetrics_allreduce / sq_adaptercounter_allreduce (the ranks agree on the longest read and the row
+ * length, pad, sum in place over xGMI, set the totals: every rank then holds the job's tables and the getters of
+ * _qc.pyi:60-75 answer for the whole job).  sq_rccl_allreduce_tables / sq_rccl_allgather_bytes are the collectives
+ * themselves, for the tables of sq_*_device_tables and the candidate lists of the sq_*_shard_* entry points.
+ * op: 0 sum of u64, 1 sum of f64, 2 max of u64.  Not yet run with more than one rank: no such node was available. */
+int sq_rccl_available(void);
+int sq_rccl_unique_id(uint8_t *out128);
+void *sq_rccl_comm_init(sq_ctx *ctx, int n_ranks, const uint8_t *id128, int rank);
+void sq_rccl_comm_destroy(void *comm);
+int sq_rccl_allreduce_tables(sq_ctx *ctx, void *comm, void *const *ptrs, const uint64_t *counts, size_t n, int op);
+int sq_rccl_allgather_bytes(sq_ctx *ctx, void *comm, const void *d_send, void *d_recv, size_t bytes);
+int sq_qcmetrics_allreduce(sq_qcmetrics *m, void *comm);
+int sq_adaptercounter_allreduce(sq_adaptercounter *a, void *comm);
+
 /* ---- synthetic FASTQ (bench / tests): counter-based, host == device bytes -- */
 #define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */
 #define SQ_SYNTH_ILLUMINA_R2 1    /* the mate of read i              */

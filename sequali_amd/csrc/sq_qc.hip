@@ -3566,6 +3566,77 @@ SQ_EXPORT int sq_qcmetrics_set_totals(sq_qcmetrics *m, uint64_t number_of_reads,
     return SQ_OK;
 }
 
+/* ---- the job's exchange step without torch: RCCL through the C ABI (sq_dist.hip) ----------------------
+ * What sequali_amd/dist.py::merge_qcmetrics / merge_adaptercounter do through torch.distributed: the ranks agree on
+ * the longest read (all-reduce max) and on the row length, pad their tables to it, sum them in place, and set the
+ * scalars the host keeps.  Afterwards every rank holds the job's tables.  SURVEY 8e; _qcmodule.c:1870-1906 (resize). */
+extern "C" int sq_rccl_allreduce_tables(sq_ctx *ctx, void *comm, void *const *ptrs, const uint64_t *counts, size_t n, int op);
+
+namespace {
+/* {a, b} -> {max over ranks of a, sum over ranks of b} */
+int rccl_max_and_sum(sq_ctx *ctx, void *comm, uint64_t *a_max, uint64_t *b_sum)
+{
+    unsigned long long *d = (unsigned long long *)sq_scratch(ctx, 27, 16);
+    if (!d) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    ctx->pinned[12] = *a_max;
+    ctx->pinned[13] = *b_sum;
+    SQ_HIP(hipMemcpyAsync(d, &ctx->pinned[12], 16, hipMemcpyHostToDevice, ctx->stream));
+    void *p0 = d, *p1 = d + 1;
+    const uint64_t one = 1;
+    int rc = sq_rccl_allreduce_tables(ctx, comm, &p0, &one, 1, 2);
+    if (rc) return rc;
+    rc = sq_rccl_allreduce_tables(ctx, comm, &p1, &one, 1, 0);
+    if (rc) return rc;
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[12], d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    *a_max = ctx->pinned[12];
+    *b_sum = ctx->pinned[13];
+    return SQ_OK;
+}
+}  // namespace
+
+SQ_EXPORT int sq_qcmetrics_allreduce(sq_qcmetrics *m, void *comm)
+{
+    sq_ctx *ctx = m->ctx;
+    uint64_t ml = m->max_length, reads = m->number_of_reads;
+    int rc = rccl_max_and_sum(ctx, comm, &ml, &reads);
+    if (rc) return rc;
+    rc = sq_qcmetrics_reserve(m, ml);   /* every rank: the job's rows, zero where this shard saw nothing */
+    if (rc) return rc;
+    void *ptrs[6] = {m->d_base, m->d_phred, m->d_ea_base, m->d_ea_phred, m->d_gc, m->d_ps};
+    const uint64_t counts[6] = {ml * 5, ml * 12, m->end_anchor * 5, m->end_anchor * 12, 101, 94};
+    rc = sq_rccl_allreduce_tables(ctx, comm, ptrs, counts, 6, 0);
+    if (rc) return rc;
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    m->number_of_reads = reads;
+    m->max_length = ml;
+    return SQ_OK;
+}
+
+SQ_EXPORT int sq_adaptercounter_allreduce(sq_adaptercounter *a, void *comm)
+{
+    sq_ctx *ctx = a->ctx;
+    uint64_t ml = a->max_length, seqs = a->number_of_sequences;
+    int rc = rccl_max_and_sum(ctx, comm, &ml, &seqs);
+    if (rc) return rc;
+    rc = sq_adaptercounter_reserve(a, ml);
+    if (rc) return rc;
+    /* rows grow geometrically: ranks with different batch histories hold different row lengths */
+    uint64_t row = a->cap, unused = 0;
+    rc = rccl_max_and_sum(ctx, comm, &row, &unused);
+    if (rc) return rc;
+    rc = sq_adaptercounter_set_row_length(a, row);
+    if (rc) return rc;
+    void *ptrs[2] = {a->d_fwd, a->d_rev};
+    const uint64_t counts[2] = {a->adapters.size() * a->cap, a->adapters.size() * a->cap};
+    rc = sq_rccl_allreduce_tables(ctx, comm, ptrs, counts, 2, 0);
+    if (rc) return rc;
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    a->number_of_sequences = seqs;
+    a->max_length = ml;
+    return SQ_OK;
+}
+
 /* ---- AdapterCounter: add, getters -------------------------------------------------------- */
 
 SQ_EXPORT int sq_adaptercounter_add(sq_adaptercounter *a, const uint8_t *buf, size_t buf_len,

@@ -435,3 +435,20 @@ def test_workgroup_shares_of_equal_cost():
     per = -(-int(nspans.sum()) // 256)
     last_lo = 255 * per
     assert len(nspans) - np.searchsorted(starts, last_lo, "right") > 50
+
+
+def test_rccl_entry_points_load_and_fail_loudly_without_a_communicator():
+    """the C ABI's own exchange step (csrc/sq_dist.hip: RCCL opened on first use, no torch): the entry points exist,
+    librccl.so and its symbols are found, and a call without a context or a communicator is an error with a message,
+    not a crash (no N > 1 run exists yet: no node with more than one GPU has been available)"""
+    import ctypes as C
+    from sequali_amd._lib import last_error, lib
+    L = lib()
+    assert L.sq_rccl_available() == 1, last_error()
+    ptrs = (C.c_void_p * 1)(None)
+    counts = (C.c_uint64 * 1)(0)
+    assert L.sq_rccl_allreduce_tables(None, None, ptrs, counts, 1, 0) < 0
+    assert "communicator" in last_error()
+    assert L.sq_rccl_allgather_bytes(None, None, None, None, 0) < 0
+    assert L.sq_rccl_comm_init(None, 2, (C.c_uint8 * 128)(), 0) is None
+    assert "context" in last_error()
