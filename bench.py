@@ -277,34 +277,58 @@ def other_configs(lib, ctx, steps, warmup):
                            "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
     del batches
     # ---- config 3: 100 M pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics ----
+    # three entries: the reads with a random tile each (what rounds 1-3 measured), the same pairs in the order a sequencer
+    # writes them (65536 reads of a tile in a row), and that order through the paired pass (PairedPass, SQ_PT_FUSED=1:
+    # PerTileQuality and the overlap scan ride in QCMetrics' passes, csrc/sq_pair.hip; opt-in until it has met the oracle on
+    # a GPU)
+    from sequali_amd import PairedPass
     n, per = 100_000_000, 25_000_000
-    r1 = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
-    r2 = [synth.device_array(synth.ILLUMINA_R2, k * per, per) for k in range(n // per)]
-    bases = sum(b._batch.total_bases for b in r1) + sum(b._batch.total_bases for b in r2)
     name_len = 36
+    for entry, kinds, fused in (("config3_paired", (synth.ILLUMINA, synth.ILLUMINA_R2), False),
+                                ("config3_paired_by_tile", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), False),
+                                ("config3_paired_by_tile_fused", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), True)):
+        r1 = [synth.device_array(kinds[0], k * per, per) for k in range(n // per)]
+        r2 = [synth.device_array(kinds[1], k * per, per) for k in range(n // per)]
+        bases = sum(b._batch.total_bases for b in r1) + sum(b._batch.total_bases for b in r2)
 
-    def c3_make():
-        return (FusedPass(QCMetrics(), None, PerTileQuality()), FusedPass(QCMetrics(), None, PerTileQuality()), InsertSizeMetrics())
+        def c3_make():
+            return (FusedPass(QCMetrics(), None, PerTileQuality()), FusedPass(QCMetrics(), None, PerTileQuality()), InsertSizeMetrics())
 
-    def c3_step(o):
-        fa, fb, isz = o
-        for a, b in zip(r1, r2):
-            fa.add_record_array(a); clear(fa)
-            fb.add_record_array(b); clear(fb)
-            isz.add_record_array_pair(a, b)
+        def c3_step(o, r1=r1, r2=r2):
+            fa, fb, isz = o
+            for a, b in zip(r1, r2):
+                fa.add_record_array(a); clear(fa)
+                fb.add_record_array(b); clear(fb)
+                isz.add_record_array_pair(a, b)
 
-    def c3_check(o, passes):
-        fa, fb, isz = o
-        return {"base_table_sums_ok": bool(int(np.array(fa.qc_metrics.base_count_table(), np.uint64).sum()) +
-                                           int(np.array(fb.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                "pertile_reads_ok": bool(fa.per_tile_quality.number_of_reads == n * passes and fb.per_tile_quality.number_of_reads == n * passes),
-                "insert_size_pairs_ok": bool(isz.total_reads == n * passes)}
+        def c3_step_fused(o, r1=r1, r2=r2):
+            fa, fb, isz = o
+            pp = PairedPass(fa.qc_metrics, fa.per_tile_quality, fb.qc_metrics, fb.per_tile_quality, isz)
+            for a, b in zip(r1, r2):
+                pp.add_record_array_pair(a, b)
+                clear(fa); clear(fb)
 
-    out["config3_paired"] = run(
-        "config3", f"{n} x 150 bp synthetic pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM",
-        "k_span<QC> + k_ptspan per side (k_tile_parse + k_tile_assign in front), k_isz_span + k_isz_adapters", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
-        c3_make, c3_step, c3_check)
-    del r1, r2
+        def c3_check(o, passes, bases=bases):
+            fa, fb, isz = o
+            return {"base_table_sums_ok": bool(int(np.array(fa.qc_metrics.base_count_table(), np.uint64).sum()) +
+                                               int(np.array(fb.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                    "pertile_reads_ok": bool(fa.per_tile_quality.number_of_reads == n * passes and fb.per_tile_quality.number_of_reads == n * passes),
+                    "insert_size_pairs_ok": bool(isz.total_reads == n * passes)}
+
+        if fused:
+            os.environ["SQ_PT_FUSED"] = "1"
+            lib.sq_knobs_reload()
+        try:
+            out[entry] = run(
+                "config3", f"{n} x 150 bp synthetic pairs ({'reads tile by tile, 65536 in a row' if kinds[0] != synth.ILLUMINA else 'a random tile per read'}), "
+                "(QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM" + (", through PairedPass with SQ_PT_FUSED=1" if fused else ""),
+                "the kernels `route` names", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
+                c3_make, c3_step_fused if fused else c3_step, c3_check)
+        finally:
+            if fused:
+                os.environ.pop("SQ_PT_FUSED", None)
+                lib.sq_knobs_reload()
+        del r1, r2
     # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
     n = 1_000_000
     arr = synth.device_array(synth.NANOPORE, 0, n)

@@ -340,6 +340,13 @@ void sq_insertsize_free(sq_insertsize *z);
 int sq_insertsize_add_pair(sq_insertsize *z, const uint8_t *buf1, size_t len1, const sq_meta *metas1,
                            const uint8_t *buf2, size_t len2, const sq_meta *metas2, size_t n); /* :5808 */
 int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2);
+/* What the reference's driver does with a pair of arrays (__main__.py:279-306) in one call: QCMetrics_add_record_array +
+ * PerTileQuality_add_record_array on read 1 and on read 2 (_qcmodule.c:2141-2165, :3224-3248), InsertSizeMetrics_
+ * add_record_array_pair on both (:5827-5872) -- the same results as those five calls in that order.  Batches of one
+ * read length each take two passes over the records instead of seven (csrc/sq_pair.hip; SQ_PT_FUSED=1).  Any module
+ * may be NULL. */
+int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1, sq_pertile *p1, sq_qcmetrics *m2,
+                          sq_pertile *p2, sq_insertsize *z);
 int sq_insertsize_flush(sq_insertsize *z);
 uint64_t sq_insertsize_total_reads(sq_insertsize *z);           /* members :5492-5502 */
 uint64_t sq_insertsize_number_of_adapters_read1(sq_insertsize *z);

@@ -20,12 +20,12 @@ from ._qc import (A, C_ as C, G, N, T, DEFAULT_BASES_FROM_END, DEFAULT_BASES_FRO
                   NUMBER_OF_PHREDS, PHRED_MAX, TABLE_SIZE, AdapterCounter, BamParser, DedupEstimator,
                   FastqParser, FastqRecordArrayView, FastqRecordView, FusedPass,
                   InsertSizeMetrics, NanoporeReadInfo, NanoStats, OverrepresentedSequences,
-                  PerTileQuality, PinnedReader, QCMetrics)
+                  PairedPass, PerTileQuality, PinnedReader, QCMetrics)
 
 __all__ = [
     "A", "C", "G", "N", "T", "AdapterCounter", "BamParser", "DedupEstimator", "FastqParser",
     "FastqRecordArrayView", "FastqRecordView", "FusedPass", "InsertSizeMetrics",
     "NanoStats", "NanoporeReadInfo",
-    "OverrepresentedSequences", "PerTileQuality", "PinnedReader", "QCMetrics", "NUMBER_OF_NUCS",
+    "OverrepresentedSequences", "PairedPass", "PerTileQuality", "PinnedReader", "QCMetrics", "NUMBER_OF_NUCS",
     "NUMBER_OF_PHREDS", "PHRED_MAX", "TABLE_SIZE", "MAX_SEQUENCE_SIZE",
 ]

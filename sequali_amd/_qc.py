@@ -1419,6 +1419,62 @@ class FusedPass(_Deferring):
             m._track(arr)
 
 
+class PairedPass(_Deferring):
+    """One call per pair of record arrays for what the reference's driver does with it (__main__.py:279-306):
+    QCMetrics + PerTileQuality on read 1, the same on read 2, InsertSizeMetrics on the pair
+    (sq_paired_add_batches) -- the results of the five add_record_array[_pair] calls in that order.  Arrays of
+    one read length each take two passes over the records instead of seven (csrc/sq_pair.hip)."""
+
+    def __init__(self, qc_metrics1: Optional[QCMetrics] = None, per_tile_quality1: Optional[PerTileQuality] = None,
+                 qc_metrics2: Optional[QCMetrics] = None, per_tile_quality2: Optional[PerTileQuality] = None,
+                 insert_size_metrics: Optional["InsertSizeMetrics"] = None):
+        self.qc_metrics1, self.per_tile_quality1 = qc_metrics1, per_tile_quality1
+        self.qc_metrics2, self.per_tile_quality2 = qc_metrics2, per_tile_quality2
+        self.insert_size_metrics = insert_size_metrics
+        self._init_defer(None)
+        for mod in self._modules():
+            mod._upstream.append(self)   # the module's getters run this pass first
+
+    def _modules(self):
+        return [m for m in (self.qc_metrics1, self.per_tile_quality1, self.qc_metrics2, self.per_tile_quality2,
+                            self.insert_size_metrics) if m is not None]
+
+    def add_record_array_pair(self, record_array1, record_array2) -> None:
+        a1 = _require_array(record_array1, "record_array1")
+        a2 = _require_array(record_array2, "record_array2")
+        if len(a1) != len(a2):   # InsertSizeMetrics_add_record_array_pair :5842-5848
+            raise ValueError("record_array1 and record_array2 must be of the same size. "
+                             f"Got {len(a1)} and {len(a2)} respectively.")
+        if self._enqueue_pair(a1, a2):
+            for m, a in ((self.qc_metrics1, a1), (self.qc_metrics2, a2)):
+                if m is not None:
+                    m._staged_in(a._staged[0], a)
+        else:
+            self._run_pair(a1, a2)
+
+    def _drain_own(self, sealed_only: bool = False, through=None) -> None:
+        for mod in self._modules():      # what the modules owe from calls of their own goes first
+            mod._drain_own(sealed_only, through)
+        _Deferring._drain_own(self, sealed_only, through)
+
+    def _run_pair(self, a1: FastqRecordArrayView, a2: FastqRecordArrayView) -> None:
+        def h(mod):
+            return mod._handle if mod is not None else None
+        p1, p2 = self.per_tile_quality1, self.per_tile_quality2
+        if p1 is not None and p1._off:
+            p1 = None            # :3126: the module has stopped
+        if p2 is not None and p2._off:
+            p2 = None
+        check(lib().sq_paired_add_batches(a1._device().handle, a2._device().handle, h(self.qc_metrics1), h(p1),
+                                          h(self.qc_metrics2), h(p2), h(self.insert_size_metrics)))
+        for p in (p1, p2):
+            if p is not None:
+                p._off = lib().sq_pertile_skipped_reason(p._handle) is not None
+        for m, a in ((self.qc_metrics1, a1), (self.qc_metrics2, a2)):
+            if m is not None:
+                m._track(a)
+
+
 def _kmer_to_sequence(kmer: int, k: int) -> str:
     """kmer_to_sequence, _qcmodule.c:3405-3414"""
     return "".join("ACGT"[(kmer >> (2 * (k - 1 - i))) & 3] for i in range(k))

@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
-# Builds of k_span (sq_span_kernel.h: <NW, AD, SEG, W4T, SPLIT, LONG, PT>) that the DEFAULT dispatch launches (sq_span_launch,
+# Builds of k_span (sq_span_kernel.h: <NW, AD, SEG, W4T, SPLIT, LONG, PT, PAIR>) that the DEFAULT dispatch launches (sq_span_launch,
 # sq_span_launch_sorted, sq_span_launch_long; tests/test_gpu_routes.py asserts the same routes on the GPU).  A register
 # spilled inside their loop is reloaded behind an `s_waitcnt vmcnt(0)`, which also waits for the span in flight: the
 # dispatcher would fall back to another kernel without a word (span_build_spills; round 2 lost a third of a route's
@@ -33,8 +33,9 @@ def default_route_builds():
         out.append((nw, True, True, nw >= 6, False))
     for ad in (False, True):
         out.append((8, ad, True, True, True))                          # segments of long reads
-    names = ["k_spanILi%dE%sE%sELi3E%sE%sELb0EE" % (nw, b(ad), b(seg), b(split), b(lng)) for nw, ad, seg, split, lng in out]
-    names += ["k_spanILi%dELb0ELb0ELi3ELb0ELb0ELb1EE" % nw for nw in range(1, 9)]   # QCMetrics with PerTileQuality riding along (sq_pair.hip)
+    names = ["k_spanILi%dE%sE%sELi3E%sE%sELb0ELi0EE" % (nw, b(ad), b(seg), b(split), b(lng)) for nw, ad, seg, split, lng in out]
+    # QCMetrics with PerTileQuality riding along; with the ends of read 2 written / the overlap scan on read 1 (sq_pair.hip)
+    names += ["k_spanILi%dELb0ELb0ELi3ELb0ELb0ELb1ELi%dEE" % (nw, pair) for nw in range(1, 9) for pair in (0, 1, 2)]
     names += ["k_ptspanILi%dEE" % nw for nw in range(1, 9)] + ["k_isz_spanILi%dEE" % nw for nw in range(1, 9)]
     return names
 

@@ -824,10 +824,20 @@ __global__ void k_insert_size(IszParams P)
 
 /* The adapter remainders of the pairs k_isz_span found one for (results[r] = their insert size):
  * InsertSizeMetrics_add_sequence_pair_ptr :5729-5742, as at the end of k_insert_size */
-__global__ void k_isz_adapters(IszParams P, const uint32_t *results)
+/* HIST: results[r] is the insert size of EVERY pair as the scan inside read 1's pass left it (k_span<PAIR = 2>,
+ * sq_span_kernel.h): the histogram and the maximum (:5722-5727) are counted here, and only the pairs whose insert size is
+ * shorter than one of the two (uniform) read lengths have their metas looked at */
+template <bool HIST>
+__global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t len1, uint32_t len2)
 {
     __shared__ unsigned int l_events[2];
     __shared__ IszCache cache;
+    __shared__ unsigned int l_hist[HIST ? 1024 : 1], l_hmax;
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) l_hist[i] = 0;
+        if (threadIdx.x == 0) l_hmax = 0;
+    }
+    uint32_t local_max = 0;
     if (threadIdx.x < 2) l_events[threadIdx.x] = 0;
     for (uint32_t i = threadIdx.x; i < 2 * ISZ_CACHE; i += blockDim.x) {
         cache.hash[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
@@ -838,7 +848,13 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results)
     __syncthreads();
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t result = results[r];
+        if (HIST) {
+            if (result < 1024) atomicAdd(&l_hist[result], 1u);
+            else atomicAdd(&P.insert_sizes[result], 1ULL);
+            local_max = max(local_max, result);
+        }
         if (!result) continue;
+        if (HIST && result >= len1 && result >= len2) continue;   /* no remainder on either side */
         const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
         const uint8_t *s1 = P.buf1 + m1.record_start + m1.sequence_offset;
         const uint8_t *s2 = P.buf2 + m2.record_start + m2.sequence_offset;
@@ -863,6 +879,13 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results)
     }
     if (threadIdx.x < 2 && l_events[threadIdx.x])
         atomicAdd(P.tab[threadIdx.x].n_events, (unsigned long long)l_events[threadIdx.x]);
+    if (HIST) {
+        if (local_max) atomicMax(&l_hmax, local_max);
+        __syncthreads();
+        if (threadIdx.x == 0 && l_hmax) atomicMax(P.max_insert, (unsigned long long)l_hmax);
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x)
+            if (l_hist[i]) atomicAdd(&P.insert_sizes[i], (unsigned long long)l_hist[i]);
+    }
 }
 
 /* used slots of an adapter table, unordered */
@@ -2071,7 +2094,33 @@ int isz_rebuild_tables(sq_insertsize *z)
 
 } // namespace
 
+static int isz_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2, const uint32_t *scanned, uint64_t scanned_pairs);
+
 SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2)
+{
+    return isz_add_batch_pair(z, b1, b2, nullptr, 0);
+}
+
+/* the same behind an overlap scan that ran inside read 1's QCMetrics pass (k_span<PAIR = 2>, sq_pair.hip): scanned[r] =
+   the insert size of pair r for the first scanned_pairs pairs (a multiple of 16); the rest is scanned here */
+int sq_insertsize_add_batch_pair_scanned(sq_insertsize *z, sq_batch *b1, sq_batch *b2, const uint32_t *scanned, uint64_t scanned_pairs)
+{
+    return isz_add_batch_pair(z, b1, b2, scanned, scanned_pairs);
+}
+
+/* where the scan inside read 1's pass leaves its results: [n] */
+uint32_t *sq_insertsize_scan_results(sq_insertsize *z, uint64_t n)
+{
+    return (uint32_t *)sq_scratch(z->ctx, 16, n * 4);
+}
+
+/* does the histogram hold the largest value calculate_insert_size can return for these batches?  (grown if not) */
+int sq_insertsize_reserve_for(sq_insertsize *z, sq_batch *b1, sq_batch *b2)
+{
+    return sq_grow_device(z->ctx, &z->d_sizes, &z->cap, (size_t)(b1->max_length + b2->max_length + 17));
+}
+
+static int isz_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2, const uint32_t *scanned, uint64_t scanned_pairs)
 {
     if (b1->n != b2->n) { /* :5842-5848 */
         sq_set_error("record_array1 and record_array2 must be of the same size. Got %zu and %zu respectively.",
@@ -2098,7 +2147,14 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
        and leaves the adapter remainders to k_isz_adapters; the last few pairs (and everything
        else) go through k_insert_size.  SQ_SPAN=0: k_insert_size for all. */
     uint64_t covered = 0;
-    if (b1->owns && b2->owns && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
+    if (scanned && scanned_pairs) {
+        IszParams A = P;
+        A.n = covered = scanned_pairs;
+        sq_route(ctx, "k_isz_adapters<hist>");
+        hipLaunchKernelGGL(k_isz_adapters<true>, dim3(blocks_for(covered, 4 * ctx->num_cus)), dim3(256), 0, ctx->stream, A, scanned,
+                           (uint32_t)b1->max_length, (uint32_t)b2->max_length);
+        SQ_HIP(hipGetLastError());
+    } else if (b1->owns && b2->owns && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
         sq_knobs().span) {
         uint32_t *d_results = (uint32_t *)sq_scratch(ctx, 16, n * 4);
         if (d_results) {
@@ -2114,7 +2170,7 @@ SQ_EXPORT int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_ba
                 A.n = covered;
                 /* a workgroup per CU: every workgroup brings its cache of remainders to the device tables when it
                    is done, all of them at about the same time and most of them the same few keys */
-                hipLaunchKernelGGL(k_isz_adapters, dim3(blocks_for(covered, 4 * ctx->num_cus)), dim3(256), 0, ctx->stream, A, (const uint32_t *)d_results);
+                hipLaunchKernelGGL(k_isz_adapters<false>, dim3(blocks_for(covered, 4 * ctx->num_cus)), dim3(256), 0, ctx->stream, A, (const uint32_t *)d_results, 0u, 0u);
                 SQ_HIP(hipGetLastError());
             }
         }

@@ -92,18 +92,23 @@ __global__ void __launch_bounds__(256) k_pt_fold(const PtRun *runs, const double
         unsafeAtomicAdd(&errors[row + pos], sums[(uint64_t)blockIdx.x * U + pos]);
 }
 
-template <int NW>
+template <int NW, int PAIR>
 int launch_pt(sq_ctx *ctx, const PassParams &P, int waves, size_t lds, int grid)
 {
     static bool attr = false;
     if (!attr) {
-        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, false, SPAN_W4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, false, false, SPAN_W4, false, false, true, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    sq_route(ctx, "k_span<%d,QCPT,uniform,both>", NW);
-    hipLaunchKernelGGL((k_span<NW, false, false, SPAN_W4, false, false, true>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, 0u);
+    sq_route(ctx, PAIR == 2 ? "k_span<%d,QCPT_scan,uniform,both>" : PAIR == 1 ? "k_span<%d,QCPT_ends,uniform,both>" : "k_span<%d,QCPT,uniform,both>", NW);
+    hipLaunchKernelGGL((k_span<NW, false, false, SPAN_W4, false, false, true, PAIR>), dim3(grid), dim3(waves * 64), lds, ctx->stream, P, 0u);
     SQ_HIP(hipGetLastError());
     return SQ_OK;
+}
+template <int NW>
+int launch_pt_any(sq_ctx *ctx, const PassParams &P, int pair, int waves, size_t lds, int grid)
+{
+    return pair == 2 ? launch_pt<NW, 2>(ctx, P, waves, lds, grid) : pair == 1 ? launch_pt<NW, 1>(ctx, P, waves, lds, grid) : launch_pt<NW, 0>(ctx, P, waves, lds, grid);
 }
 
 } // namespace
@@ -112,31 +117,32 @@ int launch_pt(sq_ctx *ctx, const PassParams &P, int waves, size_t lds, int grid)
  * staged runs on the way (P.pt_*), the records behind them by k_pt_tail (PerTileQuality only: QCMetrics' share of
  * those is the caller's).  *done = records QCMetrics has counted (0: the kernel does not take this batch and nothing
  * has been queued). */
-int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, uint64_t *done)
+int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, int pair, uint64_t *done)
 {
     *done = 0;
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
+    if (pair && (U < 16 || (pair == 2 && P.pair_L2 < 16))) return SQ_OK;   /* the needles are 16 bases */
     const int nw = (int)((U + 31) / 32);
     int waves = span_max_waves(nw, false, false, false, true);
-    while (waves >= 4 && span_lds_layout(nw, U, 0, 0, 0, waves, false, false).total > 160 * 1024) waves--;
+    while (waves >= 4 && span_lds_layout(nw, U, 0, 0, 0, waves, false, false, false, pair == 2).total > 160 * 1024) waves--;
     if (waves < 4) return SQ_OK;
     if (sq_knobs().span_waves > 0) waves = std::max(1, std::min(waves, sq_knobs().span_waves));
-    const size_t lds = span_lds_layout(nw, U, 0, 0, 0, waves, false, false).total;
+    const size_t lds = span_lds_layout(nw, U, 0, 0, 0, waves, false, false, false, pair == 2).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;
     const uint64_t nspans = C.n / SPAN_R;
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + waves - 1) / waves, (uint64_t)ctx->num_cus));
     int rc;
     switch (nw) {
-        case 1: rc = launch_pt<1>(ctx, C, waves, lds, grid); break;
-        case 2: rc = launch_pt<2>(ctx, C, waves, lds, grid); break;
-        case 3: rc = launch_pt<3>(ctx, C, waves, lds, grid); break;
-        case 4: rc = launch_pt<4>(ctx, C, waves, lds, grid); break;
-        case 5: rc = launch_pt<5>(ctx, C, waves, lds, grid); break;
-        case 6: rc = launch_pt<6>(ctx, C, waves, lds, grid); break;
-        case 7: rc = launch_pt<7>(ctx, C, waves, lds, grid); break;
-        default: rc = launch_pt<8>(ctx, C, waves, lds, grid); break;
+        case 1: rc = launch_pt_any<1>(ctx, C, pair, waves, lds, grid); break;
+        case 2: rc = launch_pt_any<2>(ctx, C, pair, waves, lds, grid); break;
+        case 3: rc = launch_pt_any<3>(ctx, C, pair, waves, lds, grid); break;
+        case 4: rc = launch_pt_any<4>(ctx, C, pair, waves, lds, grid); break;
+        case 5: rc = launch_pt_any<5>(ctx, C, pair, waves, lds, grid); break;
+        case 6: rc = launch_pt_any<6>(ctx, C, pair, waves, lds, grid); break;
+        case 7: rc = launch_pt_any<7>(ctx, C, pair, waves, lds, grid); break;
+        default: rc = launch_pt_any<8>(ctx, C, pair, waves, lds, grid); break;
     }
     if (rc) return rc;
     if (C.n < P.n) {
@@ -146,6 +152,8 @@ int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, uint64_t *done)
     *done = C.n;
     return SQ_OK;
 }
+
+/* (the scan of read 1's pass covers the pairs of the full spans; the caller hands the rest to k_insert_size) */
 
 /* the staged runs [0, n_runs) get their table rows (runs[i].pad); *n_slots afterwards = rows in use */
 int sq_pt_runs_assign(sq_ctx *ctx, PtRun *runs, uint32_t n_runs, long long *keys, int *vals, int *n_slots, int *overflow)

@@ -72,6 +72,13 @@ struct PassParams {
     double *pt_run_sums;            /* [pt_runs_cap][uniform_len] */
     unsigned int *pt_nruns;         /* runs asked for so far (more than pt_runs_cap: the rest was not stored) */
     uint32_t pt_runs_cap;
+    /* k_span<PAIR> (sq_pair.hip): the overlap scan of InsertSizeMetrics (calculate_insert_size, :5667-5707) split over
+       the passes of the two mates.  PAIR = 1 (read 2): the first and the last 16 bases of every read go to pair_ends
+       ([n][32] bytes: head, tail) on the way.  PAIR = 2 (read 1): a span's 512 bytes of ends come in by one LDS-DMA and
+       the scan runs on the sequences the pass holds in LDS anyway; pair_results[pair] = its insert size (0: none) */
+    uint8_t *pair_ends;
+    uint32_t *pair_results;
+    uint32_t pair_L2;               /* PAIR = 2: the length of the reads of read 2 (>= 16) */
 };
 struct PtRun { long long tile; uint32_t reads; uint32_t pad; };
 

@@ -2790,6 +2790,16 @@ struct PtRide {
     uint32_t cap = 0;
     bool launched = false;
 };
+/* the overlap scan of InsertSizeMetrics split over the passes of the two mates (sq_paired_add_batches): mode 1: this is
+   read 2's pass, which leaves the ends of its reads in `ends`; mode 2: read 1's pass, which scans and leaves the insert
+   sizes in `results`; covered: pairs the pass has taken (0: it did not run as k_span<PT>) */
+struct PairRide {
+    int mode = 0;
+    uint8_t *ends = nullptr;
+    uint32_t *results = nullptr;
+    uint32_t L2 = 0;
+    uint64_t covered = 0;
+};
 
 int pt_ride_setup(sq_pertile *p, sq_batch *b, PassParams &P, PtRide &R)
 {
@@ -2961,7 +2971,8 @@ void dispatch_pass(sq_ctx *ctx, const PassParams &P, bool qc, bool ad, bool pt, 
 
 } // namespace
 
-static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride = nullptr, bool *ride_done = nullptr);
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride = nullptr, bool *ride_done = nullptr,
+                           PairRide *pair = nullptr);
 
 SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p)
 {
@@ -2985,7 +2996,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
     return fused_add_batch(b, m, a, p);
 }
 
-static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride, bool *ride_done)
+static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, sq_pertile *p, sq_pertile *ride, bool *ride_done, PairRide *pair)
 {
     const SqKnobs &K = sq_knobs();
     sq_ctx *ctx = b->ctx;
@@ -3240,9 +3251,11 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                 PassParams C = P;
                 rc = pt_ride_setup(ride, b, C, R);
                 if (rc) return rc;
-                rc = sq_span_launch_pt(ctx, C, &covered);
+                if (pair && pair->mode) { C.pair_ends = pair->ends; C.pair_results = pair->results; C.pair_L2 = pair->L2; }
+                rc = sq_span_launch_pt(ctx, C, pair ? pair->mode : 0, &covered);
                 R.launched = covered != 0;
                 if (!R.launched) R = PtRide();
+                if (pair) pair->covered = covered;
             }
             if (!rc && !covered) rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
 #ifdef SQ_SPAN_PROBE
@@ -3409,6 +3422,55 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     if (p) p->records_seen += b->n;
     if (R.launched) return pt_ride_finish(ride, b, R, ride_done);
     return SQ_OK;
+}
+
+/* One call for what the reference's driver does with a pair of arrays (__main__.py:279-306): QCMetrics + PerTileQuality on
+ * read 1, the same on read 2, InsertSizeMetrics on the pair -- the results of the five add_record_array calls in that
+ * order.  Batches of one read length each (what a sequencer writes) take two passes instead of seven: read 2's pass
+ * leaves the first and the last 16 bases of every read behind (32 bytes per pair), read 1's pass scans the sequences it
+ * holds in LDS anyway against them (calculate_insert_size :5667-5707), both carry PerTileQuality (sq_pair.hip).  Anything
+ * else -- other lengths, a module that is NULL or has stopped, SQ_PT_FUSED != 1 -- is the five calls.  Any of m1, p1, m2,
+ * p2, z may be NULL. */
+SQ_EXPORT int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1, sq_pertile *p1, sq_qcmetrics *m2,
+                                    sq_pertile *p2, sq_insertsize *z)
+{
+    const SqKnobs &K = sq_knobs();
+    auto side = [](sq_batch *b, sq_qcmetrics *m, sq_pertile *p) -> int { return (m || p) ? sq_fused_add_batch(b, m, nullptr, p) : SQ_OK; };
+    auto uniform = [](const sq_batch *b) { return b->owns && b->n >= 4096 && b->min_length == b->max_length && b->max_length >= 16 && b->max_length <= 32u * SPAN_NW_MAX; };
+    const bool fuse = K.pt_fused == 1 && K.span && !K.no_split && !K.no_wide && !K.ring && m1 && p1 && m2 && p2 && z && !p1->skipped && !p2->skipped &&
+                      b1->n == b2->n && uniform(b1) && uniform(b2) && b1->n < (1ull << 32);
+    if (!fuse) {
+        int rc = side(b1, m1, p1);
+        if (rc) return rc;
+        rc = side(b2, m2, p2);
+        if (rc) return rc;
+        return z ? sq_insertsize_add_batch_pair(z, b1, b2) : SQ_OK;
+    }
+    sq_ctx *ctx = b1->ctx;
+    int rc = sq_insertsize_reserve_for(z, b1, b2);
+    if (rc) return rc;
+    PairRide r2, r1;
+    r2.mode = 1;
+    r2.ends = (uint8_t *)sq_scratch(ctx, 28, (size_t)b2->n * 32);
+    r1.mode = 2;
+    r1.ends = r2.ends;
+    r1.results = sq_insertsize_scan_results(z, b1->n);
+    r1.L2 = (uint32_t)b2->max_length;
+    if (!r2.ends || !r1.results) { sq_set_error("out of device memory for the paired pass"); return SQ_ERR_MEMORY; }
+    /* read 2 first: its ends are read 1's needles.  (The modules see the same records as in the reference's order; none
+       of their results depends on which mate was counted first.) */
+    bool pt_done = false;
+    rc = fused_add_batch(b2, m2, nullptr, nullptr, p2, &pt_done, &r2);
+    if (rc) return rc;
+    if (!pt_done) { rc = fused_add_batch(b2, nullptr, nullptr, p2); if (rc) return rc; }
+    if (!r2.covered) r1.mode = 0;   /* read 2's pass did not run as k_span<PT>: no ends, the scan keeps its own kernel */
+    pt_done = false;
+    rc = fused_add_batch(b1, m1, nullptr, nullptr, p1, &pt_done, &r1);
+    if (rc) return rc;
+    if (!pt_done) { rc = fused_add_batch(b1, nullptr, nullptr, p1); if (rc) return rc; }
+    if (r1.mode == 2 && r1.covered && r1.covered <= r2.covered)
+        return sq_insertsize_add_batch_pair_scanned(z, b1, b2, r1.results, r1.covered);
+    return sq_insertsize_add_batch_pair(z, b1, b2);
 }
 
 SQ_EXPORT int sq_qcmetrics_add_batch(sq_qcmetrics *m, sq_batch *b) { return sq_fused_add_batch(b, m, nullptr, nullptr); }

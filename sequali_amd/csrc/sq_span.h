@@ -18,14 +18,14 @@ constexpr uint32_t SPAN_META_BYTES = 16 * 40;   /* the metas of a span */
 constexpr uint32_t SPAN_META_LDS = 16 * 32;     /* what k_span keeps of them: the first 32 bytes of each (SEG: 16 bytes per row) */
 
 struct SpanLds {
-    uint32_t thr, gc, ps, prog, dfa, out, adlen, hist, first, rows, dma, meta, slots;
+    uint32_t thr, gc, ps, prog, dfa, out, adlen, hist, first, rows, dma, meta, ends, slots;
     size_t total;
 };
 
 /* nw: 32-position windows per read; U: read length; states / n_ad / ad_lds: the automaton, its
  * adapters, how many of them are counted in LDS (0 without AdapterCounter); waves per workgroup */
 __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t states, uint32_t n_ad,
-                                                   uint32_t ad_lds, int waves, bool seg = false, bool split = false, bool lng = false)
+                                                   uint32_t ad_lds, int waves, bool seg = false, bool split = false, bool lng = false, bool ends = false)
 {
     SpanLds L;
     const uint32_t hs = (U + 31u) & ~31u;
@@ -46,6 +46,7 @@ __host__ __device__ inline SpanLds span_lds_layout(int nw, uint32_t U, uint32_t 
     L.dma = o; o += ((16u * pr + 63) / 64) * 64 * 4;
     o = (o + 15u) & ~15u;
     L.meta = o; o += (uint32_t)waves * (seg ? 256 : SPAN_META_LDS);   /* one buffer: the metas of span k + 2 land where those of k + 1 were read */
+    L.ends = o; o += ends ? (uint32_t)waves * 512 + 128 : 0;   /* k_span<PAIR = 2>: the ends of read 2 of the span being counted, and 16 more parameters */
     L.slots = o;
     L.total = (size_t)o + (size_t)waves * 2 * 16 * 16 * (size_t)pr; /* two slots of 16 rows of pr pieces */
     return L;
@@ -93,8 +94,14 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
 bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len);
 /* sq_pair.hip: QCMetrics' pass with PerTileQuality riding along (k_span<PT>), and what folds its staged runs into the tables */
 struct PtRun;
-int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, uint64_t *done);
+int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, int pair, uint64_t *done);   /* pair: 0, 1 (read 2: writes the ends), 2 (read 1: the overlap scan) */
 int sq_pt_runs_assign(sq_ctx *ctx, PtRun *runs, uint32_t n_runs, long long *keys, int *vals, int *n_slots, int *overflow);
+/* sq_ends.hip: InsertSizeMetrics behind an overlap scan that ran inside read 1's pass (sq_paired_add_batches, sq_qc.hip) */
+struct sq_insertsize;
+struct sq_batch;
+int sq_insertsize_add_batch_pair_scanned(sq_insertsize *z, sq_batch *b1, sq_batch *b2, const uint32_t *scanned, uint64_t scanned_pairs);
+uint32_t *sq_insertsize_scan_results(sq_insertsize *z, uint64_t n);
+int sq_insertsize_reserve_for(sq_insertsize *z, sq_batch *b1, sq_batch *b2);
 int sq_pt_fold(sq_ctx *ctx, const PtRun *runs, const double *sums, uint32_t n_runs, uint32_t U, double *errors, unsigned long long *len_counts, uint64_t cap);
 
 #endif

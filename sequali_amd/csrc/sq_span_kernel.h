@@ -235,9 +235,33 @@ __device__ __forceinline__ uint32_t gc_percent(uint32_t gc, uint32_t acgt)
    the lines the DMA has just fetched), lane (h, pl) looks up the error rates of the qualities phase H hands it anyway
    and keeps their sums per position in registers while the wave's reads stay in one tile.  A workgroup takes a
    CONTIGUOUS stretch of the batch then, so that a wave meets a tile change once, not once per workgroup. */
-template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false, bool PT = false>
+/* PAIR (with PT): the overlap scan of InsertSizeMetrics (calculate_insert_size :5667-5707) rides along too, split over
+   the passes of the two mates: read 2's pass (PAIR = 1) leaves the first and the last 16 bases of every read in
+   P.pair_ends; read 1's pass (PAIR = 2) brings a span's 512 bytes of them in by one LDS-DMA and scans the sequences it
+   holds in LDS anyway, four lanes per pair as k_isz_span does (sq_span.hip), before the class pass turns them into
+   codes.  The insert size of every pair goes to P.pair_results; the histogram and the adapter remainders are
+   k_isz_adapters' work. */
+__device__ __forceinline__ uint32_t pair_nonzero_bytes_of(uint32_t v)
+{
+    return (uint32_t)__popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
+}
+/* NUCLEOTIDE_COMPLEMENT, _qcmodule.c:5613-5631: reverse complement of 8 bases (0 for what is no base) */
+__device__ __forceinline__ unsigned long long pair_revcomp8(unsigned long long a)
+{
+    unsigned long long r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned l = ((unsigned)(a >> (8 * i)) & 0xFFu) | 0x20u;
+        const unsigned long long cc = l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : l == 't' ? 'A' : 0;
+        r |= cc << (8 * (7 - i));
+    }
+    return r;
+}
+
+template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false, bool PT = false, int PAIR = 0>
 __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT)) k_span(PassParams P, uint32_t n_ad)
 {
+    static_assert(PAIR == 0 || PT, "the passes over pairs are builds of the pass that carries PerTileQuality");
     static_assert(!LONG || (SEG && SPLIT), "segments of long reads come as sorted rows, a wave per stream");
     static_assert(!PT || (!AD && !SEG && !SPLIT && !LONG), "PerTileQuality rides with QCMetrics alone on batches of one read length, one wave for both streams");
 #ifdef SQ_SPAN_PROBE
@@ -255,7 +279,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     uint32_t U = SEG ? 32 * NW : P.uniform_len;   /* SEG: the length of the stretch being counted */
     const uint32_t hs = hist_stride(U);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, T = blockDim.x, W = T >> 6;
-    const SpanLds L = span_lds_layout(NW, U, AD ? SPAN_STATES(P) : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT, LONG);
+    const SpanLds L = span_lds_layout(NW, U, AD ? SPAN_STATES(P) : 0, AD ? n_ad : 0, AD ? P.ad_lds : 0, W, SEG, SPLIT, LONG, PAIR == 2);
     double *l_err = (double *)smem;                        /* [SPAN_ERR_N] by raw quality byte; [SPAN_ERR_PAD]: +0.0 */
     uint16_t *l_bin = (uint16_t *)(smem + SPAN_BIN_OFF);   /* [256] byte offset of a quality byte's row in the phred histogram */
     double *l_thr = (double *)(smem + L.thr);              /* [96] */
@@ -282,7 +306,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     uint32_t *l_adf = l_hist_phred + hs * PROWS;           /* [ad_lds][hs] */
     uint32_t *l_first = (uint32_t *)(smem + L.first) + wave * SPAN_R * (AD ? n_ad : 0); /* [16][n_ad] */
     uint32_t *l_rows = (uint32_t *)(smem + L.rows) + wave * (SEG ? 4 : 2) * SPAN_R;     /* [16][2] (SEG: [16][2] of 64 bits) */
-    const uint32_t slot_base = lds_addr(smem + L.slots) + wave * 2 * SLOT;
+    /* PT: the wave's own addresses as scalars (hipcc does not know that `wave` is uniform and keeps them in vector registers, which those builds lack) */
+    const uint32_t slot_base0 = lds_addr(smem + L.slots) + wave * 2 * SLOT;
+    const uint32_t slot_base = PT ? (uint32_t)__builtin_amdgcn_readfirstlane(slot_base0) : slot_base0;
 
     if (lds_addr(l_err) != 0) __builtin_trap(); /* quality byte << 3 is the address of its error rate */
     const uint32_t dfa_root = AD ? lds_addr(l_dfa) : 0, dfa_hit = dfa_root + span_dfa_offset(P.dfa_accept);
@@ -300,7 +326,43 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     for (int i = tid; i < 96; i += T) l_ps[i] = 0;
     uint32_t *l_prog = (uint32_t *)(smem + L.prog);   /* [16] spans started by each wave */
     if (tid < 16) l_prog[tid] = 0;
+    /* PT: the pointers the pass needs now and then wait in LDS (the 64 bytes of l_prog: only the builds of a wave per
+       stream use those) instead of in scalar registers across the whole loop -- the builds of 168 registers keep their
+       loop invariants in VECTOR registers once the scalar ones are gone, and spill */
+    enum { PAR_RESULTS = 0, PAR_ENDS, PAR_SUMS, PAR_RUNS, PAR_NRUNS, PAR_TILES, PAR_BAD, PAR_N,
+           /* PAIR = 2: QCMetrics' tables too (used once, at the end: twelve scalar registers less across the loop) */
+           PAR_QC_BASE = 8, PAR_QC_PHRED, PAR_QC_EA_BASE, PAR_QC_EA_PHRED, PAR_QC_GC, PAR_QC_PS, PAR_QC_BAD };
+    const uint32_t par_base = lds_addr(l_prog), par_more = lds_addr(smem + L.ends) + W * 512;
+    auto par = [&](int k) -> uint8_t * {   /* wave-uniform */
+        const unsigned long long v = *(volatile SQ_LDS unsigned long long *)(uintptr_t)(k < 8 ? par_base + 8 * k : par_more + 8 * (k - 8));
+        return (uint8_t *)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v));
+    };
     for (uint32_t i = tid; i < hs * (BASE_COLS + PROWS); i += T) l_hist_base[i] = 0;
+    if constexpr (PT) {
+        static_assert(!SPLIT, "l_prog holds the parameter table");
+        __syncthreads();   /* behind the zeroes above */
+        if (tid == 0) {
+            unsigned long long *l_par = (unsigned long long *)l_prog;
+            l_par[PAR_RESULTS] = (unsigned long long)P.pair_results;
+            l_par[PAR_ENDS] = (unsigned long long)P.pair_ends;
+            l_par[PAR_SUMS] = (unsigned long long)P.pt_run_sums;
+            l_par[PAR_RUNS] = (unsigned long long)P.pt_runs;
+            l_par[PAR_NRUNS] = (unsigned long long)P.pt_nruns;
+            l_par[PAR_TILES] = (unsigned long long)P.pt_tiles;
+            l_par[PAR_BAD] = (unsigned long long)P.pt_bad;
+            if constexpr (PAIR == 2) {
+                unsigned long long *l_more = (unsigned long long *)(smem + L.ends + W * 512);
+                l_more[PAR_QC_BASE - 8] = (unsigned long long)P.qc_base;
+                l_more[PAR_QC_PHRED - 8] = (unsigned long long)P.qc_phred;
+                l_more[PAR_QC_EA_BASE - 8] = (unsigned long long)P.qc_ea_base;
+                l_more[PAR_QC_EA_PHRED - 8] = (unsigned long long)P.qc_ea_phred;
+                l_more[PAR_QC_GC - 8] = (unsigned long long)P.qc_gc;
+                l_more[PAR_QC_PS - 8] = (unsigned long long)P.qc_ps;
+                l_more[PAR_QC_BAD - 8] = (unsigned long long)P.qc_first_bad;
+            }
+        }
+    }
     if (AD) {
         for (uint32_t i = tid; i < P.dfa2_states * 36; i += T) {
             const uint32_t st = i / 36, k = i % 36;   /* k = first class + 6 * second class */
@@ -349,7 +411,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     /* The 640 bytes of a span's metas come through LDS too (one more DMA of 40 lanes, two buffers
        per wave): the loop below holds no load hipcc counts, or its waits for one (vmcnt counts in
        order) would wait for the DMA issued in front of it.  Meta buffer k goes with slot k. */
-    const uint32_t meta_base = lds_addr(smem + L.meta) + wave * (SEG ? 256 : SPAN_META_LDS);
+    const uint32_t meta_base0 = lds_addr(smem + L.meta) + wave * (SEG ? 256 : SPAN_META_LDS);
+    const uint32_t meta_base = PT ? (uint32_t)__builtin_amdgcn_readfirstlane(meta_base0) : meta_base0;
     auto issue_meta = [&](uint64_t sp, uint32_t maddr) {
         if constexpr (SEG) {   /* row k of span sp: read first + 16 (sp - span0) + k of the length, the last one again behind the end */
             if (lane < (int)SPAN_R) {
@@ -370,7 +433,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     uint32_t rec_next = 0;   /* SEG: the record behind row q of the span issue() was last called for */
     uint32_t urow_next = 0, urow_cur = 0, pos_base = 0;   /* LONG: positions of row q inside the segment (0: a filler row); where the segment starts */
     /* rl: SPLIT: the stream to fetch (the role the wave has in that span) */
-    auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint32_t rl) {
+    const uint32_t ends_addr = __builtin_amdgcn_readfirstlane(lds_addr(smem + L.ends) + wave * 512);   /* PAIR = 2 */
+    auto issue = [&](uint32_t slot_addr, uint32_t maddr, uint32_t rl, uint64_t sp) {
         if constexpr (SEG) {
             const uint32_t ma = maddr + 16 * q;
             unsigned long long seq = *(SQ_LDS const unsigned long long *)(uintptr_t)ma;
@@ -414,6 +478,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                takes the output of an asm statement for valid at once and is free to copy it.) */
             const uint8_t *np = g0 + (long long)(int32_t)rel + 16 * c;
             __builtin_memcpy(&name_next, np, 16);
+        }
+        if constexpr (PAIR == 2) {   /* the ends of read 2 of the span's 16 pairs: 32 lanes x 16 bytes, contiguous */
+            uint32_t lv = (uint32_t)lane;   /* opaque: the lane's part of the address is made here */
+            asm volatile("" : "+v"(lv));
+            if (lv < 32) dma16(par(PAR_ENDS) + sp * (SPAN_R * 32) + 16 * lv, __builtin_amdgcn_readfirstlane(ends_addr));
         }
         const uint32_t roff = lds_addr(l_rows) + (SPLIT ? 4 * rl : 0);
         uint32_t pk[ND];
@@ -465,12 +534,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
             }
         const uint32_t ean = LONG ? 0 : min(P.ea_len, U);   /* LONG: the end-anchored tables are k_long_ea's */
+        unsigned long long *t_base = P.qc_base, *t_phred = P.qc_phred, *t_ea_base = P.qc_ea_base, *t_ea_phred = P.qc_ea_phred;
+        if constexpr (PAIR == 2) {
+            t_base = (unsigned long long *)par(PAR_QC_BASE); t_phred = (unsigned long long *)par(PAR_QC_PHRED);
+            t_ea_base = (unsigned long long *)par(PAR_QC_EA_BASE); t_ea_phred = (unsigned long long *)par(PAR_QC_EA_PHRED);
+        }
         for (uint32_t i = tid; i < hs * BASE_COLS; i += T) {
             const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
             if (zero) l_hist_base[i] = 0;
             if (!v || pos >= U) continue;
-            atomicAdd(&P.qc_base[(uint64_t)(pos_base + pos) * 5 + cc], (unsigned long long)v);
-            if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
+            atomicAdd(&t_base[(uint64_t)(pos_base + pos) * 5 + cc], (unsigned long long)v);
+            if (pos >= U - ean) atomicAdd(&t_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
         for (uint32_t i = tid; i < hs * PROWS; i += T) {
             uint32_t v = l_hist_phred[i], cc = i / hs;
@@ -483,8 +557,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 cc = PHRED_COLS - 1;
             }
             if (!v) continue;
-            atomicAdd(&P.qc_phred[(uint64_t)(pos_base + pos) * 12 + cc], (unsigned long long)v);
-            if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
+            atomicAdd(&t_phred[(uint64_t)(pos_base + pos) * 12 + cc], (unsigned long long)v);
+            if (pos >= U - ean) atomicAdd(&t_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
         }
     };
 
@@ -502,23 +576,26 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     auto pt_flush = [&](uint32_t tlo, uint32_t thi, uint32_t reads) {
         if constexpr (PT) {
             uint32_t idx = 0;
-            if (lane == 0) idx = atomicAdd(P.pt_nruns, 1u);
+            uint32_t lv = (uint32_t)lane;   /* opaque: nothing of the lane's part is made outside and kept across the spans */
+            asm volatile("" : "+v"(lv));
+            if (lv == 0) idx = atomicAdd((unsigned int *)par(PAR_NRUNS), 1u);
             idx = __builtin_amdgcn_readfirstlane(idx);
             if (idx >= P.pt_runs_cap) pt_full = true;
             if (idx < P.pt_runs_cap) {
-                if (lane == 0) {
+                if (lv == 0) {
                     PtRun r;
                     r.tile = (long long)(((unsigned long long)thi << 32) | tlo);
                     r.reads = reads;
                     r.pad = 0;
-                    P.pt_runs[idx] = r;
+                    ((PtRun *)par(PAR_RUNS))[idx] = r;
                 }
-                double *sums = P.pt_run_sums;   /* opaque: nothing of the address is made outside (and kept in registers across the spans) */
-                uint32_t lv = (uint32_t)lane;
-                asm volatile("" : "+s"(sums), "+v"(lv));
+                double *sums = (double *)par(PAR_SUMS);
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
-                    const double other = __shfl_xor(pt_acc[w], 32);
+                    const unsigned long long mine = (unsigned long long)__double_as_longlong(pt_acc[w]);
+                    const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lv ^ 32) << 2), (int)(uint32_t)mine);
+                    const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lv ^ 32) << 2), (int)(uint32_t)(mine >> 32));
+                    const double other = __longlong_as_double((long long)(((unsigned long long)ohi << 32) | olo));
                     const uint32_t pos = 32 * w + (lv & 31);
                     if (lv < 32 && pos < U) sums[(uint64_t)idx * U + pos] = pt_acc[w] + other;
                 }
@@ -542,6 +619,23 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         SPAN_STAMP(tp);
 #endif
 
+        if constexpr (PAIR == 1) {
+            /* the first and the last 16 bases of the row, raw (the scan of read 1's pass compares raw bytes, :5699-5703): lanes
+               0, 1 of the quad the two halves of the head, lanes 2, 3 of the tail (any alignment: byte reads) */
+            unsigned long long v;
+            if (c < 2) {
+                v = *(SQ_LDS const unsigned long long *)(uintptr_t)(seq_row + 8 * c);
+            } else {
+                const uint32_t a = seq_row + U - 16 + 8 * (c - 2);
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { lo |= lds_u8(a + k) << (8 * k); hi |= lds_u8(a + 4 + k) << (8 * k); }
+                v = ((unsigned long long)hi << 32) | lo;
+            }
+            uint8_t *dst = par(PAR_ENDS) + r * 32 + 8 * c;
+            asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+            __builtin_amdgcn_sched_barrier(0);   /* done before the next block starts: the builds of 168 registers have none to spare for an overlap */
+        }
         /* PT: the tile of every row (lanes c == 0), illumina_header_to_tile_id :3088-3121 */
         uint32_t t0lo = 0, t0hi = 0;   /* wave-uniform: the tile of row 0 */
         bool one_tile = false;         /* every row has it */
@@ -564,15 +658,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 /* the rows' tiles wait in l_rows (free between two calls of issue()) for the span a tile ends in */
                 l_rows[2 * q] = tile_lo;
                 l_rows[2 * q + 1] = tile_hi;
-                if (tile < 0) atomicMin(P.pt_bad, (unsigned long long)(P.pt_first_index + r));   /* :3137-3148: PerTileQuality ends here */
-                if (P.pt_tiles) {
-                    long long *dst = P.pt_tiles + r;
+                if (tile < 0) atomicMin((unsigned long long *)par(PAR_BAD), (unsigned long long)(P.pt_first_index + r));   /* :3137-3148: PerTileQuality ends here */
+                long long *tiles_out = (long long *)par(PAR_TILES);
+                if (tiles_out) {
+                    long long *dst = tiles_out + r;
                     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(tile) : "memory");
                 }
             }
             t0lo = __builtin_amdgcn_readfirstlane(tile_lo);
             t0hi = __builtin_amdgcn_readfirstlane(tile_hi);
             one_tile = __builtin_amdgcn_ballot_w64(c == 0 && (tile_lo != t0lo || tile_hi != t0hi)) == 0 && (int32_t)t0hi >= 0;
+            __builtin_amdgcn_sched_barrier(0);   /* the parse is over before the class pass asks for its registers */
         }
         /* ---------------- phase S: four lanes per read ----------------
            (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
@@ -864,20 +960,20 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                             const uint32_t rlo = __builtin_amdgcn_readfirstlane(l_rows[2 * row]), rhi = __builtin_amdgcn_readfirstlane(l_rows[2 * row + 1]);
                             if ((int32_t)rhi < 0) continue;
                             uint32_t idx = 0;
-                            if (lane == 0) idx = atomicAdd(P.pt_nruns, 1u);
+                            uint32_t lv = (uint32_t)lane;
+                            asm volatile("" : "+v"(lv));
+                            if (lv == 0) idx = atomicAdd((unsigned int *)par(PAR_NRUNS), 1u);
                             idx = __builtin_amdgcn_readfirstlane(idx);
                             if (idx >= P.pt_runs_cap) { pt_full = true; break; }
-                            if (lane == 0) {
+                            if (lv == 0) {
                                 PtRun run;
                                 run.tile = (long long)(((unsigned long long)rhi << 32) | rlo);
                                 run.reads = 1;
                                 run.pad = 0;
-                                P.pt_runs[idx] = run;
+                                ((PtRun *)par(PAR_RUNS))[idx] = run;
                             }
                             const uint32_t qrow = sa + row * ROWB + PRE + QOFF;
-                            double *sums = P.pt_run_sums;
-                            uint32_t lv = (uint32_t)lane;
-                            asm volatile("" : "+s"(sums), "+v"(lv));
+                            double *sums = (double *)par(PAR_SUMS);
                             for (uint32_t pos = lv; pos < U; pos += 64)
                                 sums[(uint64_t)idx * U + pos] = lds_f64(lds_u8(qrow + pos) << 3);
                         }
@@ -962,13 +1058,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                     double *dst = &P.metas[r].accumulated_error_rate;
                     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(total) : "memory");
                 }
-                if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+                if (total != total) atomicMin(PAIR == 2 ? (unsigned long long *)par(PAR_QC_BAD) : P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
                 /* :2127-2137: the largest i with avg <= thresholds[i] (the table falls with i), avg = total / U.
                    l_thr holds the thresholds of the SUM for this U (total <= l_thr[i] exactly when total / U
                    <= thresholds[i]: no f64 division).  A hardware log2 names a candidate, the three thresholds
                    around it (one round trip to LDS) decide; the bisection of the other kernels only when
                    they do not (NaN: bin 0) */
-                const float lg = __builtin_amdgcn_logf((float)total) - __builtin_amdgcn_logf((float)U);   /* log2 of the average */
+                uint32_t Ul = U;
+                if constexpr (PT) asm volatile("" : "+s"(Ul));   /* made here, not kept across the spans (the builds that carry PerTileQuality have no register to spare) */
+                const float lg = __builtin_amdgcn_logf((float)total) - __builtin_amdgcn_logf((float)Ul);   /* log2 of the average */
                 const int guess = (int)floorf(-3.0103f * lg);
                 const uint32_t b0 = (uint32_t)min(max(guess, 1), 92);
                 const double t_lo = l_thr[b0 - 1], t_mid = l_thr[b0], t_hi = l_thr[b0 + 1];
@@ -1061,7 +1159,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     if (s < s_end) {
         issue_meta(s, meta_base);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue(slot_base, meta_base, role);
+        issue(slot_base, meta_base, role, s);
         rec_cur = rec_next;
         urow_cur = urow_next;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
@@ -1092,13 +1190,86 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 while (*(volatile SQ_LDS uint32_t *)(uintptr_t)prog_partner + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
             }
         }
+        if constexpr (PAIR == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            /* calculate_insert_size (:5667-5707) for the span's 16 pairs, as k_isz_span (sq_span.hip) does it: lane c of a
+               quad makes one of the four needle halves (the reverse complements of read 2's first and last 16 bases, 8
+               bases each) and scans the windows [8 NW c, 8 NW (c + 1)) of read 1 -- raw bytes, the class pass has not
+               touched the slot yet -- for places where a needle half's low dword matches; the rare candidates are looked
+               at in window order, the quad's first match is the pair's.  Before the next span is requested: its ends land
+               where these lie. */
+            constexpr uint32_t WQ = 8 * NW;
+            const uint32_t UP4 = 0xDFDFDFDFu, last = U - 16, L2 = P.pair_L2;
+            const uint32_t ea = ends_addr + 32 * q + ((c & 1) ? 0 : 8) + ((c & 2) ? 16 : 0);
+            const unsigned long long mine = pair_revcomp8(*(SQ_LDS const unsigned long long *)(uintptr_t)ea);
+            const uint32_t m_lo = (uint32_t)mine, m_hi = (uint32_t)(mine >> 32);
+            const uint32_t hl = quad_bcast<0x00>(m_lo), hl2 = quad_bcast<0x00>(m_hi), hh = quad_bcast<0x55>(m_lo), hh2 = quad_bcast<0x55>(m_hi);
+            const uint32_t tl = quad_bcast<0xAA>(m_lo), tl2 = quad_bcast<0xAA>(m_hi), th = quad_bcast<0xFF>(m_lo), th2 = quad_bcast<0xFF>(m_hi);
+            const uint32_t ra = slot_base + cur * SLOT + q * ROWB + PRE + WQ * c;
+            const unsigned long long p0 = *(SQ_LDS const unsigned long long *)(uintptr_t)ra, p1 = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8);
+            uint32_t w0 = (uint32_t)p0, w1 = (uint32_t)(p0 >> 32), w2 = (uint32_t)p1, w3 = (uint32_t)(p1 >> 32);
+            unsigned long long nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 16);
+            uint32_t cand_lo = 0, cand_hi = 0;
+#pragma unroll 1
+            for (uint32_t k = 0; k < (uint32_t)NW; k++) {
+                uint32_t n0 = (uint32_t)nxt, n1 = (uint32_t)(nxt >> 32);
+                if (k + 1 < (uint32_t)NW) nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 24 + 8 * k);   /* the last lane's last one lies in the row's qualities: behind `last`, never looked at */
+                uint32_t bits = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
+                    const bool maybe = (u0 == hl) | (u2 == hh) | (u0 == tl) | (u2 == th);
+                    bits |= maybe ? 1u << j : 0u;
+                    w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); /* slide the window by one base */
+                    w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+                    w2 = __builtin_amdgcn_alignbyte(w3, w2, 1);
+                    w3 = __builtin_amdgcn_alignbyte(n0, w3, 1);
+                    n0 = __builtin_amdgcn_alignbyte(n1, n0, 1);
+                    n1 >>= 8;
+                }
+                if (k < 4) cand_lo |= bits << (8 * k); else cand_hi |= bits << (8 * (k - 4));
+            }
+            uint32_t result = 0;
+            unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
+            while (cand) {   /* :5695-5704: a half matches case-insensitively, then at most one raw byte of the 16 may differ */
+                const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1, i = WQ * c + j;
+                cand &= cand - 1;
+                if (i > last) break;
+                uint32_t b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t a = ra + j + 4 * t;   /* any alignment */
+                    b[t] = lds_u8(a) | (lds_u8(a + 1) << 8) | (lds_u8(a + 2) << 16) | (lds_u8(a + 3) << 24);
+                }
+                const uint32_t u0 = b[0] & UP4, u1 = b[1] & UP4, u2 = b[2] & UP4, u3 = b[3] & UP4;
+                if ((u0 == hl && u1 == hl2) || (u2 == hh && u3 == hh2)) {
+                    const uint32_t d = pair_nonzero_bytes_of(b[0] ^ hl) + pair_nonzero_bytes_of(b[1] ^ hl2) +
+                                       pair_nonzero_bytes_of(b[2] ^ hh) + pair_nonzero_bytes_of(b[3] ^ hh2);
+                    if (d <= 1) { result = i + 16; break; }
+                }
+                if ((u0 == tl && u1 == tl2) || (u2 == th && u3 == th2)) {
+                    const uint32_t d = pair_nonzero_bytes_of(b[0] ^ tl) + pair_nonzero_bytes_of(b[1] ^ tl2) +
+                                       pair_nonzero_bytes_of(b[2] ^ th) + pair_nonzero_bytes_of(b[3] ^ th2);
+                    if (d <= 1) { result = i + L2; break; }
+                }
+            }
+            /* the first match in window order: the lowest quarter that has one */
+            const uint32_t r0 = quad_bcast<0x00>(result), r1 = quad_bcast<0x55>(result), r2 = quad_bcast<0xAA>(result), r3 = quad_bcast<0xFF>(result);
+            result = r0 ? r0 : r1 ? r1 : r2 ? r2 : r3;
+            if (c == 0) {
+                uint32_t *dst = (uint32_t *)par(PAR_RESULTS) + s * SPAN_R + q;
+                asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(result) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the ends have been read: the next span's may land on them */
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (s + stride < s_end) {
 #ifdef SQ_SPAN_PROBE
             if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
-                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u));
+                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u), s + stride);
             else if (!(P.blocked & 1))
 #endif
-            issue(slot_base + (cur ^ 1) * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u));
+            issue(slot_base + (cur ^ 1) * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u), s + stride);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
             if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base);
         }
@@ -1149,9 +1320,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         merge_hist(false, 0);
     }
     for (uint32_t i = tid; i < 101; i += T)
-        if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
+        if (l_gc[i]) atomicAdd(&(PAIR == 2 ? (unsigned long long *)par(PAR_QC_GC) : P.qc_gc)[i], (unsigned long long)l_gc[i]);
     for (uint32_t i = tid; i < 94; i += T)
-        if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
+        if (l_ps[i]) atomicAdd(&(PAIR == 2 ? (unsigned long long *)par(PAR_QC_PS) : P.qc_ps)[i], (unsigned long long)l_ps[i]);
 }
 
 } // namespace

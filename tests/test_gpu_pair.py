@@ -195,3 +195,141 @@ def test_pertile_ride_on_device_batches_by_tile():
         compare_qc(rq, gq, metas, dev)
         _compare_pertile(gp, rp)
         assert len(rp.get_tile_counts()) >= 5
+
+
+# ---- the pass over PAIRS of arrays (sq_paired_add_batches / PairedPass): read 2's pass leaves the ends of its reads
+# behind, read 1's pass scans against them (calculate_insert_size, _qcmodule.c:5667-5707), both carry PerTileQuality ----
+
+def _pair_batches(rng, n, L1, L2, tiles):
+    """pairs cut from fragments of every length around the read lengths (read-through into the adapters, overlaps, none),
+    with the cases the scan has to get right: one and two mismatches under a needle, N and lower case (the comparison is
+    case-insensitive for the prefilter and raw for the verdict, :5695-5704), half a needle where it does not belong"""
+    from tests.test_gpu_vs_oracle import _revcomp
+    ad1, ad2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+
+    def rand(k):
+        return rng.choice(LETTERS, size=k).tobytes().decode()
+    n1, s1, q1, n2, s2, q2 = [], [], [], [], [], []
+    for i in range(n):
+        flen = 16 + (i * 7) % (L1 + L2) if i % 5 else int(rng.integers(16, L1 + L2 + 40))
+        frag = rand(flen)
+        r1 = (frag + ad1 + "G" * 300)[:L1]
+        r2 = (_revcomp(frag) + ad2 + "G" * 300)[:L2]
+        kind = i % 11
+        if kind == 1:
+            at = min(max(flen - 16 + 5, 0), L1 - 1)
+            r1 = r1[:at] + ("A" if r1[at] != "A" else "C") + r1[at + 1:]
+        elif kind == 2:
+            for at in (min(max(flen - 16 + 2, 0), L1 - 1), min(max(flen - 16 + 9, 0), L1 - 1)):
+                r1 = r1[:at] + ("A" if r1[at] != "A" else "C") + r1[at + 1:]
+        elif kind == 3:
+            r2 = r2[:3] + "N" + r2[4:]
+        elif kind == 4:
+            at = int(rng.integers(0, L1))
+            r1 = r1[:at] + "N" + r1[at + 1:]
+        elif kind == 5:
+            r1 = r1.lower()
+        elif kind == 6 and L1 >= 40:
+            r1 = r1[:20] + _revcomp(r2[:16])[:8] + r1[28:]
+        elif kind == 7:
+            r2 = r2[:L2 - 5] + r2[L2 - 5:].lower()
+        t = tiles[i]
+        n1.append(f"M0:7:FCX:{1 + i % 4}:{t}:{1000 + i}:{L1} 1:N:0:ACGT")
+        n2.append(f"M0:7:FCX:{1 + i % 4}:{t}:{1000 + i}:{L2} 2:N:0:ACGT")
+        s1.append(r1[:L1]); q1.append((rng.integers(0, 60, size=L1) + 33).astype(np.uint8).tobytes().decode())
+        s2.append(r2[:L2]); q2.append((rng.integers(0, 60, size=L2) + 33).astype(np.uint8).tobytes().decode())
+    return oracle.make_batch(n1, s1, q1), oracle.make_batch(n2, s2, q2)
+
+
+def _compare_insert_sizes(got, ref):
+    np.testing.assert_array_equal(u64(got.insert_sizes()), ref.insert_sizes())
+    assert got.adapters_read1() == ref.adapters_read1()
+    assert got.adapters_read2() == ref.adapters_read2()
+    assert got.number_of_adapters_read1 == ref.number_of_adapters_read1
+    assert got.number_of_adapters_read2 == ref.number_of_adapters_read2
+    assert got.total_reads == ref.total_reads
+
+
+@pytest.mark.parametrize("L1,L2,n", [(150, 150, 16 * 300), (150, 150, 16 * 300 + 9), (151, 75, 16 * 280 + 3), (64, 200, 16 * 260),
+                                     (16, 16, 4096), (250, 250, 16 * 257 + 1), (40, 31, 16 * 300), (100, 16, 16 * 256 + 15)])
+def test_paired_pass_equals_the_five_calls(L1, L2, n):
+    """two batches of pairs through PairedPass against the oracle's five modules: QCMetrics and PerTileQuality of both
+    mates, InsertSizeMetrics (histogram, both adapter tables in slot order, the counters), with a small max_adapters so
+    that the first-come cap is crossed; the route is asserted (two passes and the remainders' kernel, no k_isz_span)"""
+    from sequali_amd import FastqRecordArrayView, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(L1 * 1000 + L2 + n)
+    ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics(50))
+    got = (QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics(50))
+    pp = PairedPass(*got)
+    nw1, nw2 = (L1 + 31) // 32, (L2 + 31) // 32
+    for part in range(2):
+        tiles = _runs(rng, n, [3, 16, 40, 700], [1101, 1102, 2203])
+        (b1, m1), (b2, m2) = _pair_batches(rng, n, L1, L2, tiles)
+        ref[0].add(b1, m1); ref[1].add(b1, m1); ref[2].add(b2, m2); ref[3].add(b2, m2); ref[4].add_pair(b1, m1, b2, m2)
+        a1 = FastqRecordArrayView._from_buffer(b1, m1.copy())
+        a2 = FastqRecordArrayView._from_buffer(b2, m2.copy())
+        r = _route_of(lambda: with_env(RIDE, lambda: (pp.add_record_array_pair(a1, a2), got[0].flush(), got[2].flush(), got[4].insert_sizes())))
+        want = [f"k_span<{nw2},QCPT_ends,uniform,both>", "k_pt_fold", f"k_span<{nw1},QCPT_scan,uniform,both>", "k_pt_fold", "k_isz_adapters<hist>"]
+        parts = [p for p in r.split("+") if not p.startswith("k_pass")]     # (the records behind the last full span: QCMetrics by k_pass)
+        assert parts[:5] == want and "k_isz_span" not in r, r
+        compare_qc(ref[0], got[0], m1, a1)
+        compare_qc(ref[2], got[2], m2, a2)
+        _compare_pertile(got[1], ref[1])
+        _compare_pertile(got[3], ref[3])
+        _compare_insert_sizes(got[4], ref[4])
+
+
+def test_paired_pass_falls_back_to_the_five_calls():
+    """what the paired kernels do not take goes through the modules' own passes with the same results: reads of many
+    lengths, a mate shorter than the 16 bases of a needle, the default SQ_PT_FUSED=0, modules left out"""
+    from sequali_amd import FastqRecordArrayView, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(11)
+    n = 16 * 280 + 2
+    tiles = _runs(rng, n, [50, 900], [1101, 1102])
+    (b1, m1), (b2, m2) = _pair_batches(rng, n, 120, 90, tiles)
+    m1r = m1.copy()
+    m1r["sequence_length"][::3] -= 7            # ragged read 1 (the qualities start where they did: only the length moves)
+    (c1, k1), (c2, k2) = _pair_batches(rng, n, 150, 12, tiles)
+    cases = [(b1, m1r, b2, m2, RIDE), (c1, k1, c2, k2, RIDE), (b1, m1, b2, m2, {})]
+    for x1, y1, x2, y2, env in cases:
+        ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics())
+        ref[0].add(x1, y1); ref[1].add(x1, y1); ref[2].add(x2, y2); ref[3].add(x2, y2); ref[4].add_pair(x1, y1, x2, y2)
+        got = (QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics())
+        a1 = FastqRecordArrayView._from_buffer(x1, y1.copy())
+        a2 = FastqRecordArrayView._from_buffer(x2, y2.copy())
+        r = _route_of(lambda: with_env(env, lambda: (PairedPass(*got).add_record_array_pair(a1, a2), got[0].flush(), got[2].flush(), got[4].insert_sizes())))
+        assert "QCPT_scan" not in r, r
+        compare_qc(ref[0], got[0], y1, a1)
+        compare_qc(ref[2], got[2], y2, a2)
+        _compare_pertile(got[1], ref[1])
+        _compare_pertile(got[3], ref[3])
+        _compare_insert_sizes(got[4], ref[4])
+    # modules left out: QCMetrics of read 1 and InsertSizeMetrics alone
+    ref_q, ref_z = oracle.QCMetrics(), oracle.InsertSizeMetrics()
+    ref_q.add(b1, m1); ref_z.add_pair(b1, m1, b2, m2)
+    q, z = QCMetrics(), InsertSizeMetrics()
+    a1 = FastqRecordArrayView._from_buffer(b1, m1.copy())
+    a2 = FastqRecordArrayView._from_buffer(b2, m2.copy())
+    with_env(RIDE, lambda: (PairedPass(q, None, None, None, z).add_record_array_pair(a1, a2), q.flush()))
+    compare_qc(ref_q, q, m1, a1)
+    _compare_insert_sizes(z, ref_z)
+
+
+def test_paired_pass_on_device_batches_by_tile():
+    """the bench's config 3 at a small size: device-generated pairs in the order a sequencer writes"""
+    from sequali_amd import InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics, synth
+    n, first = 500_000, 3 * 65536 - 1000
+    d1 = synth.device_array(synth.ILLUMINA_BY_TILE, first, n)
+    d2 = synth.device_array(synth.ILLUMINA_R2_BY_TILE, first, n)
+    b1, m1 = d1._batch.download()
+    b2, m2 = d2._batch.download()
+    ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics())
+    ref[0].add(b1, m1); ref[1].add(b1, m1); ref[2].add(b2, m2); ref[3].add(b2, m2); ref[4].add_pair(b1, m1, b2, m2)
+    got = (QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics())
+    r = _route_of(lambda: with_env(RIDE, lambda: (PairedPass(*got).add_record_array_pair(d1, d2), got[0].flush(), got[2].flush(), got[4].insert_sizes())))
+    assert r == "k_span<5,QCPT_ends,uniform,both>+k_pt_fold+k_span<5,QCPT_scan,uniform,both>+k_pt_fold+k_isz_adapters<hist>", r
+    compare_qc(ref[0], got[0], m1, d1)
+    compare_qc(ref[2], got[2], m2, d2)
+    _compare_pertile(got[1], ref[1])
+    _compare_pertile(got[3], ref[3])
+    _compare_insert_sizes(got[4], ref[4])
