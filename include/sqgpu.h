@@ -474,6 +474,9 @@ int sq_rccl_allgather_bytes(sq_ctx *ctx, void *comm, const void *d_send, void *d
 int sq_qcmetrics_allreduce(sq_qcmetrics *m, void *comm);
 int sq_adaptercounter_allreduce(sq_adaptercounter *a, void *comm);
 
+/* test hook: the header parse of k_span<PT> (csrc/sq_pair.hip) compiled for the host; `name` has 64 readable bytes */
+int64_t sq_test_tile_of_header(const uint8_t *name, uint32_t n);
+
 /* ---- synthetic FASTQ (bench / tests): counter-based, host == device bytes -- */
 #define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */
 #define SQ_SYNTH_ILLUMINA_R2 1    /* the mate of read i              */

@@ -271,7 +271,7 @@ __device__ __forceinline__ uint32_t sq_load_u32_unaligned(const uint8_t *p)
     return v;
 }
 
-__device__ __forceinline__ uint64_t sq_load_u64_unaligned(const uint8_t *p)
+__host__ __device__ __forceinline__ uint64_t sq_load_u64_unaligned(const uint8_t *p)
 {
     uint64_t v;
     __builtin_memcpy(&v, p, 8);

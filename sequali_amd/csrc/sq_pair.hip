@@ -172,3 +172,19 @@ int sq_pt_fold(sq_ctx *ctx, const PtRun *runs, const double *sums, uint32_t n_ru
     SQ_HIP(hipGetLastError());
     return SQ_OK;
 }
+
+/* What k_span<PT> makes of a header (illumina_header_to_tile_id, _qcmodule.c:3088-3121): the first 64 bytes in registers
+ * (tile_id_of_words<8>), a longer header or a tile of 9 .. 18 digits byte by byte (tile_id_of) -- the same functions,
+ * compiled for the host, so that the parse can be checked without a GPU (tests/test_boundary_cpu.py).  `name` must have 64
+ * readable bytes (the kernel's loads fetch 64 whatever the name's length; what lies behind the name must not matter). */
+SQ_EXPORT int64_t sq_test_tile_of_header(const uint8_t *name, uint32_t n)
+{
+    long long tile = -2;
+    if (n <= 64) {
+        uint64_t w[8];
+        memcpy(w, name, 64);
+        tile = tile_id_of_words<8>(w, n);
+    }
+    if (tile == -2) tile = tile_id_of(name, n);
+    return tile;
+}

@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t xor_add(uint32_t x, uint32_t s, uint32_t b)
 /* illumina_header_to_tile_id, _qcmodule.c:3088-3121 (+ :159-180): the decimal number
  * between the 4th and the 5th ':' of the header.  Colons are found eight bytes at a
  * time (headers are 7-bit ASCII, so x + 0x7F sets bit 7 of every non-zero byte). */
-__device__ long long tile_id_of(const uint8_t *name, uint32_t n)
+__host__ __device__ inline long long tile_id_of(const uint8_t *name, uint32_t n)
 {
     uint32_t colons = 0, c4 = n, c5 = n;
     for (uint32_t off = 0; off < n && c5 == n; off += 8) {
@@ -266,7 +266,7 @@ __device__ long long tile_id_of(const uint8_t *name, uint32_t n)
         const uint64_t x = w ^ 0x3A3A3A3A3A3A3A3AULL;
         uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
         while (m) {
-            const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
+            const uint32_t at = off + ((uint32_t)__builtin_ffsll((long long)m) - 1) / 8;
             m &= m - 1;
             colons++;
             if (colons == 4) c4 = at;
@@ -290,7 +290,7 @@ __device__ long long tile_id_of(const uint8_t *name, uint32_t n)
  * of the one before: the slowest way to gather).  w[] holds the bytes little endian.  Returns
  * -2 when the tile field is longer than 8 digits: the caller falls back to tile_id_of. */
 template <int NWORDS>
-__device__ long long tile_id_of_words(const uint64_t (&w)[NWORDS], uint32_t n)
+__host__ __device__ inline long long tile_id_of_words(const uint64_t (&w)[NWORDS], uint32_t n)
 {
     uint32_t colons = 0, c4 = n, c5 = n;
 #pragma unroll
@@ -302,7 +302,7 @@ __device__ long long tile_id_of_words(const uint64_t (&w)[NWORDS], uint32_t n)
             x ^= 0x3A3A3A3A3A3A3A3AULL;
             uint64_t m = ~((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL | x) & 0x8080808080808080ULL;
             while (m) {
-                const uint32_t at = off + ((uint32_t)__ffsll((long long)m) - 1) / 8;
+                const uint32_t at = off + ((uint32_t)__builtin_ffsll((long long)m) - 1) / 8;
                 m &= m - 1;
                 colons++;
                 if (colons == 4) c4 = at;

@@ -452,3 +452,56 @@ def test_rccl_entry_points_load_and_fail_loudly_without_a_communicator():
     assert L.sq_rccl_allgather_bytes(None, None, None, None, 0) < 0
     assert L.sq_rccl_comm_init(None, 2, (C.c_uint8 * 128)(), 0) is None
     assert "context" in last_error()
+
+
+def _reference_tile_id(name: bytes) -> int:
+    """illumina_header_to_tile_id + unsigned_decimal_integer_from_string (_qcmodule.c:3088-3121, :159-180), as plain
+    Python: the decimal number between the 4th and the 5th colon (at most 18 digits), -1 for anything else"""
+    n, colons, cursor = len(name), 0, 0
+    while cursor < n:
+        if name[cursor] == 0x3A:
+            colons += 1
+            if colons == 4:
+                break
+        cursor += 1
+    cursor += 1
+    start = cursor
+    while cursor < n:
+        if name[cursor] == 0x3A:
+            digits = name[start:cursor]
+            if not 1 <= len(digits) <= 18 or any(not 0x30 <= c <= 0x39 for c in digits):
+                return -1
+            return int(digits)
+        cursor += 1
+    return -1
+
+
+def test_header_parse_of_the_paired_pass_on_the_host():
+    """k_span<PT> parses the tile id out of the first 64 bytes of a header held in registers (tile_id_of_words<8>) and
+    falls back to a byte-by-byte walk (tile_id_of) for longer headers and tiles of 9 .. 18 digits; both are compiled for
+    the host too (sq_test_tile_of_header).  Headers of every length from 0 to 100, the tile field at every offset (also
+    across bytes 48 and 64), tiles of 0 to 20 digits, non-digits, too few colons; whatever lies behind the name (the
+    kernel's loads fetch 64 bytes whatever the length) must not matter"""
+    import ctypes as C
+    from sequali_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(7)
+    cases = [b"", b":", b"::::", b":::::", b"::::1:", b"::::12", b"a:b:c:d:007:x", b"a:b:c:d::x", b"a:b:c:d:12a:x",
+             b"SIM:1:FCX:3:2221:22916:753886 1:N:0:ATCCGA", b"@:@:@:@:" + b"9" * 18 + b":", b"@:@:@:@:" + b"9" * 19 + b":",
+             b"a:b:c:d:123456789:e", b"a:b:c:d:12345678:e"]
+    for pad in range(0, 70):                       # the tile field slides over the word boundaries 8 .. 64
+        for digits in (1, 4, 8, 9, 12):
+            t = "".join(str(int(x)) for x in rng.integers(0, 10, size=digits))
+            cases.append(b"I" * pad + f":1:F:2:{t}:55:66 1:N:0:AC".encode())
+            cases.append(b"I" * pad + f":1:F:2:{t}".encode())             # no fifth colon
+    for n in range(0, 101):
+        raw = rng.choice(np.frombuffer(b"AC:019: x", np.uint8), size=n).tobytes()
+        cases.append(raw)
+    checked = 0
+    for name in cases:
+        for fill in (b"\xff", b":", b"7"):
+            buf = (name + fill * 72)[:max(len(name), 64) + 8]
+            got = L.sq_test_tile_of_header(C.c_char_p(buf), len(name))
+            assert got == _reference_tile_id(name), (name, fill, got)
+            checked += 1
+    assert checked > 2000
