@@ -22,7 +22,7 @@ from ._qc import (DEFAULT_DEDUP_MAX_STORED_FINGERPRINTS, DEFAULT_FINGERPRINT_BAC
                   DEFAULT_FINGERPRINT_BACK_SEQUENCE_OFFSET, DEFAULT_FINGERPRINT_FRONT_SEQUENCE_LENGTH,
                   DEFAULT_FINGERPRINT_FRONT_SEQUENCE_OFFSET, DEFAULT_FRAGMENT_LENGTH,
                   DEFAULT_MAX_UNIQUE_FRAGMENTS, DEFAULT_UNIQUE_SAMPLE_EVERY, AdapterCounter, BamParser,
-                  DedupEstimator, FastqParser, FusedPass, InsertSizeMetrics, NanoStats,
+                  DedupEstimator, FastqParser, FusedPass, InsertSizeMetrics, NanoStats, PairedPass,
                   OverrepresentedSequences, PerTileQuality, QCMetrics)
 
 # __main__.py:40-41
@@ -238,13 +238,16 @@ def run(input_path: str, input_reverse: Optional[str] = None, *,
             adapter_counter1 = AdapterCounter(a.sequence for a in adapters)
         # one read of each array from HBM for the three per-base modules (same tables as
         # the three separate calls of the reference's loop)
-        fused1 = FusedPass(metrics1, adapter_counter1, per_tile1)
-        fused2 = FusedPass(metrics2, None, per_tile2) if paired else None
+        fused1 = FusedPass(metrics1, adapter_counter1, per_tile1) if not paired else None
+        # paired input: the five calls the reference makes per pair of arrays (metrics, per tile quality on both mates,
+        # insert sizes: __main__.py:279-306) as one (sq_paired_add_batches; csrc/sq_pair.hip)
+        paired_pass = PairedPass(metrics1, per_tile1, metrics2, per_tile2, insert_sizes) if paired else None
         try:
             for arr1 in reader1:
-                fused1.add_record_array(arr1)
-                overrep1.add_record_array(arr1)
-                nanostats1.add_record_array(arr1)
+                if not paired:
+                    fused1.add_record_array(arr1)
+                    overrep1.add_record_array(arr1)
+                    nanostats1.add_record_array(arr1)
                 if paired:
                     arr2 = reader2.read(len(arr1))
                     if len(arr1) != len(arr2):
@@ -256,9 +259,10 @@ def run(input_path: str, input_reverse: Optional[str] = None, *,
                             if not sequence_names_match(n1, n2):
                                 raise RuntimeError(f"Mismatching names found! {n1} {n2}")
                         raise RuntimeError("Mismatching names found!")
+                    paired_pass.add_record_array_pair(arr1, arr2)
+                    overrep1.add_record_array(arr1)
+                    nanostats1.add_record_array(arr1)      # behind QCMetrics' pass over arr1: it reads accumulated_error_rate (:5314)
                     dedup.add_record_array_pair(arr1, arr2)
-                    insert_sizes.add_record_array_pair(arr1, arr2)
-                    fused2.add_record_array(arr2)
                     overrep2.add_record_array(arr2)
                 else:
                     dedup.add_record_array(arr1)
