@@ -50,6 +50,8 @@ def parse_args():
                     help="times the CPU baseline walks its sample (about 12 s of CPU work by default)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="records of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--configs", default=None,
+                    help="comma-separated entries of other_configs to run (default: all); for profiling one configuration at a time")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
                     help="skip configs 3, 4 and the ragged variant (other_configs of the JSON line)")
     ap.add_argument("--modules", default="qc,adapter", help="qc,adapter[,pertile]")
@@ -197,7 +199,7 @@ def cpu_baseline(sample_reads: int, passes: int = 1):
                       f"QCMetrics+AdapterCounter on one thread (the reference's second thread only decompresses), {dt:.2f} s"}
 
 
-def other_configs(lib, ctx, steps, warmup):
+def other_configs(lib, ctx, steps, warmup, only=None):
     """BASELINE configs 3 and 4 and the ragged variant of config 2, each timed like the headline:
     records resident in HBM, `steps` passes behind `warmup`, HIP events on the library's stream
     around every pass; achieved = algorithmic bytes / pass time."""
@@ -236,9 +238,14 @@ def other_configs(lib, ctx, steps, warmup):
     def route_of_step():
         return compact_route((lib.sq_last_route(ctx) or b"").decode())
 
+    def wanted(name):   # --configs: a subset of the entries (profiling one configuration at a time)
+        return only is None or name in only
+
     out = {}
     # ---- batches of one read length other than 150: 200 and 250 bases (2 x 250 is a real Illumina length) ----
     for L in (200, 250):
+        if not wanted(f"uniform_{L}bp"):
+            continue
         n, per = 50_000_000, 25_000_000
         batches = [synth.device_array(synth.with_length(synth.ILLUMINA, L), k * per, per) for k in range(n // per)]
         bases = sum(b._batch.total_bases for b in batches)
@@ -257,25 +264,26 @@ def other_configs(lib, ctx, steps, warmup):
                 "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del batches
     # ---- ragged: the config-2 records cut to 50 .. 150 bases (what adapter trimming leaves) ----
-    n, per = 50_000_000, 25_000_000
-    batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
-    for k, b in enumerate(batches):
-        _lib.check(lib.sq_synth_trim(b._batch.handle, 77 + k, 50))
-    bases = sum(b._batch.total_bases for b in batches)
+    if wanted("ragged_50_150"):
+        n, per = 50_000_000, 25_000_000
+        batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
+        for k, b in enumerate(batches):
+            _lib.check(lib.sq_synth_trim(b._batch.handle, 77 + k, 50))
+        bases = sum(b._batch.total_bases for b in batches)
 
-    def ragged_step(f):
-        for b in batches:
-            f.add_record_array(b)
-            clear(f)
+        def ragged_step(f):
+            for b in batches:
+                f.add_record_array(b)
+                clear(f)
 
-    out["ragged_50_150"] = run(
-        "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
-        "QCMetrics + AdapterCounter fused, records resident in HBM",
-        "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
-        lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
-        lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                           "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
-    del batches
+        out["ragged_50_150"] = run(
+            "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
+            "QCMetrics + AdapterCounter fused, records resident in HBM",
+            "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
+            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
+            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+        del batches
     # ---- config 3: 100 M pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics ----
     # three entries: the reads with a random tile each (what rounds 1-3 measured), the same pairs in the order a sequencer
     # writes them (65536 reads of a tile in a row), and that order through the paired pass (PairedPass, SQ_PT_FUSED=1:
@@ -287,6 +295,8 @@ def other_configs(lib, ctx, steps, warmup):
     for entry, kinds, fused in (("config3_paired", (synth.ILLUMINA, synth.ILLUMINA_R2), False),
                                 ("config3_paired_by_tile", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), False),
                                 ("config3_paired_by_tile_fused", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), True)):
+        if not wanted(entry):
+            continue
         r1 = [synth.device_array(kinds[0], k * per, per) for k in range(n // per)]
         r2 = [synth.device_array(kinds[1], k * per, per) for k in range(n // per)]
         bases = sum(b._batch.total_bases for b in r1) + sum(b._batch.total_bases for b in r2)
@@ -330,72 +340,74 @@ def other_configs(lib, ctx, steps, warmup):
                 lib.sq_knobs_reload()
         del r1, r2
     # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
-    n = 1_000_000
-    arr = synth.device_array(synth.NANOPORE, 0, n)
-    bases = arr._batch.total_bases
+    if wanted("config4_nanopore"):
+        n = 1_000_000
+        arr = synth.device_array(synth.NANOPORE, 0, n)
+        bases = arr._batch.total_bases
 
-    def c4_step(f):
-        f.add_record_array(arr)
-        clear(f)
+        def c4_step(f):
+            f.add_record_array(arr)
+            clear(f)
 
-    out["config4_nanopore"] = run(
-        "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
-        "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
-        lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
-        lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                           "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
-    del arr
+        out["config4_nanopore"] = run(
+            "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
+            "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
+            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
+            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+        del arr
     # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
-    import io
-    from sequali_amd import FastqParser, PinnedReader
-    n = 2_000_000
-    text = synth.illumina_fastq(0, n)
+    if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split"):
+        import io
+        from sequali_amd import FastqParser, PinnedReader
+        n = 2_000_000
+        text = synth.illumina_fastq(0, n)
 
-    def e2e(make_file, **parser_kw):
-        f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
-        fobj = make_file()
-        _lib.synchronize()
-        t0 = time.perf_counter()
-        arrays = 0
-        for a in FastqParser(fobj, **parser_kw):
-            f.add_record_array(a)
-            arrays += 1
-        f.qc_metrics.flush()
-        _lib.synchronize()
-        dt = time.perf_counter() - t0
-        ok = bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)
-        return dt, arrays, ok
+        def e2e(make_file, **parser_kw):
+            f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
+            fobj = make_file()
+            _lib.synchronize()
+            t0 = time.perf_counter()
+            arrays = 0
+            for a in FastqParser(fobj, **parser_kw):
+                f.add_record_array(a)
+                arrays += 1
+            f.qc_metrics.flush()
+            _lib.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)
+            return dt, arrays, ok
 
-    first_dt, _, _ = e2e(lambda: io.BytesIO(text))       # first pass: page-locks its 64 MiB staging blocks (they go to a pool)
-    runs = [e2e(lambda: io.BytesIO(text)) for _ in range(3)]   # the reference's call pattern: default initial_buffersize
-    dt, arrays, ok = sorted(runs)[1]                     # host bound, ~0.1 s a pass: the median of three
-    ok = all(r[2] for r in runs)
-    out["e2e_host_fastq_default_buffer"] = {
-        "workload": f"{n} x 150 bp FASTQ text in host memory (io.BytesIO) through FastqParser at its default 128 KiB ({arrays} arrays, "
-                    "~380 reads each), QCMetrics + AdapterCounter called once per array as __main__.py:279-306 does; the parser's buffer logic "
-                    "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), one upload and one launch per block; file read, record "
-                    "split, upload and counting included",
-        "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
-        "first_pass_seconds": round(first_dt, 3), "seconds_of_three_passes": [round(r[0], 3) for r in runs],
-        "checks": {"base_table_sum_ok": ok}}
-    big = dict(initial_buffersize=64 << 20, split_on_device=True)
-    reader = PinnedReader(text)                            # the text in page-locked memory, as a file object
+        first_dt, _, _ = e2e(lambda: io.BytesIO(text))       # first pass: page-locks its 64 MiB staging blocks (they go to a pool)
+        runs = [e2e(lambda: io.BytesIO(text)) for _ in range(3)]   # the reference's call pattern: default initial_buffersize
+        dt, arrays, ok = sorted(runs)[1]                     # host bound, ~0.1 s a pass: the median of three
+        ok = all(r[2] for r in runs)
+        out["e2e_host_fastq_default_buffer"] = {
+            "workload": f"{n} x 150 bp FASTQ text in host memory (io.BytesIO) through FastqParser at its default 128 KiB ({arrays} arrays, "
+                        "~380 reads each), QCMetrics + AdapterCounter called once per array as __main__.py:279-306 does; the parser's buffer logic "
+                        "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), one upload and one launch per block; file read, record "
+                        "split, upload and counting included",
+            "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+            "first_pass_seconds": round(first_dt, 3), "seconds_of_three_passes": [round(r[0], 3) for r in runs],
+            "checks": {"base_table_sum_ok": ok}}
+        big = dict(initial_buffersize=64 << 20, split_on_device=True)
+        reader = PinnedReader(text)                            # the text in page-locked memory, as a file object
 
-    def rewound():
-        reader.seek(0)
-        return reader
+        def rewound():
+            reader.seek(0)
+            return reader
 
-    e2e(rewound, **big)
-    runs = [e2e(rewound, **big) for _ in range(3)]
-    dt, arrays, ok = sorted(runs)[1]
-    ok = all(r[2] for r in runs)
-    out["e2e_pinned_64MiB_device_split"] = {
-        "workload": f"the same {n} reads as text in page-locked host memory (PinnedReader) through FastqParser(initial_buffersize=64 MiB, "
-                    f"split_on_device=True): {arrays} arrays, uploaded from where they lie, records split on the GPU (k_split_*), "
-                    "QCMetrics + AdapterCounter; upload, split and counting included",
-        "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
-        "seconds_of_three_passes": [round(r[0], 3) for r in runs],
-        "checks": {"base_table_sum_ok": ok}}
+        e2e(rewound, **big)
+        runs = [e2e(rewound, **big) for _ in range(3)]
+        dt, arrays, ok = sorted(runs)[1]
+        ok = all(r[2] for r in runs)
+        out["e2e_pinned_64MiB_device_split"] = {
+            "workload": f"the same {n} reads as text in page-locked host memory (PinnedReader) through FastqParser(initial_buffersize=64 MiB, "
+                        f"split_on_device=True): {arrays} arrays, uploaded from where they lie, records split on the GPU (k_split_*), "
+                        "QCMetrics + AdapterCounter; upload, split and counting included",
+            "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+            "seconds_of_three_passes": [round(r[0], 3) for r in runs],
+            "checks": {"base_table_sum_ok": ok}}
     return out
 
 
@@ -578,7 +590,8 @@ def main():
         if world == 1 and not use_dist and args.other_configs and args.kind == "illumina":
             del batches[:]
             try:
-                out["other_configs"] = other_configs(lib, ctx, max(1, min(args.steps, 3)), 1)
+                out["other_configs"] = other_configs(lib, ctx, max(1, min(args.steps, 3)), 1,
+                                                     set(args.configs.split(",")) if args.configs else None)
                 # HBM-side bytes per pass of every config (PMC passes of scripts/profile_r3.sh), under the same rule
                 # as the headline's: only a measurement of THIS build of the kernels counts
                 if os.path.exists(tpath) and tj.get("csrc_sha") == csrc_sha():
