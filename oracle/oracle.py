@@ -297,6 +297,8 @@ class PerTileQuality:
 
     def add(self, buf, metas: np.ndarray) -> None:
         r = LIB.oq_ptq_add(self._h, _ptr(buf), metas.ctypes.data, len(metas))
+        if r == -(1 << 63):
+            raise MemoryError("a tile id beyond 2^27: the reference's tile array (16 bytes per id, _qcmodule.c:3026-3044) has no memory for it")
         if r < 0:
             raise ValueErrorWithIndex("Not a valid phred character", -r - 1)
 

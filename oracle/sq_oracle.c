@@ -405,6 +405,7 @@ oq_ptq_free(oq_ptq *p)
     free(p);
 }
 
+#define OQ_MAX_TILE_ID (1ull << 27)
 /* PerTileQuality_add_meta, _qcmodule.c:3123-3222 */
 static int
 oq_ptq_add_one(oq_ptq *p, const uint8_t *name, size_t name_len,
@@ -429,7 +430,13 @@ oq_ptq_add_one(oq_ptq *p, const uint8_t *name, size_t name_len,
         p->max_length = L;
     }
     if ((size_t)tile + 1 > p->n_tiles) { /* resize_tile_array :3026-3044 */
+        /* The reference indexes an array by the tile id (16 bytes per id up to the largest one seen; PyMem_Realloc fails
+           for ids it has no memory for, :3036-3039).  This checker refuses ids beyond 2^27 (2 GB of table) instead of
+           trying: a test that fed it a 12-digit id asked for 2 TB, which a machine with overcommit grants and then dies
+           of when the memset below touches it (round 4 lost two GPU boxes that way). */
+        if ((uint64_t)tile >= OQ_MAX_TILE_ID) return -2;
         p->tiles = realloc(p->tiles, ((size_t)tile + 1) * sizeof(oq_tile));
+        if (!p->tiles) return -2;
         memset(p->tiles + p->n_tiles, 0, ((size_t)tile + 1 - p->n_tiles) * sizeof(oq_tile));
         p->n_tiles = (size_t)tile + 1;
     }
@@ -465,6 +472,7 @@ oq_ptq_add(oq_ptq *p, const uint8_t *buf, const oq_meta *metas, size_t n)
                                  rec + metas[r].qualities_offset,
                                  metas[r].sequence_length);
         p->records_seen += 1;
+        if (ret == -2) return INT64_MIN;   /* a tile id the reference's tile array has no memory for */
         if (ret != 0) return -(int64_t)(r + 1);
     }
     return 0;

@@ -4,8 +4,10 @@
 #   tests/test_gpu_pair.py  tests/test_gpu_routes.py
 #   tests/test_gpu_span_edges.py::test_few_very_long_reads_with_more_than_64_adapters
 #   tests/test_gpu_vs_oracle.py::test_config3_one_million_pairs
-# takes the machine down (or the pool did; the calls reported "run 0.0s").  Find it ONE test per gpurun call, each under
-# its own short timeout, the least suspicious first:
+# took the machine down.  FOUND on the CPU afterwards: two tests fed the oracle tile ids of 12 / 18 digits; the
+# oracle, like the reference, indexes an array by the tile id -> realloc + memset of 2 TB -> the box's host memory.  The
+# oracle now refuses such ids and the tests no longer make them.  All the same: the round's new GPU tests have never run,
+# so run them ONE per gpurun call, each under its own short timeout, the plainest first:
 #   gpurun --timeout 300 -- 'bash scripts/gpu_bisect_r5.sh 1'      (then 2, 3, ...)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/bisect

@@ -50,7 +50,9 @@ def test_pertile_rides_in_the_qcmetrics_pass(U, n):
     behind the last full span (k_pt_tail).  The route is asserted: nothing falls back."""
     from sequali_amd import FastqRecordArrayView, FusedPass, PerTileQuality, QCMetrics
     rng = np.random.default_rng(U * 1000 + n)
-    tiles = [1101, 1102, 1203, 2101, 2224, 7, 0, 99999999, 123456789012]   # 0, 8 and 12 digits: the 64-bit paths of the parse
+    # (tile ids the ORACLE can hold: like the reference it indexes an array by the id, 16 bytes per id up to the largest --
+    # ids of 8 and more digits are checked without it, test_pertile_ride_tile_ids_of_many_digits)
+    tiles = [1101, 1102, 1203, 2101, 2224, 7, 0, 65535, 40000]
     rq, rp = oracle.QCMetrics(), oracle.PerTileQuality()
     gq, gp = QCMetrics(), PerTileQuality()
     f = FusedPass(gq, None, gp)
@@ -68,8 +70,8 @@ def test_pertile_rides_in_the_qcmetrics_pass(U, n):
 
 
 def test_pertile_ride_headers_of_every_shape():
-    """headers longer than the 64 bytes the pass looks at (the tile field in front of and behind byte 64), a tile field
-    of 18 digits, read-2 style comments, names of different lengths inside one span"""
+    """headers longer than the 64 bytes the pass looks at (the tile field in front of and behind byte 64), read-2 style
+    comments, names of different lengths inside one span"""
     from sequali_amd import FastqRecordArrayView, FusedPass, PerTileQuality, QCMetrics
     rng = np.random.default_rng(5)
     U, n = 100, 16 * 300
@@ -88,7 +90,7 @@ def test_pertile_ride_headers_of_every_shape():
             return f"::::{t}:"
         return f"M:1:F:{i % 4}:{t}:{i}:{U} 1:N:0:X"
 
-    tl = _runs(rng, n, [16, 32, 48, 64, 160], [5, 1101, 123456789012345678, 22])
+    tl = _runs(rng, n, [16, 32, 48, 64, 160], [5, 1101, 31999, 22])
     buf, metas = _batch(rng, tl, U, name_of)
     rq, rp = oracle.QCMetrics(), oracle.PerTileQuality()
     rq.add(buf, metas)
@@ -100,6 +102,37 @@ def test_pertile_ride_headers_of_every_shape():
     compare_qc(rq, gq, metas, arr)
     _compare_pertile(gp, rp)
     assert gp.skipped_reason is None
+
+
+def test_pertile_ride_tile_ids_of_many_digits():
+    """tile ids of 8, 9, 12 and 18 digits (the reference takes up to 18, :159-180; the pass parses up to 8 in registers and
+    the rest byte by byte).  NOT against the oracle: like the reference it indexes an array by the tile id and would ask
+    for terabytes (that took two GPU boxes down in round 4); the expectation is made here from the definition --
+    total_errors[tile][pos] = sum of 10^(-q/10) over the tile's reads, length_counts = the reads -- within the module's
+    1e-6"""
+    from sequali_amd import FastqRecordArrayView, FusedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(18)
+    U, n = 64, 16 * 300 + 3
+    ids = [99999999, 100000000, 123456789012, 123456789012345678, 7]
+    tl = _runs(rng, n, [1, 16, 33, 400], ids)
+    buf, metas = _batch(rng, tl, U, qual_hi=60)
+    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq, gp = QCMetrics(), PerTileQuality()
+    r = _route_of(lambda: with_env(RIDE, lambda: (FusedPass(gq, None, gp).add_record_array(arr), gq.flush(), gp.flush())))
+    assert r.split("+")[0] == "k_span<2,QCPT,uniform,both>" and "k_pt_fold" in r, r
+    raw = np.frombuffer(buf, np.uint8)
+    want_err = {t: np.zeros(U) for t in ids}
+    want_cnt = {t: 0 for t in ids}
+    for i, t in enumerate(tl):
+        q0 = int(metas["record_start"][i]) + int(metas["qualities_offset"][i])
+        want_err[t] += 10.0 ** (-(raw[q0:q0 + U].astype(np.float64) - 33.0) / 10.0)
+        want_cnt[t] += 1
+    got = gp.get_tile_counts()
+    assert [t for t, _, _ in got] == sorted(t for t in ids if want_cnt[t])
+    assert gp.number_of_reads == n and gp.skipped_reason is None
+    for t, e, c in got:
+        np.testing.assert_allclose(np.array(e), want_err[t], rtol=1e-6, atol=0, err_msg=f"tile {t}")
+        assert int(c[U - 1]) == want_cnt[t] and int(c[0]) == want_cnt[t]    # reverse-cumulated: every read has U bases
 
 
 @pytest.mark.parametrize("bad_at", [0, 5000, 16 * 400 - 1, 16 * 400 + 3])
