@@ -67,6 +67,7 @@ struct SqKnobs {
     bool long_spans = true;
     int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
+    int long_block = 0;        /* SQ_LONG_BLOCK: k_span<LONG> walks the sorted reads in blocks of that many reads, all segments of a block before the next block (0: all reads' segment 0, then all reads' segment 1, ..) */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;
 };

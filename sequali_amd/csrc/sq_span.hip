@@ -853,17 +853,30 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<SpanSeg> segs;
     uint64_t spans = 0;
-    for (uint32_t j = 0; j < n_segs && counts[j]; j++) {
-        SpanSeg g{};
-        g.span0 = (uint32_t)spans;
-        g.nspans = (uint32_t)((counts[j] + SPAN_R - 1) / SPAN_R);
-        g.U = LSEG;
-        g.last_rows = (uint32_t)(counts[j] - (uint64_t)(g.nspans - 1) * SPAN_R);
-        g.first = 0;
-        g.pos_base = j * LSEG;
-        segs.push_back(g);
-        spans += g.nspans;
-        if (spans >= (1ull << 32)) return SQ_OK;
+    /* The order of the stretches.  Segment j of ALL reads, then segment j + 1 of all reads (one stretch per j): the
+       128-byte line that segments j and j + 1 of a read share (rows of 272 bytes start anywhere), and the 16 bases in
+       front of a segment, come from HBM twice -- half a GB of other rows has gone through the caches in between
+       (k_span<8,AD,LONG> fetched 33 GB for 19 GB of records, profiles/r3/pmc_all.txt).  SQ_LONG_BLOCK = B: the sorted
+       reads in blocks of B, all segments of a block before the next block -- a block's segment j + 1 follows its segment j
+       B / 16 spans later (B = 4096: 2 MB of rows), while the lines are still in the L2 / the 256 MB of MALL.  The rows are
+       sorted longest first, so the reads of a block that reach segment j are a prefix of the block: no new table, the
+       kernel is the same (SpanSeg::first).  More stretches (blocks x segments instead of segments): the workgroups'
+       shares go by cost as before. */
+    const uint64_t block = sq_knobs().long_block > 0 ? (uint64_t)std::max(sq_knobs().long_block, 256) / SPAN_R * SPAN_R : n;
+    for (uint64_t b0 = 0; b0 < n; b0 += block) {
+        for (uint32_t j = 0; j < n_segs && counts[j] > b0; j++) {
+            const uint64_t count = std::min<uint64_t>(block, counts[j] - b0);   /* reads of the block that are longer than 256 j */
+            SpanSeg g{};
+            g.span0 = (uint32_t)spans;
+            g.nspans = (uint32_t)((count + SPAN_R - 1) / SPAN_R);
+            g.U = LSEG;
+            g.last_rows = (uint32_t)(count - (uint64_t)(g.nspans - 1) * SPAN_R);
+            g.first = (uint32_t)b0;
+            g.pos_base = j * LSEG;
+            segs.push_back(g);
+            spans += g.nspans;
+            if (spans >= (1ull << 32)) return SQ_OK;
+        }
     }
     if (segs.empty()) return SQ_OK;
     SpanSeg *d_segs = (SpanSeg *)sq_scratch(ctx, 14, segs.size() * sizeof(SpanSeg));

@@ -771,7 +771,8 @@ def test_long_reads_in_segments(which):
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(adapters)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({}, {"SQ_LONG": "0"}):   # k_span<LONG> where the adapters allow it (<= 13 characters), k_seg
+    # k_span<LONG> where the adapters allow it (<= 13 characters); the same with the reads walked in blocks (all segments of 512 / 4096 reads before the next ones); k_seg
+    for env in ({}, {"SQ_LONG_BLOCK": "512"}, {"SQ_LONG_BLOCK": "4096"}, {"SQ_LONG": "0"}):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(adapters)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
@@ -863,7 +864,7 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}):   # k_span<LONG>; k_seg; stripes of k_pass
+    for env in ({}, {"SQ_LONG_BLOCK": "1024"}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}):   # k_span<LONG>; in blocks of 1024 reads; k_seg; stripes of k_pass
         dev = synth.device_array(synth.NANOPORE, first, n)
         gq, ga = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(dev), gq.flush()))
