@@ -476,6 +476,7 @@ int sq_adaptercounter_allreduce(sq_adaptercounter *a, void *comm);
 
 /* test hook: the header parse of k_span<PT> (csrc/sq_pair.hip) compiled for the host; `name` has 64 readable bytes */
 int64_t sq_test_tile_of_header(const uint8_t *name, uint32_t n);
+int64_t sq_test_tile_of_header_quad(const uint8_t *name, uint32_t n);   /* the parse shared by the four lanes of a quad, emulated */
 
 /* ---- synthetic FASTQ (bench / tests): counter-based, host == device bytes -- */
 #define SQ_SYNTH_ILLUMINA 0       /* 150 bp single end / R1          */

@@ -188,3 +188,11 @@ SQ_EXPORT int64_t sq_test_tile_of_header(const uint8_t *name, uint32_t n)
     if (tile == -2) tile = tile_id_of(name, n);
     return tile;
 }
+/* the same through the parse the four lanes of a quad share (quad_tile_id_host, sq_pass.h): what the kernel's DPP exchanges
+   compute, emulated lane by lane; the byte-by-byte parse where that one declines */
+SQ_EXPORT int64_t sq_test_tile_of_header_quad(const uint8_t *name, uint32_t n)
+{
+    long long tile = quad_tile_id_host(name, n);
+    if (tile == QUAD_TILE_SLOW) tile = tile_id_of(name, n);
+    return tile;
+}

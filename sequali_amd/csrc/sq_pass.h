@@ -332,6 +332,103 @@ __host__ __device__ inline long long tile_id_of_words(const uint64_t (&w)[NWORDS
 }
 
 
+
+/* ---- the same parse by the four lanes of a read's quad (k_span<PT>: lane c holds bytes 16 c .. 16 c + 15 of the header)
+ * tile_id_of_words runs on one lane in four with loops that diverge between rows; here every lane works on its own 16
+ * bytes and the quad exchanges five small values.  Pure per-lane functions (compiled for the host too and checked
+ * there, quad_tile_id_host below); the kernel does the exchanges by DPP.  Anything out of the ordinary -- fewer than five
+ * colons inside the first 64 bytes of a longer header, a tile field of more than 8 or of no digits -- is left to the
+ * caller's byte-by-byte parse (QUAD_TILE_SLOW). */
+constexpr long long QUAD_TILE_SLOW = -2;
+/* bit i set: byte i of the lane's 16 is a ':' and lies inside the name */
+__host__ __device__ inline uint32_t quad_colon_mask(const uint32_t (&w)[4], uint32_t c, uint32_t nlen)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t x = w[k] ^ 0x3A3A3A3Au;
+        const uint32_t z = ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u) ^ 0x80808080u;   /* bit 7 of the bytes that are ':' */
+        m |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);                                  /* bits 7, 15, 23, 31 -> 4 bits */
+    }
+    const uint32_t first = 16 * c, valid = nlen > first ? (nlen - first < 16 ? nlen - first : 16) : 0;
+    return m & ((1u << valid) - 1u);   /* valid <= 16: no shift by 32 */
+}
+/* position in the header of the k-th colon (k = 1 ..) if it lies in this lane's bytes (`before` colons lie in the lanes in
+   front, `m` is this lane's mask), else 0xFF */
+__host__ __device__ inline uint32_t quad_kth_colon(uint32_t m, uint32_t before, uint32_t k, uint32_t c)
+{
+    const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+    if (!(before < k && k <= before + cnt)) return 0xFFu;
+    uint32_t r = k - before;   /* 1 .. 5 */
+#pragma unroll
+    for (int i = 1; i < 5; i++)
+        if ((uint32_t)i < r) m &= m - 1;
+    return 16 * c + (uint32_t)__builtin_ctz(m);
+}
+/* this lane's share of the 8 bytes of the header from byte s0 on (bytes of other lanes: 0), little endian.  (Scalars, no
+   arrays: a local array that is indexed by anything but a literal lands in scratch memory on the device.) */
+__host__ __device__ inline uint64_t quad_window8(const uint32_t (&w)[4], uint32_t c, uint32_t s0)
+{
+    const int d = (int)s0 - (int)(16 * c);
+    const bool none = d >= 16 || d <= -8;
+    const uint32_t off = (uint32_t)(8 + (none ? 0 : d)), sh = off & 3;   /* the window starts `off` bytes into [8 zero bytes | the 16 | 8 zero bytes] */
+    const bool s4 = (off & 16) != 0, s2 = (off & 8) != 0, s1 = (off & 4) != 0;   /* its first dword: off >> 2 = 4 s4 + 2 s2 + s1 (<= 5) */
+    /* A = 0 0 w0 w1 w2 w3 0 0; B[k] = s4 ? A[k + 4] : A[k] (k < 6) */
+    const uint32_t b0 = s4 ? w[2] : 0u, b1 = s4 ? w[3] : 0u, b2 = s4 ? 0u : w[0], b3 = s4 ? 0u : w[1], b4 = s4 ? 0u : w[2], b5 = s4 ? 0u : w[3];
+    /* C[k] = s2 ? B[k + 2] : B[k] (k < 4) */
+    const uint32_t c0 = s2 ? b2 : b0, c1 = s2 ? b3 : b1, c2 = s2 ? b4 : b2, c3 = s2 ? b5 : b3;
+    /* D[k] = s1 ? C[k + 1] : C[k] (k < 3) */
+    const uint32_t d0 = s1 ? c1 : c0, d1 = s1 ? c2 : c1, d2 = s1 ? c3 : c2;
+    const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> (8 * sh), hi = (((uint64_t)d2 << 32) | d1) >> (8 * sh);
+    const uint64_t v = (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+    return none ? 0 : v;
+}
+/* unsigned_decimal_integer_from_string (:159-180) of the first `len` (1 .. 8) bytes of d8; -1 for a byte that is no digit */
+__host__ __device__ inline long long quad_digits_value(uint64_t d8, uint32_t len)
+{
+    uint32_t v = 0;
+    bool bad = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t dgt = (uint32_t)((d8 >> (8 * i)) & 0xFF) - '0';
+        if (i < len) {
+            bad |= dgt > 9;
+            v = v * 10 + dgt;
+        }
+    }
+    return bad ? -1 : (long long)v;
+}
+/* what the quad makes of it once the exchanges are done: c4 / c5 = positions of the 4th / 5th colon (0xFF: none inside the
+   bytes looked at), nlen = the name's length, d8 = the 8 bytes behind the 4th colon */
+__host__ __device__ inline long long quad_tile_value(uint32_t c4, uint32_t c5, uint32_t nlen, uint64_t d8)
+{
+    if (c5 == 0xFFu) return nlen > 64 ? QUAD_TILE_SLOW : -1;   /* fewer than five colons (:3116-3120) -- as far as the 64 bytes show */
+    const uint32_t len = c5 - c4 - 1;
+    if (len < 1 || len > 18) return -1;                         /* :164-166 */
+    if (len > 8) return QUAD_TILE_SLOW;
+    return quad_digits_value(d8, len);
+}
+/* the whole parse on the host, lane by lane and exchange by exchange as the kernel does it (tests) */
+inline long long quad_tile_id_host(const uint8_t *name64, uint32_t nlen)
+{
+    uint32_t w[4][4], m[4], before[4], c4 = 0xFFu, c5 = 0xFFu;
+    for (uint32_t c = 0; c < 4; c++) {
+        memcpy(w[c], name64 + 16 * c, 16);
+        m[c] = quad_colon_mask(w[c], c, nlen);
+    }
+    for (uint32_t c = 0; c < 4; c++) {
+        before[c] = 0;
+        for (uint32_t j = 0; j < c; j++) before[c] += (uint32_t)__builtin_popcount(m[j]);
+    }
+    for (uint32_t c = 0; c < 4; c++) {
+        c4 = std::min(c4, quad_kth_colon(m[c], before[c], 4, c));
+        c5 = std::min(c5, quad_kth_colon(m[c], before[c], 5, c));
+    }
+    uint64_t d8 = 0;
+    for (uint32_t c = 0; c < 4; c++) d8 |= quad_window8(w[c], c, c4 == 0xFFu ? 0 : c4 + 1);
+    return quad_tile_value(c4, c5, nlen, d8);
+}
+
 } // namespace
 
 #endif

@@ -487,8 +487,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         const uint32_t roff = lds_addr(l_rows) + (SPLIT ? 4 * rl : 0);
         uint32_t pk[ND];
         int32_t rr[ND];
+        int lane_i = lane;   /* PT: opaque, so that the address of the lane's table entries is made here and not kept across the spans */
+        if constexpr (PT) asm volatile("" : "+v"(lane_i));
 #pragma unroll
-        for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane];
+        for (int k = 0; k < (int)ND; k++) pk[k] = l_dma[64 * k + lane_i];
 #pragma unroll
         for (int k = 0; k < (int)ND; k++) rr[k] = (int32_t)lds_u32(roff + (pk[k] & 0xFFu));
 #pragma unroll
@@ -505,9 +507,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     for (int w = 0; w < NW; w++) cnt[w] = 0;
     uint32_t since_flush = 0;
     auto flush_counts = [&]() {
+        uint32_t plv = pl;   /* PT: opaque -- the positions 32 w + pl are made here, not kept in NW registers across the spans */
+        if constexpr (PT) asm volatile("" : "+v"(plv));
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            const uint32_t p = 32 * w + pl;
+            const uint32_t p = 32 * w + plv;
             if (p < U) {
 #pragma unroll
                 for (uint32_t f = 0; f < 5; f++) {
@@ -524,8 +528,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
        fill: SEG: filler rows the workgroup counted in this stretch (their qualities sit in row 12
        of every position; what else is there are real 0x80 bytes, bin 11 like every invalid byte) */
     auto merge_hist = [&](bool zero, uint32_t fill) {
+        int tid_m = tid;   /* PT builds make the thread's index again here instead of keeping it across the loop (their registers are gone) */
+        if constexpr (PT) { tid_m = (int)threadIdx.x; asm volatile("" : "+v"(tid_m)); }
         if (AD)
-            for (uint32_t i = tid; i < P.ad_lds * hs; i += T) {
+            for (uint32_t i = tid_m; i < P.ad_lds * hs; i += T) {
                 const uint32_t v = l_adf[i];
                 if (!v) continue;
                 if (zero) l_adf[i] = 0;
@@ -539,14 +545,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             t_base = (unsigned long long *)par(PAR_QC_BASE); t_phred = (unsigned long long *)par(PAR_QC_PHRED);
             t_ea_base = (unsigned long long *)par(PAR_QC_EA_BASE); t_ea_phred = (unsigned long long *)par(PAR_QC_EA_PHRED);
         }
-        for (uint32_t i = tid; i < hs * BASE_COLS; i += T) {
+        for (uint32_t i = tid_m; i < hs * BASE_COLS; i += T) {
             const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
             if (zero) l_hist_base[i] = 0;
             if (!v || pos >= U) continue;
             atomicAdd(&t_base[(uint64_t)(pos_base + pos) * 5 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&t_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
-        for (uint32_t i = tid; i < hs * PROWS; i += T) {
+        for (uint32_t i = tid_m; i < hs * PROWS; i += T) {
             uint32_t v = l_hist_phred[i], cc = i / hs;
             const uint32_t pos = i % hs;
             if (zero) l_hist_phred[i] = 0;
@@ -637,22 +643,32 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             __builtin_amdgcn_sched_barrier(0);   /* done before the next block starts: the builds of 168 registers have none to spare for an overlap */
         }
         /* PT: the tile of every row (lanes c == 0), illumina_header_to_tile_id :3088-3121 */
+#ifdef SQ_SPAN_MARK
+        asm volatile("; PT_PARSE_BEGIN" ::: "memory");
+#endif
         uint32_t t0lo = 0, t0hi = 0;   /* wave-uniform: the tile of row 0 */
         bool one_tile = false;         /* every row has it */
         if constexpr (PT) {
-            uint64_t w8[8];   /* the first 64 bytes of the header, little endian: lane c holds bytes 16 c .. 16 c + 15 */
-            w8[0] = name_cur.x | (uint64_t)name_cur.y << 32;
-            w8[1] = name_cur.z | (uint64_t)name_cur.w << 32;
-            w8[2] = quad_bcast<0x55>(name_cur.x) | (uint64_t)quad_bcast<0x55>(name_cur.y) << 32;
-            w8[3] = quad_bcast<0x55>(name_cur.z) | (uint64_t)quad_bcast<0x55>(name_cur.w) << 32;
-            w8[4] = quad_bcast<0xAA>(name_cur.x) | (uint64_t)quad_bcast<0xAA>(name_cur.y) << 32;
-            w8[5] = quad_bcast<0xAA>(name_cur.z) | (uint64_t)quad_bcast<0xAA>(name_cur.w) << 32;
-            w8[6] = quad_bcast<0xFF>(name_cur.x) | (uint64_t)quad_bcast<0xFF>(name_cur.y) << 32;
-            w8[7] = quad_bcast<0xFF>(name_cur.z) | (uint64_t)quad_bcast<0xFF>(name_cur.w) << 32;
+            /* every lane of the quad on its own 16 bytes, five small values exchanged by DPP (sq_pass.h: quad_*; the same
+               functions run on the host under tests/test_boundary_cpu.py).  What they decline -- a header of more than 64
+               bytes whose fifth colon lies behind byte 64, a tile of 9 .. 18 digits -- lane 0 parses byte by byte. */
+            const uint32_t wv[4] = {name_cur.x, name_cur.y, name_cur.z, name_cur.w};
+            const uint32_t m16 = quad_colon_mask(wv, c, nlen_cur);
+            const uint32_t cnt16 = (uint32_t)__builtin_popcount(m16);
+            const uint32_t k0 = quad_bcast<0x00>(cnt16), k1 = quad_bcast<0x55>(cnt16), k2 = quad_bcast<0xAA>(cnt16);
+            const uint32_t before = (c > 0 ? k0 : 0u) + (c > 1 ? k1 : 0u) + (c > 2 ? k2 : 0u);
+            uint32_t p4 = quad_kth_colon(m16, before, 4, c), p5 = quad_kth_colon(m16, before, 5, c);
+            p4 = min(p4, quad_bcast<0xB1>(p4)); p4 = min(p4, quad_bcast<0x4E>(p4));   /* the quad's minimum: quad_perm [1,0,3,2], [2,3,0,1] */
+            p5 = min(p5, quad_bcast<0xB1>(p5)); p5 = min(p5, quad_bcast<0x4E>(p5));
+            const unsigned long long part = quad_window8(wv, c, p4 == 0xFFu ? 0u : p4 + 1);
+            uint32_t d_lo = (uint32_t)part, d_hi = (uint32_t)(part >> 32);
+            d_lo |= quad_bcast<0xB1>(d_lo); d_lo |= quad_bcast<0x4E>(d_lo);
+            d_hi |= quad_bcast<0xB1>(d_hi); d_hi |= quad_bcast<0x4E>(d_hi);
+            const long long quad_tile = quad_tile_value(p4, p5, nlen_cur, ((unsigned long long)d_hi << 32) | d_lo);
             uint32_t tile_lo = 0, tile_hi = 0;
             if (c == 0) {
-                long long tile = nlen_cur <= 64 ? tile_id_of_words<8>(w8, nlen_cur) : -2;
-                if (tile == -2) tile = tile_id_of(P.buf + P.metas[r].record_start, nlen_cur);   /* a long header, a tile of 9 .. 18 digits */
+                long long tile = quad_tile;
+                if (tile == QUAD_TILE_SLOW) tile = tile_id_of(P.buf + P.metas[r].record_start, nlen_cur);
                 tile_lo = (uint32_t)tile;
                 tile_hi = (uint32_t)((unsigned long long)tile >> 32);
                 /* the rows' tiles wait in l_rows (free between two calls of issue()) for the span a tile ends in */
@@ -669,6 +685,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             t0hi = __builtin_amdgcn_readfirstlane(tile_hi);
             one_tile = __builtin_amdgcn_ballot_w64(c == 0 && (tile_lo != t0lo || tile_hi != t0hi)) == 0 && (int32_t)t0hi >= 0;
             __builtin_amdgcn_sched_barrier(0);   /* the parse is over before the class pass asks for its registers */
+#ifdef SQ_SPAN_MARK
+            asm volatile("; PT_PARSE_END" ::: "memory");
+#endif
         }
         /* ---------------- phase S: four lanes per read ----------------
            (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
@@ -1319,9 +1338,11 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         __syncthreads();
         merge_hist(false, 0);
     }
-    for (uint32_t i = tid; i < 101; i += T)
+    int tid_end = tid;
+    if constexpr (PT) { tid_end = (int)threadIdx.x; asm volatile("" : "+v"(tid_end)); }
+    for (uint32_t i = tid_end; i < 101; i += T)
         if (l_gc[i]) atomicAdd(&(PAIR == 2 ? (unsigned long long *)par(PAR_QC_GC) : P.qc_gc)[i], (unsigned long long)l_gc[i]);
-    for (uint32_t i = tid; i < 94; i += T)
+    for (uint32_t i = tid_end; i < 94; i += T)
         if (l_ps[i]) atomicAdd(&(PAIR == 2 ? (unsigned long long *)par(PAR_QC_PS) : P.qc_ps)[i], (unsigned long long)l_ps[i]);
 }
 

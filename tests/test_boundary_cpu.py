@@ -503,5 +503,7 @@ def test_header_parse_of_the_paired_pass_on_the_host():
             buf = (name + fill * 72)[:max(len(name), 64) + 8]
             got = L.sq_test_tile_of_header(C.c_char_p(buf), len(name))
             assert got == _reference_tile_id(name), (name, fill, got)
+            got = L.sq_test_tile_of_header_quad(C.c_char_p(buf), len(name))     # the parse the four lanes of a quad share
+            assert got == _reference_tile_id(name), ("quad", name, fill, got)
             checked += 1
     assert checked > 2000
