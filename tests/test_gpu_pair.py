@@ -366,3 +366,41 @@ def test_paired_pass_on_device_batches_by_tile():
     _compare_pertile(got[1], ref[1])
     _compare_pertile(got[3], ref[3])
     _compare_insert_sizes(got[4], ref[4])
+
+
+def test_paired_pass_through_the_parsers_at_the_default_buffer_size():
+    """the reference's call pattern (__main__.py:279-306): two FastqParsers at 128 KiB, read 2 by read(len(array 1)), one
+    PairedPass call per pair of arrays (a few hundred reads each).  The arrays are staged by the parsers' blocks and counted
+    a block at a time; the results are those of the oracle on the whole files"""
+    import io
+    from sequali_amd import FastqParser, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics, synth
+    from tests.helpers import split_fastq
+    n = 120_000
+    t1, t2 = synth.host_records(synth.ILLUMINA_BY_TILE, 65536 - 40_000, n)[0], synth.host_records(synth.ILLUMINA_R2_BY_TILE, 65536 - 40_000, n)[0]
+    (b1, m1), (b2, m2) = split_fastq(t1), split_fastq(t2)
+    ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics())
+    ref[0].add(b1, m1); ref[1].add(b1, m1); ref[2].add(b2, m2); ref[3].add(b2, m2); ref[4].add_pair(b1, m1, b2, m2)
+    for env in (RIDE, {}):
+        got = (QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics())
+
+        def run():
+            pp = PairedPass(*got)
+            r1, r2 = FastqParser(io.BytesIO(t1)), FastqParser(io.BytesIO(t2))
+            arrays = 0
+            for a1 in r1:
+                a2 = r2.read(len(a1))
+                assert a1.is_mate(a2)
+                pp.add_record_array_pair(a1, a2)
+                arrays += 1
+            assert arrays > 100
+            got[0].flush(); got[2].flush(); got[4].insert_sizes()
+        with_env(env, run)
+        for g, r in ((got[0], ref[0]), (got[2], ref[2])):
+            assert g.number_of_reads == r.number_of_reads == n
+            np.testing.assert_array_equal(u64(g.base_count_table()), r.base_count_table())
+            np.testing.assert_array_equal(u64(g.phred_count_table()), r.phred_count_table())
+            np.testing.assert_array_equal(u64(g.gc_content()), r.gc_content())
+            np.testing.assert_array_equal(u64(g.phred_scores()), r.phred_scores())
+        _compare_pertile(got[1], ref[1])
+        _compare_pertile(got[3], ref[3])
+        _compare_insert_sizes(got[4], ref[4])
