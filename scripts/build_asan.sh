@@ -10,7 +10,7 @@ OUT=build/asan
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -munsafe-fp-atomics -Wno-option-ignored -O1 -g -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wno-unused-function"
 pids=()
-for f in sq_api sq_qc sq_span sq_pair sq_ends sq_nano sq_feed sq_dist; do
+for f in sq_api sq_qc sq_span sq_span_w6 sq_pair sq_ends sq_nano sq_feed sq_dist; do
   /opt/rocm/bin/hipcc $FLAGS -c csrc/$f.hip -o $OUT/$f.o &
   pids+=($!)
 done

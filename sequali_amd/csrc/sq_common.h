@@ -54,6 +54,7 @@ void sq_set_error(const char *fmt, ...);
 struct SqKnobs {
     bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span_w6 = false;      /* SQ_SPAN_W6: adapters of 14 .. 25 characters through k_span (sq_span_w6.hip) instead of k_wide; opt-in until checked on a GPU */
     bool span_split_qc = false;   /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream too */
     bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
     bool span_sorted_split = false;   /* SQ_SPAN_SORTED_SPLIT: the length-sorted route with a wave per stream */

@@ -92,6 +92,10 @@ int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, const uint32_t *len_hist, uint64_t *done);
 int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len);
+/* sq_span_w6.hip: the builds of k_span for adapters of 14 .. 25 characters (the automaton restarted six dwords in front of a quarter) */
+bool sq_span_w6_exists(int nw, bool seg, bool split);
+bool sq_span_w6_spills(int nw, bool seg, bool split);
+int sq_span_launch_w6(int nw, bool seg, bool split, sq_ctx *ctx, const PassParams &P, uint32_t n_ad, int waves, size_t lds, int grid);
 /* sq_pair.hip: QCMetrics' pass with PerTileQuality riding along (k_span<PT>), and what folds its staged runs into the tables */
 struct PtRun;
 int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, int pair, uint64_t *done);   /* pair: 0, 1 (read 2: writes the ends), 2 (read 1: the overlap scan) */

@@ -145,12 +145,19 @@ bool span_build_spills_any(int nw, bool ad)
 #endif
 }
 
+static bool span_needs_w6(const PassParams &P, bool ad) { return ad && (P.ad_maxlen + 2) / 4 > SPAN_W4; }
+
 /* does k_span take this pass at all, and with how many waves per workgroup (split: an even number) */
 int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, bool seg, bool split)
 {
     if (nw < 1 || nw > SPAN_NW_MAX || (ad && nw > (split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD))) return 0; /* unsplit: the automaton's rounds spill registers from 161 positions on */
-    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64 || (P.ad_maxlen + 2) / 4 > SPAN_W4)) return 0; /* W4T dwords hold >= maxlen - 1 positions */
-    if (!sq_knobs().span_spills_ok &&
+    if (ad && (SPAN_STATES(P) > SPAN_DFA_MAX_STATES || n_ad > 64)) return 0;
+    /* the restart in front of a lane's quarter holds >= maxlen - 1 positions: three dwords (adapters of up to 13
+       characters) in the builds of this file, six (up to 25) in those of sq_span_w6.hip */
+    if (span_needs_w6(P, ad)) {
+        if (!sq_knobs().span_w6 || (P.ad_maxlen + 2) / 4 > 6 || !sq_span_w6_exists(nw, seg, split)) return 0;
+        if (!sq_knobs().span_spills_ok && sq_span_w6_spills(nw, seg, split)) return 0;
+    } else if (!sq_knobs().span_spills_ok &&
         (seg ? (split ? span_build_spills_any<true, true>(nw, ad) : span_build_spills_any<true, false>(nw, ad))
              : (split ? span_build_spills_any<false, true>(nw, ad) : span_build_spills_any<false, false>(nw, ad)))) return 0;
     const int step = split ? 2 : 1;
@@ -947,7 +954,8 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint64_t nspans = C.n / SPAN_R;
     const int seqs = split ? waves / 2 : waves;   /* sequences of spans per workgroup */
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((nspans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
-    int rc = split ? launch_any<false, true>(nw, ctx, C, ad, n_ad, waves, lds, grid) : launch_any<false, false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
+    int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(nw, false, split, ctx, C, n_ad, waves, lds, grid)
+                                  : split ? launch_any<false, true>(nw, ctx, C, ad, n_ad, waves, lds, grid) : launch_any<false, false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
     span_print_stamps(ctx, nw);
     *done = C.n;
@@ -1064,7 +1072,8 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
         const int seqs = split ? l.waves / 2 : l.waves;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
-        int rc = split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
+        int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(l.nw, true, split, ctx, C, n_ad, l.waves, lds, grid)
+                                      : split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
         if (rc) return rc;
         span_print_stamps(ctx, l.nw);
         seg_off += l.segs.size();

@@ -263,3 +263,71 @@ def test_few_very_long_reads_with_more_than_64_adapters():
     assert "k_span<8,AD,long>" in r, r
     compare_qc(rq, gq, metas, arr)
     assert _compare_adapters(ga, ra) > n
+
+
+A25, A20, A14 = "ACGGTCATTGCACTTAGGCATCGAT", "TGACCGTTAGCAGGATCCTA", "GTTACCAGTCAGGA"
+
+
+@pytest.mark.parametrize("U", [150, 97, 200, 224])
+@pytest.mark.parametrize("route", ["uniform", "sorted", "unsplit"])
+def test_adapters_of_14_to_25_characters_on_every_quarter_seam(U, route):
+    """adapters of 25, 20 and 14 characters (AdapterCounter takes up to 64, _qcmodule.c:2549-2591) through the builds of
+    k_span whose automaton is restarted six dwords in front of a lane's quarter (csrc/sq_span_w6.hip, SQ_SPAN_W6=1):
+    planted so that they end on the first base, the last base and next to both seams of every quarter, and start up to
+    24 positions inside the quarter in front; a second plant elsewhere in a third of the reads.  Without the switch the
+    same batch takes k_wide (the cross-check)."""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    from tests.test_gpu_vs_oracle import _route_of
+    rng = np.random.default_rng(77 * U)
+    qs = _quarter(U)
+    ends = sorted({e for c in range(5) for e in (qs * c - 2, qs * c - 1, qs * c, qs * c + 1, qs * c + 11, qs * c + 23, qs * c + qs - 1) if 0 <= e < U} | {U - 1, 24, 13})
+    probes = [A25, A20, A14]
+    names, seqs, quals = [], [], []
+
+    def add(s):
+        names.append(f"r{len(names)}")
+        seqs.append(s)
+        quals.append((rng.integers(0, 94, size=len(s)) + 33).astype(np.uint8).tobytes().decode())
+
+    for rep in range(3):
+        for ad in probes:
+            for e in ends:
+                if e < len(ad) - 1:
+                    continue
+                s = rng.choice(LETTERS, size=U).tobytes().decode()
+                at = e - len(ad) + 1
+                s = s[:at] + ad + s[at + len(ad):]
+                if rep == 2:
+                    other = probes[(probes.index(ad) + 1) % 3]
+                    at2 = int(rng.integers(0, U - len(other) + 1))
+                    if at2 + len(other) <= at or at2 >= at + len(ad):
+                        s = s[:at2] + other + s[at2 + len(other):]
+                add(s)
+    while len(names) % 16 or len(names) < 256:
+        add(rng.choice(LETTERS, size=U).tobytes().decode())
+    if route == "sorted":
+        for L in (U - 1, U - 7, max(70, U // 2), 70, 65):
+            for _ in range(5):
+                s = rng.choice(LETTERS, size=L).tobytes().decode()
+                add(s[:L - 25] + A25)
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    nw = (U + 31) // 32
+    for w6 in (True, False):
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(), AdapterCounter(probes)
+        env = {"uniform": {}, "sorted": {"SQ_SPAN_SORTED": "1"}, "unsplit": {"SQ_SPAN_SPLIT": "0"}}[route]
+        env = dict(env, **({"SQ_SPAN_W6": "1"} if w6 else {}))
+        r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush())))
+        if w6 and route == "uniform":
+            assert r.split("+")[0] == f"k_span<{nw},AD,uniform,split,w6>", r
+        elif w6 and route == "sorted":
+            assert any(p.startswith(f"k_span<{nw},AD,sorted,") and p.endswith(",w6>") for p in r.split("+")), r
+        elif w6 and nw <= 5:
+            assert r.split("+")[0] == f"k_span<{nw},AD,uniform,both,w6>", r
+        elif not w6:
+            assert "w6" not in r and "k_span<" not in r.split("+")[0], r     # k_wide / k_pass as before
+        compare_qc(rq, gq, metas, arr)
+        assert _compare_adapters(ga, ra) >= 3 * len(ends)
