@@ -416,6 +416,21 @@ int sq_dedup_resolve(sq_dedup *d);
 uint64_t sq_dedup_state_bytes(sq_dedup *d);
 int sq_dedup_export_state(sq_dedup *d, void *out, size_t cap);
 int sq_dedup_import_state(sq_dedup *d, const void *in, size_t len);
+/* The same estimator by gathering instead of relaying (sq_ends.hip "by gathering" has the argument): every shard
+ * settles (the hashes of short pairs at its start finished with the store of the shards in front; lower_bound = the
+ * least b with at most max_stored distinct resident hashes of b trailing zero bits, counted on the device), hands the
+ * head its hashes that pass a mask of B bits (B = the largest lower bound of the shards in front of it, read order,
+ * HOST array) and drops its stream; the head resolves its own shard and feeds the others' hashes in shard order.
+ * sq_dedup_feed_hashes answers SQ_DEDUP_FEED_TOO_STRICT, with nothing done, when the estimator has fewer than
+ * filtered_bits bits (hashes whose low bits are not spread): finish with the relay from that shard on. */
+#define SQ_DEDUP_FEED_TOO_STRICT 1
+uint64_t sq_dedup_lower_bound_of(const uint64_t *hist65, uint64_t max_stored);
+int64_t sq_dedup_shard_store(sq_dedup *d, int head, uint8_t *bytes, uint8_t *known, size_t cap); /* -> fingerprint length */
+int sq_dedup_shard_settle(sq_dedup *d, const uint8_t *store_in, size_t len, uint64_t *lower_bound);
+int64_t sq_dedup_shard_passing(sq_dedup *d, uint64_t bits, uint64_t *out, size_t cap);
+int sq_dedup_shard_drop(sq_dedup *d);
+int sq_dedup_feed_hashes(sq_dedup *d, const uint64_t *hashes, size_t n, uint64_t filtered_bits,
+                         const uint8_t *store_after, size_t store_len);
 
 /* InsertSizeMetrics adapter tables (first-come cap, :5583,5599): ranks count the pairs
  * of the whole job and the shard's tables (2^table_bits slots) never close.  Keys are

@@ -946,6 +946,22 @@ __global__ void k_dedup_gather(const unsigned long long *idx, uint64_t n_keep,
     }
 }
 
+/* sorted hashes -> how many DISTINCT ones have exactly c trailing zero bits (c = 64: the hash 0), hist[65] */
+__global__ void k_dedup_ctz_hist(const unsigned long long *sorted, uint64_t n, unsigned long long *hist)
+{
+    __shared__ unsigned int l_hist[65];
+    for (int i = threadIdx.x; i < 65; i += blockDim.x) l_hist[i] = 0;
+    __syncthreads();
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = sorted[i];
+        if (i != 0 && sorted[i - 1] == h) continue;
+        atomicAdd(&l_hist[h ? __builtin_ctzll(h) : 64], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 65; i += blockDim.x)
+        if (l_hist[i]) atomicAdd(&hist[i], (unsigned long long)l_hist[i]);
+}
+
 __global__ void k_iota(unsigned long long *p, uint64_t n)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
@@ -1414,6 +1430,10 @@ struct sq_dedup {
         std::vector<uint8_t> bytes, known;
     };
     std::vector<Unresolved> unresolved;
+    /* gather merge: the resident hashes that pass a mask of pass_bits bits, in read order */
+    std::vector<unsigned long long> pass;
+    uint64_t pass_bits = 0;
+    bool pass_valid = false;
 };
 
 SQ_EXPORT sq_dedup *sq_dedup_new(sq_ctx *ctx, int64_t max_stored_fingerprints, int64_t front_sequence_length,
@@ -1927,6 +1947,177 @@ SQ_EXPORT int sq_dedup_import_state(sq_dedup *d, const void *in, size_t len)
     if (!d->deferred || (d->stream_n == 0 && d->unresolved.empty() &&
                          std::find(d->store_known.begin(), d->store_known.end(), 1) == d->store_known.end()))
         d->store = d->store_in; /* nothing of this shard is pending: the store is the imported one */
+    return SQ_OK;
+}
+
+/* ---- DedupEstimator across shards, by gathering -------------------------------
+ *
+ * The relay above costs one insertion tail and one broadcast of the table (12 bytes a slot) PER SHARD, one after the
+ * other.  This merge lets every shard do its part at the same time and leaves one tail to the head (the first shard):
+ *
+ *   1. sq_dedup_shard_store      the store bytes the shard wrote, and which of them (a few bytes: gathered)
+ *   2. sq_dedup_shard_settle     with the store of the shards in front: the hashes of short pairs at the shard's start
+ *                                are finished, and the shard's LOWER BOUND is counted on the device: the least b such
+ *                                that at most max_stored DISTINCT hashes of the shard have b trailing zero bits
+ *   3. sq_dedup_shard_passing    the shard's hashes that pass a mask of B bits, in read order, where B is the largest
+ *                                lower bound of the shards in front (gathered to the head)
+ *   4. sq_dedup_feed_hashes      the head, after sq_dedup_resolve() of its own shard: those hashes through the
+ *                                insertion tail, shard after shard
+ *   5. sq_dedup_export_state / _import_state   the head's table to everyone, once
+ *
+ * Why that is the sequential estimator, bit for bit.  A hash that arrives when the estimator has b modulo bits and
+ * does not pass a mask of b bits changes nothing (:4433); the bits only grow; so leaving out of a shard's stream
+ * every hash that fails a mask of B bits changes nothing IF the estimator has at least B bits when the shard's first
+ * hash arrives.  After a stream that held the distinct hashes X the table holds every one of them that passes the
+ * mask in force (it passed every earlier, weaker mask, was inserted, and survives each rebuild), and the table holds
+ * at most max_stored entries -- so the bits in force are at least the shard's lower bound, whatever came before or
+ * between.  "At most max_stored" has one way out (:4436-4451 rebuilds once per arriving hash: if a rebuild drops
+ * nothing the insert behind it overfills the table), which takes hashes whose low bits are not spread at all; the
+ * feed therefore CHECKS the premise (the head's bits against the mask the hashes were filtered with) and answers
+ * SQ_DEDUP_FEED_TOO_STRICT without touching the estimator if it does not hold: the caller finishes with the relay
+ * from that shard on (dist.merge_dedup does), and the result is exact either way.
+ */
+/* hist[c] = distinct hashes with exactly c trailing zero bits (c = 64: the hash 0) -> the least b such that at most
+ * max_stored of them have b trailing zero bits or more; no device, no object: the host half of the settle step */
+SQ_EXPORT uint64_t sq_dedup_lower_bound_of(const uint64_t *hist65, uint64_t max_stored)
+{
+    uint64_t at_least[66];
+    at_least[65] = 0;
+    for (int c = 64; c >= 0; c--) at_least[c] = at_least[c + 1] + hist65[c];
+    uint64_t b = 0;
+    while (b < 63 && at_least[b] > max_stored) b++;
+    return b;
+}
+
+/* head != 0 (the job's first shard): the bytes the shard did not write are those the estimator held when deferred
+ * mode began, so all of them are known */
+SQ_EXPORT int64_t sq_dedup_shard_store(sq_dedup *d, int head, uint8_t *bytes, uint8_t *known, size_t cap)
+{
+    const uint64_t fp_len = d->front_len + d->back_len;
+    if (!d->deferred) { sq_set_error("sq_dedup_shard_store: the estimator is not in deferred mode"); return SQ_ERR_VALUE; }
+    if (bytes && known) {
+        if (cap < fp_len) { sq_set_error("sq_dedup_shard_store: destination too small"); return SQ_ERR_VALUE; }
+        for (uint64_t i = 0; i < fp_len; i++) {
+            const bool k = d->store_known[i] != 0;
+            bytes[i] = k || !head ? d->store[i] : d->store_in[i];
+            known[i] = k || head;
+        }
+    }
+    return (int64_t)fp_len;
+}
+
+SQ_EXPORT int sq_dedup_shard_settle(sq_dedup *d, const uint8_t *store_in, size_t len, uint64_t *lower_bound)
+{
+    sq_ctx *ctx = d->ctx;
+    const uint64_t fp_len = d->front_len + d->back_len;
+    if (!d->deferred) { sq_set_error("sq_dedup_shard_settle: the estimator is not in deferred mode"); return SQ_ERR_VALUE; }
+    if (store_in) {
+        if (len != fp_len) { sq_set_error("sq_dedup_shard_settle: a store of %zu bytes, the estimator's has %llu", len, (unsigned long long)fp_len); return SQ_ERR_VALUE; }
+        d->store_in.assign(store_in, store_in + fp_len);
+    }
+    for (auto &u : d->unresolved) {
+        for (uint64_t i = 0; i < fp_len; i++)
+            if (!u.known[i]) u.bytes[i] = d->store_in[i];
+        const uint8_t *sp = u.bytes.data();
+        const unsigned long long h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, u.seed);
+        SQ_HIP(hipMemcpy(d->d_stream + u.pos, &h, 8, hipMemcpyHostToDevice));
+    }
+    d->unresolved.clear();
+    for (uint64_t i = 0; i < fp_len; i++)
+        if (!d->store_known[i]) d->store[i] = d->store_in[i];
+    d->store_known.assign(fp_len, 1); /* the store is final: a later import or resolve leaves it alone */
+    d->pass_valid = false;
+    if (!lower_bound) return SQ_OK;
+    *lower_bound = 0;
+    const uint64_t n = d->stream_n;
+    if (n <= d->max_stored) return SQ_OK; /* not even all of them distinct could make a rebuild certain */
+    if (n > 0x7fffffffull) { sq_set_error("sq_dedup_shard_settle: %llu resident hashes (the sort takes 2^31-1)", (unsigned long long)n); return SQ_ERR_VALUE; }
+    unsigned long long *d_sorted = (unsigned long long *)sq_scratch(ctx, 29, n * 8);
+    unsigned long long *d_hist = (unsigned long long *)sq_scratch(ctx, 31, 65 * 8);
+    if (!d_sorted || !d_hist) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    size_t temp_bytes = 0;
+    SQ_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d->d_stream, d_sorted, (int)n, 0, 64, ctx->stream));
+    void *d_temp = sq_scratch(ctx, 30, temp_bytes ? temp_bytes : 8);
+    if (!d_temp) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d->d_stream, d_sorted, (int)n, 0, 64, ctx->stream));
+    SQ_HIP(hipMemsetAsync(d_hist, 0, 65 * 8, ctx->stream));
+    hipLaunchKernelGGL(k_dedup_ctz_hist, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_sorted, n, d_hist);
+    SQ_HIP(hipGetLastError());
+    unsigned long long hist[65];
+    SQ_HIP(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    *lower_bound = sq_dedup_lower_bound_of((const uint64_t *)hist, d->max_stored);
+    return SQ_OK;
+}
+
+/* the count, and with `out` the hashes themselves (as many as fit in cap) */
+SQ_EXPORT int64_t sq_dedup_shard_passing(sq_dedup *d, uint64_t bits, uint64_t *out, size_t cap)
+{
+    sq_ctx *ctx = d->ctx;
+    if (!d->deferred) { sq_set_error("sq_dedup_shard_passing: the estimator is not in deferred mode"); return SQ_ERR_VALUE; }
+    if (!d->unresolved.empty()) { sq_set_error("sq_dedup_shard_passing: sq_dedup_shard_settle first"); return SQ_ERR_VALUE; }
+    if (bits > 63) { sq_set_error("sq_dedup_shard_passing: a mask of %llu bits", (unsigned long long)bits); return SQ_ERR_VALUE; }
+    if (!d->pass_valid || d->pass_bits != bits) {
+        d->pass.clear();
+        const uint64_t chunk = 1ull << 23;
+        for (uint64_t off = 0; off < d->stream_n; off += chunk) {
+            const uint64_t n = std::min(chunk, d->stream_n - off);
+            const unsigned long long *d_hashes = d->d_stream + off;
+            unsigned long long *d_idx = nullptr;
+            uint64_t n_keep = 0;
+            int rc = ordered_select(ctx, n, DedupKeep{(1ULL << bits) - 1, d_hashes, nullptr}, &d_idx, &n_keep);
+            if (rc) return rc;
+            if (!n_keep) continue;
+            unsigned long long *d_kh = (unsigned long long *)sq_scratch(ctx, 10, n_keep * 8);
+            unsigned char *d_ks = (unsigned char *)sq_scratch(ctx, 11, n_keep);
+            if (!d_kh || !d_ks) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+            hipLaunchKernelGGL(k_dedup_gather, dim3(blocks_for(n_keep)), dim3(256), 0, ctx->stream, d_idx, n_keep, d_hashes,
+                               (const unsigned char *)nullptr, d_kh, d_ks);
+            const size_t at = d->pass.size();
+            d->pass.resize(at + n_keep);
+            SQ_HIP(hipMemcpyAsync(d->pass.data() + at, d_kh, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
+            SQ_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        d->pass_bits = bits;
+        d->pass_valid = true;
+    }
+    if (out) memcpy(out, d->pass.data(), std::min(cap, d->pass.size()) * 8);
+    return (int64_t)d->pass.size();
+}
+
+/* the shard's hashes went to the head: forget them (the table arrives with sq_dedup_import_state) */
+SQ_EXPORT int sq_dedup_shard_drop(sq_dedup *d)
+{
+    if (!d->unresolved.empty()) { sq_set_error("sq_dedup_shard_drop: sq_dedup_shard_settle first"); return SQ_ERR_VALUE; }
+    d->stream_n = 0;
+    d->pass.clear();
+    d->pass.shrink_to_fit();
+    d->pass_valid = false;
+    return SQ_OK;
+}
+
+/* the head: n hashes of one later shard (HOST array, read order, filtered with a mask of filtered_bits bits) through
+ * the insertion tail, then the store that shard leaves.  SQ_DEDUP_FEED_TOO_STRICT (1) and nothing done when the
+ * estimator has fewer bits than the filter assumed. */
+SQ_EXPORT int sq_dedup_feed_hashes(sq_dedup *d, const uint64_t *hashes, size_t n, uint64_t filtered_bits,
+                                   const uint8_t *store_after, size_t store_len)
+{
+    const uint64_t fp_len = d->front_len + d->back_len;
+    if (d->stream_n || !d->unresolved.empty()) { sq_set_error("sq_dedup_feed_hashes: resolve the pending hashes first"); return SQ_ERR_VALUE; }
+    if (store_after && store_len != fp_len) { sq_set_error("sq_dedup_feed_hashes: a store of %zu bytes, the estimator's has %llu", store_len, (unsigned long long)fp_len); return SQ_ERR_VALUE; }
+    if (d->modulo_bits < filtered_bits) return SQ_DEDUP_FEED_TOO_STRICT;
+    for (size_t e = 0; e < n; e++) {
+        if (e + 12 < n) {
+            const uint64_t slot = (hashes[e + 12] >> d->modulo_bits) & (d->table_size - 1);
+            __builtin_prefetch(&d->count[slot]);
+            __builtin_prefetch(&d->hash[slot]);
+        }
+        dedup_insert(d, hashes[e]);
+    }
+    if (store_after) {
+        d->store.assign(store_after, store_after + fp_len);
+        d->store_in = d->store;
+    }
     return SQ_OK;
 }
 

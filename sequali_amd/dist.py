@@ -224,35 +224,161 @@ def merge_overrepresented(shards: Sequence, device, group=None) -> None:
         o._warned = int(sums[3].item())
 
 
-def merge_dedup(shards: Sequence, device=None, group=None) -> None:
-    """DedupEstimator objects in deferred mode -> every one holds the job's estimator.
-    The fingerprints were hashed in parallel and are resident; the insertion tail
-    (_qcmodule.c:4426-4460) runs shard after shard, each continuing from the table, the
-    modulo bits and the fingerprint store of the one in front."""
-    from ._lib import check, lib
-    L = lib()
+def _dedup_export(L, d) -> bytes:
+    from ._lib import check
+    buf = (ctypes.c_uint8 * L.sq_dedup_state_bytes(d._h))()
+    check(L.sq_dedup_export_state(d._h, buf, len(buf)))
+    return bytes(buf)
 
-    def export(d) -> bytes:
-        buf = (ctypes.c_uint8 * L.sq_dedup_state_bytes(d._h))()
-        check(L.sq_dedup_export_state(d._h, buf, len(buf)))
-        return bytes(buf)
+
+def _shard_counts(n_local: int, device, group=None) -> List[int]:
+    """how many shards every rank holds, in rank order"""
+    if not _active(group):
+        return [n_local]
+    t = all_gather_ragged(torch.tensor([n_local], dtype=torch.int64, device=device), group)
+    return [int(x) for x in t.tolist()]
+
+
+def _dedup_relay(L, shards, base: int, counts: List[int], state, start: int, device, group=None):
+    """The insertion tail shard after shard, from the job's shard `start` on, beginning with
+    `state` (None: a fresh estimator); shards[i] is the job's shard base + i.  Returns the
+    state behind the last shard."""
+    from ._lib import check
 
     def run_local(state):
-        for d in shards:
+        for i, d in enumerate(shards):
+            if base + i < start:
+                continue
             if state is not None:
                 check(L.sq_dedup_import_state(d._h, state, len(state)))
             check(L.sq_dedup_resolve(d._h))
-            state = export(d)
+            state = _dedup_export(L, d)
         return state
 
-    if _active(group):
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        state = None
-        for r in range(world):
+    if not _active(group):
+        return run_local(state)
+    rank = dist.get_rank(group)
+    first = 0
+    for r, n in enumerate(counts):
+        if first + n > start:          # rank r holds a shard that is still to run
             mine = run_local(state) if rank == r else b""
             state = _broadcast_bytes(mine, r, device, group)
+        first += n
+    return state
+
+
+def dedup_store_chain(records: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """records[g] = (bytes, known) of the job's shard g, the head's all known ->
+    (store_in[g], store_after[g]): a shard starts from the store the one in front leaves,
+    and leaves its own bytes where it wrote and that store elsewhere (_qcmodule.c:4503-4516:
+    a pair writes the front of read 1 and the back of read 2 over the buffer, short reads
+    leave the rest)."""
+    n = len(records)
+    store_in = np.zeros((n, records.shape[2]), dtype=np.uint8)
+    after = np.zeros_like(store_in)
+    for g in range(n):
+        if g:
+            store_in[g] = after[g - 1]
+        known = records[g, 1].astype(bool)
+        after[g] = np.where(known, records[g, 0], store_in[g])
+    return store_in, after
+
+
+def _dedup_gather(L, shards, base: int, counts: List[int], device, group=None):
+    """sq_ends.hip "DedupEstimator across shards, by gathering": every shard counts its
+    lower bound and filters its hashes at the same time, the head (rank 0, the job's first
+    shard) runs one insertion tail.  Returns the job's state."""
+    from ._lib import check
+    total = sum(counts)
+    rank = dist.get_rank(group) if _active(group) else 0
+    fp_len = check(L.sq_dedup_shard_store(shards[0]._h, 0, None, None, 0))
+    # 1. the stores, and what every shard starts from
+    rec = np.zeros((len(shards), 2, fp_len), dtype=np.uint8)
+    for i, d in enumerate(shards):
+        check(L.sq_dedup_shard_store(d._h, int(base + i == 0), rec[i, 0].ctypes.data, rec[i, 1].ctypes.data, fp_len))
+    rec = all_gather_ragged(torch.from_numpy(rec.reshape(len(shards), 2 * fp_len)).to(device), group)
+    rec = np.ascontiguousarray(rec.cpu().numpy()).reshape(total, 2, fp_len)
+    store_in, store_after = dedup_store_chain(rec)
+    # 2. settle: short pairs at the shard's start, the lower bound
+    lb = np.zeros(len(shards), dtype=np.int64)
+    for i, d in enumerate(shards):
+        g = base + i
+        out = ctypes.c_uint64(0)
+        si = np.ascontiguousarray(store_in[g])
+        check(L.sq_dedup_shard_settle(d._h, si.ctypes.data if g else None, fp_len, ctypes.byref(out)))
+        lb[i] = out.value
+    lb = all_gather_ragged(torch.from_numpy(lb).to(device), group).cpu().numpy()
+    filtered = np.zeros(total, dtype=np.int64)      # filtered[g] = the largest bound in front of shard g
+    for g in range(1, total):
+        filtered[g] = max(filtered[g - 1], int(lb[g - 1]))
+    # 3. the hashes that can still matter, to the head
+    parts, sizes = [], []
+    for i, d in enumerate(shards):
+        g = base + i
+        if g == 0:
+            continue
+        n = check(L.sq_dedup_shard_passing(d._h, int(filtered[g]), None, 0))
+        h = np.zeros(max(n, 1), dtype=np.uint64)
+        if n:
+            check(L.sq_dedup_shard_passing(d._h, int(filtered[g]), h.ctypes.data, n))
+        parts.append(h[:n])
+        sizes.append(n)
+    mine = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+    sizes = all_gather_ragged(torch.tensor(sizes, dtype=torch.int64, device=device), group).cpu().numpy()
+    hashes = all_gather_ragged(torch.from_numpy(mine.view(np.int64)).to(device), group)
+    # 4. the head's tail: its own shard, then the others' survivors in shard order
+    stop = total
+    state = b""
+    if rank == 0:
+        hashes = np.ascontiguousarray(hashes.cpu().numpy()).view(np.uint64)
+        head = shards[0]
+        check(L.sq_dedup_resolve(head._h))
+        at = 0
+        for g in range(1, total):
+            n = int(sizes[g - 1])
+            part = np.ascontiguousarray(hashes[at:at + n])
+            after = np.ascontiguousarray(store_after[g])
+            rc = check(L.sq_dedup_feed_hashes(head._h, part.ctypes.data, n, int(filtered[g]), after.ctypes.data, fp_len))
+            if rc:          # SQ_DEDUP_FEED_TOO_STRICT: the relay takes it from here
+                stop = g
+                break
+            at += n
+        state = _dedup_export(L, head)
+    if _active(group):
+        t = _wire(torch.tensor([stop], dtype=torch.int64, device=device), group)
+        dist.broadcast(t, src=0, group=group)
+        stop = int(t.item())
+        state = _broadcast_bytes(state, 0, device, group)
+    for i, d in enumerate(shards):
+        if 0 < base + i < stop:
+            check(L.sq_dedup_shard_drop(d._h))
+    if stop < total:
+        state = _dedup_relay(L, shards, base, counts, state, stop, device, group)
+    return state
+
+
+def merge_dedup(shards: Sequence, device=None, group=None, method: str = None) -> None:
+    """DedupEstimator objects in deferred mode -> every one holds the job's estimator.
+    The fingerprints were hashed in parallel and are resident.  method "relay": the
+    insertion tail (_qcmodule.c:4426-4460) runs shard after shard, each continuing from the
+    table, the modulo bits and the fingerprint store of the one in front (one tail and one
+    broadcast of the table per shard, in sequence).  method "gather": every shard filters
+    its hashes with a mask it can prove the estimator has reached by then, the head runs one
+    tail over what is left (sq_ends.hip "by gathering"; falls back to the relay for the
+    rest when the proof's premise fails).  Default: $SQ_DEDUP_MERGE, else "relay"."""
+    import os
+    from ._lib import check, lib
+    L = lib()
+    method = method or os.environ.get("SQ_DEDUP_MERGE", "relay")
+    if method not in ("relay", "gather"):
+        raise ValueError(f"merge_dedup: method {method!r} (relay or gather)")
+    counts = _shard_counts(len(shards), device, group)
+    rank = dist.get_rank(group) if _active(group) else 0
+    base = sum(counts[:rank])
+    if method == "gather" and sum(counts) > 1:
+        state = _dedup_gather(L, shards, base, counts, device, group)
     else:
-        state = run_local(None)
+        state = _dedup_relay(L, shards, base, counts, None, 0, device, group)
     for d in shards:
         check(L.sq_dedup_set_deferred(d._h, 0))
         check(L.sq_dedup_import_state(d._h, state, len(state)))

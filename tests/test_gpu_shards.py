@@ -115,10 +115,13 @@ def test_overrepresented_shard_table_grows():
     assert shards[0].total_fragments == ref.total_fragments
 
 
+@pytest.mark.parametrize("method", ["relay", "gather"])
 @pytest.mark.parametrize("paired,max_len", [(False, 90), (True, 90), (True, 14)])
-def test_dedup_shards_equal_one_run(paired, max_len):
+def test_dedup_shards_equal_one_run(paired, max_len, method):
     """max_len 14: pairs shorter than the fingerprint, whose hashes show bytes of the pair
-    in front -- also across a shard boundary (:4512-4516)"""
+    in front -- also across a shard boundary (:4512-4516).  method "gather": every shard counts
+    its lower bound (sort + histogram on the device) and filters its hashes, the first shard
+    runs the one insertion tail (tests/test_dedup_gather_cpu.py has the host halves)"""
     from sequali_amd import DedupEstimator, dist
     kw = dict(max_stored_fingerprints=250, front_sequence_offset=4, back_sequence_offset=0)
     n = 12000
@@ -139,7 +142,7 @@ def test_dedup_shards_equal_one_run(paired, max_len):
             else:
                 d.add_record_array(sub_array(b1, m1, a, b))
         shards.append(d)
-    dist.merge_dedup(shards, DEV)
+    dist.merge_dedup(shards, DEV, method=method)
     assert ref._modulo_bits >= 3
     for d in shards:
         assert d._modulo_bits == ref._modulo_bits
@@ -209,7 +212,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, n, out_dir):
+def _rank_main(rank, world, port, n, out_dir, dedup_method="relay"):
     import torch.distributed as tdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SQ_DEVICE="0")
     tdist.init_process_group("gloo", rank=rank, world_size=world)
@@ -230,7 +233,7 @@ def _rank_main(rank, world, port, n, out_dir):
     p = PerTileQuality()
     p.add_record_array(a1)
     dist.merge_overrepresented([o], DEV)
-    dist.merge_dedup([d], DEV)
+    dist.merge_dedup([d], DEV, method=dedup_method)
     dist.merge_insertsize([z], DEV)
     dist.merge_pertile([p], [first], DEV)
     tiles = p.get_tile_counts()
@@ -248,14 +251,14 @@ def _rank_main(rank, world, port, n, out_dir):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_processes_merge_equals_one_run(tmp_path, world):
-    """world 4: the DedupEstimator relay and the candidate selection of OverrepresentedSequences /
+@pytest.mark.parametrize("world,dedup_method", [(2, "relay"), (4, "relay"), (4, "gather"), (3, "gather")])
+def test_processes_merge_equals_one_run(tmp_path, world, dedup_method):
+    """world 4: the DedupEstimator relay (or gather) and the candidate selection of OverrepresentedSequences /
     InsertSizeMetrics run over more than one hop (four processes on cuda:0, gloo)"""
     import torch.multiprocessing as mp
     from sequali_amd import synth
     n = 20000
-    mp.spawn(_rank_main, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), n, str(tmp_path), dedup_method), nprocs=world, join=True)
     b1, m1 = synth.host_records(synth.ILLUMINA, 0, n)
     b2, m2 = synth.host_records(synth.ILLUMINA_R2, 0, n)
     o = oracle.OverrepresentedSequences(max_unique_fragments=3000, sample_every=2)
