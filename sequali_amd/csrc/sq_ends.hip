@@ -1416,6 +1416,9 @@ struct sq_dedup {
     std::vector<unsigned long long> h_idx, h_hashes;
     std::vector<unsigned char> h_special, h_state;
     unsigned parallel_skip = 0; /* pieces that skip the parallel attempt after one was taken back */
+    /* the fingerprint store while a batch of pairs walks through the tail: short pairs come by in read order */
+    std::vector<uint8_t> run_store;
+    uint64_t run_prev = UINT64_MAX; /* the last short pair of this batch that went through */
     /* deferred mode (a shard of a multi-GPU job): add_* only hashes; the hashes
        stay in HBM until sq_dedup_resolve() runs the insertion tail over them, after the
        state of the shard in front has been imported */
@@ -1554,23 +1557,6 @@ int pair_store_bytes(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::v
     return SQ_OK;
 }
 
-/* contents of the reference's fingerprint store right after pair r of this batch */
-int store_after_pair(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::vector<uint8_t> &store)
-{
-    const uint64_t fp_len = d->front_len + d->back_len;
-    store = d->store; /* state carried in from earlier batches */
-    std::vector<bool> known(fp_len, false);
-    uint64_t unknown = fp_len;
-    for (uint64_t j = r + 1; j-- > 0 && unknown;) {
-        std::vector<uint8_t> w;
-        int rc = pair_store_bytes(d, b1, b2, j, w);
-        if (rc) return rc;
-        for (uint64_t i = 0; i < w.size(); i++)
-            if (!known[i]) { store[i] = w[i]; known[i] = true; unknown--; }
-    }
-    return SQ_OK;
-}
-
 /* the sequential part: hashes [0,n) on the device, in read order, through the
  * estimator.  Only hashes that pass the mask in force at the start can matter; the mask
  * only ever gets stricter (H3). */
@@ -1688,18 +1674,24 @@ int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned c
         const uint64_t r = r_base + idx[e];
         uint64_t h = hashes[e];
         if (special[e]) {
-            std::vector<uint8_t> store;
-            rc = store_after_pair(d, b1, b2, r, store);
-            if (rc) return rc;
-            sq_meta m1, m2;
-            if (!b1->h_metas.empty()) { m1 = b1->h_metas[r]; m2 = b2->h_metas[r]; }
-            else {
-                SQ_HIP(hipMemcpy(&m1, b1->d_metas + r, sizeof(sq_meta), hipMemcpyDeviceToHost));
-                SQ_HIP(hipMemcpy(&m2, b2->d_metas + r, sizeof(sq_meta), hipMemcpyDeviceToHost));
+            /* a pair shorter than the fingerprint: bytes of the store shine through (:4512-4516).  Every such pair
+               of the batch comes by here, in read order (the filter keeps them whatever the mask, the threads above
+               leave them alone), so the store is carried: a pair in front that did not come by is a long one and
+               rewrote all of it.  (Walking back from every short pair to the last long one is quadratic in a batch
+               of nothing but short pairs.) */
+            std::vector<uint8_t> w;
+            if (r != 0 && d->run_prev != r - 1) {
+                rc = pair_store_bytes(d, b1, b2, r - 1, w);
+                if (rc) return rc;
+                d->run_store = w;
             }
-            const uint8_t *sp = store.data();
-            h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len,
-                               ((uint64_t)m1.sequence_length + m2.sequence_length) >> 6);
+            uint64_t total = 0;
+            rc = pair_store_bytes(d, b1, b2, r, w, &total);
+            if (rc) return rc;
+            std::copy(w.begin(), w.end(), d->run_store.begin());
+            d->run_prev = r;
+            const uint8_t *sp = d->run_store.data();
+            h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, total >> 6);
         }
         dedup_insert(d, h);
     }
@@ -1792,17 +1784,17 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
            so that is the piece: a fresh estimator does not drag a whole batch through the host
            at mask 0, a settled one takes the batch in one piece */
         rc = SQ_OK;
+        d->run_store = d->store;
+        d->run_prev = UINT64_MAX;
         for (uint64_t off = 0; off < n && rc == SQ_OK;) {
             const uint64_t piece = std::min<uint64_t>(n - off, std::max<uint64_t>(d->max_stored, 1u << 16)
                                                                    << std::min<uint64_t>(d->modulo_bits, 20));
             rc = dedup_tail(d, d_hashes + off, d_special + off, piece, b1, b2, off);
             off += piece;
         }
-        if (rc == SQ_OK && b2) { /* carry the store into the next batch (usually one step: the
-                                    last pair rewrote all of it) */
-            std::vector<uint8_t> store;
-            rc = store_after_pair(d, b1, b2, n - 1, store);
-            if (rc == SQ_OK) d->store = store;
+        if (rc == SQ_OK && b2) { /* carry the store into the next batch: the last pair's if it was a long one */
+            if (d->run_prev == n - 1) d->store = d->run_store;
+            else rc = pair_store_bytes(d, b1, b2, n - 1, d->store);
         }
     }
     (void)hipStreamSynchronize(ctx->stream);

@@ -267,6 +267,29 @@ def test_dedup_pairs_with_short_reads_stale_bytes():
     np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
 
 
+@pytest.mark.timeout(120)
+def test_dedup_batches_of_nothing_but_short_pairs():
+    """6000 pairs of at most 5 bases (what scripts/fuzz.py 30 4 draws in its second iteration): no pair ever
+    rewrites the whole 16-byte store, so each fingerprint shows bytes of several pairs in front -- over batch
+    borders too.  The store is carried from short pair to short pair; walking back from each of them to the
+    last long pair, as the tail did until round 4, took minutes here."""
+    import time
+    from sequali_amd import DedupEstimator
+    rng = np.random.default_rng(53)
+    kw = dict(max_stored_fingerprints=100, front_sequence_offset=0, back_sequence_offset=0)
+    ref, got = oracle.DedupEstimator(**kw), DedupEstimator(**kw)
+    t0 = time.time()
+    for n, max_len in ((6000, 5), (3000, 9), (1, 3), (2000, 5)):      # 9: a long pair now and then
+        b1, m1, a1 = random_batch(rng, n, max_len, alphabet=b"ACGT")
+        b2, m2, a2 = random_batch(rng, n, max_len, alphabet=b"ACGT")
+        ref.add_pair(b1, m1, b2, m2)
+        got.add_record_array_pair(a1, a2)
+    assert time.time() - t0 < 60
+    assert got._modulo_bits == ref._modulo_bits
+    assert got.tracked_sequences == ref.tracked_sequences
+    np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
+
+
 def test_insert_size_vs_oracle():
     from sequali_amd import InsertSizeMetrics, synth
     ref, got = oracle.InsertSizeMetrics(50), InsertSizeMetrics(50)
