@@ -8,7 +8,7 @@
 # oracle, like the reference, indexes an array by the tile id -> realloc + memset of 2 TB -> the box's host memory.  The
 # oracle now refuses such ids and the tests no longer make them.  All the same: the round's new GPU tests have never run,
 # so run them ONE per gpurun call, each under its own short timeout, the plainest first:
-#   gpurun --timeout 300 -- 'bash scripts/gpu_bisect_r5.sh 1'      (then 2, 3, ... 15)
+#   gpurun --timeout 300 -- 'bash scripts/gpu_bisect_r5.sh 1'      (then 2, 3, ... 17)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/bisect
 case "$1" in
@@ -26,8 +26,10 @@ case "$1" in
   12) T="tests/test_gpu_pair.py::test_paired_pass_falls_back_to_the_five_calls tests/test_gpu_pair.py::test_paired_pass_through_the_parsers_at_the_default_buffer_size" ;;
   13) T="tests/test_gpu_vs_oracle.py::test_long_reads_in_segments tests/test_gpu_vs_oracle.py::test_config4_nanopore_reads_through_the_segment_kernels" ;;
   14) T="tests/test_gpu_span_edges.py::test_adapters_of_14_to_25_characters_on_every_quarter_seam" ;;
-  15) timeout 500 python -u scripts/fuzz.py 30 4 > gpurun_out/bisect/step15.log 2>&1; echo "step 15 rc=$?"; tail -8 gpurun_out/bisect/step15.log; exit 0 ;;   # round 4: did not finish in 300 s -- which iteration?
-  *) echo "usage: $0 1..15"; exit 2 ;;
+  16) T="tests/test_gpu_vs_oracle.py::test_dedup_batches_of_nothing_but_short_pairs tests/test_gpu_vs_oracle.py::test_dedup_pairs_with_short_reads_stale_bytes" ;;
+  17) T="tests/test_gpu_shards.py::test_dedup_shards_equal_one_run tests/test_gpu_shards.py::test_processes_merge_equals_one_run" ;;
+  15) timeout 500 python -u scripts/fuzz.py 30 4 > gpurun_out/bisect/step15.log 2>&1; echo "step 15 rc=$?"; tail -8 gpurun_out/bisect/step15.log; exit 0 ;;   # round 4: did not finish in 300 s: its second iteration, 6000 pairs of at most 5 bases, cured in the DedupEstimator's tail
+  *) echo "usage: $0 1..17"; exit 2 ;;
 esac
 timeout 240 python -m pytest $T -q -x -p no:cacheprovider > gpurun_out/bisect/step$1.log 2>&1
 echo "step $1 rc=$?"; tail -5 gpurun_out/bisect/step$1.log
