@@ -264,7 +264,7 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                 "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del batches
     # ---- ragged: the config-2 records cut to 50 .. 150 bases (what adapter trimming leaves) ----
-    if wanted("ragged_50_150"):
+    if wanted("ragged_50_150") or wanted("ragged_50_150_side_streams"):
         n, per = 50_000_000, 25_000_000
         batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
         for k, b in enumerate(batches):
@@ -276,13 +276,26 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                 f.add_record_array(b)
                 clear(f)
 
-        out["ragged_50_150"] = run(
-            "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
-            "QCMetrics + AdapterCounter fused, records resident in HBM",
-            "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
-            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
-            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+        # the second entry: the same pass with its four launches on streams of their own (SQ_SORTED_STREAMS=1, opt-in:
+        # written in round 4 without a GPU; the entry is there to measure it)
+        for entry, env in (("ragged_50_150", None), ("ragged_50_150_side_streams", "SQ_SORTED_STREAMS")):
+            if not wanted(entry):
+                continue
+            if env:
+                os.environ[env] = "1"
+                lib.sq_knobs_reload()
+            try:
+                out[entry] = run(
+                    "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
+                    "QCMetrics + AdapterCounter fused, records resident in HBM" + (f", {env}=1" if env else ""),
+                    "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
+                    lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
+                    lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                                       "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+            finally:
+                if env:
+                    os.environ.pop(env, None)
+                    lib.sq_knobs_reload()
         del batches
     # ---- config 3: 100 M pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics ----
     # three entries: the reads with a random tile each (what rounds 1-3 measured), the same pairs in the order a sequencer

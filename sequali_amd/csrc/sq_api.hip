@@ -60,6 +60,7 @@ static void knobs_load()
     k.long_nw = num("SQ_LONG_NW", 8);
     k.long_stretch_cost = num("SQ_LONG_STRETCH_COST", 16);
     k.long_block = num("SQ_LONG_BLOCK", 0);
+    k.sorted_streams = flag("SQ_SORTED_STREAMS");
     k.lds_pad = num("SQ_LDS_PAD", 0);
     k.probe_mode = num("SQ_PROBE_MODE", -1);
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
@@ -111,6 +112,11 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
     if (ctx->copied) (void)hipEventDestroy(ctx->copied);
+    for (hipStream_t st : ctx->side_streams)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (ctx->side_ready) (void)hipEventDestroy(ctx->side_ready);
+    for (hipEvent_t e : ctx->side_done)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_stats) (void)hipHostFree(ctx->pinned_stats);
     for (void *p : ctx->scratch)

@@ -69,6 +69,7 @@ struct SqKnobs {
     int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
     int long_block = 0;        /* SQ_LONG_BLOCK: k_span<LONG> walks the sorted reads in blocks of that many reads, all segments of a block before the next block (0: all reads' segment 0, then all reads' segment 1, ..) */
+    bool sorted_streams = false;   /* SQ_SORTED_STREAMS: the launches of the length-sorted route (one per window count) on streams of their own, so that one launch's last workgroups do not stand between it and the next */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;
 };
@@ -80,6 +81,8 @@ struct sq_ctx {
     hipStream_t copy_stream = nullptr;   /* uploads of FASTQ text (sq_batch_from_fastq): they run beside the counting of the batch before */
     hipEvent_t copied = nullptr;
     hipStream_t prep_stream = nullptr;   /* PerTileQuality's pass over the headers (tile ids, table slots): it runs beside the counting of the batch before */
+    hipStream_t side_streams[7] = {};    /* SQ_SORTED_STREAMS: made on first use */
+    hipEvent_t side_ready = nullptr, side_done[7] = {};
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */

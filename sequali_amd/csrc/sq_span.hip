@@ -1061,6 +1061,21 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     std::vector<SpanSeg> all_segs;
     for (const Launch &l : launches) all_segs.insert(all_segs.end(), l.segs.begin(), l.segs.end());
     SQ_HIP(hipMemcpyAsync(d_segs, sq_host_keep(ctx, all_segs.data(), all_segs.size() * sizeof(SpanSeg)), all_segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
+    /* SQ_SORTED_STREAMS: every launch behind the first on a stream of its own.  The launches share nothing but
+       read-only rows and the device tables they add to at their ends (atomics); side by side, the workgroups of
+       the next launch take the CUs the last workgroups of this one leave idle.  The work stream waits for all of
+       them before anything behind this pass runs. */
+    const bool fan = sq_knobs().sorted_streams && launches.size() > 1 && launches.size() <= 8;
+    hipStream_t work = ctx->stream;
+    if (fan) {
+        if (!ctx->side_ready) SQ_HIP(hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming));
+        for (size_t i = 0; i + 1 < launches.size(); i++) {
+            if (!ctx->side_streams[i]) SQ_HIP(hipStreamCreateWithFlags(&ctx->side_streams[i], hipStreamNonBlocking));
+            if (!ctx->side_done[i]) SQ_HIP(hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming));
+        }
+        SQ_HIP(hipEventRecord(ctx->side_ready, work));   /* the rows and the segments are in place */
+    }
+    size_t li = 0;
     for (const Launch &l : launches) {
         PassParams C = P;
         C.uniform_len = 0;
@@ -1072,11 +1087,22 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
         const int seqs = split ? l.waves / 2 : l.waves;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
+        const bool aside = fan && li > 0;
+        if (aside) {
+            ctx->stream = ctx->side_streams[li - 1];
+            if (hipStreamWaitEvent(ctx->stream, ctx->side_ready, 0) != hipSuccess) { ctx->stream = work; sq_set_error("hipStreamWaitEvent failed"); return SQ_ERR_HIP; }
+        }
         int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(l.nw, true, split, ctx, C, n_ad, l.waves, lds, grid)
                                       : split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
+        if (aside) {
+            const hipError_t e = hipEventRecord(ctx->side_done[li - 1], ctx->stream);
+            ctx->stream = work;
+            if (e != hipSuccess || hipStreamWaitEvent(work, ctx->side_done[li - 1], 0) != hipSuccess) { sq_set_error("the side stream of the sorted route could not be joined"); return SQ_ERR_HIP; }
+        }
         if (rc) return rc;
         span_print_stamps(ctx, l.nw);
         seg_off += l.segs.size();
+        li++;
     }
     *done = n;
     return SQ_OK;

@@ -583,7 +583,8 @@ def test_sorted_spans_every_length(max_len, with_adapters, ea):
     rq, ra = oracle.QCMetrics(ea), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({"SQ_SPAN_SORTED": "1"}, {"SQ_SPAN": "0"}):
+    # the last: the launches of the window counts side by side on streams of their own
+    for env in ({"SQ_SPAN_SORTED": "1"}, {"SQ_SPAN": "0"}, {"SQ_SPAN_SORTED": "1", "SQ_SORTED_STREAMS": "1"}):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(ea), AdapterCounter(probes)
 
@@ -663,8 +664,8 @@ def test_sorted_spans_two_million_trimmed_reads():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     gq, ga = QCMetrics(), AdapterCounter(probes)
     f = FusedPass(gq, ga)
-    # rows in order by the batch's length counts (k_span_scatter) / by a radix sort of keys / the general k_pass
-    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}):
+    # rows in order by the batch's length counts (k_span_scatter) / by a radix sort of keys / the general k_pass / the four launches side by side
+    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}, {"SQ_SORTED_STREAMS": "1"}):
         rq.add(buf, metas)
         ra.add(buf, metas)
         _with_env(env, lambda: (f.add_record_array(dev), gq.flush()))
