@@ -9,6 +9,7 @@
 # oracle now refuses such ids and the tests no longer make them.  All the same: the round's new GPU tests have never run,
 # so run them ONE per gpurun call, each under its own short timeout, the plainest first:
 #   gpurun --timeout 300 -- 'bash scripts/gpu_bisect_r5.sh 1'      (then 2, 3, ... 17)
+# or, one box for all of them:  gpurun --timeout 2400 -- 'bash scripts/gpu_bisect_r5.sh all'
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/bisect
 case "$1" in
@@ -29,7 +30,11 @@ case "$1" in
   16) T="tests/test_gpu_vs_oracle.py::test_dedup_batches_of_nothing_but_short_pairs tests/test_gpu_vs_oracle.py::test_dedup_pairs_with_short_reads_stale_bytes" ;;
   17) T="tests/test_gpu_shards.py::test_dedup_shards_equal_one_run tests/test_gpu_shards.py::test_processes_merge_equals_one_run" ;;
   15) timeout 500 python -u scripts/fuzz.py 30 4 > gpurun_out/bisect/step15.log 2>&1; echo "step 15 rc=$?"; tail -8 gpurun_out/bisect/step15.log; exit 0 ;;   # round 4: did not finish in 300 s: its second iteration, 6000 pairs of at most 5 bases, cured in the DedupEstimator's tail
-  *) echo "usage: $0 1..17"; exit 2 ;;
+  all)   # every step in ONE call, each under its own timeout (the box-killer is cured and tests/conftest.py now ends a run that passes 40 GiB resident): ~25 min
+    for k in 1 2 3 4 5 6 9 10 11 12 16 17 7 8 13 14; do bash "$0" $k; done
+    bash "$0" 15
+    exit 0 ;;
+  *) echo "usage: $0 1..17 | all"; exit 2 ;;
 esac
 timeout 240 python -m pytest $T -q -x -p no:cacheprovider > gpurun_out/bisect/step$1.log 2>&1
 echo "step $1 rc=$?"; tail -5 gpurun_out/bisect/step$1.log

@@ -8,8 +8,46 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _memory_watchdog(limit_gb: float) -> None:
+    """Round 4 lost two GPU boxes to a TEST, not to a kernel: the oracle (like the reference) was handed a tile id
+    of twelve digits and memset an array of 2 TB.  The oracle refuses such ids now; this is the belt to
+    those braces: a thread that ends the whole test process, loudly, once the resident memory of it and its
+    children passes the limit ($SQ_TEST_RSS_LIMIT_GB, default 40; 0 = no watchdog).  A runaway memset fills ~10 GB a
+    second, the thread looks four times a second."""
+    import threading
+    import time
+    try:
+        import psutil
+    except ImportError:
+        return
+    me = psutil.Process()
+    saved_stderr = os.dup(2)
+
+    def watch():
+        while True:
+            try:
+                rss = me.memory_info().rss + sum(c.memory_info().rss for c in me.children(recursive=True))
+            except psutil.Error:
+                rss = 0
+            if rss > limit_gb * 2 ** 30:
+                msg = (f"\ntests/conftest.py: {rss / 2 ** 30:.1f} GiB resident, limit {limit_gb:g} GiB "
+                       f"(SQ_TEST_RSS_LIMIT_GB): ending the test run before the machine does; "
+                       f"the test: {os.environ.get('PYTEST_CURRENT_TEST', '?')}\n")
+                for fd in (saved_stderr, 2):      # pytest holds fd 2 while it captures: the duplicate made at start still shows
+                    try:
+                        os.write(fd, msg.encode())
+                    except OSError:
+                        pass
+                os._exit(97)
+            time.sleep(0.25)
+    threading.Thread(target=watch, name="rss-watchdog", daemon=True).start()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    limit = float(os.environ.get("SQ_TEST_RSS_LIMIT_GB", "40"))
+    if limit > 0:
+        _memory_watchdog(limit)
 
 
 def _has_gpu() -> bool:
