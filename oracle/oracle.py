@@ -55,7 +55,7 @@ def _load() -> C.CDLL:
         "oq_tile_id": (i64, [u8p, sz]),
         "oq_ptq_new": (vp, []), "oq_ptq_free": (None, [vp]),
         "oq_ptq_add": (i64, [vp, u8p, vp, sz]),
-        "oq_ptq_skipped": (C.c_int, [vp]), "oq_ptq_skipped_record": (i64, [vp]),
+        "oq_ptq_skipped": (C.c_int, [vp]), "oq_ptq_skipped_record": (i64, [vp]), "oq_ptq_bad_char": (C.c_int, [vp]),
         "oq_ptq_max_length": (sz, [vp]), "oq_ptq_number_of_reads": (u64, [vp]),
         "oq_ptq_n_tiles_seen": (sz, [vp]), "oq_ptq_get": (None, [vp, vp, vp, vp]),
         "oq_wanghash64": (u64, [u64]), "oq_wanghash64_inverse": (u64, [u64]),
@@ -300,7 +300,7 @@ class PerTileQuality:
         if r == -(1 << 63):
             raise MemoryError("a tile id beyond 2^27: the reference's tile array (16 bytes per id, _qcmodule.c:3026-3044) has no memory for it")
         if r < 0:
-            raise ValueErrorWithIndex("Not a valid phred character", -r - 1)
+            raise ValueErrorWithIndex("Not a valid phred character: %c" % LIB.oq_ptq_bad_char(self._h), -r - 1)
 
     @property
     def skipped(self) -> bool: return bool(LIB.oq_ptq_skipped(self._h))

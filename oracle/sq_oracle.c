@@ -479,6 +479,7 @@ oq_ptq_add(oq_ptq *p, const uint8_t *buf, const oq_meta *metas, size_t n)
 }
 
 int oq_ptq_skipped(oq_ptq *p) { return p->skipped; }
+int oq_ptq_bad_char(oq_ptq *p) { return p->bad_char; }   /* the byte of the last failed add (:3212-3215 puts it in the message) */
 int64_t oq_ptq_skipped_record(oq_ptq *p) { return p->skipped_record; }
 size_t oq_ptq_max_length(oq_ptq *p) { return p->max_length; }
 uint64_t oq_ptq_number_of_reads(oq_ptq *p) { return p->number_of_reads; }

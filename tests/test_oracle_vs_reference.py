@@ -213,3 +213,40 @@ def test_paired_modules(seed):
     np.testing.assert_array_equal(gz.insert_sizes(), u64(rz.insert_sizes()))
     assert gz.adapters_read1() == list(rz.adapters_read1())     # slot order
     assert gz.adapters_read2() == list(rz.adapters_read2())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_a_byte_that_is_no_phred_character(seed):
+    """:2102-2105 (QCMetrics) and :3212-3215 (PerTileQuality): ValueError with the character; what was counted up to
+    there stays counted -- the same message and the same tables afterwards"""
+    rng = np.random.default_rng(11000 + seed)
+    n = int(rng.choice([1, 40, 300]))
+    names, seqs, quals = draw(rng, n, int(rng.choice([30, 151, 400])), bool(seed % 2), "illumina", None)
+    victims = [i for i in range(n) if len(seqs[i]) > 0]
+    if not victims:
+        pytest.skip("no read with a base")
+    v = victims[int(rng.integers(0, len(victims)))]
+    at = int(rng.integers(0, len(quals[v])))
+    bad = chr(int(rng.choice([32, 127, 10 + 22])))          # ' ', DEL, ' ' again: below '!' and above '~'
+    quals[v] = quals[v][:at] + bad + quals[v][at + 1:]
+    arrays = reference_arrays(fastq(names, seqs, quals), 1 << 22)
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    for make_ref, make_got in ((lambda: REF.QCMetrics(), lambda: oracle.QCMetrics()),
+                               (lambda: REF.PerTileQuality(), lambda: oracle.PerTileQuality())):
+        r, g = make_ref(), make_got()
+        with pytest.raises(ValueError) as er:
+            r.add_record_array(arrays[0])
+        with pytest.raises(ValueError) as eg:
+            g.add(buf, metas.copy())
+        assert str(eg.value) == str(er.value)
+        assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length)
+        if isinstance(g, oracle.QCMetrics):
+            for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                         "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+                np.testing.assert_array_equal(getattr(g, name)(), u64(getattr(r, name)()), err_msg=name)
+        else:
+            rt, gt = r.get_tile_counts(), g.get_tile_counts()
+            assert [t for t, _, _ in gt] == [t for t, _, _ in rt]
+            for (_, e, c), (_, er_, cr) in zip(gt, rt):
+                np.testing.assert_array_equal(np.asarray(e, dtype=np.float64).view(np.uint64), np.array(er_, dtype=np.float64).view(np.uint64))
+                np.testing.assert_array_equal(c, u64(cr))
