@@ -71,6 +71,7 @@ typedef struct sq_feeder sq_feeder;
 /* ---- library / context ------------------------------------------------ */
 int sq_abi_version(void);
 const char *sq_last_error(void);
+size_t sq_last_error_length(void);   /* the message may hold a zero byte ("... but with %c" of the input's byte, _qcmodule.c:1076) */
 /* One context per process and GPU: selects `device`, creates the stream all
  * work of its modules is ordered on.  NULL on failure. */
 sq_ctx *sq_init(int device);

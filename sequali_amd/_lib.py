@@ -73,7 +73,12 @@ def lib() -> C.CDLL:
 
 
 def last_error() -> str:
-    return (lib().sq_last_error() or b"").decode("latin-1")  # bytes echoed from the input -> code points, like %c
+    L = lib()
+    # bytes echoed from the input -> code points, like %c; by address and length: one of them may be a zero byte
+    raw = L["sq_last_error"]        # a function object of its own (CDLL.__getitem__ makes one per call): c_char_p would cut at the zero
+    raw.restype = C.c_void_p
+    raw.argtypes = []
+    return C.string_at(raw(), L.sq_last_error_length()).decode("latin-1")
 
 
 _EXC = {-1: RuntimeError, -2: ValueError, -3: MemoryError, -4: TypeError, -5: EOFError,

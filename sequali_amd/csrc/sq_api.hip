@@ -16,7 +16,7 @@ void sq_set_error(const char *fmt, ...)
     const int need = vsnprintf(tmp, sizeof(tmp), fmt, ap);
     va_end(ap);
     if (need >= 0 && (size_t)need < sizeof(tmp)) {
-        g_last_error = tmp;
+        g_last_error.assign(tmp, (size_t)need);   /* by length: "%c" of a zero byte of the input is part of the message (sq_last_error_length) */
     } else if (need > 0) {   /* the reference puts whole buffers into its messages (:1076): no cut */
         g_last_error.resize((size_t)need + 1);
         vsnprintf(&g_last_error[0], (size_t)need + 1, fmt, ap2);
@@ -77,6 +77,7 @@ SQ_EXPORT void sq_knobs_reload(void) { knobs_load(); }
 
 SQ_EXPORT int sq_abi_version(void) { return SQ_ABI_VERSION; }
 SQ_EXPORT const char *sq_last_error(void) { return g_last_error.c_str(); }
+SQ_EXPORT size_t sq_last_error_length(void) { return g_last_error.size(); }
 
 SQ_EXPORT sq_ctx *sq_init(int device)
 {
@@ -250,8 +251,7 @@ static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_
         const uint8_t *qual_end = next_newline(qual);
         if (!qual_end) break;
         if (seq_end - seq != qual_end - qual) {
-            std::string nm((const char *)name, name_end - name);
-            sq_set_error("Record sequence and qualities do not have equal length, '%s'", nm.c_str());
+            sq_set_error("Record sequence and qualities do not have equal length, %s", sq_py_repr_ascii((const char *)name, name_end - name).c_str());   /* :1141-1146: %R */
             finish_ascii();
             return SQ_ERR_VALUE;
         }
@@ -706,7 +706,7 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
                     std::string name(m.name_length, ' ');
                     if (m.name_length)
                         (void)hipMemcpy(&name[0], d_text + m.record_start, m.name_length, hipMemcpyDeviceToHost);
-                    sq_set_error("Record sequence and qualities do not have equal length, '%s'", name.c_str());
+                    sq_set_error("Record sequence and qualities do not have equal length, %s", sq_py_repr_ascii(name.data(), name.size()).c_str());   /* :1141-1146: %R */
                     break;
                 }
                 default:

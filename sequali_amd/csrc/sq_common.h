@@ -75,6 +75,29 @@ struct SqKnobs {
 };
 const SqKnobs &sq_knobs();
 
+/* repr() of an ASCII str, as CPython writes it (unicode_repr): what PyErr_Format's %R puts into the reference's messages
+ * (_qcmodule.c:1141-1146: the record's name).  Single quotes unless the text holds one and no double quote; backslash,
+ * the quote in use, tab, newline and carriage return escaped; other control characters and DEL as \xNN. */
+inline std::string sq_py_repr_ascii(const char *p, size_t n)
+{
+    bool single = false, dbl = false;
+    for (size_t i = 0; i < n; i++) { single |= p[i] == '\''; dbl |= p[i] == '"'; }
+    const char quote = single && !dbl ? '"' : '\'';
+    std::string out(1, quote);
+    static const char hex[] = "0123456789abcdef";
+    for (size_t i = 0; i < n; i++) {
+        const unsigned char ch = (unsigned char)p[i];
+        if (ch == (unsigned char)quote || ch == '\\') { out += '\\'; out += (char)ch; }
+        else if (ch == '\t') out += "\\t";
+        else if (ch == '\n') out += "\\n";
+        else if (ch == '\r') out += "\\r";
+        else if (ch < 0x20 || ch == 0x7F) { out += "\\x"; out += hex[ch >> 4]; out += hex[ch & 15]; }
+        else out += (char)ch;
+    }
+    out += quote;
+    return out;
+}
+
 struct sq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
