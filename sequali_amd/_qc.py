@@ -246,7 +246,9 @@ class FastqRecordArrayView:
     def __getitem__(self, i: int) -> FastqRecordView:
         n = len(self)
         if i < 0:
-            i += n
+            i += n      # what the interpreter does before it calls a C type's sq_item ...
+            if i < 0:
+                i += n  # ... and what _qcmodule.c:693-695 then does once more: arr[-len - 1] is the LAST record there, and here
         if i < 0 or i >= n:
             raise IndexError("array index out of range")
         metas = self._host_metas()
