@@ -72,3 +72,56 @@ def test_damaged_texts(seed):
     for buffer_size in (1, 33, 512, 1 << 16):
         got, want = outcome(FastqParser, text, buffer_size), outcome(REF.FastqParser, text, buffer_size)
         assert got == want, (buffer_size, text[:200])
+
+
+def read_outcome(parser_class, text, buffer_size, plan):
+    """what a run of read(n) calls -- and next() in between -- hands out: per call (records, len(obj), the names), or the
+    exception that ended it"""
+    out = []
+    try:
+        p = parser_class(io.BytesIO(text), buffer_size)
+        for n in plan:
+            if n is None:
+                try:
+                    arr = next(p)
+                except StopIteration:
+                    out.append("stop")
+                    continue
+            else:
+                arr = p.read(n)
+            out.append((len(arr), len(arr.obj), [arr[i].name() for i in range(len(arr))]))
+    except (ValueError, EOFError, OverflowError, TypeError) as e:
+        out.append((type(e).__name__, str(e) if not isinstance(e, TypeError) else ""))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_read_in_lock_step(seed):
+    """FastqParser.read(number_of_records) (:1186-1245; what the driver uses to keep two files of a pair in step): any
+    mixture of counts, iteration steps in between, calls at the end of the file.
+
+    Where the reference is defined, that is.  Two of its paths are not, and are left out: (1) read(n) stops at n records
+    and leaves the rest of its buffer to the next call, whose fresh buffer of `buffer_size` bytes is filled with that rest
+    unchecked (:984-992) -- with a buffer smaller than the rest it writes past its allocation (seen: buffer size 1, names
+    that are no ASCII); hence buffers that hold the whole text.  (2) read(n) for more records than the file still has
+    parses what is there, meets the end of the file, copies the buffer to its true size -- and leaves the parsed records
+    pointing into the buffer it has just released (:1040-1051); hence no count above what is left, except at the very end
+    (nothing parsed, nothing dangling).  This parser hands out the records in both cases."""
+    from sequali_amd import FastqParser
+    rng = np.random.default_rng(15000 + seed)
+    n_records = int(rng.choice([0, 1, 5, 80]))
+    text = random_text(rng, n_records, int(rng.choice([1, 30, 400])))
+    left, plan = n_records, []
+    for _ in range(int(rng.integers(1, 12))):
+        op = rng.choice([0, 1, 2, 7, 50, None, -1])
+        if op is None:
+            plan.append(None)
+            left = 0            # the buffer holds the whole text: one step of the iteration hands out all of it
+        elif op <= 0 or left == 0:
+            plan.append(int(op))
+        else:
+            plan.append(int(min(op, left)))
+            left -= plan[-1]
+    for buffer_size in (len(text) + 1, 1 << 20):
+        got, want = read_outcome(FastqParser, text, buffer_size, plan), read_outcome(REF.FastqParser, text, buffer_size, plan)
+        assert got == want, (buffer_size, plan)
