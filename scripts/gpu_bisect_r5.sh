@@ -29,12 +29,13 @@ case "$1" in
   14) T="tests/test_gpu_span_edges.py::test_adapters_of_14_to_25_characters_on_every_quarter_seam" ;;
   16) T="tests/test_gpu_vs_oracle.py::test_dedup_batches_of_nothing_but_short_pairs tests/test_gpu_vs_oracle.py::test_dedup_pairs_with_short_reads_stale_bytes" ;;
   17) T="tests/test_gpu_shards.py::test_dedup_shards_equal_one_run tests/test_gpu_shards.py::test_processes_merge_equals_one_run" ;;
+  18) T="tests/test_gpu_vs_reference.py tests/test_bam_vs_reference.py tests/test_nanostats_vs_reference.py -m gpu" ;;   # the product against the compiled reference itself (oracle/_ref travels)
   15) timeout 500 python -u scripts/fuzz.py 30 4 > gpurun_out/bisect/step15.log 2>&1; echo "step 15 rc=$?"; tail -8 gpurun_out/bisect/step15.log; exit 0 ;;   # round 4: did not finish in 300 s: its second iteration, 6000 pairs of at most 5 bases, cured in the DedupEstimator's tail
   all)   # every step in ONE call, each under its own timeout (the box-killer is cured and tests/conftest.py now ends a run that passes 40 GiB resident): ~25 min
-    for k in 1 2 3 4 5 6 9 10 11 12 16 17 7 8 13 14; do bash "$0" $k; done
+    for k in 1 2 3 4 5 6 9 10 11 12 16 17 18 7 8 13 14; do bash "$0" $k; done
     bash "$0" 15
     exit 0 ;;
-  *) echo "usage: $0 1..17 | all"; exit 2 ;;
+  *) echo "usage: $0 1..18 | all"; exit 2 ;;
 esac
 timeout 240 python -m pytest $T -q -x -p no:cacheprovider > gpurun_out/bisect/step$1.log 2>&1
 echo "step $1 rc=$?"; tail -5 gpurun_out/bisect/step$1.log
