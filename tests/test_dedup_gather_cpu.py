@@ -323,3 +323,62 @@ def test_merge_flow_over_gloo(tmp_path, case, method):
     assert counts[counts != 0].tolist() == want[3]
     if method == "gather" and case != "lagging":
         assert states[0][40:48] == store.tobytes()
+
+
+# ---- the tail's walk over pairs shorter than the fingerprint, as a model --------------------------------------
+def _pair_store_bytes(s1, s2, fl0, bl0, fo0, bo0):
+    """what a pair writes into the fingerprint store (_qcmodule.c:4503-4514; pair_store_bytes in sq_ends.hip)"""
+    fl = min(fl0, len(s1)); fo = min(fo0, len(s1) - fl)
+    bl = min(bl0, len(s2)); bo = min(bo0, len(s2) - bl)
+    return s1[fo:fo + fl] + s2[bo:bo + bl], len(s1) + len(s2)
+
+
+def _tail_model(batches, max_stored, fl0, bl0, fo0, bo0):
+    """dedup_run / dedup_tail of sq_ends.hip restated: long pairs are hashed on their own (the device's k_dedup_hash), a
+    short pair's fingerprint is the store with its bytes laid over -- the store CARRIED from short pair to short pair of
+    a batch (run_store, run_prev), taken from the pair in front when that one was long, and handed from batch to batch"""
+    fp = fl0 + bl0
+    est = oracle.DedupEstimator(max_stored, front_sequence_length=fl0, back_sequence_length=bl0,
+                                front_sequence_offset=fo0, back_sequence_offset=bo0)
+    store = bytearray(fp)
+    for s1, s2 in batches:
+        run_store, run_prev = bytearray(store), None
+        for r in range(len(s1)):
+            w, total = _pair_store_bytes(s1[r], s2[r], fl0, bl0, fo0, bo0)
+            if len(w) == fp:
+                h = oracle.murmur3_x64_64(bytes(w), total >> 6)
+            else:
+                if r != 0 and run_prev != r - 1:
+                    run_store = bytearray(_pair_store_bytes(s1[r - 1], s2[r - 1], fl0, bl0, fo0, bo0)[0])
+                run_store[:len(w)] = w
+                run_prev = r
+                h = oracle.murmur3_x64_64(bytes(run_store), total >> 6)
+            est.add_hash(h)
+        if len(s1):
+            store = bytearray(run_store) if run_prev == len(s1) - 1 else bytearray(_pair_store_bytes(s1[-1], s2[-1], fl0, bl0, fo0, bo0)[0])
+    return est
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_the_walk_over_short_pairs_is_the_sequential_store(seed):
+    """the ALGORITHM of the library's tail for pairs shorter than the fingerprint (round 4: the store is carried instead of
+    rebuilt by walking back from every short pair) against the oracle's pair by pair -- several batches, four geometries,
+    batches of nothing but short pairs.  The library's own run of it needs a GPU
+    (tests/test_gpu_vs_oracle.py::test_dedup_batches_of_nothing_but_short_pairs)."""
+    rng = np.random.default_rng(300 + seed)
+    for _ in range(25):
+        max_len = int(rng.choice([3, 7, 9, 12, 20]))
+        geom = (int(rng.choice([8, 3])), int(rng.choice([8, 5])), int(rng.choice([0, 4])), int(rng.choice([0, 2])))
+        ref = oracle.DedupEstimator(100, front_sequence_length=geom[0], back_sequence_length=geom[1],
+                                    front_sequence_offset=geom[2], back_sequence_offset=geom[3])
+        batches = []
+        for _ in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([1, 2, 50, 400]))
+            s1 = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, max_len + 1))).tobytes() for _ in range(n)]
+            s2 = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, max_len + 1))).tobytes() for _ in range(n)]
+            batches.append((s1, s2))
+            for a, b in zip(s1, s2):
+                ref.add_sequence_pair(a.decode(), b.decode())
+        got = _tail_model(batches, 100, *geom)
+        assert (got._modulo_bits, got.tracked_sequences, got.duplication_counts().tolist()) == \
+            (ref._modulo_bits, ref.tracked_sequences, ref.duplication_counts().tolist())
