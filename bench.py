@@ -353,7 +353,7 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                 lib.sq_knobs_reload()
         del r1, r2
     # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
-    if wanted("config4_nanopore"):
+    if wanted("config4_nanopore") or wanted("config4_nanopore_sums_beside"):
         n = 1_000_000
         arr = synth.device_array(synth.NANOPORE, 0, n)
         bases = arr._batch.total_bases
@@ -362,12 +362,26 @@ def other_configs(lib, ctx, steps, warmup, only=None):
             f.add_record_array(arr)
             clear(f)
 
-        out["config4_nanopore"] = run(
-            "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
-            "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
-            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
-            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+        # the second entry: k_read_sums on a stream of its own beside k_span<LONG> (SQ_LONG_OVERLAP=1, opt-in: written in round 4
+        # without a GPU; the entry is there to measure it)
+        for entry, env in (("config4_nanopore", None), ("config4_nanopore_sums_beside", {"SQ_LONG_OVERLAP": "2", "SQ_SPAN_WAVES": "8"})):
+            if not wanted(entry):
+                continue
+            if env:
+                os.environ.update(env)
+                lib.sq_knobs_reload()
+            try:
+                out[entry] = run(
+                    "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM" + (f", {env}" if env else ""),
+                    "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
+                    lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
+                    lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                                       "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
+            finally:
+                if env:
+                    for k in env:
+                        os.environ.pop(k, None)
+                    lib.sq_knobs_reload()
         del arr
     # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
     if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split"):

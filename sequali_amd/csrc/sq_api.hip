@@ -61,6 +61,7 @@ static void knobs_load()
     k.long_stretch_cost = num("SQ_LONG_STRETCH_COST", 16);
     k.long_block = num("SQ_LONG_BLOCK", 0);
     k.sorted_streams = flag("SQ_SORTED_STREAMS");
+    k.long_overlap = num("SQ_LONG_OVERLAP", 0);
     k.lds_pad = num("SQ_LDS_PAD", 0);
     k.probe_mode = num("SQ_PROBE_MODE", -1);
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");

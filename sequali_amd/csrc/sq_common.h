@@ -69,6 +69,7 @@ struct SqKnobs {
     int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
     int long_block = 0;        /* SQ_LONG_BLOCK: k_span<LONG> walks the sorted reads in blocks of that many reads, all segments of a block before the next block (0: all reads' segment 0, then all reads' segment 1, ..) */
+    int long_overlap = 0;          /* SQ_LONG_OVERLAP=W: k_read_sums on a stream of its own, W workgroups per CU, BESIDE k_span<LONG> instead of in front of it (the one reads qualities at the speed of the memory, the other is bound by its instructions); a batch the sums then flag has the pass taken back (PassParams::negate) */
     bool sorted_streams = false;   /* SQ_SORTED_STREAMS: the launches of the length-sorted route (one per window count) on streams of their own, so that one launch's last workgroups do not stand between it and the next */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;

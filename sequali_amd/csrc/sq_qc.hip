@@ -808,6 +808,7 @@ __global__ void __launch_bounds__(256) k_read_sums(PassParams P)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
+
 /* QCMetrics' GC histogram alone (:1997-2060), a wave per read: the error path behind k_read_sums<false>
  * (a batch with an invalid phred byte keeps k_seg, which counts no G/C) */
 __global__ void __launch_bounds__(256) k_read_gc(PassParams P)
@@ -3319,11 +3320,31 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                read on its way and this pass reads the qualities only */
             const bool try_long = K.long_spans && K.span && b->owns &&
                                   sq_span_long_takes(P, ad, ad ? (uint32_t)a->groups[0].count : 0, (uint32_t)b->max_length);
-            sq_route(ctx, try_long ? "k_read_sums<qualities>" : "k_read_sums<GC>");
-            if (try_long)
-                hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
-                                   ctx->stream, P);
-            else
+            /* SQ_LONG_OVERLAP: the sums BESIDE the pass, on a stream of their own -- k_read_sums streams the qualities at the
+               speed of the memory with a few waves per CU, k_span<LONG> is bound by its instructions and leaves both free.  The
+               pass then runs before anybody knows whether the batch holds an invalid byte; if it does, the same launch with its
+               merges negated takes the counts back (integers: exactly) and the batch goes the way it goes today. */
+            const bool beside = try_long && K.long_overlap > 0;
+            hipStream_t sums_stream = ctx->stream;
+            if (beside) {
+                if (!ctx->side_ready) SQ_HIP(hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming));
+                if (!ctx->side_streams[0]) SQ_HIP(hipStreamCreateWithFlags(&ctx->side_streams[0], hipStreamNonBlocking));
+                if (!ctx->side_done[0]) SQ_HIP(hipEventCreateWithFlags(&ctx->side_done[0], hipEventDisableTiming));
+                sums_stream = ctx->side_streams[0];
+                SQ_HIP(hipEventRecord(ctx->side_ready, ctx->stream));   /* the batch, its order by length and the tables are in place */
+                SQ_HIP(hipStreamWaitEvent(sums_stream, ctx->side_ready, 0));
+            }
+            sq_route(ctx, beside ? "k_read_sums<qualities,beside>" : try_long ? "k_read_sums<qualities>" : "k_read_sums<GC>");
+            if (try_long) {
+                /* beside the pass: SQ_LONG_OVERLAP workgroups per CU, no more -- a grid that fills the chip would keep the pass's
+                   workgroups (130 KB of LDS, ten waves of 136 registers each) waiting for CUs until the sums are done.  What
+                   fits beside them: this kernel's waves hold 120 registers; a SIMD with three of the pass's waves has 104 left,
+                   one with two has 240 (SQ_SPAN_WAVES=8: two on every SIMD) */
+                const uint64_t sums_grid = beside ? (uint64_t)ctx->num_cus * (uint64_t)K.long_overlap : 4096;
+                hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, sums_grid)), dim3(256), 0,
+                                   sums_stream, P);
+                if (beside) SQ_HIP(hipEventRecord(ctx->side_done[0], sums_stream));
+            } else
                 hipLaunchKernelGGL(k_read_sums<true>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
                                    ctx->stream, P);
             /* (2) everything per position.  k_span<LONG> (sq_span.hip) streams segments of 128 positions
@@ -3332,7 +3353,36 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                one 8-byte read-back) keeps k_seg, whose counts k_qc_uncount knows how to take back.
                SQ_LONG=0: k_seg for all */
             const uint32_t n_ad_long = ad ? (uint32_t)a->groups[0].count : 0;
-            if (try_long) {
+            if (beside) {
+                PassParams Lp = P;
+                if (ad) {
+                    Lp.long_first = (unsigned int *)sq_scratch(ctx, 5, b->n * n_ad_long * 4);
+                    if (!Lp.long_first) { (void)hipStreamWaitEvent(ctx->stream, ctx->side_done[0], 0); sq_set_error("out of device memory for the adapter candidates"); return SQ_ERR_MEMORY; }
+                    SQ_HIP(hipMemsetAsync(Lp.long_first, 0xFF, b->n * n_ad_long * 4, ctx->stream));
+                }
+                uint64_t covered = 0;
+                int rc = sq_span_launch_long(ctx, Lp, ad, n_ad_long, (uint32_t)b->max_length, &covered, 1);
+                SQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_done[0], 0));   /* whatever follows on the work stream follows the sums too */
+                if (rc) return rc;
+                SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+                SQ_HIP(hipStreamSynchronize(ctx->stream));
+                if (covered == b->n && ctx->pinned[9] == UINT64_MAX) {
+                    rc = sq_span_long_followups(ctx, Lp);
+                    if (rc) return rc;
+                    if (ad)
+                        hipLaunchKernelGGL(k_adapter_first, dim3((unsigned)std::min<uint64_t>((b->n * n_ad_long + 255) / 256, 8192)),
+                                           dim3(256), 0, ctx->stream, Lp.long_first, b->d_metas, (uint64_t)b->n, n_ad_long, P.ad_len,
+                                           P.ad_fwd, P.ad_rev, P.ad_cap);
+                    SQ_HIP(hipGetLastError());
+                    continue;
+                }
+                if (covered == b->n) {   /* counted, and flagged: taken back */
+                    sq_route(ctx, "taken_back");
+                    rc = sq_span_launch_long(ctx, Lp, ad, n_ad_long, (uint32_t)b->max_length, &covered, 2);
+                    if (rc) return rc;
+                }
+                hipLaunchKernelGGL(k_read_gc, dim3((unsigned)std::min<uint64_t>((b->n + 3) / 4, 4096)), dim3(256), 0, ctx->stream, P);
+            } else if (try_long) {
                 SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
                 SQ_HIP(hipStreamSynchronize(ctx->stream));
                 if (ctx->pinned[9] == UINT64_MAX) {

@@ -796,7 +796,7 @@ def test_long_reads_in_segments(which):
     rq.add(buf, metas)
     ra.add(buf, metas)
     # k_span<LONG> where the adapters allow it (<= 13 characters); the same with the reads walked in blocks (all segments of 512 / 4096 reads before the next ones); k_seg
-    for env in ({}, {"SQ_LONG_BLOCK": "512"}, {"SQ_LONG_BLOCK": "4096"}, {"SQ_LONG": "0"}):
+    for env in ({}, {"SQ_LONG_BLOCK": "512"}, {"SQ_LONG_BLOCK": "4096"}, {"SQ_LONG": "0"}, {"SQ_LONG_OVERLAP": "2"}):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(adapters)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
@@ -888,7 +888,7 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({}, {"SQ_LONG_BLOCK": "1024"}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}):   # k_span<LONG>; in blocks of 1024 reads; k_seg; stripes of k_pass
+    for env in ({}, {"SQ_LONG_BLOCK": "1024"}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}, {"SQ_LONG_OVERLAP": "2"}):   # k_span<LONG>; in blocks of 1024 reads; k_seg; stripes of k_pass
         dev = synth.device_array(synth.NANOPORE, first, n)
         gq, ga = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(dev), gq.flush()))
@@ -967,12 +967,14 @@ def test_config3_one_million_pairs(by_tile):
         assert d._modulo_bits == rd._modulo_bits and d.tracked_sequences == rd.tracked_sequences
 
 
+@pytest.mark.parametrize("beside", [False, True])
 @pytest.mark.parametrize("bad_byte", [0x20, 0x80])
-def test_long_reads_with_an_invalid_phred_byte(bad_byte):
+def test_long_reads_with_an_invalid_phred_byte(bad_byte, beside):
     """>= 4096 long reads, one of them with a byte that is no phred character (0x80: what BAM
     quality 95 becomes, and the code k_span<LONG> pads with): k_read_sums flags the batch, the
     per-position pass falls back to k_seg, the flush raises the reference's ValueError and leaves
-    the reference's state behind it (:2073-2075, :2102-2105)"""
+    the reference's state behind it (:2073-2075, :2102-2105).  beside (SQ_LONG_OVERLAP=1): k_span<LONG> has
+    counted the batch beside k_read_sums by the time the flag is known, and is run once more with its merges negated"""
     from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
     rng = np.random.default_rng(bad_byte)
     n, bad = 4200, 2777
@@ -995,9 +997,13 @@ def test_long_reads_with_an_invalid_phred_byte(bad_byte):
         ref.add(buf, ref_metas)
     probes = ["ACGTACGTACGT", "GGGGGGGGGGGG"]
     m, a = QCMetrics(), AdapterCounter(probes)
-    FusedPass(m, a).add_record_array(FastqRecordArrayView._from_buffer(buf, metas.copy()))
-    with pytest.raises(ValueError, match="Not a valid phred character"):
-        m.flush()
+
+    def run():
+        FusedPass(m, a).add_record_array(FastqRecordArrayView._from_buffer(buf, metas.copy()))
+        with pytest.raises(ValueError, match="Not a valid phred character"):
+            m.flush()
+    route = _route_of(lambda: _with_env({"SQ_LONG_OVERLAP": "2"} if beside else {}, run))
+    assert ("taken_back" in route) == beside, route
     assert m.number_of_reads == ref.number_of_reads and m.max_length == ref.max_length
     for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
                  "end_anchored_phred_count_table", "gc_content", "phred_scores"):
