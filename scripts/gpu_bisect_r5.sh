@@ -25,7 +25,7 @@ case "$1" in
   10) T="tests/test_gpu_pair.py::test_paired_pass_on_device_batches_by_tile" ;;
   11) T="tests/test_gpu_pair.py::test_paired_pass_equals_the_five_calls" ;;
   12) T="tests/test_gpu_pair.py::test_paired_pass_falls_back_to_the_five_calls tests/test_gpu_pair.py::test_paired_pass_through_the_parsers_at_the_default_buffer_size" ;;
-  13) T="tests/test_gpu_vs_oracle.py::test_long_reads_in_segments tests/test_gpu_vs_oracle.py::test_config4_nanopore_reads_through_the_segment_kernels" ;;
+  13) T="tests/test_gpu_vs_oracle.py::test_long_reads_in_segments tests/test_gpu_vs_oracle.py::test_config4_nanopore_reads_through_the_segment_kernels tests/test_gpu_vs_oracle.py::test_long_reads_with_an_invalid_phred_byte" ;;
   14) T="tests/test_gpu_span_edges.py::test_adapters_of_14_to_25_characters_on_every_quarter_seam" ;;
   16) T="tests/test_gpu_vs_oracle.py::test_dedup_batches_of_nothing_but_short_pairs tests/test_gpu_vs_oracle.py::test_dedup_pairs_with_short_reads_stale_bytes" ;;
   17) T="tests/test_gpu_shards.py::test_dedup_shards_equal_one_run tests/test_gpu_shards.py::test_processes_merge_equals_one_run" ;;
