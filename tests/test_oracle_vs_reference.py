@@ -250,3 +250,67 @@ def test_a_byte_that_is_no_phred_character(seed):
             for (_, e, c), (_, er_, cr) in zip(gt, rt):
                 np.testing.assert_array_equal(np.asarray(e, dtype=np.float64).view(np.uint64), np.array(er_, dtype=np.float64).view(np.uint64))
                 np.testing.assert_array_equal(c, u64(cr))
+
+
+@pytest.mark.parametrize("kind,first,n", [("ILLUMINA", 33_000_000, 20_000), ("ILLUMINA", 0, 5_000), ("NANOPORE", 777, 250),
+                                          ("ILLUMINA_BY_TILE", 1_000_000, 8_000)])
+def test_slices_of_the_benchmark_generator(kind, first, n):
+    """what bench.py feeds the GPU (sequali_amd/synth.py, counter-based: any slice on its own), far from the slices the golden
+    vectors hold: all six single-end modules with caps small enough to be crossed (8 modulo increments of the estimator, the
+    fragment table full)"""
+    from sequali_amd import synth
+    k = getattr(synth, kind)
+    buf, metas = synth.host_records(k, first, n)
+    text = bytes(buf)
+    arrays = reference_arrays(text, 1 << 26)
+    assert sum(len(a) for a in arrays) == n
+    probes = list(synth.NANOPORE_PROBES if kind == "NANOPORE" else synth.ILLUMINA_PROBES)
+    ref = dict(q=REF.QCMetrics(), a=REF.AdapterCounter(probes), p=REF.PerTileQuality(),
+               o=REF.OverrepresentedSequences(max_unique_fragments=3000, sample_every=2), d=REF.DedupEstimator(300))
+    got = dict(q=oracle.QCMetrics(), a=oracle.AdapterCounter(probes), p=oracle.PerTileQuality(),
+               o=oracle.OverrepresentedSequences(max_unique_fragments=3000, sample_every=2), d=oracle.DedupEstimator(300))
+    metas = metas.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for arr in arrays:
+            for m in ref.values():
+                m.add_record_array(arr)
+        for m in got.values():
+            m.add(buf, metas)
+    for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                 "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+        np.testing.assert_array_equal(getattr(got["q"], name)(), u64(getattr(ref["q"], name)()), err_msg=name)
+    for (_, f, rv), (_, fr, rr) in zip(got["a"].get_counts(), ref["a"].get_counts()):
+        np.testing.assert_array_equal(f, u64(fr))
+        np.testing.assert_array_equal(rv, u64(rr))
+    assert got["p"].skipped == (ref["p"].skipped_reason is not None)
+    gt, rt = got["p"].get_tile_counts(), ref["p"].get_tile_counts()
+    assert [t for t, _, _ in gt] == [t for t, _, _ in rt]
+    for (_, e, c), (_, er, cr) in zip(gt, rt):
+        np.testing.assert_array_equal(np.asarray(e, dtype=np.float64).view(np.uint64), np.array(er, dtype=np.float64).view(np.uint64))
+        np.testing.assert_array_equal(c, u64(cr))
+    assert got["o"].sequence_counts() == ref["o"].sequence_counts()
+    assert got["o"].collected_unique_fragments == ref["o"].collected_unique_fragments
+    assert (got["d"]._modulo_bits, got["d"].tracked_sequences) == (ref["d"]._modulo_bits, ref["d"].tracked_sequences)
+    np.testing.assert_array_equal(got["d"].duplication_counts(), u64(ref["d"].duplication_counts()))
+    if kind != "NANOPORE":
+        assert got["d"]._modulo_bits >= 4
+
+
+def test_pairs_of_the_benchmark_generator():
+    from sequali_amd import synth
+    first, n = 12_345_678, 10_000
+    b1, m1 = synth.host_records(synth.ILLUMINA, first, n)
+    b2, m2 = synth.host_records(synth.ILLUMINA_R2, first, n)
+    a1, a2 = reference_arrays(bytes(b1), 1 << 26), reference_arrays(bytes(b2), 1 << 26)
+    rd, rz = REF.DedupEstimator(400, front_sequence_offset=0, back_sequence_offset=0), REF.InsertSizeMetrics()
+    gd, gz = oracle.DedupEstimator(400, front_sequence_offset=0, back_sequence_offset=0), oracle.InsertSizeMetrics()
+    rd.add_record_array_pair(a1[0], a2[0])
+    rz.add_record_array_pair(a1[0], a2[0])
+    gd.add_pair(b1, m1.copy(), b2, m2.copy())
+    gz.add_pair(b1, m1.copy(), b2, m2.copy())
+    assert (gd._modulo_bits, gd.tracked_sequences) == (rd._modulo_bits, rd.tracked_sequences)
+    np.testing.assert_array_equal(gd.duplication_counts(), u64(rd.duplication_counts()))
+    np.testing.assert_array_equal(gz.insert_sizes(), u64(rz.insert_sizes()))
+    assert int(gz.insert_sizes()[1:].sum()) > 1000
+    assert gz.adapters_read1() == list(rz.adapters_read1()) and gz.adapters_read2() == list(rz.adapters_read2())
