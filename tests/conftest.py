@@ -8,38 +8,80 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _memory_watchdog(limit_gb: float) -> None:
+def _resident_bytes_of_the_tree(root_pid: int, page: int) -> int:
+    """Resident bytes of `root_pid` and every process below it, read from /proc alone (no psutil: nobody has
+    checked that the GPU box has it, and a watchdog that silently does nothing is worse than none)."""
+    parent, rss = {}, {}
+    for d in os.listdir("/proc"):
+        if not d.isdigit():
+            continue
+        try:
+            with open(f"/proc/{d}/stat", "rb") as f:
+                st = f.read()
+            # pid (comm) state ppid ...: comm may hold spaces and brackets, so split after the LAST ')'
+            rest = st[st.rindex(b")") + 2:].split()
+            parent[int(d)] = int(rest[1])
+            rss[int(d)] = int(rest[21]) * page      # field 24 of stat(5): resident pages
+        except (OSError, ValueError, IndexError):
+            continue
+    total = 0
+    for pid in rss:
+        q, hops = pid, 0
+        while q != root_pid and q in parent and hops < 64:
+            q, hops = parent[q], hops + 1
+        if q == root_pid:
+            total += rss[pid]
+    return total
+
+
+def _mem_available_bytes() -> int:
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except (OSError, ValueError):
+        pass
+    return -1
+
+
+def _memory_watchdog(limit_gb: float, floor_gb: float) -> None:
     """Round 4 lost two GPU boxes to a TEST, not to a kernel: the oracle (like the reference) was handed a tile id
     of twelve digits and memset an array of 2 TB.  The oracle refuses such ids now; this is the belt to
-    those braces: a thread that ends the whole test process, loudly, once the resident memory of it and its
-    children passes the limit ($SQ_TEST_RSS_LIMIT_GB, default 40; 0 = no watchdog).  A runaway memset fills ~10 GB a
-    second, the thread looks four times a second."""
+    those braces: a thread that ends the whole test process, loudly and with a non-zero code, once the resident
+    memory of it and its children passes the limit ($SQ_TEST_RSS_LIMIT_GB, default 40; 0 = no watchdog) OR the
+    machine's MemAvailable falls below $SQ_TEST_MEM_FLOOR_GB (default 6) after having been above twice that.
+    Everything is read from /proc.  A runaway memset fills ~10 GB a second, the thread looks ten times a second."""
     import threading
     import time
-    try:
-        import psutil
-    except ImportError:
-        return
-    me = psutil.Process()
+    me = os.getpid()
+    page = os.sysconf("SC_PAGE_SIZE")
     saved_stderr = os.dup(2)
+    if _resident_bytes_of_the_tree(me, page) <= 0:
+        raise RuntimeError("tests/conftest.py: /proc does not give this process's resident size; the memory "
+                           "watchdog cannot work here (set SQ_TEST_RSS_LIMIT_GB=0 to run without it)")
+    armed_floor = _mem_available_bytes() > 2 * floor_gb * 2 ** 30
+
+    def end(msg: str):
+        msg = (f"\ntests/conftest.py: {msg}: ending the test run before the machine does; "
+               f"the test: {os.environ.get('PYTEST_CURRENT_TEST', '?')}\n")
+        for fd in (saved_stderr, 2):      # pytest holds fd 2 while it captures: the duplicate made at start still shows
+            try:
+                os.write(fd, msg.encode())
+            except OSError:
+                pass
+        os._exit(97)
 
     def watch():
         while True:
-            try:
-                rss = me.memory_info().rss + sum(c.memory_info().rss for c in me.children(recursive=True))
-            except psutil.Error:
-                rss = 0
+            rss = _resident_bytes_of_the_tree(me, page)
             if rss > limit_gb * 2 ** 30:
-                msg = (f"\ntests/conftest.py: {rss / 2 ** 30:.1f} GiB resident, limit {limit_gb:g} GiB "
-                       f"(SQ_TEST_RSS_LIMIT_GB): ending the test run before the machine does; "
-                       f"the test: {os.environ.get('PYTEST_CURRENT_TEST', '?')}\n")
-                for fd in (saved_stderr, 2):      # pytest holds fd 2 while it captures: the duplicate made at start still shows
-                    try:
-                        os.write(fd, msg.encode())
-                    except OSError:
-                        pass
-                os._exit(97)
-            time.sleep(0.25)
+                end(f"{rss / 2 ** 30:.1f} GiB resident, limit {limit_gb:g} GiB (SQ_TEST_RSS_LIMIT_GB)")
+            if armed_floor and floor_gb > 0:
+                avail = _mem_available_bytes()
+                if 0 <= avail < floor_gb * 2 ** 30:
+                    end(f"MemAvailable {avail / 2 ** 30:.1f} GiB, floor {floor_gb:g} GiB (SQ_TEST_MEM_FLOOR_GB)")
+            time.sleep(0.1)
     threading.Thread(target=watch, name="rss-watchdog", daemon=True).start()
 
 
@@ -47,7 +89,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     limit = float(os.environ.get("SQ_TEST_RSS_LIMIT_GB", "40"))
     if limit > 0:
-        _memory_watchdog(limit)
+        _memory_watchdog(limit, float(os.environ.get("SQ_TEST_MEM_FLOOR_GB", "6")))
 
 
 def _has_gpu() -> bool:
