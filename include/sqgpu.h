@@ -163,6 +163,11 @@ sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_len,
 /* Wraps memory that already lives on the device (borrowed, not freed). */
 sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t buf_len, void *d_metas,
                                size_t n);
+/* Records [first, first + n) of a batch as a batch of their own (borrowed: `parent` must outlive it).  Unlike
+ * sq_batch_wrap_device over the same pointers it keeps what the library knows about the parent's memory (the spare
+ * bytes behind the text), so the view takes the same kernels as the parent.  The reference's counterpart is a
+ * FastqRecordArrayView made from a slice of records of one buffer (_qcmodule.c:690-719). */
+sq_batch *sq_batch_view(sq_batch *parent, size_t first, size_t n);
 /* FastqParser's record split on the GPU (FastqParser_create_record_array, the loop at
  * _qcmodule.c:1093-1171, and the ASCII check :203-237, :1055-1067): finds every
  * complete 4-line record of `text`, builds the metas in HBM and returns the batch.

@@ -408,9 +408,7 @@ class _Block:
         else:
             parent = self.array._device()
             r0, r1 = self.starts[s0], self.starts[s1]
-            h = lib().sq_batch_wrap_device(context(), lib().sq_batch_device_text(parent.handle),
-                                           lib().sq_batch_bytes(parent.handle),
-                                           lib().sq_batch_device_metas(parent.handle) + 40 * r0, r1 - r0)
+            h = lib().sq_batch_view(parent.handle, r0, r1 - r0)
             if not h:
                 raise MemoryError(_lib.last_error())
             v = FastqRecordArrayView._from_device(_DeviceBatch(h))

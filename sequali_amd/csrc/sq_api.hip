@@ -419,7 +419,7 @@ SQ_EXPORT sq_batch *sq_batch_upload(sq_ctx *ctx, const uint8_t *buf, size_t buf_
     b->ctx = ctx;
     b->buf_len = buf_len;
     b->n = n;
-    b->owns = true;
+    b->owns = b->slack = true;
     b->len_hist.assign(SQ_LEN_BINS, 0);
     for (size_t i = 0; i < n; i++) {
         const sq_meta &m = metas[i];
@@ -471,6 +471,14 @@ SQ_EXPORT sq_batch *sq_batch_wrap_device(sq_ctx *ctx, const void *d_buf, size_t 
         SQ_HIP_NULL(hipStreamSynchronize(ctx->stream));
         stats_take(ctx, b);
     }
+    return b;
+}
+
+SQ_EXPORT sq_batch *sq_batch_view(sq_batch *parent, size_t first, size_t n)
+{
+    if (!parent || first > parent->n || n > parent->n - first) { sq_set_error("sq_batch_view: records out of range"); return nullptr; }
+    sq_batch *b = sq_batch_wrap_device(parent->ctx, parent->d_buf, parent->buf_len, parent->d_metas + first, n);
+    if (b) b->slack = parent->slack;    /* the same text: the same spare bytes behind it */
     return b;
 }
 
@@ -622,7 +630,7 @@ sq_batch *split_on_device(sq_ctx *ctx, uint8_t *d_text, bool owns_text, const ui
     b->ctx = ctx;
     b->d_buf = d_text;
     b->buf_len = len;
-    b->owns = owns_text;
+    b->owns = b->slack = owns_text;
     b->pooled = true;
     if (len == 0 || n_blocks == 0) {
         if (!(b->d_metas = (sq_meta *)sq_dev_get(ctx, sizeof(sq_meta)))) return fail(b);
@@ -977,7 +985,7 @@ SQ_EXPORT sq_batch *sq_batch_from_bam(sq_ctx *ctx, const uint8_t *bam, size_t le
 {
     sq_batch *b = new sq_batch();
     b->ctx = ctx;
-    b->owns = true;
+    b->owns = b->slack = true;
     b->n = n;
     uint8_t *d_bam = nullptr;
     unsigned long long *d_off = nullptr, *d_sizes = nullptr, *d_starts = nullptr;
@@ -1179,7 +1187,7 @@ SQ_EXPORT sq_batch *sq_synth_device(sq_ctx *ctx, int kind, uint64_t seed, uint64
     sq_batch *b = new sq_batch();
     b->ctx = ctx;
     b->n = n;
-    b->owns = true;
+    b->owns = b->slack = true;
     uint64_t *d_offs = nullptr;
     uint64_t fixed = 0, total = 0;
     if (sqs_base_kind(kind) == SQ_SYNTH_NANOPORE) {

@@ -234,6 +234,9 @@ struct sq_batch {
     bool pooled = false;     /* d_buf and d_metas are blocks of the context's pool (sq_dev_get) */
     bool owns = false;       /* frees d_buf (and d_metas) */
     bool owns_metas = false; /* frees d_metas although d_buf is borrowed */
+    bool slack = false;      /* 64 readable bytes follow d_buf + buf_len (the library allocated the text): the kernels whose
+                                wide loads run past the last record may take the batch.  True for every batch that owns its
+                                text and for a view of such a batch (sq_batch_view) */
     std::vector<uint32_t> len_hist;   /* [SQ_LEN_BINS] reads per length (the last bin: 256 and more); empty: not counted */
     uint64_t total_bases = 0;
     uint64_t max_length = 0;

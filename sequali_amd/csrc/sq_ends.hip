@@ -2337,7 +2337,7 @@ static int isz_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2, cons
         hipLaunchKernelGGL(k_isz_adapters<true>, dim3(blocks_for(covered, 4 * ctx->num_cus)), dim3(256), 0, ctx->stream, A, scanned,
                            (uint32_t)b1->max_length, (uint32_t)b2->max_length);
         SQ_HIP(hipGetLastError());
-    } else if (b1->owns && b2->owns && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
+    } else if (b1->slack && b2->slack && b1->min_length == b1->max_length && b2->min_length == b2->max_length &&
         sq_knobs().span) {
         uint32_t *d_results = (uint32_t *)sq_scratch(ctx, 16, n * 4);
         if (d_results) {

@@ -411,7 +411,7 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     b->ctx = ctx;
     b->buf_len = fb->sealed_bytes;
     b->n = fb->n_records;
-    b->owns = true;
+    b->owns = b->slack = true;
     b->total_bases = fb->stats[0];
     b->max_length = fb->stats[1];
     b->max_name_length = fb->stats[2];

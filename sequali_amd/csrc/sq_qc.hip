@@ -2983,7 +2983,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
        still beat the one k_pass that carries all three (3.5 against 3.7 ms per 10 M reads) */
     /* ... and since k_span and k_ptspan (sq_span.hip) QCMetrics + PerTileQuality without the
        adapters too: 2.5 + 1.5 ms per 25 M reads against 7.0 for k_pass<QC,PT> */
-    if (m && p && !p->skipped && b->owns && b->n >= 4096 && b->min_length == b->max_length &&
+    if (m && p && !p->skipped && b->slack && b->n >= 4096 && b->min_length == b->max_length &&
         b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !K.no_wide && !K.ring &&
         !K.no_split && (a || (b->max_length <= 32u * SPAN_NW_MAX && K.span))) {
         /* without the adapters: PerTileQuality rides in QCMetrics' pass (sq_pair.hip) -- the tile ids from the header
@@ -3065,14 +3065,14 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     }
     /* reads of many lengths, none longer than k_span takes: sorted by length inside sq_span_launch_sorted */
     const bool span_sorted =
-        m && !pt_active && !stripes && !P.uniform_len && b->owns && b->min_length >= 1 && b->n < (1ull << 31) &&
+        m && !pt_active && !stripes && !P.uniform_len && b->slack && b->min_length >= 1 && b->n < (1ull << 31) &&
         (!a || a->groups[0].states <= DFA_LDS_MAX_STATES) && b->max_length <= 32u * (a ? (K.span_split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD) : SPAN_NW_MAX) &&
         K.span && !K.ring && !K.no_ring && !K.no_wide && K.wide < 0 &&
         (K.span_sorted >= 0 ? K.span_sorted != 0 : b->n >= 65536);
     /* PerTileQuality alone on a batch of one read length whose table fits LDS: k_ptspan streams the
        batch as it lies (no sort by tile) */
     uint64_t pt_covered = 0;
-    const bool ptspan = !m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes &&
+    const bool ptspan = !m && !a && pt_active && P.uniform_len && b->slack && b->n >= 64 && !stripes &&
                         p->n_slots > 0 && !K.no_ptq && K.span;
     if (ptspan) {
         int rc = sq_ptspan_launch(ctx, P, (uint32_t)p->n_slots, &pt_covered);
@@ -3153,7 +3153,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         P.pt_slot += pt_covered;
         P.first_read_index += pt_covered;
         P.n = b->n - pt_covered;
-    } else if (!m && !a && pt_active && P.uniform_len && b->owns && b->n >= 64 && !stripes && !K.no_ptq &&
+    } else if (!m && !a && pt_active && P.uniform_len && b->slack && b->n >= 64 && !stripes && !K.no_ptq &&
         ptq_lds_bytes(P.uniform_len) <= 80 * 1024) {
         PassParams C = P;
         C.n = (b->n / 64) * 64;
@@ -3223,7 +3223,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
 #ifdef SQ_SPAN_PROBE
             if (K.span_probe >= 0) S.blocked = (uint32_t)K.span_probe;   /* timing builds: DMA alone, counting alone (wrong tables) */
 #endif
-            int rc = sq_span_launch_sorted(ctx, S, ad, ad ? (uint32_t)a->groups[gi].count : 0, (uint32_t)b->max_length,
+            int rc = sq_span_launch_sorted(ctx, S, ad, ad ? (uint32_t)a->groups[gi].count : 0, (uint32_t)b->min_length, (uint32_t)b->max_length,
                                            S.n == b->n && S.metas == b->d_metas && b->len_hist.size() == SQ_LEN_BINS ? b->len_hist.data() : nullptr, &covered);
             if (rc) return rc;
             if (covered == b->n) continue;
@@ -3232,7 +3232,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         const bool uniform_fast = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && (!ad || dfa_lds);
         const bool wide_set = K.wide >= 0;
         const size_t wlds = wide_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
-        const bool wide = uniform_fast && b->owns && wlds <= 160 * 1024 && !K.no_wide &&
+        const bool wide = uniform_fast && b->slack && wlds <= 160 * 1024 && !K.no_wide &&
                           (ad ? !K.ring : K.wide > 0);
         const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
         const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !K.no_ring &&
@@ -3242,7 +3242,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
              Gbases/s at 150 against k_ring's 1020), with the automaton up to 160 (1015 against
              k_wide's 1000; adapters of up to 13 characters).  SQ_SPAN=0: the other two. */
         bool span_done = false;
-        if (uniform_fast && b->owns && K.span && !K.ring && !K.no_ring && !K.no_wide && !wide_set) {
+        if (uniform_fast && b->slack && K.span && !K.ring && !K.no_ring && !K.no_wide && !wide_set) {
             uint64_t covered = 0;
 #ifdef SQ_SPAN_PROBE
             if (K.span_probe >= 0) P.blocked = (uint32_t)K.span_probe;
@@ -3318,7 +3318,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         if (qc && segments) {
             /* (1) what is sequential per read; where k_span<LONG> takes the per-position pass it counts G/C per
                read on its way and this pass reads the qualities only */
-            const bool try_long = K.long_spans && K.span && b->owns &&
+            const bool try_long = K.long_spans && K.span && b->slack &&
                                   sq_span_long_takes(P, ad, ad ? (uint32_t)a->groups[0].count : 0, (uint32_t)b->max_length);
             /* SQ_LONG_OVERLAP: the sums BESIDE the pass, on a stream of their own -- k_read_sums streams the qualities at the
                speed of the memory with a few waves per CU, k_span<LONG> is bound by its instructions and leaves both free.  The
@@ -3486,7 +3486,7 @@ SQ_EXPORT int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1
 {
     const SqKnobs &K = sq_knobs();
     auto side = [](sq_batch *b, sq_qcmetrics *m, sq_pertile *p) -> int { return (m || p) ? sq_fused_add_batch(b, m, nullptr, p) : SQ_OK; };
-    auto uniform = [](const sq_batch *b) { return b->owns && b->n >= 4096 && b->min_length == b->max_length && b->max_length >= 16 && b->max_length <= 32u * SPAN_NW_MAX; };
+    auto uniform = [](const sq_batch *b) { return b->slack && b->n >= 4096 && b->min_length == b->max_length && b->max_length >= 16 && b->max_length <= 32u * SPAN_NW_MAX; };
     const bool fuse = K.pt_fused == 1 && K.span && !K.no_split && !K.no_wide && !K.ring && m1 && p1 && m2 && p2 && z && !p1->skipped && !p2->skipped &&
                       b1->n == b2->n && uniform(b1) && uniform(b2) && b1->n < (1ull << 32);
     if (!fuse) {

@@ -987,7 +987,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
  * and the reads of the lengths that share a window count go through one launch of
  * k_span<NW, ., SEG>, cut into spans of 16 reads of one length.  *done = records covered: all of
  * them or none. */
-int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, const uint32_t *len_hist, uint64_t *done)
+int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t min_len, uint32_t max_len, const uint32_t *len_hist, uint64_t *done)
 {
     *done = 0;
     const uint64_t n = P.n;
@@ -1000,7 +1000,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
        own: reads of 161-224 bases with adapters exist as a wave per stream only, the 4-window build of a wave per
        stream does not fit its registers) */
     bool split_of[SPAN_NW_MAX + 1] = {};
-    for (int nw = 1; nw <= (int)((max_len + 31) / 32); nw++) {
+    for (int nw = (int)((std::max(min_len, 1u) + 31) / 32); nw <= (int)((max_len + 31) / 32); nw++) {   /* (the window counts the batch's lengths span) */
         bool found = false;
         /* the build the default dispatch names for this window count (sequali_amd/build.py::default_route_builds fails
            the build when one of them spills): one wave for both streams, except where that build does not exist (the

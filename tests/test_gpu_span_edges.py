@@ -241,8 +241,9 @@ def test_few_very_long_reads_with_more_than_64_adapters():
     lens = rng.integers(300, 1500, size=n)
     lens[17] = 1_300_000
     lens[18] = 70_000
-    # the first group of 64 must fit k_span's automaton (336 states of the two-character one): all 64 three-letter words
-    adapters = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT"]
+    # the first group of 64 must fit k_span's automaton (336 states of the two-character one; all 64 three-letter words
+    # alone make 409, counted on the host with sq_adapter_automaton_tables): twelve letters, the first nine shared: 244
+    adapters = ["GATTACAGA" + a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT"]
     while len(adapters) < 70:
         w = rng.choice(LETTERS, size=int(rng.integers(8, 13))).tobytes().decode()
         if w not in adapters:
