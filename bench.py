@@ -264,7 +264,7 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                 "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del batches
     # ---- ragged: the config-2 records cut to 50 .. 150 bases (what adapter trimming leaves) ----
-    if wanted("ragged_50_150") or wanted("ragged_50_150_side_streams"):
+    if wanted("ragged_50_150"):
         n, per = 50_000_000, 25_000_000
         batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
         for k, b in enumerate(batches):
@@ -276,38 +276,26 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                 f.add_record_array(b)
                 clear(f)
 
-        # the second entry: the same pass with its four launches on streams of their own (SQ_SORTED_STREAMS=1, opt-in:
-        # written in round 4 without a GPU; the entry is there to measure it)
-        for entry, env in (("ragged_50_150", None), ("ragged_50_150_side_streams", "SQ_SORTED_STREAMS")):
-            if not wanted(entry):
-                continue
-            if env:
-                os.environ[env] = "1"
-                lib.sq_knobs_reload()
-            try:
-                out[entry] = run(
-                    "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
-                    "QCMetrics + AdapterCounter fused, records resident in HBM" + (f", {env}=1" if env else ""),
-                    "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
-                    lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
-                    lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                                       "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
-            finally:
-                if env:
-                    os.environ.pop(env, None)
-                    lib.sq_knobs_reload()
+        out["ragged_50_150"] = run(
+            "ragged", f"{n} synthetic reads of 50..150 bases (the 150 bp records cut by a hash of the record index), "
+            "QCMetrics + AdapterCounter fused, records resident in HBM",
+            "k_span<NW,AD,SEG> x 4 window counts (rows in order of length, spans of 16 reads of one length; k_span_scatter in front: the batch knows how many reads have each length)", (bases, n, 2 * bases + 48 * n),
+            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES))), ragged_step,
+            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del batches
     # ---- config 3: 100 M pairs, (QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics ----
-    # three entries: the reads with a random tile each (what rounds 1-3 measured), the same pairs in the order a sequencer
-    # writes them (65536 reads of a tile in a row), and that order through the paired pass (PairedPass, SQ_PT_FUSED=1:
-    # PerTileQuality and the overlap scan ride in QCMetrics' passes, csrc/sq_pair.hip; opt-in until it has met the oracle on
-    # a GPU)
+    # three entries: the reads with a random tile each (SURVEY 8d's generator: the config BASELINE.json names), the same pairs in the
+    # order a sequencer writes them (65536 reads of a tile in a row) -- both through PairedPass, what the driver calls per pair of
+    # arrays (sq_paired_add_batches: PerTileQuality's tile ids and the overlap scan ride in QCMetrics' passes, csrc/sq_pair.hip;
+    # reads of one tile in a row also keep PerTileQuality's sums in the pass) -- and the random tiles through the five separate
+    # calls of the reference's driver loop with SQ_PT_FUSED=0 (the seven passes of rounds 1-3, for comparison)
     from sequali_amd import PairedPass
     n, per = 100_000_000, 25_000_000
     name_len = 36
-    for entry, kinds, fused in (("config3_paired", (synth.ILLUMINA, synth.ILLUMINA_R2), False),
-                                ("config3_paired_by_tile", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), False),
-                                ("config3_paired_by_tile_fused", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), True)):
+    for entry, kinds, fused in (("config3_paired", (synth.ILLUMINA, synth.ILLUMINA_R2), True),
+                                ("config3_paired_by_tile", (synth.ILLUMINA_BY_TILE, synth.ILLUMINA_R2_BY_TILE), True),
+                                ("config3_paired_five_calls_unfused", (synth.ILLUMINA, synth.ILLUMINA_R2), False)):
         if not wanted(entry):
             continue
         r1 = [synth.device_array(kinds[0], k * per, per) for k in range(n // per)]
@@ -338,22 +326,22 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                     "pertile_reads_ok": bool(fa.per_tile_quality.number_of_reads == n * passes and fb.per_tile_quality.number_of_reads == n * passes),
                     "insert_size_pairs_ok": bool(isz.total_reads == n * passes)}
 
-        if fused:
-            os.environ["SQ_PT_FUSED"] = "1"
+        if not fused:
+            os.environ["SQ_PT_FUSED"] = "0"
             lib.sq_knobs_reload()
         try:
             out[entry] = run(
                 "config3", f"{n} x 150 bp synthetic pairs ({'reads tile by tile, 65536 in a row' if kinds[0] != synth.ILLUMINA else 'a random tile per read'}), "
-                "(QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM" + (", through PairedPass with SQ_PT_FUSED=1" if fused else ""),
+                "(QCMetrics + PerTileQuality) x 2 + InsertSizeMetrics, records resident in HBM" + (", through PairedPass" if fused else ", five calls per pair of arrays, SQ_PT_FUSED=0"),
                 "the kernels `route` names", (bases, 2 * n, 2 * bases + (48 + name_len) * 2 * n),
                 c3_make, c3_step_fused if fused else c3_step, c3_check)
         finally:
-            if fused:
+            if not fused:
                 os.environ.pop("SQ_PT_FUSED", None)
                 lib.sq_knobs_reload()
         del r1, r2
     # ---- config 4: 1 M x ~10 kb nanopore reads, QCMetrics + AdapterCounter (14 probes) ----
-    if wanted("config4_nanopore") or wanted("config4_nanopore_sums_beside"):
+    if wanted("config4_nanopore"):
         n = 1_000_000
         arr = synth.device_array(synth.NANOPORE, 0, n)
         bases = arr._batch.total_bases
@@ -362,26 +350,12 @@ def other_configs(lib, ctx, steps, warmup, only=None):
             f.add_record_array(arr)
             clear(f)
 
-        # the second entry: k_read_sums on a stream of its own beside k_span<LONG> (SQ_LONG_OVERLAP=1, opt-in: written in round 4
-        # without a GPU; the entry is there to measure it)
-        for entry, env in (("config4_nanopore", None), ("config4_nanopore_sums_beside", {"SQ_LONG_OVERLAP": "2", "SQ_SPAN_WAVES": "8"})):
-            if not wanted(entry):
-                continue
-            if env:
-                os.environ.update(env)
-                lib.sq_knobs_reload()
-            try:
-                out[entry] = run(
-                    "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM" + (f", {env}" if env else ""),
-                    "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
-                    lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
-                    lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
-                                       "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
-            finally:
-                if env:
-                    for k in env:
-                        os.environ.pop(k, None)
-                    lib.sq_knobs_reload()
+        out["config4_nanopore"] = run(
+            "config4", f"{n} synthetic nanopore reads (~10 kb, 200 .. 100000), QCMetrics + AdapterCounter (14 probes), records resident in HBM",
+            "k_span<8,AD,LONG> (segments of 256 positions of the reads sorted by length, streamed through LDS; + k_read_sums for the per-read chains, k_long_ea, k_long_gc_bins, k_adapter_first)", (bases, n, 2 * bases + 48 * n),
+            lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.NANOPORE_PROBES))), c4_step,
+            lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
+                               "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del arr
     # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
     if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split"):

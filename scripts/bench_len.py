@@ -24,7 +24,12 @@ buf[:, 2 + name:2 + name + L] = rng.choice(np.frombuffer(b"ACGT", np.uint8), siz
 buf[:, 2 + name + L] = 10; buf[:, 3 + name + L] = ord("+"); buf[:, 4 + name + L] = 10
 buf[:, 5 + name + L:5 + name + 2 * L] = rng.integers(35, 74, size=(n, L), dtype=np.uint8)
 buf[:, -1] = 10
-probe = np.frombuffer(synth.ILLUMINA_PROBES[0].encode(), np.uint8)
+# SQ_BENCH_PROBES=long: the six probes with eight more letters each (20 characters: the adapter lengths k_span takes only
+# in its six-dword builds, csrc/sq_span_w6.hip)
+PROBES = list(synth.ILLUMINA_PROBES)
+if os.environ.get("SQ_BENCH_PROBES") == "long":
+    PROBES = [p + "ACGTTGCA"[i % 8:] + "ACGTTGCA"[:i % 8] for i, p in enumerate(PROBES)]
+probe = np.frombuffer(PROBES[0].encode(), np.uint8)
 hit = rng.random(n) < 0.05
 at = rng.integers(0, L - len(probe), size=n)
 for i in np.nonzero(hit)[0][:50000]:
@@ -37,8 +42,8 @@ metas["sequence_length"] = L
 metas["qualities_offset"] = name + 1 + L + 3
 metas["tags_offset"] = name + 1 + L + 3 + L
 arr = FastqRecordArrayView._from_buffer(buf.tobytes(), metas)
-for label, make in (("QCMetrics + AdapterCounter", lambda: FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))),
-                    ("QCMetrics alone", lambda: FusedPass(QCMetrics(), None))):
+for label, make in ((f"QCMetrics + AdapterCounter ({len(PROBES[0])}-mers)", lambda: FusedPass(QCMetrics(), AdapterCounter(PROBES))),
+                    ("QCMetrics alone", lambda: FusedPass(QCMetrics(), None)))[:1 if os.environ.get("SQ_BENCH_PROBES") else 2]:
     f = make()
     f.add_record_array(arr); f.qc_metrics.flush(); _lib.synchronize()
     lib().sq_route_reset(context())

@@ -27,15 +27,15 @@ PY
 }
 : > $OUT/summary.txt
 run headline--no-other                  -- --no-other-configs
-run config4_default                     -- --configs config4_nanopore,config4_nanopore_sums_beside
+run config4_default                     -- --configs config4_nanopore
 run config4_block1024   SQ_LONG_BLOCK=1024 -- --configs config4_nanopore
 run config4_block4096   SQ_LONG_BLOCK=4096 -- --configs config4_nanopore
 run config4_block16384  SQ_LONG_BLOCK=16384 -- --configs config4_nanopore
 run config4_beside1_w10 SQ_LONG_OVERLAP=1 -- --configs config4_nanopore
 run config4_beside2_w8  SQ_LONG_OVERLAP=2 SQ_SPAN_WAVES=8 -- --configs config4_nanopore
 run config4_beside4_w8  SQ_LONG_OVERLAP=4 SQ_SPAN_WAVES=8 -- --configs config4_nanopore
-run ragged                              -- --configs ragged_50_150,ragged_50_150_side_streams
-run config3                             -- --configs config3_paired,config3_paired_by_tile,config3_paired_by_tile_fused
+run ragged                              -- --configs ragged_50_150
+run config3                             -- --configs config3_paired,config3_paired_by_tile,config3_paired_five_calls_unfused
 run uniform_250_w6      SQ_SPAN_W6=1    -- --configs uniform_250bp,uniform_200bp
 run uniform_250                         -- --configs uniform_250bp,uniform_200bp
 cat $OUT/summary.txt

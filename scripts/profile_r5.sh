@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r5
 mkdir -p $OUT
-WHAT="${@:-stats headline uniform_200bp uniform_250bp ragged_50_150 config3_paired config3_paired_by_tile config3_paired_by_tile_fused config4_nanopore}"
+WHAT="${@:-stats headline uniform_200bp uniform_250bp ragged_50_150 config3_paired config3_paired_by_tile config3_paired_five_calls_unfused config4_nanopore}"
 SMALL="--steps 1 --warmup 1 --cpu-sample 0 --reads 25000000"
 stats() {   # $1: tag, rest: bench.py arguments
   tag=$1; shift
@@ -37,7 +37,7 @@ for w in $WHAT; do
       stats $w $SMALL --configs $w
       pmc ${w}_f FETCH_SIZE $SMALL --configs $w
       pmc ${w}_w WRITE_SIZE $SMALL --configs $w
-      case $w in config3_paired_by_tile_fused)
+      case $w in config3_paired)
         pmc ${w}_a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" $SMALL --configs $w
         pmc ${w}_b "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAVES" $SMALL --configs $w ;;
       esac ;;

@@ -41,9 +41,9 @@ static void knobs_load()
     k.span_sorted_split = num("SQ_SPAN_SORTED_SPLIT", 0) != 0;
     k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
     k.span_split_qc = num("SQ_SPAN_SPLIT_QC", 0) != 0;
-    k.span_w6 = flag("SQ_SPAN_W6");
+    k.span_w6 = num("SQ_SPAN_W6", -1);
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
-    k.pt_fused = num("SQ_PT_FUSED", 0);
+    k.pt_fused = num("SQ_PT_FUSED", 1);
     k.span_waves = num("SQ_SPAN_WAVES", 0);
     k.span_probe = num("SQ_SPAN_PROBE", -1);
     k.span_stamps = flag("SQ_SPAN_STAMPS");
@@ -59,9 +59,6 @@ static void knobs_load()
     k.long_spans = num("SQ_LONG", 1) != 0;
     k.long_nw = num("SQ_LONG_NW", 8);
     k.long_stretch_cost = num("SQ_LONG_STRETCH_COST", 16);
-    k.long_block = num("SQ_LONG_BLOCK", 0);
-    k.sorted_streams = flag("SQ_SORTED_STREAMS");
-    k.long_overlap = num("SQ_LONG_OVERLAP", 0);
     k.lds_pad = num("SQ_LDS_PAD", 0);
     k.probe_mode = num("SQ_PROBE_MODE", -1);
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
@@ -114,11 +111,6 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
     if (ctx->copied) (void)hipEventDestroy(ctx->copied);
-    for (hipStream_t st : ctx->side_streams)
-        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    if (ctx->side_ready) (void)hipEventDestroy(ctx->side_ready);
-    for (hipEvent_t e : ctx->side_done)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_stats) (void)hipHostFree(ctx->pinned_stats);
     for (void *p : ctx->scratch)

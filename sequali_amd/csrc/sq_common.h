@@ -54,7 +54,7 @@ void sq_set_error(const char *fmt, ...);
 struct SqKnobs {
     bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
     int span_sorted = -1, span_waves = 0, span_probe = -1;
-    bool span_w6 = false;      /* SQ_SPAN_W6: adapters of 14 .. 25 characters through k_span (sq_span_w6.hip) instead of k_wide; opt-in until checked on a GPU */
+    int span_w6 = -1;          /* SQ_SPAN_W6: adapters of 14 .. 25 characters through k_span (sq_span_w6.hip) instead of k_wide / k_pass.  -1 (default, measured in round 5, scripts/exp_w6.sh): batches of one read length from 129 bases on (914 / 910 / 1029 against k_wide's 876 / 830 / 901 Gbases/s at 150 / 200 / 224 bases; at 100 bases k_wide's 776 against 694) and every length-sorted batch (the alternative there is k_pass); 0: never; 1: wherever a build exists */
     bool span_split_qc = false;   /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream too */
     bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
     bool span_sorted_split = false;   /* SQ_SPAN_SORTED_SPLIT: the length-sorted route with a wave per stream */
@@ -63,14 +63,11 @@ struct SqKnobs {
     int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
     bool no_wide = false, ring = false, no_ring = false, no_split = false;
     bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
-    int pt_fused = 0;          /* SQ_PT_FUSED: 1: PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan.  Default 0 until the new pass has met the oracle on a GPU (round 4 lost its GPU access before tests/test_gpu_pair.py had run: DESIGN 5.0) */
+    int pt_fused = 1;          /* SQ_PT_FUSED: 1 (default since round 5: tests/test_gpu_pair.py is green on a GPU): PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan */
     bool pt_prep_inline = false;   /* SQ_PT_PREP_INLINE: PerTileQuality's pass over the headers on the work stream (round 2) */
     bool long_spans = true;
     int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
     int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
-    int long_block = 0;        /* SQ_LONG_BLOCK: k_span<LONG> walks the sorted reads in blocks of that many reads, all segments of a block before the next block (0: all reads' segment 0, then all reads' segment 1, ..) */
-    int long_overlap = 0;          /* SQ_LONG_OVERLAP=W: k_read_sums on a stream of its own, W workgroups per CU, BESIDE k_span<LONG> instead of in front of it (the one reads qualities at the speed of the memory, the other is bound by its instructions); a batch the sums then flag has the pass taken back (PassParams::negate) */
-    bool sorted_streams = false;   /* SQ_SORTED_STREAMS: the launches of the length-sorted route (one per window count) on streams of their own, so that one launch's last workgroups do not stand between it and the next */
     int lds_pad = 0, probe_mode = -1;
     bool dedup_sequential = false, dedup_debug = false;
 };
@@ -105,8 +102,6 @@ struct sq_ctx {
     hipStream_t copy_stream = nullptr;   /* uploads of FASTQ text (sq_batch_from_fastq): they run beside the counting of the batch before */
     hipEvent_t copied = nullptr;
     hipStream_t prep_stream = nullptr;   /* PerTileQuality's pass over the headers (tile ids, table slots): it runs beside the counting of the batch before */
-    hipStream_t side_streams[7] = {};    /* SQ_SORTED_STREAMS: made on first use */
-    hipEvent_t side_ready = nullptr, side_done[7] = {};
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */
     uint64_t *pinned = nullptr; /* 64 words */

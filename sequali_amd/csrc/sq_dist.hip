@@ -15,12 +15,15 @@
  * points (include/sqgpu.h "multi-GPU"); their collectives are ragged gathers of small candidate lists, which
  * sq_rccl_allgather_bytes serves.
  *
- * No N > 1 run over RCCL has happened yet (no node with more than one GPU has been available to this build): these
- * entry points compile, load their symbols and fail loudly without a device; tests/test_boundary_cpu.py checks that much.
+ * No N > 1 run over RCCL has happened yet (no node with more than one GPU has been available to this build).  What has
+ * run: a communicator of ONE rank on one MI355X (tests/test_gpu_rccl.py: ncclCommInitRank, the grouped all-reduces of
+ * both modules, the all-gather); the enum values below are pinned against rccl.h where the header is installed
+ * (tests/test_boundary_cpu.py).
  */
 #include <dlfcn.h>
 
 #include <mutex>
+#include <string>
 
 #include "sq_common.h"
 
@@ -51,10 +54,13 @@ Rccl *rccl()
 {
     static Rccl R;
     static std::once_flag once;
+    static std::string why;   /* what dlopen / dlsym said, kept: dlerror() answers once and forgets */
     std::call_once(once, [] {
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (R.handle) break;
+            const char *e = dlerror();
+            why = e ? e : "dlopen failed";
         }
         if (!R.handle) return;
         auto sym = [&](const char *n) { return dlsym(R.handle, n); };
@@ -69,10 +75,11 @@ Rccl *rccl()
         if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.AllGather || !R.GroupStart || !R.GroupEnd) {
             dlclose(R.handle);
             R.handle = nullptr;
+            why = "one of ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllReduce, ncclAllGather, ncclGroupStart, ncclGroupEnd is missing";
         }
     });
     if (!R.handle) {
-        sq_set_error("librccl.so could not be loaded: %s", dlerror() ? dlerror() : "a symbol is missing");
+        sq_set_error("librccl.so could not be loaded: %s", why.c_str());
         return nullptr;
     }
     return &R;

@@ -1592,7 +1592,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
     const uint32_t l_row = (uint32_t)lane >> 2, piece16 = ((uint32_t)lane & 3) * 16;
 
     const uint64_t ngroups = P.n / 64;
-    const uint64_t n_waves = (uint64_t)gridDim.x * WIDE_WAVES, wave_id = (uint64_t)blockIdx.x * WIDE_WAVES + wave;
+    /* the wave's number as a scalar (hipcc does not know that tid >> 6 is uniform): the group counter g lives in scalar registers instead of
+       in a vector pair that was spilled across the chunk loop */
+    const uint64_t n_waves = (uint64_t)gridDim.x * WIDE_WAVES, wave_id = (uint64_t)blockIdx.x * WIDE_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     const uint32_t c_last = WIDE_CW * ((U - 1) / WIDE_CW);   /* the chunk that holds the end of the reads */
 
     /* One pipeline over all (group, chunk) steps of the wave: the loads of the step after the
@@ -1631,10 +1633,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
         fetch(0);
     }
     while (g < ngroups) {
-        const uint64_t r = g * 64 + lane;
         const bool has_next = g + n_waves < ngroups;
         if (has_next) {
-            const sq_meta m = P.metas[r + n_waves * 64];
+            uint32_t lane_n = (uint32_t)lane;   /* opaque: the lane's part of the address is made here (kept across the loop it was spilled) */
+            asm volatile("" : "+v"(lane_n));
+            const sq_meta m = P.metas[(g + n_waves) * 64 + lane_n];
             soff_n = m.record_start + m.sequence_offset;
             qoff_n = m.record_start + m.qualities_offset;
         }
@@ -1774,10 +1777,15 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
             total += l_err[(qt >> 16) & 0xFF];
             total += l_err[qt >> 24];
         }
-        P.metas[r].accumulated_error_rate = total; /* :2126 */
-        if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r));
+        uint32_t lane_e = (uint32_t)lane;   /* the record's index made again (kept from the top of the group it was spilled across the chunk loop) */
+        asm volatile("" : "+v"(lane_e));
+        const uint64_t r_e = g * 64 + lane_e;
+        P.metas[r_e].accumulated_error_rate = total; /* :2126 */
+        if (total != total) atomicMin(P.qc_first_bad, (unsigned long long)(P.first_read_index + r_e));
         if (acgt_cnt > 0) atomicAdd(&l_gc[(uint32_t)round((double)gc_cnt * 100.0 / (double)acgt_cnt)], 1u);
-        const double avg = total / (double)U;
+        uint32_t Ud = U;   /* opaque: (double)U kept across the loop was spilled to scratch and reloaded here behind an s_waitcnt vmcnt(0) */
+        asm volatile("" : "+s"(Ud));
+        const double avg = total / (double)Ud;
         uint32_t lo = 0, hi = 93;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
@@ -1792,8 +1800,10 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
 
     /* ---- merge the workgroup's histograms (end-anchored = a window of the positional) ---- */
     __syncthreads();
+    uint32_t tid_e = threadIdx.x;   /* made again here: what the merge derives from the thread's index was kept from the top of the kernel and spilled across the whole loop */
+    asm volatile("" : "+v"(tid_e));
     if (AD)
-        for (uint32_t i = tid; i < P.ad_lds * hs; i += WIDE_THREADS) {
+        for (uint32_t i = tid_e; i < P.ad_lds * hs; i += WIDE_THREADS) {
             const uint32_t v = l_adf[i];
             if (!v) continue;
             const uint32_t a = i / hs, start = i % hs;
@@ -1801,21 +1811,21 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_wide(PassParams P)
             atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
         }
     const uint32_t ean = min(P.ea_len, U);
-    for (uint32_t i = tid; i < hs * BASE_COLS; i += WIDE_THREADS) {
+    for (uint32_t i = tid_e; i < hs * BASE_COLS; i += WIDE_THREADS) {
         const uint32_t v = l_hist_base[i], c = i / hs, pos = i % hs;
         if (!v || pos >= U) continue; /* columns behind U collected the padding */
         atomicAdd(&P.qc_base[(uint64_t)pos * 5 + c], (unsigned long long)v);
         if (pos >= U - ean) atomicAdd(&P.qc_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + c], (unsigned long long)v);
     }
-    for (uint32_t i = tid; i < hs * PHRED_COLS; i += WIDE_THREADS) {
+    for (uint32_t i = tid_e; i < hs * PHRED_COLS; i += WIDE_THREADS) {
         const uint32_t v = l_hist_phred[i], c = i / hs, pos = i % hs;
         if (!v || pos >= U) continue;
         atomicAdd(&P.qc_phred[(uint64_t)pos * 12 + c], (unsigned long long)v);
         if (pos >= U - ean) atomicAdd(&P.qc_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + c], (unsigned long long)v);
     }
-    for (uint32_t i = tid; i < 101; i += WIDE_THREADS)
+    for (uint32_t i = tid_e; i < 101; i += WIDE_THREADS)
         if (l_gc[i]) atomicAdd(&P.qc_gc[i], (unsigned long long)l_gc[i]);
-    for (uint32_t i = tid; i < 94; i += WIDE_THREADS)
+    for (uint32_t i = tid_e; i < 94; i += WIDE_THREADS)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
@@ -3320,30 +3330,10 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                read on its way and this pass reads the qualities only */
             const bool try_long = K.long_spans && K.span && b->slack &&
                                   sq_span_long_takes(P, ad, ad ? (uint32_t)a->groups[0].count : 0, (uint32_t)b->max_length);
-            /* SQ_LONG_OVERLAP: the sums BESIDE the pass, on a stream of their own -- k_read_sums streams the qualities at the
-               speed of the memory with a few waves per CU, k_span<LONG> is bound by its instructions and leaves both free.  The
-               pass then runs before anybody knows whether the batch holds an invalid byte; if it does, the same launch with its
-               merges negated takes the counts back (integers: exactly) and the batch goes the way it goes today. */
-            const bool beside = try_long && K.long_overlap > 0;
-            hipStream_t sums_stream = ctx->stream;
-            if (beside) {
-                if (!ctx->side_ready) SQ_HIP(hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming));
-                if (!ctx->side_streams[0]) SQ_HIP(hipStreamCreateWithFlags(&ctx->side_streams[0], hipStreamNonBlocking));
-                if (!ctx->side_done[0]) SQ_HIP(hipEventCreateWithFlags(&ctx->side_done[0], hipEventDisableTiming));
-                sums_stream = ctx->side_streams[0];
-                SQ_HIP(hipEventRecord(ctx->side_ready, ctx->stream));   /* the batch, its order by length and the tables are in place */
-                SQ_HIP(hipStreamWaitEvent(sums_stream, ctx->side_ready, 0));
-            }
-            sq_route(ctx, beside ? "k_read_sums<qualities,beside>" : try_long ? "k_read_sums<qualities>" : "k_read_sums<GC>");
+            sq_route(ctx, try_long ? "k_read_sums<qualities>" : "k_read_sums<GC>");
             if (try_long) {
-                /* beside the pass: SQ_LONG_OVERLAP workgroups per CU, no more -- a grid that fills the chip would keep the pass's
-                   workgroups (130 KB of LDS, ten waves of 136 registers each) waiting for CUs until the sums are done.  What
-                   fits beside them: this kernel's waves hold 120 registers; a SIMD with three of the pass's waves has 104 left,
-                   one with two has 240 (SQ_SPAN_WAVES=8: two on every SIMD) */
-                const uint64_t sums_grid = beside ? (uint64_t)ctx->num_cus * (uint64_t)K.long_overlap : 4096;
-                hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, sums_grid)), dim3(256), 0,
-                                   sums_stream, P);
-                if (beside) SQ_HIP(hipEventRecord(ctx->side_done[0], sums_stream));
+                hipLaunchKernelGGL(k_read_sums<false>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
+                                   ctx->stream, P);
             } else
                 hipLaunchKernelGGL(k_read_sums<true>, dim3((unsigned)std::min<uint64_t>((b->n + 63) / 64, 4096)), dim3(256), 0,
                                    ctx->stream, P);
@@ -3353,36 +3343,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                one 8-byte read-back) keeps k_seg, whose counts k_qc_uncount knows how to take back.
                SQ_LONG=0: k_seg for all */
             const uint32_t n_ad_long = ad ? (uint32_t)a->groups[0].count : 0;
-            if (beside) {
-                PassParams Lp = P;
-                if (ad) {
-                    Lp.long_first = (unsigned int *)sq_scratch(ctx, 5, b->n * n_ad_long * 4);
-                    if (!Lp.long_first) { (void)hipStreamWaitEvent(ctx->stream, ctx->side_done[0], 0); sq_set_error("out of device memory for the adapter candidates"); return SQ_ERR_MEMORY; }
-                    SQ_HIP(hipMemsetAsync(Lp.long_first, 0xFF, b->n * n_ad_long * 4, ctx->stream));
-                }
-                uint64_t covered = 0;
-                int rc = sq_span_launch_long(ctx, Lp, ad, n_ad_long, (uint32_t)b->max_length, &covered, 1);
-                SQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_done[0], 0));   /* whatever follows on the work stream follows the sums too */
-                if (rc) return rc;
-                SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-                SQ_HIP(hipStreamSynchronize(ctx->stream));
-                if (covered == b->n && ctx->pinned[9] == UINT64_MAX) {
-                    rc = sq_span_long_followups(ctx, Lp);
-                    if (rc) return rc;
-                    if (ad)
-                        hipLaunchKernelGGL(k_adapter_first, dim3((unsigned)std::min<uint64_t>((b->n * n_ad_long + 255) / 256, 8192)),
-                                           dim3(256), 0, ctx->stream, Lp.long_first, b->d_metas, (uint64_t)b->n, n_ad_long, P.ad_len,
-                                           P.ad_fwd, P.ad_rev, P.ad_cap);
-                    SQ_HIP(hipGetLastError());
-                    continue;
-                }
-                if (covered == b->n) {   /* counted, and flagged: taken back */
-                    sq_route(ctx, "taken_back");
-                    rc = sq_span_launch_long(ctx, Lp, ad, n_ad_long, (uint32_t)b->max_length, &covered, 2);
-                    if (rc) return rc;
-                }
-                hipLaunchKernelGGL(k_read_gc, dim3((unsigned)std::min<uint64_t>((b->n + 3) / 4, 4096)), dim3(256), 0, ctx->stream, P);
-            } else if (try_long) {
+            if (try_long) {
                 SQ_HIP(hipMemcpyAsync(&ctx->pinned[9], m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
                 SQ_HIP(hipStreamSynchronize(ctx->stream));
                 if (ctx->pinned[9] == UINT64_MAX) {

@@ -155,7 +155,8 @@ int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, 
     /* the restart in front of a lane's quarter holds >= maxlen - 1 positions: three dwords (adapters of up to 13
        characters) in the builds of this file, six (up to 25) in those of sq_span_w6.hip */
     if (span_needs_w6(P, ad)) {
-        if (!sq_knobs().span_w6 || (P.ad_maxlen + 2) / 4 > 6 || !sq_span_w6_exists(nw, seg, split)) return 0;
+        const int w6 = sq_knobs().span_w6;
+        if (w6 == 0 || (w6 < 0 && !seg && nw < 5) || (P.ad_maxlen + 2) / 4 > 6 || !sq_span_w6_exists(nw, seg, split)) return 0;
         if (!sq_knobs().span_spills_ok && sq_span_w6_spills(nw, seg, split)) return 0;
     } else if (!sq_knobs().span_spills_ok &&
         (seg ? (split ? span_build_spills_any<true, true>(nw, ad) : span_build_spills_any<true, false>(nw, ad))
@@ -860,16 +861,10 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     SQ_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<SpanSeg> segs;
     uint64_t spans = 0;
-    /* The order of the stretches.  Segment j of ALL reads, then segment j + 1 of all reads (one stretch per j): the
-       128-byte line that segments j and j + 1 of a read share (rows of 272 bytes start anywhere), and the 16 bases in
-       front of a segment, come from HBM twice -- half a GB of other rows has gone through the caches in between
-       (k_span<8,AD,LONG> fetched 33 GB for 19 GB of records, profiles/r3/pmc_all.txt).  SQ_LONG_BLOCK = B: the sorted
-       reads in blocks of B, all segments of a block before the next block -- a block's segment j + 1 follows its segment j
-       B / 16 spans later (B = 4096: 2 MB of rows), while the lines are still in the L2 / the 256 MB of MALL.  The rows are
-       sorted longest first, so the reads of a block that reach segment j are a prefix of the block: no new table, the
-       kernel is the same (SpanSeg::first).  More stretches (blocks x segments instead of segments): the workgroups'
-       shares go by cost as before. */
-    const uint64_t block = sq_knobs().long_block > 0 ? (uint64_t)std::max(sq_knobs().long_block, 256) / SPAN_R * SPAN_R : n;
+    /* The order of the stretches: segment j of ALL reads, then segment j + 1 of all reads (one stretch per j).  (Walking the sorted
+       reads in blocks, all segments of a block before the next block -- so that the line two segments of a read share is still
+       cached -- measured 2-38 % SLOWER at blocks of 16 K-1 K reads: round 5, scripts/exp_r5.sh; removed.) */
+    const uint64_t block = n;
     for (uint64_t b0 = 0; b0 < n; b0 += block) {
         for (uint32_t j = 0; j < n_segs && counts[j] > b0; j++) {
             const uint64_t count = std::min<uint64_t>(block, counts[j] - b0);   /* reads of the block that are longer than 256 j */
@@ -962,7 +957,7 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
-    if (ad && nw >= 8) return SQ_OK;   /* 225-256 positions with adapters: k_wide is 9 % ahead of the 8-wave build (scripts/bench_len.py); that build serves the sorted route */
+    if (ad && nw >= 8) return SQ_OK;   /* 225-256 positions with adapters: k_wide is 3-11 % ahead of the 8-wave build (scripts/bench_len.py; round 5 again: 932 / 918 / 950 against 839 / 895 / 908 Gbases/s at 240 / 250 / 256 bases, profiles/r5/exp_w6.txt); that build serves the sorted route */
     bool split = sq_knobs().span_split && (ad || sq_knobs().span_split_qc);   /* QCMetrics alone: one wave for both streams was 2-3 % ahead (SQ_SPAN_SPLIT_QC=1: a wave per stream there too) */
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
@@ -1080,21 +1075,6 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     std::vector<SpanSeg> all_segs;
     for (const Launch &l : launches) all_segs.insert(all_segs.end(), l.segs.begin(), l.segs.end());
     SQ_HIP(hipMemcpyAsync(d_segs, sq_host_keep(ctx, all_segs.data(), all_segs.size() * sizeof(SpanSeg)), all_segs.size() * sizeof(SpanSeg), hipMemcpyHostToDevice, ctx->stream));
-    /* SQ_SORTED_STREAMS: every launch behind the first on a stream of its own.  The launches share nothing but
-       read-only rows and the device tables they add to at their ends (atomics); side by side, the workgroups of
-       the next launch take the CUs the last workgroups of this one leave idle.  The work stream waits for all of
-       them before anything behind this pass runs. */
-    const bool fan = sq_knobs().sorted_streams && launches.size() > 1 && launches.size() <= 8;
-    hipStream_t work = ctx->stream;
-    if (fan) {
-        if (!ctx->side_ready) SQ_HIP(hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming));
-        for (size_t i = 0; i + 1 < launches.size(); i++) {
-            if (!ctx->side_streams[i]) SQ_HIP(hipStreamCreateWithFlags(&ctx->side_streams[i], hipStreamNonBlocking));
-            if (!ctx->side_done[i]) SQ_HIP(hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming));
-        }
-        SQ_HIP(hipEventRecord(ctx->side_ready, work));   /* the rows and the segments are in place */
-    }
-    size_t li = 0;
     for (const Launch &l : launches) {
         PassParams C = P;
         C.uniform_len = 0;
@@ -1106,22 +1086,11 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         const size_t lds = span_lds_layout(l.nw, 32 * l.nw, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, l.waves, true, split).total;
         const int seqs = split ? l.waves / 2 : l.waves;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)l.spans + seqs - 1) / seqs, (uint64_t)ctx->num_cus));
-        const bool aside = fan && li > 0;
-        if (aside) {
-            ctx->stream = ctx->side_streams[li - 1];
-            if (hipStreamWaitEvent(ctx->stream, ctx->side_ready, 0) != hipSuccess) { ctx->stream = work; sq_set_error("hipStreamWaitEvent failed"); return SQ_ERR_HIP; }
-        }
         int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(l.nw, true, split, ctx, C, n_ad, l.waves, lds, grid)
                                       : split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
-        if (aside) {
-            const hipError_t e = hipEventRecord(ctx->side_done[li - 1], ctx->stream);
-            ctx->stream = work;
-            if (e != hipSuccess || hipStreamWaitEvent(work, ctx->side_done[li - 1], 0) != hipSuccess) { sq_set_error("the side stream of the sorted route could not be joined"); return SQ_ERR_HIP; }
-        }
         if (rc) return rc;
         span_print_stamps(ctx, l.nw);
         seg_off += l.segs.size();
-        li++;
     }
     *done = n;
     return SQ_OK;

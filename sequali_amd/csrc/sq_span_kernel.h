@@ -245,17 +245,23 @@ __device__ __forceinline__ uint32_t pair_nonzero_bytes_of(uint32_t v)
 {
     return (uint32_t)__popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
 }
-/* NUCLEOTIDE_COMPLEMENT, _qcmodule.c:5613-5631: reverse complement of 8 bases (0 for what is no base) */
+/* NUCLEOTIDE_COMPLEMENT, _qcmodule.c:5613-5631: reverse complement of 8 bases (0 for what is no base).  Four bases per
+   v_perm, as cls6_of_dword looks its classes up: the low three bits of a letter name the complement and the letter itself
+   (A 1, C 3, G 7, T 4); what is not that letter (either case) gives 0; the last v_perm turns the four bytes round.  (Byte by
+   byte with compares this took 112 instructions per lane and span, a seventh of the scan.) */
+__device__ __forceinline__ uint32_t pair_revcomp4(uint32_t w)
+{
+    const uint32_t idx = w & 0x07070707u;
+    const uint32_t comp = __builtin_amdgcn_perm(0x43000041u, 0x47005400u, idx);
+    const uint32_t want = __builtin_amdgcn_perm(0x47000054u, 0x43004100u, idx);
+    const uint32_t d = (w & 0xDFDFDFDFu) ^ want;
+    const uint32_t ne4 = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 5;
+    const uint32_t c = __builtin_amdgcn_perm(comp, 0u, 0x07060504u - ne4);
+    return __builtin_amdgcn_perm(0u, c, 0x00010203u);
+}
 __device__ __forceinline__ unsigned long long pair_revcomp8(unsigned long long a)
 {
-    unsigned long long r = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const unsigned l = ((unsigned)(a >> (8 * i)) & 0xFFu) | 0x20u;
-        const unsigned long long cc = l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : l == 't' ? 'A' : 0;
-        r |= cc << (8 * (7 - i));
-    }
-    return r;
+    return ((unsigned long long)pair_revcomp4((uint32_t)a) << 32) | pair_revcomp4((uint32_t)(a >> 32));
 }
 
 template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false, bool PT = false, int PAIR = 0>
@@ -1226,34 +1232,48 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             const uint32_t hl = quad_bcast<0x00>(m_lo), hl2 = quad_bcast<0x00>(m_hi), hh = quad_bcast<0x55>(m_lo), hh2 = quad_bcast<0x55>(m_hi);
             const uint32_t tl = quad_bcast<0xAA>(m_lo), tl2 = quad_bcast<0xAA>(m_hi), th = quad_bcast<0xFF>(m_lo), th2 = quad_bcast<0xFF>(m_hi);
             const uint32_t ra = slot_base + cur * SLOT + q * ROWB + PRE + WQ * c;
-            const unsigned long long p0 = *(SQ_LDS const unsigned long long *)(uintptr_t)ra, p1 = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8);
-            uint32_t w0 = (uint32_t)p0, w1 = (uint32_t)(p0 >> 32), w2 = (uint32_t)p1, w3 = (uint32_t)(p1 >> 32);
-            unsigned long long nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 16);
-            uint32_t cand_lo = 0, cand_hi = 0;
-#pragma unroll 1
-            for (uint32_t k = 0; k < (uint32_t)NW; k++) {
-                uint32_t n0 = (uint32_t)nxt, n1 = (uint32_t)(nxt >> 32);
-                if (k + 1 < (uint32_t)NW) nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 24 + 8 * k);   /* the last lane's last one lies in the row's qualities: behind `last`, never looked at */
-                uint32_t bits = 0;
+            /* The prefilter, a position at a time: are the 8 bases at i a needle's first half, or the 8 at i + 8 its second half
+               (:5695-5698; at most one byte of the 16 may differ, so one of the halves is exact; whole halves, not their low dwords
+               as in round 4: a dword matches somewhere in every other lane by chance, and every chance match sent the whole wave
+               through the byte-by-byte look below).
+               No compares: v_sad_u8 of two dwords is 0 exactly when they are equal (a compare into a scalar pair costs 2.3
+               plain instructions here, scripts/ubench_qsad.hip), the four sums of a position meet in one v_min and one
+               v_min3, `- 1` turns "zero" into the sign bit and v_alignbit shifts it into the lane's mask: 14 instructions per
+               position where round 4's sliding compare took 20 (5.94 ms for read 1's pass against 3.29 for read 2's).  The
+               lane's 8 NW + 16 bytes wait in registers as dwords (upper case: & 0xDF); position 4 m + j is
+               v_alignbyte(d[m + 1], d[m], j).  Bit 63 - k of `cand` = position WQ c + k. */
+            constexpr int NDW = 2 * NW + 6;   /* (the last two: only so that the unrolled code below names no dword that does not exist; positions behind `last` are never looked at) */
+            uint32_t dm[NDW];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
-                    const bool maybe = (u0 == hl) | (u2 == hh) | (u0 == tl) | (u2 == th);
-                    bits |= maybe ? 1u << j : 0u;
-                    w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); /* slide the window by one base */
-                    w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-                    w2 = __builtin_amdgcn_alignbyte(w3, w2, 1);
-                    w3 = __builtin_amdgcn_alignbyte(n0, w3, 1);
-                    n0 = __builtin_amdgcn_alignbyte(n1, n0, 1);
-                    n1 >>= 8;
-                }
-                if (k < 4) cand_lo |= bits << (8 * k); else cand_hi |= bits << (8 * (k - 4));
+            for (int k = 0; k < NDW / 2; k++) {
+                const unsigned long long v = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8 * k);   /* the last lane's last ones lie in the row's qualities: behind `last`, never looked at */
+                dm[2 * k] = (uint32_t)v & UP4;
+                dm[2 * k + 1] = (uint32_t)(v >> 32) & UP4;
             }
+            uint32_t acc_lo = 0, acc_hi = 0;
+            static_for<0, (int)WQ>([&](auto pc) {
+                constexpr int pp = decltype(pc)::value, m = pp / 4, j = pp % 4;
+                auto dw = [&](auto kc) {   /* the dword at position pp + 4 k */
+                    constexpr int k = decltype(kc)::value;
+                    return j ? __builtin_amdgcn_alignbyte(dm[m + k + 1], dm[m + k], j) : dm[m + k];
+                };
+                const uint32_t u = dw(std::integral_constant<int, 0>{}), u4 = dw(std::integral_constant<int, 1>{});
+                const uint32_t u8 = dw(std::integral_constant<int, 2>{}), u12 = dw(std::integral_constant<int, 3>{});
+                /* a whole half (8 bases) per sum: the second v_sad_u8 adds to the first */
+                const uint32_t second = min(__builtin_amdgcn_sad_u8(u12, hh2, __builtin_amdgcn_sad_u8(u8, hh, 0u)),
+                                            __builtin_amdgcn_sad_u8(u12, th2, __builtin_amdgcn_sad_u8(u8, th, 0u)));
+                const uint32_t any = min(min(__builtin_amdgcn_sad_u8(u4, hl2, __builtin_amdgcn_sad_u8(u, hl, 0u)),
+                                             __builtin_amdgcn_sad_u8(u4, tl2, __builtin_amdgcn_sad_u8(u, tl, 0u))), second);
+                if constexpr (pp < 32) acc_lo = __builtin_amdgcn_alignbit(acc_lo, any - 1u, 31);
+                else acc_hi = __builtin_amdgcn_alignbit(acc_hi, any - 1u, 31);
+            });
+            constexpr int N_LO = WQ < 32 ? (int)WQ : 32, N_HI = (int)WQ - N_LO;
+            unsigned long long cand = (unsigned long long)acc_lo << (64 - N_LO);
+            if constexpr (N_HI > 0) cand |= (unsigned long long)acc_hi << (32 - N_HI);
             uint32_t result = 0;
-            unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
             while (cand) {   /* :5695-5704: a half matches case-insensitively, then at most one raw byte of the 16 may differ */
-                const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1, i = WQ * c + j;
-                cand &= cand - 1;
+                const uint32_t j = (uint32_t)__clzll((long long)cand), i = WQ * c + j;
+                cand &= ~(0x8000000000000000ull >> j);
                 if (i > last) break;
                 uint32_t b[4];
 #pragma unroll

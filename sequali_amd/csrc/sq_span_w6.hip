@@ -2,8 +2,10 @@
  * sq_span_w6.hip -- the builds of k_span (sq_span_kernel.h) whose automaton is restarted SIX dwords (24 positions) in front
  * of a lane's quarter instead of three: adapters of 14 to 25 characters (AdapterCounter takes up to 64,
  * _qcmodule.c:2549-2591; the reference's own list holds 12-mers).  A quarter must be at least as long as the restart, so
- * these builds exist from 3 windows (65 positions) on: Q4 = 2 NW + 1 >= 7 dwords.  Opt-in (SQ_SPAN_W6=1) until they have
- * met the oracle on a GPU: round 4 wrote them without one; without the switch such adapter sets keep k_wide.
+ * these builds exist from 3 windows (65 positions) on: Q4 = 2 NW + 1 >= 7 dwords.  Round 5 ran them against the oracle
+ * (tests/test_gpu_span_edges.py::test_adapters_of_14_to_25_characters_on_every_quarter_seam) and against k_wide
+ * (profiles/r5/exp_w6.txt): the default from 129 bases on for batches of one read length and for every length-sorted batch
+ * (SQ_SPAN_W6, sq_common.h).
  */
 #include "sq_span_kernel.h"
 

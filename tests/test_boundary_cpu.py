@@ -507,3 +507,20 @@ def test_header_parse_of_the_paired_pass_on_the_host():
             assert got == _reference_tile_id(name), ("quad", name, fill, got)
             checked += 1
     assert checked > 2000
+
+
+def test_rccl_enum_values_of_sq_dist_are_those_of_rccl_h():
+    """csrc/sq_dist.hip keeps its own copy of the five enum values it passes to RCCL (so that building libsqgpu.so
+    needs no RCCL header): pinned here against the installed rccl.h and against the source's own text"""
+    import re
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("rccl.h is not installed here")
+    text = open(hdr).read()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sequali_amd", "csrc", "sq_dist.hip")).read()
+    for name in ("ncclSum", "ncclMax", "ncclUint8", "ncclUint64", "ncclFloat64", "ncclSuccess"):
+        in_hdr = re.search(r"\b%s\s*=\s*(\d+)" % name, text)
+        in_src = re.search(r"\b%s\s*=\s*(\d+)" % name, src)
+        assert in_hdr and in_src, name
+        assert int(in_hdr.group(1)) == int(in_src.group(1)), name
+    assert re.search(r"char\s+internal\[128\]", text)      # ncclUniqueId is the 128 bytes the ABI hands around

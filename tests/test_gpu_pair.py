@@ -314,7 +314,7 @@ def test_paired_pass_equals_the_five_calls(L1, L2, n):
 
 def test_paired_pass_falls_back_to_the_five_calls():
     """what the paired kernels do not take goes through the modules' own passes with the same results: reads of many
-    lengths, a mate shorter than the 16 bases of a needle, the default SQ_PT_FUSED=0, modules left out"""
+    lengths, a mate shorter than the 16 bases of a needle, SQ_PT_FUSED=0, modules left out"""
     from sequali_amd import FastqRecordArrayView, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics
     rng = np.random.default_rng(11)
     n = 16 * 280 + 2
@@ -323,7 +323,7 @@ def test_paired_pass_falls_back_to_the_five_calls():
     m1r = m1.copy()
     m1r["sequence_length"][::3] -= 7            # ragged read 1 (the qualities start where they did: only the length moves)
     (c1, k1), (c2, k2) = _pair_batches(rng, n, 150, 12, tiles)
-    cases = [(b1, m1r, b2, m2, RIDE), (c1, k1, c2, k2, RIDE), (b1, m1, b2, m2, {})]
+    cases = [(b1, m1r, b2, m2, RIDE), (c1, k1, c2, k2, RIDE), (b1, m1, b2, m2, {"SQ_PT_FUSED": "0"})]
     for x1, y1, x2, y2, env in cases:
         ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics())
         ref[0].add(x1, y1); ref[1].add(x1, y1); ref[2].add(x2, y2); ref[3].add(x2, y2); ref[4].add_pair(x1, y1, x2, y2)

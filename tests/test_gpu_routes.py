@@ -59,14 +59,14 @@ def test_config3_route():
     d2 = synth.device_array(synth.ILLUMINA_R2_BY_TILE, 0, 100_000)
     from tests.helpers import with_env
     fa, z = FusedPass(QCMetrics(), None, PerTileQuality()), InsertSizeMetrics()
-    r = route_of(lambda: (fa.add_record_array(d1), fa.qc_metrics.flush()))
-    assert r == "k_span<5,QC,uniform,both>+k_ptspan<5>", r          # the default until SQ_PT_FUSED=1 has met the oracle on a GPU
+    r = route_of(lambda: with_env({"SQ_PT_FUSED": "0"}, lambda: (fa.add_record_array(d1), fa.qc_metrics.flush())))
+    assert r == "k_span<5,QC,uniform,both>+k_ptspan<5>", r          # the passes of round 2
     fa = FusedPass(QCMetrics(), None, PerTileQuality())
-    r = route_of(lambda: with_env({"SQ_PT_FUSED": "1"}, lambda: (fa.add_record_array(d1), fa.qc_metrics.flush())))
-    assert r == "k_span<5,QCPT,uniform,both>+k_pt_fold", r
+    r = route_of(lambda: (fa.add_record_array(d1), fa.qc_metrics.flush()))
+    assert r == "k_span<5,QCPT,uniform,both>+k_pt_fold", r          # the default since round 5
     fr = FusedPass(QCMetrics(), None, PerTileQuality())
     dr = synth.device_array(synth.ILLUMINA, 0, 100_000)
-    r = route_of(lambda: with_env({"SQ_PT_FUSED": "1"}, lambda: (fr.add_record_array(dr), fr.qc_metrics.flush())))
+    r = route_of(lambda: (fr.add_record_array(dr), fr.qc_metrics.flush()))
     assert r == "k_span<5,QCPT,uniform,both>+k_ptspan<5>", r
     r = route_of(lambda: z.add_record_array_pair(d1, d2))
     assert r.startswith("k_isz_span<5>"), r

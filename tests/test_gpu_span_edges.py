@@ -326,7 +326,7 @@ def test_adapters_of_14_to_25_characters_on_every_quarter_seam(U, route):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(probes)
         env = {"uniform": {}, "sorted": {"SQ_SPAN_SORTED": "1"}, "unsplit": {"SQ_SPAN_SPLIT": "0"}}[route]
-        env = dict(env, **({"SQ_SPAN_W6": "1"} if w6 else {}))
+        env = dict(env, SQ_SPAN_W6="1" if w6 else "0")
         r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush())))
         if w6 and route == "uniform":
             assert r.split("+")[0] == f"k_span<{nw},AD,uniform,split,w6>", r

@@ -584,7 +584,7 @@ def test_sorted_spans_every_length(max_len, with_adapters, ea):
     rq.add(buf, metas)
     ra.add(buf, metas)
     # the last: the launches of the window counts side by side on streams of their own
-    for env in ({"SQ_SPAN_SORTED": "1"}, {"SQ_SPAN": "0"}, {"SQ_SPAN_SORTED": "1", "SQ_SORTED_STREAMS": "1"}):
+    for env in ({"SQ_SPAN_SORTED": "1"}, {"SQ_SPAN": "0"}):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(ea), AdapterCounter(probes)
 
@@ -665,7 +665,7 @@ def test_sorted_spans_two_million_trimmed_reads():
     gq, ga = QCMetrics(), AdapterCounter(probes)
     f = FusedPass(gq, ga)
     # rows in order by the batch's length counts (k_span_scatter) / by a radix sort of keys / the general k_pass / the four launches side by side
-    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}, {"SQ_SORTED_STREAMS": "1"}):
+    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}):
         rq.add(buf, metas)
         ra.add(buf, metas)
         _with_env(env, lambda: (f.add_record_array(dev), gq.flush()))
@@ -796,7 +796,7 @@ def test_long_reads_in_segments(which):
     rq.add(buf, metas)
     ra.add(buf, metas)
     # k_span<LONG> where the adapters allow it (<= 13 characters); the same with the reads walked in blocks (all segments of 512 / 4096 reads before the next ones); k_seg
-    for env in ({}, {"SQ_LONG_BLOCK": "512"}, {"SQ_LONG_BLOCK": "4096"}, {"SQ_LONG": "0"}, {"SQ_LONG_OVERLAP": "2"}):
+    for env in ({}, {"SQ_LONG": "0"}):
         arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
         gq, ga = QCMetrics(), AdapterCounter(adapters)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
@@ -888,7 +888,7 @@ def test_config4_nanopore_reads_through_the_segment_kernels():
     rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
     rq.add(buf, metas)
     ra.add(buf, metas)
-    for env in ({}, {"SQ_LONG_BLOCK": "1024"}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}, {"SQ_LONG_OVERLAP": "2"}):   # k_span<LONG>; in blocks of 1024 reads; k_seg; stripes of k_pass
+    for env in ({}, {"SQ_LONG": "0"}, {"SQ_NO_SEGMENTS": "1"}):   # k_span<LONG>; k_seg; stripes of k_pass
         dev = synth.device_array(synth.NANOPORE, first, n)
         gq, ga = QCMetrics(), AdapterCounter(probes)
         _with_env(env, lambda: (FusedPass(gq, ga).add_record_array(dev), gq.flush()))
@@ -940,14 +940,14 @@ def test_config3_one_million_pairs(by_tile):
         q1.flush(); q2.flush()
         return q1, q2, p1, p2, z, d
 
-    # the default (the pass over the headers on a stream of its own, beside the counting) / that pass on the
-    # work stream / the round-1 kernels
-    for env in ({"SQ_PT_FUSED": "1"}, {}, {"SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
+    # the default (PerTileQuality rides in QCMetrics' pass) / the passes of round 2 (the pass over the headers on a stream
+    # of its own, beside the counting) / that pass on the work stream / the round-1 kernels
+    for env in ({}, {"SQ_PT_FUSED": "0"}, {"SQ_PT_FUSED": "0", "SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
         route = _route_of(lambda: _with_env(env, run))
-        if env.get("SQ_PT_FUSED") == "1":
+        if not env:      # the default since round 5
             want = "k_span<5,QCPT,uniform,both>+k_pt_fold" if by_tile else "k_span<5,QCPT,uniform,both>+k_ptspan<5>"
             assert route.startswith(want + "+" + want + "+k_isz_span<5>"), route
-        elif not env:
+        elif env == {"SQ_PT_FUSED": "0"}:
             assert route.startswith("k_span<5,QC,uniform,both>+k_ptspan<5>+k_span<5,QC,uniform,both>+k_ptspan<5>+k_isz_span<5>"), route
         q1, q2, p1, p2, z, d = _with_env(env, run)
         for g, r, dev, metas in ((q1, rq1, d1, m1), (q2, rq2, d2, m2)):
@@ -967,14 +967,12 @@ def test_config3_one_million_pairs(by_tile):
         assert d._modulo_bits == rd._modulo_bits and d.tracked_sequences == rd.tracked_sequences
 
 
-@pytest.mark.parametrize("beside", [False, True])
 @pytest.mark.parametrize("bad_byte", [0x20, 0x80])
-def test_long_reads_with_an_invalid_phred_byte(bad_byte, beside):
+def test_long_reads_with_an_invalid_phred_byte(bad_byte):
     """>= 4096 long reads, one of them with a byte that is no phred character (0x80: what BAM
     quality 95 becomes, and the code k_span<LONG> pads with): k_read_sums flags the batch, the
     per-position pass falls back to k_seg, the flush raises the reference's ValueError and leaves
-    the reference's state behind it (:2073-2075, :2102-2105).  beside (SQ_LONG_OVERLAP=1): k_span<LONG> has
-    counted the batch beside k_read_sums by the time the flag is known, and is run once more with its merges negated"""
+    the reference's state behind it (:2073-2075, :2102-2105)"""
     from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
     rng = np.random.default_rng(bad_byte)
     n, bad = 4200, 2777
@@ -1002,8 +1000,8 @@ def test_long_reads_with_an_invalid_phred_byte(bad_byte, beside):
         FusedPass(m, a).add_record_array(FastqRecordArrayView._from_buffer(buf, metas.copy()))
         with pytest.raises(ValueError, match="Not a valid phred character"):
             m.flush()
-    route = _route_of(lambda: _with_env({"SQ_LONG_OVERLAP": "2"} if beside else {}, run))
-    assert ("taken_back" in route) == beside, route
+    route = _route_of(run)
+    assert "k_seg" in route and "k_span<8,AD,long>" not in route, route
     assert m.number_of_reads == ref.number_of_reads and m.max_length == ref.max_length
     for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
                  "end_anchored_phred_count_table", "gc_content", "phred_scores"):
