@@ -454,18 +454,6 @@ __device__ __forceinline__ uint32_t isz_nonzero_bytes_of(uint32_t v)
 {
     return (uint32_t)__popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
 }
-/* NUCLEOTIDE_COMPLEMENT, _qcmodule.c:5613-5631: reverse complement of 8 bases (0 for what is no base) */
-__device__ __forceinline__ unsigned long long isz_revcomp8(unsigned long long a)
-{
-    unsigned long long r = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const unsigned l = ((unsigned)(a >> (8 * i)) & 0xFFu) | 0x20u;
-        const unsigned long long cc = l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : l == 't' ? 'A' : 0;
-        r |= cc << (8 * (7 - i));
-    }
-    return r;
-}
 
 template <int NW>
 __global__ void __launch_bounds__(1024) k_isz_span(IszSpanParams P)
@@ -544,45 +532,19 @@ __global__ void __launch_bounds__(1024) k_isz_span(IszSpanParams P)
         }
         /* the needles: lane c makes one of the four halves (h_lo, h_hi, t_lo, t_hi), the quad shares them */
         const uint32_t ea = ends_base + cur * 512 + 32 * q + ((c & 1) ? 0 : 8) + ((c & 2) ? 16 : 0);
-        const unsigned long long mine = isz_revcomp8(*(SQ_LDS const unsigned long long *)(uintptr_t)ea);
+        const unsigned long long mine = pair_revcomp8(*(SQ_LDS const unsigned long long *)(uintptr_t)ea);
         const uint32_t m_lo = (uint32_t)mine, m_hi = (uint32_t)(mine >> 32);
         const uint32_t hl = quad_bcast<0x00>(m_lo), hl2 = quad_bcast<0x00>(m_hi), hh = quad_bcast<0x55>(m_lo), hh2 = quad_bcast<0x55>(m_hi);
         const uint32_t tl = quad_bcast<0xAA>(m_lo), tl2 = quad_bcast<0xAA>(m_hi), th = quad_bcast<0xFF>(m_lo), th2 = quad_bcast<0xFF>(m_hi);
-        /* This lane's windows of read 1 start at bytes [WQ c, WQ c + WQ).  The scan proper only asks
-           whether a window can match at all -- a needle half matches (:5695) only if its low dword
-           does -- and keeps the answers as a bit per window: five byte-aligns, two ands, four
-           compares and an or per base, no branch (with the verdict inline the unrolled scan was
-           35 KB of code and ran at a third of its issue rate).  The rare candidates are looked
-           at again below, in window order. */
+        /* This lane's windows of read 1 start at bytes [WQ c, WQ c + WQ): the prefilter names the positions where a needle
+           half can match (pair_scan_candidates, sq_span_kernel.h: the same scan as in read 1's pass of the paired route); the
+           rare candidates are looked at below, in window order. */
         const uint32_t ra = slot_base + cur * SLOT + q * ROWB + WQ * c;
-        const unsigned long long p0 = *(SQ_LDS const unsigned long long *)(uintptr_t)ra, p1 = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8);
-        uint32_t w0 = (uint32_t)p0, w1 = (uint32_t)(p0 >> 32), w2 = (uint32_t)p1, w3 = (uint32_t)(p1 >> 32);
-        unsigned long long nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 16);
-        uint32_t cand_lo = 0, cand_hi = 0;
-#pragma unroll 1
-        for (uint32_t k = 0; k < (uint32_t)NW; k++) {
-            uint32_t n0 = (uint32_t)nxt, n1 = (uint32_t)(nxt >> 32);
-            if (k + 1 < (uint32_t)NW) nxt = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 24 + 8 * k);   /* the last lane's last one lies in the spare piece of the row */
-            uint32_t bits = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t u0 = w0 & UP4, u2 = w2 & UP4;
-                const bool maybe = (u0 == hl) | (u2 == hh) | (u0 == tl) | (u2 == th);
-                bits |= maybe ? 1u << j : 0u;
-                w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); /* slide the window by one base */
-                w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-                w2 = __builtin_amdgcn_alignbyte(w3, w2, 1);
-                w3 = __builtin_amdgcn_alignbyte(n0, w3, 1);
-                n0 = __builtin_amdgcn_alignbyte(n1, n0, 1);
-                n1 >>= 8;
-            }
-            if (k < 4) cand_lo |= bits << (8 * k); else cand_hi |= bits << (8 * (k - 4));
-        }
         uint32_t result = 0;
-        unsigned long long cand = ((unsigned long long)cand_hi << 32) | cand_lo;
+        unsigned long long cand = pair_scan_candidates<NW>(ra, hl, hl2, hh, hh2, tl, tl2, th, th2);   /* bit 63 - k: position WQ c + k */
         while (cand) {   /* :5695-5704: a half matches case-insensitively, then at most one raw byte of the 16 may differ */
-            const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1, i = WQ * c + j;
-            cand &= cand - 1;
+            const uint32_t j = (uint32_t)__clzll((long long)cand), i = WQ * c + j;
+            cand &= ~(0x8000000000000000ull >> j);
             if (i > last) break;
             uint32_t b[4];
 #pragma unroll

@@ -264,6 +264,56 @@ __device__ __forceinline__ unsigned long long pair_revcomp8(unsigned long long a
     return ((unsigned long long)pair_revcomp4((uint32_t)a) << 32) | pair_revcomp4((uint32_t)(a >> 32));
 }
 
+/* The prefilter of the overlap scan (calculate_insert_size :5667-5707) for one lane of a pair's quad: the WQ = 8 NW positions
+   that start at LDS address `ra` (8-byte aligned; the lane's WQ + 16 bytes must be readable).  Is the 8-base word at i a
+   needle's first half, or the one at i + 8 its second half (:5695-5698: at most one byte of the 16 may differ, so one of the
+   halves is exact)?  Whole halves, not their low dwords as in round 4 (a dword matches somewhere in every other lane by
+   chance, and every chance match sent the wave through the byte-by-byte look that follows), and a half as ONE word,
+   f(i) = dword(i) + 8 dword(i + 4) (not injective: what it lets through, the look behind it turns away).  No compares:
+   v_sad_u8 of two words is 0 exactly when they are equal (a compare into a scalar pair costs 2.3 plain instructions here,
+   scripts/ubench_qsad.hip); the four sums of a position meet in one v_min and one v_min3, `- 1` turns "zero" into the sign
+   bit and v_alignbit shifts it into the mask: 9 instructions per position where the sliding compare of rounds 3-4 took 20
+   (read 1's pass of config 3: 6.14 -> 4.77 ms per 25 M pairs).  The bytes wait in registers as dwords (upper case: & 0xDF);
+   the dword at position 4 m + j is v_alignbyte(d[m + 1], d[m], j).  Returns the candidates: bit 63 - k = position k.
+   hl / hl2: low / high dword of the first half of the head needle, hh / hh2: of its second half; tl .. th2: the tail needle. */
+template <int NW>
+__device__ __forceinline__ unsigned long long pair_scan_candidates(uint32_t ra, uint32_t hl, uint32_t hl2, uint32_t hh, uint32_t hh2,
+                                                                   uint32_t tl, uint32_t tl2, uint32_t th, uint32_t th2)
+{
+    constexpr int WQ = 8 * NW, NDW = 2 * NW + 4;
+    const uint32_t UP4 = 0xDFDFDFDFu;
+    uint32_t dm[NDW];
+#pragma unroll
+    for (int k = 0; k < NDW / 2; k++) {
+        const unsigned long long v = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8 * k);
+        dm[2 * k] = (uint32_t)v & UP4;
+        dm[2 * k + 1] = (uint32_t)(v >> 32) & UP4;
+    }
+    const uint32_t f_hl = hl + (hl2 << 3), f_hh = hh + (hh2 << 3), f_tl = tl + (tl2 << 3), f_th = th + (th2 << 3);
+    uint32_t fold[WQ + 8];
+    {
+        uint32_t at[WQ + 12];   /* the dword at every position the lane looks at */
+        static_for<0, WQ + 12>([&](auto pc) {
+            constexpr int pp = decltype(pc)::value, m = pp / 4, j = pp % 4;
+            at[pp] = j ? __builtin_amdgcn_alignbyte(dm[m + 1], dm[m], j) : dm[m];
+        });
+        static_for<0, WQ + 8>([&](auto pc) { constexpr int pp = decltype(pc)::value; fold[pp] = at[pp] + (at[pp + 4] << 3); });
+    }
+    uint32_t acc_lo = 0, acc_hi = 0;
+    static_for<0, WQ>([&](auto pc) {
+        constexpr int pp = decltype(pc)::value;
+        const uint32_t f = fold[pp], f8 = fold[pp + 8];
+        const uint32_t second = min(__builtin_amdgcn_sad_u8(f8, f_hh, 0u), __builtin_amdgcn_sad_u8(f8, f_th, 0u));
+        const uint32_t any = min(min(__builtin_amdgcn_sad_u8(f, f_hl, 0u), __builtin_amdgcn_sad_u8(f, f_tl, 0u)), second);
+        if constexpr (pp < 32) acc_lo = __builtin_amdgcn_alignbit(acc_lo, any - 1u, 31);
+        else acc_hi = __builtin_amdgcn_alignbit(acc_hi, any - 1u, 31);
+    });
+    constexpr int N_LO = WQ < 32 ? WQ : 32, N_HI = WQ - N_LO;
+    unsigned long long cand = (unsigned long long)acc_lo << (64 - N_LO);
+    if constexpr (N_HI > 0) cand |= (unsigned long long)acc_hi << (32 - N_HI);
+    return cand;
+}
+
 template <int NW, bool AD, bool SEG = false, int W4T = SPAN_W4, bool SPLIT = false, bool LONG = false, bool PT = false, int PAIR = 0>
 __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT)) k_span(PassParams P, uint32_t n_ad)
 {
@@ -1232,44 +1282,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             const uint32_t hl = quad_bcast<0x00>(m_lo), hl2 = quad_bcast<0x00>(m_hi), hh = quad_bcast<0x55>(m_lo), hh2 = quad_bcast<0x55>(m_hi);
             const uint32_t tl = quad_bcast<0xAA>(m_lo), tl2 = quad_bcast<0xAA>(m_hi), th = quad_bcast<0xFF>(m_lo), th2 = quad_bcast<0xFF>(m_hi);
             const uint32_t ra = slot_base + cur * SLOT + q * ROWB + PRE + WQ * c;
-            /* The prefilter, a position at a time: are the 8 bases at i a needle's first half, or the 8 at i + 8 its second half
-               (:5695-5698; at most one byte of the 16 may differ, so one of the halves is exact; whole halves, not their low dwords
-               as in round 4: a dword matches somewhere in every other lane by chance, and every chance match sent the whole wave
-               through the byte-by-byte look below).
-               No compares: v_sad_u8 of two dwords is 0 exactly when they are equal (a compare into a scalar pair costs 2.3
-               plain instructions here, scripts/ubench_qsad.hip), the four sums of a position meet in one v_min and one
-               v_min3, `- 1` turns "zero" into the sign bit and v_alignbit shifts it into the lane's mask: 14 instructions per
-               position where round 4's sliding compare took 20 (5.94 ms for read 1's pass against 3.29 for read 2's).  The
-               lane's 8 NW + 16 bytes wait in registers as dwords (upper case: & 0xDF); position 4 m + j is
-               v_alignbyte(d[m + 1], d[m], j).  Bit 63 - k of `cand` = position WQ c + k. */
-            constexpr int NDW = 2 * NW + 6;   /* (the last two: only so that the unrolled code below names no dword that does not exist; positions behind `last` are never looked at) */
-            uint32_t dm[NDW];
-#pragma unroll
-            for (int k = 0; k < NDW / 2; k++) {
-                const unsigned long long v = *(SQ_LDS const unsigned long long *)(uintptr_t)(ra + 8 * k);   /* the last lane's last ones lie in the row's qualities: behind `last`, never looked at */
-                dm[2 * k] = (uint32_t)v & UP4;
-                dm[2 * k + 1] = (uint32_t)(v >> 32) & UP4;
-            }
-            uint32_t acc_lo = 0, acc_hi = 0;
-            static_for<0, (int)WQ>([&](auto pc) {
-                constexpr int pp = decltype(pc)::value, m = pp / 4, j = pp % 4;
-                auto dw = [&](auto kc) {   /* the dword at position pp + 4 k */
-                    constexpr int k = decltype(kc)::value;
-                    return j ? __builtin_amdgcn_alignbyte(dm[m + k + 1], dm[m + k], j) : dm[m + k];
-                };
-                const uint32_t u = dw(std::integral_constant<int, 0>{}), u4 = dw(std::integral_constant<int, 1>{});
-                const uint32_t u8 = dw(std::integral_constant<int, 2>{}), u12 = dw(std::integral_constant<int, 3>{});
-                /* a whole half (8 bases) per sum: the second v_sad_u8 adds to the first */
-                const uint32_t second = min(__builtin_amdgcn_sad_u8(u12, hh2, __builtin_amdgcn_sad_u8(u8, hh, 0u)),
-                                            __builtin_amdgcn_sad_u8(u12, th2, __builtin_amdgcn_sad_u8(u8, th, 0u)));
-                const uint32_t any = min(min(__builtin_amdgcn_sad_u8(u4, hl2, __builtin_amdgcn_sad_u8(u, hl, 0u)),
-                                             __builtin_amdgcn_sad_u8(u4, tl2, __builtin_amdgcn_sad_u8(u, tl, 0u))), second);
-                if constexpr (pp < 32) acc_lo = __builtin_amdgcn_alignbit(acc_lo, any - 1u, 31);
-                else acc_hi = __builtin_amdgcn_alignbit(acc_hi, any - 1u, 31);
-            });
-            constexpr int N_LO = WQ < 32 ? (int)WQ : 32, N_HI = (int)WQ - N_LO;
-            unsigned long long cand = (unsigned long long)acc_lo << (64 - N_LO);
-            if constexpr (N_HI > 0) cand |= (unsigned long long)acc_hi << (32 - N_HI);
+            unsigned long long cand = pair_scan_candidates<NW>(ra, hl, hl2, hh, hh2, tl, tl2, th, th2);   /* bit 63 - k: position WQ c + k */
             uint32_t result = 0;
             while (cand) {   /* :5695-5704: a half matches case-insensitively, then at most one raw byte of the 16 may differ */
                 const uint32_t j = (uint32_t)__clzll((long long)cand), i = WQ * c + j;
