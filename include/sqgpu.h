@@ -349,8 +349,9 @@ int sq_insertsize_add_batch_pair(sq_insertsize *z, sq_batch *b1, sq_batch *b2);
 /* What the reference's driver does with a pair of arrays (__main__.py:279-306) in one call: QCMetrics_add_record_array +
  * PerTileQuality_add_record_array on read 1 and on read 2 (_qcmodule.c:2141-2165, :3224-3248), InsertSizeMetrics_
  * add_record_array_pair on both (:5827-5872) -- the same results as those five calls in that order.  Batches of one
- * read length each take two passes over the records instead of seven (csrc/sq_pair.hip; SQ_PT_FUSED=1).  Any module
- * may be NULL. */
+ * read length each take two passes over the records instead of seven (csrc/sq_pair.hip; the default, SQ_PT_FUSED=0: the
+ * five calls).  Any module may be NULL.  After a non-zero return the modules hold some prefix of the work (read 2's pass
+ * runs first): partial, as the reference's state is behind an error in the middle of an array. */
 int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1, sq_pertile *p1, sq_qcmetrics *m2,
                           sq_pertile *p2, sq_insertsize *z);
 int sq_insertsize_flush(sq_insertsize *z);

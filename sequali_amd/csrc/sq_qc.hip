@@ -3441,7 +3441,11 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
  * leaves the first and the last 16 bases of every read behind (32 bytes per pair), read 1's pass scans the sequences it
  * holds in LDS anyway against them (calculate_insert_size :5667-5707), both carry PerTileQuality (sq_pair.hip).  Anything
  * else -- other lengths, a module that is NULL or has stopped, SQ_PT_FUSED != 1 -- is the five calls.  Any of m1, p1, m2,
- * p2, z may be NULL. */
+ * p2, z may be NULL.
+ * On an error (out of device memory, a HIP error) the call returns at once and the modules' state is that of SOME prefix of
+ * the work, not of the reference's five calls cut at the same point: the two-pass route counts read 2 first (its ends are
+ * read 1's needles), so read 2's modules may have counted a batch read 1's have not.  Results after a non-zero return are
+ * undefined here as they are partial in the reference (_qcmodule.c:2196-2203 returns NULL mid-array too). */
 SQ_EXPORT int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1, sq_pertile *p1, sq_qcmetrics *m2,
                                     sq_pertile *p2, sq_insertsize *z)
 {

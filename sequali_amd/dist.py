@@ -365,17 +365,21 @@ def merge_dedup(shards: Sequence, device=None, group=None, method: str = None) -
     broadcast of the table per shard, in sequence).  method "gather": every shard filters
     its hashes with a mask it can prove the estimator has reached by then, the head runs one
     tail over what is left (sq_ends.hip "by gathering"; falls back to the relay for the
-    rest when the proof's premise fails).  Default: $SQ_DEDUP_MERGE, else "relay"."""
+    rest when the proof's premise fails, and for the whole merge when some rank holds no shard).  Default: $SQ_DEDUP_MERGE,
+    else "gather" (since round 5: tests/test_gpu_shards.py ran both against one sequential run on a GPU)."""
     import os
     from ._lib import check, lib
     L = lib()
-    method = method or os.environ.get("SQ_DEDUP_MERGE", "relay")
+    method = method or os.environ.get("SQ_DEDUP_MERGE", "gather")
     if method not in ("relay", "gather"):
         raise ValueError(f"merge_dedup: method {method!r} (relay or gather)")
     counts = _shard_counts(len(shards), device, group)
     rank = dist.get_rank(group) if _active(group) else 0
     base = sum(counts[:rank])
-    if method == "gather" and sum(counts) > 1:
+    # the gather names the job's first shard through rank 0 and takes fp_len from every rank's first shard: a rank without a
+    # shard would raise while the others wait in a collective.  `counts` is the same list on every rank, so every rank takes the
+    # same branch: with such a rank the relay (which handles any counts) runs the whole merge
+    if method == "gather" and sum(counts) > 1 and all(c > 0 for c in counts):
         state = _dedup_gather(L, shards, base, counts, device, group)
     else:
         state = _dedup_relay(L, shards, base, counts, None, 0, device, group)

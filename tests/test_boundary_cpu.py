@@ -512,6 +512,7 @@ def test_header_parse_of_the_paired_pass_on_the_host():
 def test_rccl_enum_values_of_sq_dist_are_those_of_rccl_h():
     """csrc/sq_dist.hip keeps its own copy of the five enum values it passes to RCCL (so that building libsqgpu.so
     needs no RCCL header): pinned here against the installed rccl.h and against the source's own text"""
+    import os
     import re
     hdr = "/opt/rocm/include/rccl/rccl.h"
     if not os.path.exists(hdr):
@@ -523,4 +524,4 @@ def test_rccl_enum_values_of_sq_dist_are_those_of_rccl_h():
         in_src = re.search(r"\b%s\s*=\s*(\d+)" % name, src)
         assert in_hdr and in_src, name
         assert int(in_hdr.group(1)) == int(in_src.group(1)), name
-    assert re.search(r"char\s+internal\[128\]", text)      # ncclUniqueId is the 128 bytes the ABI hands around
+    assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b", text) and re.search(r"char\s+internal\[NCCL_UNIQUE_ID_BYTES\]", text)   # ncclUniqueId is the 128 bytes the ABI hands around
