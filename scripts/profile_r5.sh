@@ -69,7 +69,7 @@ with open("pmc_all.txt", "w") as out:
     for tag in tags:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         dur = collections.defaultdict(list)
-        for f in glob.glob(f"pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
+        for f in [g for sfx in "fwab" for g in glob.glob(f"pmc_{tag}_{sfx}/**/*counter_collection.csv", recursive=True)]:   # (exactly this tag: config3_paired is a prefix of two others)
             for row in csv.DictReader(open(f)):
                 acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for f in glob.glob(f"pmc_{tag}_f/**/*kernel_trace.csv", recursive=True):
