@@ -846,15 +846,17 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t le
         cache.ready[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
     }
     __syncthreads();
-    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < P.n; r += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t result = results[r];
-        if (HIST) {
-            if (result < 1024) atomicAdd(&l_hist[result], 1u);
-            else atomicAdd(&P.insert_sizes[result], 1ULL);
-            local_max = max(local_max, result);
-        }
-        if (!result) continue;
-        if (HIST && result >= len1 && result >= len2) continue;   /* no remainder on either side */
+    /* Few pairs leave a remainder (0.6 % of the synthetic ones), but nearly every wave holds one: handled where it is met, the
+       long path (two metas, the remainder's bytes, a hash, the workgroup's cache) ran for one or two lanes of almost every
+       wave -- 0.85 ms per 25 M pairs for 0.1 GB of results.  So the pairs that need it are queued in LDS (their index and insert
+       size) and the workgroup works the queue off with all its lanes.  Four pairs per thread and turn: one 16-byte load of
+       results.  The loop's trip count is the same for every thread of the workgroup (barriers inside). */
+    constexpr uint32_t QCAP = 2048;
+    __shared__ uint32_t l_queue[3 * QCAP];   /* the pair's index (64 bits), its insert size */
+    __shared__ unsigned int l_qn;
+    if (threadIdx.x == 0) l_qn = 0;
+    __syncthreads();
+    auto remainder = [&](uint64_t r, uint32_t result) {   /* :5729-5742 */
         const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
         const uint8_t *s1 = P.buf1 + m1.record_start + m1.sequence_offset;
         const uint8_t *s2 = P.buf2 + m2.record_start + m2.sequence_offset;
@@ -870,8 +872,56 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t le
             isz_count_adapter(P.tab[1], cache, 1, s2 + result, min(L2 - result, (uint32_t)SQ_ADAPTER_STORE_SIZE),
                               rank + 1, P.closed, P.buf2 + P.len2);
         }
+    };
+    auto drain = [&]() {   /* every thread of the workgroup */
+        __syncthreads();
+        const uint32_t nq = min(l_qn, QCAP);
+        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x)
+            remainder(((uint64_t)l_queue[3 * i + 1] << 32) | l_queue[3 * i], l_queue[3 * i + 2]);
+        __syncthreads();
+        if (threadIdx.x == 0) l_qn = 0;
+        __syncthreads();
+    };
+    const bool aligned16 = ((uintptr_t)results & 15u) == 0;
+    const uint64_t per_turn = (uint64_t)blockDim.x * 4, n4 = (P.n + 3) & ~3ULL;
+    for (uint64_t base = blockIdx.x * per_turn; base < n4; base += (uint64_t)gridDim.x * per_turn) {
+        const uint64_t r0 = base + (uint64_t)threadIdx.x * 4;
+        uint32_t res[4] = {0, 0, 0, 0};
+        if (aligned16 && r0 + 4 <= P.n) {
+            const uint4 v = *(const uint4 *)(results + r0);
+            res[0] = v.x; res[1] = v.y; res[2] = v.z; res[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (r0 + k < P.n) res[k] = results[r0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t r = r0 + k;
+            const uint32_t result = res[k];
+            const bool valid = r < P.n;
+            if (HIST) {
+                /* most pairs have no overlap (result 0): 64 lanes adding to ONE LDS word take 64 turns; the wave counts its
+                   zeroes with a ballot and one lane adds them */
+                const unsigned long long zeroes = __builtin_amdgcn_ballot_w64(valid && result == 0);
+                if (valid) {
+                    if (result == 0) {
+                        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)zeroes) - 1u) atomicAdd(&l_hist[0], (unsigned int)__popcll(zeroes));
+                    } else if (result < 1024) atomicAdd(&l_hist[result], 1u);
+                    else atomicAdd(&P.insert_sizes[result], 1ULL);
+                    local_max = max(local_max, result);
+                }
+            }
+            if (!valid || !result) continue;
+            if (HIST && result >= len1 && result >= len2) continue;   /* no remainder on either side */
+            const uint32_t at = atomicAdd(&l_qn, 1u);
+            if (at < QCAP) { l_queue[3 * at] = (uint32_t)r; l_queue[3 * at + 1] = (uint32_t)(r >> 32); l_queue[3 * at + 2] = result; }
+            else remainder(r, result);   /* (cannot happen: the queue is worked off before a turn could overflow it) */
+        }
+        __syncthreads();
+        if (l_qn + 4 * blockDim.x > QCAP) drain();   /* the same answer in every thread: read behind the barrier, written before it */
+        else __syncthreads();                          /* (nobody adds to l_qn before everybody has read it) */
     }
-    __syncthreads();
+    drain();
     for (uint32_t t = threadIdx.x; t < 2 * ISZ_CACHE; t += blockDim.x) { /* the workgroup's remainders, each once */
         const uint32_t w = t / ISZ_CACHE, e = t % ISZ_CACHE;
         if (cache.hash[w][e] && cache.count[w][e])
