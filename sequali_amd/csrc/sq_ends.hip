@@ -623,11 +623,10 @@ struct IszCache {
     unsigned int count[2][ISZ_CACHE], ready[2][ISZ_CACHE];
 };
 
-__device__ void isz_count_adapter(const IszTable &T, IszCache &C, int which, const uint8_t *a, uint32_t len,
-                                  unsigned long long rank, int closed, const uint8_t *buf_end)
+/* `count` occurrences of the key, the earliest at `rank`: into the workgroup's cache, or past it into the device table */
+__device__ void isz_cache_add(const IszTable &T, IszCache &C, int which, const unsigned long long key[4], unsigned long long h,
+                              unsigned int count, unsigned long long rank, int closed)
 {
-    unsigned long long key[4];
-    const unsigned long long h = isz_key_of(a, len, buf_end, key);
     const uint32_t e = (uint32_t)(h >> 20) & (ISZ_CACHE - 1);
     unsigned long long cur = atomicCAS(&C.hash[which][e], 0ULL, h);
     if (cur == 0) { /* this lane opens the entry */
@@ -639,12 +638,21 @@ __device__ void isz_count_adapter(const IszTable &T, IszCache &C, int which, con
         bool same = true;
         for (int k = 0; k < 4; k++) same &= C.key[which][e][k] == key[k];
         if (same) {
-            atomicAdd(&C.count[which][e], 1u);
+            atomicAdd(&C.count[which][e], count);
             atomicMin(&C.rank[which][e], rank);
             return;
         }
     }
-    isz_table_add(T, key, h, 1, rank, closed); /* entry taken by another key (or not published yet) */
+    isz_table_add(T, key, h, count, rank, closed); /* entry taken by another key (or not published yet) */
+}
+
+/* one remainder of the calling lane (any set of lanes may call) */
+__device__ void isz_count_adapter(const IszTable &T, IszCache &C, int which, const uint8_t *a, uint32_t len,
+                                  unsigned long long rank, int closed, const uint8_t *buf_end)
+{
+    unsigned long long key[4];
+    const unsigned long long h = isz_key_of(a, len, buf_end, key);
+    isz_cache_add(T, C, which, key, h, 1u, rank, closed);
 }
 
 /* bytes of v that are not zero */
@@ -828,7 +836,7 @@ __global__ void k_insert_size(IszParams P)
  * sq_span_kernel.h): the histogram and the maximum (:5722-5727) are counted here, and only the pairs whose insert size is
  * shorter than one of the two (uniform) read lengths have their metas looked at */
 template <bool HIST>
-__global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t len1, uint32_t len2)
+__global__ void __launch_bounds__(256) k_isz_adapters(IszParams P, const uint32_t *results, uint32_t len1, uint32_t len2)
 {
     __shared__ unsigned int l_events[2];
     __shared__ IszCache cache;
@@ -846,16 +854,19 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t le
         cache.ready[i / ISZ_CACHE][i % ISZ_CACHE] = 0;
     }
     __syncthreads();
-    /* Few pairs leave a remainder (0.6 % of the synthetic ones), but nearly every wave holds one: handled where it is met, the
-       long path (two metas, the remainder's bytes, a hash, the workgroup's cache) ran for one or two lanes of almost every
-       wave -- 0.85 ms per 25 M pairs for 0.1 GB of results.  So the pairs that need it are queued in LDS (their index and insert
-       size) and the workgroup works the queue off with all its lanes.  Four pairs per thread and turn: one 16-byte load of
-       results.  The loop's trip count is the same for every thread of the workgroup (barriers inside). */
-    constexpr uint32_t QCAP = 2048;
-    __shared__ uint32_t l_queue[3 * QCAP];   /* the pair's index (64 bits), its insert size */
-    __shared__ unsigned int l_qn;
-    if (threadIdx.x == 0) l_qn = 0;
-    __syncthreads();
+    /* One pair in ten of the synthetic ones leaves a remainder, so every wave holds some: handled where it is met, the long path
+       (two metas, the remainder's bytes, a hash, the workgroup's cache: chains of dependent loads) ran for a few lanes of
+       every wave -- 0.85 ms per 25 M pairs for 0.1 GB of results.  Now a wave queues the pairs that need it (index, insert
+       size: a queue of its own in LDS, slots handed out by a ballot, no barrier) and works 64 of them off with all its lanes
+       whenever it holds that many: 0.85 -> 0.53 ms.  (Tried on top and dropped: the wave sorting its lanes by remainder first, one
+       lane adding a group's count and earliest rank to the cache -- 0.74 ms: the remainders of a wave are of many lengths, and a
+       round of ballots and a 64-bit reduction per distinct one costs more than the queueing at the cache's entries.)  Four pairs
+       per thread and turn: one 16-byte load of results. */
+    constexpr uint32_t WQ = 128;                       /* a wave adds at most 64 to fewer than 64 */
+    __shared__ uint32_t l_queue[4][3 * WQ];            /* per wave (256 threads): the pair's index (64 bits), its insert size */
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *wq = l_queue[wave];
+    uint32_t wq_n = 0;                                  /* wave-uniform */
     auto remainder = [&](uint64_t r, uint32_t result) {   /* :5729-5742 */
         const sq_meta m1 = P.metas1[r], m2 = P.metas2[r];
         const uint8_t *s1 = P.buf1 + m1.record_start + m1.sequence_offset;
@@ -873,19 +884,23 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t le
                               rank + 1, P.closed, P.buf2 + P.len2);
         }
     };
-    auto drain = [&]() {   /* every thread of the workgroup */
-        __syncthreads();
-        const uint32_t nq = min(l_qn, QCAP);
-        for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x)
-            remainder(((uint64_t)l_queue[3 * i + 1] << 32) | l_queue[3 * i], l_queue[3 * i + 2]);
-        __syncthreads();
-        if (threadIdx.x == 0) l_qn = 0;
-        __syncthreads();
+    auto work_off = [&](uint32_t count) {   /* the wave's first `count` (<= 64) entries, then the rest moves down */
+        if (lane < count) remainder(((uint64_t)wq[3 * lane + 1] << 32) | wq[3 * lane], wq[3 * lane + 2]);
+        const uint32_t left = wq_n - count;           /* < 64 */
+        uint32_t e0 = 0, e1 = 0, e2 = 0;
+        if (lane < left) { e0 = wq[3 * (count + lane)]; e1 = wq[3 * (count + lane) + 1]; e2 = wq[3 * (count + lane) + 2]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < left) { wq[3 * lane] = e0; wq[3 * lane + 1] = e1; wq[3 * lane + 2] = e2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wq_n = left;
     };
     const bool aligned16 = ((uintptr_t)results & 15u) == 0;
-    const uint64_t per_turn = (uint64_t)blockDim.x * 4, n4 = (P.n + 3) & ~3ULL;
-    for (uint64_t base = blockIdx.x * per_turn; base < n4; base += (uint64_t)gridDim.x * per_turn) {
-        const uint64_t r0 = base + (uint64_t)threadIdx.x * 4;
+    const uint64_t n4 = (P.n + 3) & ~3ULL;
+    /* whole waves stay in the loop (ballots): a lane behind the last pair has four invalid ones */
+    for (uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) * 4; w0 < n4; w0 += (uint64_t)gridDim.x * blockDim.x * 4) {
+        const uint64_t r0 = w0 + (uint64_t)lane * 4;
         uint32_t res[4] = {0, 0, 0, 0};
         if (aligned16 && r0 + 4 <= P.n) {
             const uint4 v = *(const uint4 *)(results + r0);
@@ -905,23 +920,26 @@ __global__ void k_isz_adapters(IszParams P, const uint32_t *results, uint32_t le
                 const unsigned long long zeroes = __builtin_amdgcn_ballot_w64(valid && result == 0);
                 if (valid) {
                     if (result == 0) {
-                        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)zeroes) - 1u) atomicAdd(&l_hist[0], (unsigned int)__popcll(zeroes));
+                        if (lane == (uint32_t)__ffsll((long long)zeroes) - 1u) atomicAdd(&l_hist[0], (unsigned int)__popcll(zeroes));
                     } else if (result < 1024) atomicAdd(&l_hist[result], 1u);
                     else atomicAdd(&P.insert_sizes[result], 1ULL);
                     local_max = max(local_max, result);
                 }
             }
-            if (!valid || !result) continue;
-            if (HIST && result >= len1 && result >= len2) continue;   /* no remainder on either side */
-            const uint32_t at = atomicAdd(&l_qn, 1u);
-            if (at < QCAP) { l_queue[3 * at] = (uint32_t)r; l_queue[3 * at + 1] = (uint32_t)(r >> 32); l_queue[3 * at + 2] = result; }
-            else remainder(r, result);   /* (cannot happen: the queue is worked off before a turn could overflow it) */
+            const bool need = valid && result && !(HIST && result >= len1 && result >= len2);   /* a remainder on one side at least */
+            const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
+            if (need) {
+                const uint32_t at = wq_n + (uint32_t)__popcll(needs & ((1ULL << lane) - 1));
+                wq[3 * at] = (uint32_t)r; wq[3 * at + 1] = (uint32_t)(r >> 32); wq[3 * at + 2] = result;
+            }
+            wq_n += (uint32_t)__popcll(needs);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (wq_n >= 64) work_off(64);
         }
-        __syncthreads();
-        if (l_qn + 4 * blockDim.x > QCAP) drain();   /* the same answer in every thread: read behind the barrier, written before it */
-        else __syncthreads();                          /* (nobody adds to l_qn before everybody has read it) */
     }
-    drain();
+    if (wq_n) work_off(wq_n);
+    __syncthreads();
     for (uint32_t t = threadIdx.x; t < 2 * ISZ_CACHE; t += blockDim.x) { /* the workgroup's remainders, each once */
         const uint32_t w = t / ISZ_CACHE, e = t % ISZ_CACHE;
         if (cache.hash[w][e] && cache.count[w][e])
