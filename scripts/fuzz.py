@@ -14,6 +14,8 @@ from sequali_amd import (AdapterCounter, DedupEstimator, FastqRecordArrayView, F
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None   # run this iteration alone (a failure seen before)
+SKIP = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))   # modules left out of the GPU side's calls AND of the checks (bisecting a failure): o,d,dp,z,n
 
 
 def u64(a):
@@ -47,9 +49,23 @@ def make(rng, n, max_len, uniform, illumina, adapters):
     return oracle.make_batch(names, seqs, quals)
 
 
+if os.environ.get("FUZZ_TRACE"):   # which pass runs when, on which metas in HBM
+    import sequali_amd._qc as _Q
+    for _name in ("FusedPass", "NanoStats", "InsertSizeMetrics", "QCMetrics", "DedupEstimator", "OverrepresentedSequences", "AdapterCounter", "PerTileQuality"):
+        _cls = getattr(_Q, _name)
+        def _wrap(orig, name, pair):
+            def run(self, arr, *a):
+                print(f"   RUN{'_PAIR' if pair else ''} {name} on {len(arr)} records, device metas at {_Q.lib().sq_batch_device_metas(arr._device().handle):#x}", flush=True)
+                return orig(self, arr, *a)
+            return run
+        if "_run" in _cls.__dict__: _cls._run = _wrap(_cls._run, _name, False)
+        if "_run_pair" in _cls.__dict__: _cls._run_pair = _wrap(_cls._run_pair, _name, True)
+
 ADS = [["AGATCGGAAGAG", "CTGTCTCTTATA", "GGGGGGGGGGGG"], ["ACG", "NN", "GTAC", "TTTTTTTT"], ["ACGT" * 16, "A" * 40]]
 failures = 0
 for it in range(iters):
+    if only is not None and it != only:
+        continue
     rng = np.random.default_rng(seed0 * 1000 + it)
     n = int(rng.choice([1, 63, 64, 65, 500, 3000, 4500, 6000]))
     max_len = int(rng.choice([5, 40, 151, 300, 700, 2500]))
@@ -84,30 +100,40 @@ for it in range(iters):
                 fused.add_record_array(a1)
             else:
                 got["q"].add_record_array(a1); got["a"].add_record_array(a1); got["p"].add_record_array(a1)
-            got["o"].add_record_array(a1); got["d"].add_record_array(a1); got["dp"].add_record_array_pair(a1, a2)
-            got["z"].add_record_array_pair(a1, a2); got["n"].add_record_array(a1)
+            if "o" not in SKIP: got["o"].add_record_array(a1)
+            if "d" not in SKIP: got["d"].add_record_array(a1)
+            if "dp" not in SKIP: got["dp"].add_record_array_pair(a1, a2)
+            if "z" not in SKIP: got["z"].add_record_array_pair(a1, a2)
+            if "n" not in SKIP: got["n"].add_record_array(a1)
     try:
         g, r = got["q"], ref["q"]
-        assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length)
+        assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length), ("qc counters", g.number_of_reads, g.max_length, r.number_of_reads, r.max_length)
         for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
                      "end_anchored_phred_count_table", "gc_content", "phred_scores"):
             assert np.array_equal(u64(getattr(g, name)()), getattr(r, name)()), name
         for (_, f, rv), (_, fr, rr) in zip(got["a"].get_counts(), ref["a"].get_counts()):
             assert np.array_equal(u64(f), fr) and np.array_equal(u64(rv), rr), "adapter"
-        assert got["p"].number_of_reads == ref["p"].number_of_reads
+        assert got["p"].number_of_reads == ref["p"].number_of_reads, ("pertile reads", got["p"].number_of_reads, ref["p"].number_of_reads)
         for (t, e, c), (tr, er, cr) in zip(got["p"].get_tile_counts(), ref["p"].get_tile_counts()):
             assert t == tr and np.array_equal(u64(c), cr) and np.allclose(np.array(e), er, rtol=1e-6), "pertile"
-        assert got["o"].sequence_counts() == ref["o"].sequence_counts(), "overrep"
-        assert got["o"].total_fragments == ref["o"].total_fragments
-        for k in ("d", "dp"):
-            assert got[k]._modulo_bits == ref[k]._modulo_bits
+        if "o" not in SKIP:
+            assert got["o"].sequence_counts() == ref["o"].sequence_counts(), "overrep"
+            assert got["o"].total_fragments == ref["o"].total_fragments, "overrep total_fragments"
+        for k in [k for k in ("d", "dp") if k not in SKIP]:
+            assert got[k]._modulo_bits == ref[k]._modulo_bits, (k, "modulo bits", got[k]._modulo_bits, ref[k]._modulo_bits)
             assert np.array_equal(u64(got[k].duplication_counts()), ref[k].duplication_counts()), k
-        assert np.array_equal(u64(got["z"].insert_sizes()), ref["z"].insert_sizes())
-        assert got["z"].adapters_read1() == ref["z"].adapters_read1() and got["z"].adapters_read2() == ref["z"].adapters_read2()
-        assert got["n"].number_of_reads == ref["n"].number_of_reads
+        if "z" in SKIP: got["z"] = ref["z"]
+        if "n" in SKIP: got["n"] = ref["n"]
+        gz, rz = u64(got["z"].insert_sizes()), ref["z"].insert_sizes()
+        assert np.array_equal(gz, rz), ("insert sizes", len(gz), len(rz), [(int(i), int(gz[i]) if i < len(gz) else None, int(rz[i]) if i < len(rz) else None)
+                                                                            for i in range(max(len(gz), len(rz))) if i >= len(gz) or i >= len(rz) or gz[i] != rz[i]][:8])
+        assert got["z"].adapters_read1() == ref["z"].adapters_read1(), "insert size adapters of read 1"
+        assert got["z"].adapters_read2() == ref["z"].adapters_read2(), "insert size adapters of read 2"
+        assert got["n"].number_of_reads == ref["n"].number_of_reads, "nanostats reads"
         gi, ri = got["n"].nano_infos(), ref["n"].nano_infos()
-        assert np.array_equal(gi["cumulative_error_rate"].view(np.uint64), ri["cumulative_error_rate"].view(np.uint64))
-        assert np.array_equal(gi["start_time"], ri["start_time"])
+        badn = np.nonzero(gi["cumulative_error_rate"].view(np.uint64) != ri["cumulative_error_rate"].view(np.uint64))[0]
+        assert len(badn) == 0, ("nanostats error rates", len(badn), badn[:6].tolist(), badn[-3:].tolist(), gi["cumulative_error_rate"][badn[:3]].tolist(), ri["cumulative_error_rate"][badn[:3]].tolist())
+        assert np.array_equal(gi["start_time"], ri["start_time"]), "nanostats start times"
         print(f"[{it}] ok  n={n} max_len={max_len} uniform={uniform} cuts={cuts} fused={bool(fused)}", flush=True)
     except AssertionError as e:
         failures += 1

@@ -279,6 +279,18 @@ class FastqRecordArrayView:
     # -- device side ---------------------------------------------------------
     def _device(self) -> _DeviceBatch:
         if self._batch is None:
+            st = getattr(self, "_staged", None)
+            if st is not None:
+                # The array lies in a staging block already (a module that defers its work copied it there): its records in
+                # HBM are the block's, not a second upload.  With two copies a QCMetrics pass that was staged wrote
+                # accumulated_error_rate (:2126) into one and a NanoStats that ran on the array itself read the other
+                # (scripts/fuzz.py 200 55, iteration 4: a pair whose mate was too large to stage sent InsertSizeMetrics --
+                # and with it this array -- down the unstaged path between the two).
+                blk, slot = st
+                v = blk.view(slot, slot + 1)
+                self._staged_view = v          # keeps the view (and through it the block's batch) alive
+                self._batch = v._device()
+                return self._batch
             h = lib().sq_batch_upload(context(), _addr(self.obj), len(self.obj),
                                       self._metas.ctypes.data, len(self._metas))
             if not h:

@@ -164,3 +164,40 @@ def test_sealed_blocks_return_to_the_pinned_pool_without_the_cycle_collector():
                 assert out[3] == 0, "a later parser had to lock staging memory afresh"
     finally:
         gc.enable()
+
+
+def test_an_array_staged_by_one_module_and_run_on_its_own_by_another_has_one_copy_in_hbm():
+    """QCMetrics_add_meta leaves accumulated_error_rate IN the array's metas (_qcmodule.c:2126) and NanoStats reads it there
+    (:5314).  A module that defers its work copies a small array into a staging block; a pair whose MATE is too large to
+    stage sends the pair's module -- and with it the small array -- down the unstaged path.  The array's records in HBM must
+    then be the block's: with a second upload the staged QCMetrics pass wrote the error rates into one copy and NanoStats
+    read the other (all 0.0; found by scripts/fuzz.py 200 55, round 5)."""
+    from sequali_amd import FastqRecordArrayView, FusedPass, InsertSizeMetrics, NanoStats, QCMetrics
+    rng = np.random.default_rng(55)
+
+    def batch(n, U):
+        names = [f"read{i} ch={i % 512} start_time=2021-09-30T11:34:{i % 60:02d}Z" for i in range(n)]
+        seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=U).tobytes().decode() for _ in range(n)]
+        quals = [(rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode() for _ in range(n)]
+        return oracle.make_batch(names, seqs, quals)
+
+    n = 3000
+    b1, m1 = batch(n, 200)
+    b2, m2 = batch(n, 1500)
+    assert len(b1) < (8 << 20) < len(b2)          # the mate alone is beyond what is staged
+    rq, rz, rn = oracle.QCMetrics(), oracle.InsertSizeMetrics(), oracle.NanoStats()
+    q, z, ns = QCMetrics(), InsertSizeMetrics(), NanoStats()
+    f = FusedPass(q, None, None)
+    for lo, hi in ((0, 1700), (1700, n)):
+        x1, x2 = m1[lo:hi].copy(), m2[lo:hi].copy()
+        rq.add(b1, x1); rz.add_pair(b1, x1, b2, x2); rn.add(b1, x1)
+        a1 = FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy())
+        a2 = FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy())
+        f.add_record_array(a1)               # staged
+        z.add_record_array_pair(a1, a2)      # not staged: a2 is too large
+        ns.add_record_array(a1)              # a1 is in HBM by now: not staged either
+        np.testing.assert_array_equal(a1.accumulated_error_rates().view(np.uint64), x1["accumulated_error_rate"].view(np.uint64))
+    gi, ri = ns.nano_infos(), rn.nano_infos()
+    np.testing.assert_array_equal(gi["cumulative_error_rate"].view(np.uint64), ri["cumulative_error_rate"].view(np.uint64))
+    np.testing.assert_array_equal(np.array(q.phred_scores(), np.uint64), rq.phred_scores())
+    np.testing.assert_array_equal(np.array(z.insert_sizes(), np.uint64), rz.insert_sizes())
