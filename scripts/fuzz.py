@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle  # noqa: E402
 from sequali_amd import (AdapterCounter, DedupEstimator, FastqRecordArrayView, FusedPass, InsertSizeMetrics,  # noqa: E402
-                         NanoStats, OverrepresentedSequences, PerTileQuality, QCMetrics)
+                         NanoStats, OverrepresentedSequences, PairedPass, PerTileQuality, QCMetrics)
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -88,12 +88,17 @@ for it in range(iters):
     got = dict(q=QCMetrics(ea), a=AdapterCounter(adapters), p=PerTileQuality(), o=OverrepresentedSequences(**okw),
                d=DedupEstimator(**dkw), dp=DedupEstimator(**dkw), z=InsertSizeMetrics(zcap), n=NanoStats())
     fused = FusedPass(got["q"], got["a"], got["p"]) if rng.random() < 0.5 else None
+    # the driver's call for paired input (PairedPass = the five calls per pair of arrays, __main__.py:279-306), objects of its own
+    ref.update(q2=oracle.QCMetrics(ea), p2=oracle.PerTileQuality())
+    pair = dict(q1=QCMetrics(ea), p1=PerTileQuality(), q2=QCMetrics(ea), p2=PerTileQuality(), z=InsertSizeMetrics(zcap))
+    paired = PairedPass(pair["q1"], pair["p1"], pair["q2"], pair["p2"], pair["z"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             x1, x2 = m1[lo:hi].copy(), m2[lo:hi].copy()
             ref["q"].add(b1, x1); ref["a"].add(b1, x1); ref["p"].add(b1, x1); ref["o"].add(b1, x1)
             ref["d"].add(b1, x1); ref["dp"].add_pair(b1, x1, b2, x2); ref["z"].add_pair(b1, x1, b2, x2); ref["n"].add(b1, x1)
+            ref["q2"].add(b2, x2); ref["p2"].add(b2, x2)
             a1 = FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy())
             a2 = FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy())
             if fused:
@@ -105,6 +110,8 @@ for it in range(iters):
             if "dp" not in SKIP: got["dp"].add_record_array_pair(a1, a2)
             if "z" not in SKIP: got["z"].add_record_array_pair(a1, a2)
             if "n" not in SKIP: got["n"].add_record_array(a1)
+            if "pair" not in SKIP:
+                paired.add_record_array_pair(FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy()), FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy()))
     try:
         g, r = got["q"], ref["q"]
         assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length), ("qc counters", g.number_of_reads, g.max_length, r.number_of_reads, r.max_length)
@@ -134,6 +141,24 @@ for it in range(iters):
         badn = np.nonzero(gi["cumulative_error_rate"].view(np.uint64) != ri["cumulative_error_rate"].view(np.uint64))[0]
         assert len(badn) == 0, ("nanostats error rates", len(badn), badn[:6].tolist(), badn[-3:].tolist(), gi["cumulative_error_rate"][badn[:3]].tolist(), ri["cumulative_error_rate"][badn[:3]].tolist())
         assert np.array_equal(gi["start_time"], ri["start_time"]), "nanostats start times"
+        if "pair" not in SKIP:
+            for gk, rk in (("q1", "q"), ("q2", "q2")):
+                g, r = pair[gk], ref[rk]
+                assert (g.number_of_reads, g.max_length) == (r.number_of_reads, r.max_length), ("paired", gk, "counters")
+                for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                             "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+                    assert np.array_equal(u64(getattr(g, name)()), getattr(r, name)()), ("paired", gk, name)
+            for gk, rk in (("p1", "p"), ("p2", "p2")):
+                assert pair[gk].number_of_reads == ref[rk].number_of_reads, ("paired", gk, "reads", pair[gk].number_of_reads, ref[rk].number_of_reads)
+                gt, rt = pair[gk].get_tile_counts(), ref[rk].get_tile_counts()
+                assert len(gt) == len(rt), ("paired", gk, "tiles")
+                for (t, e, c), (tr, er, cr) in zip(gt, rt):
+                    assert t == tr and np.array_equal(u64(c), cr) and np.allclose(np.array(e), er, rtol=1e-6), ("paired", gk, "tile", t)
+            assert np.array_equal(u64(pair["z"].insert_sizes()), ref["z"].insert_sizes()), ("paired", "insert sizes")
+            for which in ("adapters_read1", "adapters_read2"):
+                ga, ra, sa = getattr(pair["z"], which)(), getattr(ref["z"], which)(), getattr(got["z"], which)()
+                assert ga == ra, ("paired", which, "paired:", ga[:5], "oracle:", ra[:5], "standalone:", sa[:5],
+                                  "counters", pair["z"].total_reads, pair["z"].number_of_adapters_read1, ref["z"].number_of_adapters_read1)
         print(f"[{it}] ok  n={n} max_len={max_len} uniform={uniform} cuts={cuts} fused={bool(fused)}", flush=True)
     except AssertionError as e:
         failures += 1

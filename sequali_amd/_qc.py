@@ -709,6 +709,21 @@ class _Deferring:
         self._drain_own(sealed_only, through)
 
     def _drain_own(self, sealed_only: bool = False, through=None) -> None:
+        # Not re-entrant: running an entry first lets the QCMetrics objects that write into the block go ahead
+        # (_before_run), and a QCMetrics that THIS pass feeds sends the call straight back here -- the nested call then
+        # ran the entries behind the one being run first, i.e. the batches of a block in REVERSE order.  Sums do not care;
+        # PerTileQuality (it stops for good at the first header that does not parse, :3137-3148) and InsertSizeMetrics
+        # (the first max_adapters remainders in pair order, :5570-5611) do (scripts/fuzz.py 200 11, iteration 192).  The
+        # drain in progress gets to everything that is owed, in order.
+        if getattr(self, "_draining", False):
+            return
+        self._draining = True
+        try:
+            self._drain_entries(sealed_only, through)
+        finally:
+            self._draining = False
+
+    def _drain_entries(self, sealed_only: bool, through) -> None:
         while self._todo:
             e = self._todo[0]
             blocks = [e[0]] + ([e[3]] if len(e) == 6 else [])

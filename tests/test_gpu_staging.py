@@ -201,3 +201,49 @@ def test_an_array_staged_by_one_module_and_run_on_its_own_by_another_has_one_cop
     np.testing.assert_array_equal(gi["cumulative_error_rate"].view(np.uint64), ri["cumulative_error_rate"].view(np.uint64))
     np.testing.assert_array_equal(np.array(q.phred_scores(), np.uint64), rq.phred_scores())
     np.testing.assert_array_equal(np.array(z.insert_sizes(), np.uint64), rz.insert_sizes())
+
+
+def test_batches_of_one_block_run_in_call_order():
+    """Arrays of several streams staged into ONE block leave a pass several stretches of it to run.  They must run in call
+    order: InsertSizeMetrics keeps the first max_adapters remainders in pair order (_qcmodule.c:5570-5611) and
+    PerTileQuality stops for good at the first header that does not parse (:3137-3148).  (The drain was re-entrant through
+    the QCMetrics objects a pass feeds and ran the stretches last first: scripts/fuzz.py 200 11, iteration 192, round 5.)"""
+    from sequali_amd import DedupEstimator, FastqRecordArrayView, FusedPass, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics
+    from tests.test_gpu_pair import _pair_batches, _runs
+    rng = np.random.default_rng(192)
+    n = 1500
+    tiles = _runs(rng, n, [40, 300], [1101, 1102, 2203])
+    (b1, m1), (b2, m2) = _pair_batches(rng, n, 100, 90, tiles)
+    # a header that does not parse in the SECOND of three stretches
+    bad = 700
+    names_start = int(m1["record_start"][bad])
+    b1 = bytearray(b1)
+    b1[names_start:names_start + 4] = b"xxxx"
+    for k in range(names_start, names_start + int(m1["name_length"][bad])):
+        if b1[k] == ord(":"):
+            b1[k] = ord("_")
+    b1 = bytes(b1)
+    cuts = [0, 500, 1000, n]
+    ref = (oracle.QCMetrics(), oracle.PerTileQuality(), oracle.QCMetrics(), oracle.PerTileQuality(), oracle.InsertSizeMetrics(2))
+    got = (QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics(2))
+    pp = PairedPass(*got)
+    fq, fp = QCMetrics(), PerTileQuality()
+    ff = FusedPass(fq, None, fp)
+    other = DedupEstimator()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        x1, x2 = m1[lo:hi].copy(), m2[lo:hi].copy()
+        ref[0].add(b1, x1); ref[1].add(b1, x1); ref[2].add(b2, x2); ref[3].add(b2, x2); ref[4].add_pair(b1, x1, b2, x2)
+        pp.add_record_array_pair(FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy()), FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy()))
+        ff.add_record_array(FastqRecordArrayView._from_buffer(b1, m1[lo:hi].copy()))
+        other.add_record_array(FastqRecordArrayView._from_buffer(b2, m2[lo:hi].copy()))    # another stream in between
+    assert got[4].adapters_read1() == ref[4].adapters_read1() and got[4].adapters_read2() == ref[4].adapters_read2()
+    np.testing.assert_array_equal(np.array(got[4].insert_sizes(), np.uint64), ref[4].insert_sizes())
+    assert ref[1].number_of_reads == bad        # the reference counted the reads in front of the bad header and nothing behind
+    for p in (got[1], fp):
+        assert p.number_of_reads == ref[1].number_of_reads and p.skipped_reason is not None
+        for (t, e, c), (tr, er, cr) in zip(p.get_tile_counts(), ref[1].get_tile_counts()):
+            assert t == tr
+            np.testing.assert_array_equal(np.array(c, np.uint64), cr)
+            np.testing.assert_allclose(np.array(e), er, rtol=1e-6)
+    assert got[3].number_of_reads == ref[3].number_of_reads == n
+    np.testing.assert_array_equal(np.array(fq.phred_scores(), np.uint64), ref[0].phred_scores())
