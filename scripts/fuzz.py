@@ -61,13 +61,14 @@ if os.environ.get("FUZZ_TRACE"):   # which pass runs when, on which metas in HBM
         if "_run" in _cls.__dict__: _cls._run = _wrap(_cls._run, _name, False)
         if "_run_pair" in _cls.__dict__: _cls._run_pair = _wrap(_cls._run_pair, _name, True)
 
-ADS = [["AGATCGGAAGAG", "CTGTCTCTTATA", "GGGGGGGGGGGG"], ["ACG", "NN", "GTAC", "TTTTTTTT"], ["ACGT" * 16, "A" * 40]]
+ADS = [["AGATCGGAAGAG", "CTGTCTCTTATA", "GGGGGGGGGGGG"], ["ACG", "NN", "GTAC", "TTTTTTTT"], ["ACGT" * 16, "A" * 40],
+       ["ACGGTCATTGCACTTAGGCATCGAT", "TGACCGTTAGCAGGATCCTA", "GTTACCAGTCAGGA"]]   # (the last: 14-25 characters, the six-dword builds of k_span)
 failures = 0
 for it in range(iters):
     if only is not None and it != only:
         continue
     rng = np.random.default_rng(seed0 * 1000 + it)
-    n = int(rng.choice([1, 63, 64, 65, 500, 3000, 4500, 6000]))
+    n = int(rng.choice([1, 63, 64, 65, 500, 3000, 4500, 6000, 70000], p=[.12, .12, .12, .12, .12, .12, .12, .12, .04]))   # (70000: the length-sorted route takes batches from 65536 reads on)
     max_len = int(rng.choice([5, 40, 151, 300, 700, 2500]))
     if n * max_len > 16_000_000:
         n = 16_000_000 // max_len
