@@ -28,12 +28,8 @@ PY
 : > $OUT/summary.txt
 run headline--no-other                  -- --no-other-configs
 run config4_default                     -- --configs config4_nanopore
-run config4_block1024   SQ_LONG_BLOCK=1024 -- --configs config4_nanopore
-run config4_block4096   SQ_LONG_BLOCK=4096 -- --configs config4_nanopore
-run config4_block16384  SQ_LONG_BLOCK=16384 -- --configs config4_nanopore
-run config4_beside1_w10 SQ_LONG_OVERLAP=1 -- --configs config4_nanopore
-run config4_beside2_w8  SQ_LONG_OVERLAP=2 SQ_SPAN_WAVES=8 -- --configs config4_nanopore
-run config4_beside4_w8  SQ_LONG_OVERLAP=4 SQ_SPAN_WAVES=8 -- --configs config4_nanopore
+# (round 5 also ran SQ_LONG_BLOCK=1024/4096/16384, SQ_LONG_OVERLAP=1/2/4 and SQ_SORTED_STREAMS=1 here: all lost and were deleted,
+# profiles/r5/exp_opt_ins_summary.txt)
 run ragged                              -- --configs ragged_50_150
 run config3                             -- --configs config3_paired,config3_paired_by_tile,config3_paired_five_calls_unfused
 run uniform_250_w6      SQ_SPAN_W6=1    -- --configs uniform_250bp,uniform_200bp

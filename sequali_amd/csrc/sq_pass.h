@@ -79,8 +79,6 @@ struct PassParams {
     uint8_t *pair_ends;
     uint32_t *pair_results;
     uint32_t pair_L2;               /* PAIR = 2: the length of the reads of read 2 (>= 16) */
-    uint32_t negate;                /* k_span<LONG>: the workgroups SUBTRACT their histograms from the device tables -- the same launch a second time takes
-                                       back what the first one counted (SQ_LONG_OVERLAP: the pass has run beside k_read_sums, which then flagged the batch) */
 };
 struct PtRun { long long tile; uint32_t reads; uint32_t pad; };
 

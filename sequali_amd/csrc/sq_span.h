@@ -90,10 +90,8 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
 int sq_isz_span_launch(sq_ctx *ctx, const IszSpanParams &P, uint64_t *done);
 int sq_ptspan_launch(sq_ctx *ctx, const PassParams &P, uint32_t nslots, uint64_t *done);
 int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t min_len, uint32_t max_len, const uint32_t *len_hist, uint64_t *done);
-/* mode 0: the pass and what follows it (the G/C bins, the end-anchored tables); 1: the pass only -- sq_span_long_followups later; 2: the pass again with its
-   merges negated: takes back what mode 1 counted (SQ_LONG_OVERLAP) */
-int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done, int mode = 0);
-int sq_span_long_followups(sq_ctx *ctx, const PassParams &P);
+/* the pass over the segments of long reads and what follows it (the G/C bins, the end-anchored tables) */
+int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done);
 bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len);
 /* sq_span_w6.hip: the builds of k_span for adapters of 14 .. 25 characters (the automaton restarted six dwords in front of a quarter) */
 bool sq_span_w6_exists(int nw, bool seg, bool split);

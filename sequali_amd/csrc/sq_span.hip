@@ -804,7 +804,9 @@ bool sq_span_long_takes(const PassParams &P, bool ad, uint32_t n_ad, uint32_t ma
     return long_waves(P, ad, n_ad, max_len, &nw) > 0;
 }
 
-int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done, int mode)
+static int sq_span_long_followups(sq_ctx *ctx, const PassParams &P);
+
+int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, uint64_t *done)
 {
     *done = 0;
     const uint64_t n = P.n;
@@ -875,20 +877,13 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     }
     C.long_gc = (unsigned int *)sq_scratch(ctx, 16, n * 8);
     if (!C.long_gc) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
-    C.negate = mode == 2;
-    if (mode == 2) {   /* what the per-read scratch of the pass would collect a second time goes nowhere that is read again */
-        C.long_gc = (unsigned int *)sq_scratch(ctx, 17, n * 8);
-        if (!C.long_gc) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
-    }
     SQ_HIP(hipMemsetAsync(C.long_gc, 0, n * 8, ctx->stream));
     int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : nw == 6 ? launch_long<6>(ctx, C, ad, n_ad, waves, lds, grid)
                                                                        : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
     span_print_stamps(ctx, nw);
-    if (mode == 0) {
-        rc = sq_span_long_followups(ctx, P);
-        if (rc) return rc;
-    }
+    rc = sq_span_long_followups(ctx, P);
+    if (rc) return rc;
     SQ_HIP(hipGetLastError());
     SQ_HIP(hipStreamSynchronize(ctx->stream));   /* the host vector of the segments goes out of scope */
     *done = n;
@@ -896,7 +891,7 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
 }
 
 /* behind k_span<LONG>: the G/C histogram from the reads' counts (scratch 16, where the pass left them) and the end-anchored tables */
-int sq_span_long_followups(sq_ctx *ctx, const PassParams &P)
+static int sq_span_long_followups(sq_ctx *ctx, const PassParams &P)
 {
     const uint64_t n = P.n;
     unsigned int *long_gc = (unsigned int *)sq_scratch(ctx, 16, n * 8);

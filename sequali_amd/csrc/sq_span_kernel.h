@@ -596,7 +596,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 atomicAdd(&P.ad_rev[a * P.ad_cap + (U - 1 - start)], (unsigned long long)v);
             }
         const uint32_t ean = LONG ? 0 : min(P.ea_len, U);   /* LONG: the end-anchored tables are k_long_ea's */
-        const unsigned long long sgn = LONG && P.negate ? ~0ULL : 0ULL;   /* (v ^ sgn) - sgn = -v: the launch takes its counts back (PassParams::negate) */
         unsigned long long *t_base = P.qc_base, *t_phred = P.qc_phred, *t_ea_base = P.qc_ea_base, *t_ea_phred = P.qc_ea_phred;
         if constexpr (PAIR == 2) {
             t_base = (unsigned long long *)par(PAR_QC_BASE); t_phred = (unsigned long long *)par(PAR_QC_PHRED);
@@ -606,7 +605,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             const uint32_t v = l_hist_base[i], cc = i / hs, pos = i % hs;
             if (zero) l_hist_base[i] = 0;
             if (!v || pos >= U) continue;
-            atomicAdd(&t_base[(uint64_t)(pos_base + pos) * 5 + cc], ((unsigned long long)v ^ sgn) - sgn);
+            atomicAdd(&t_base[(uint64_t)(pos_base + pos) * 5 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&t_ea_base[(uint64_t)(P.ea_len - U + pos) * 5 + cc], (unsigned long long)v);
         }
         for (uint32_t i = tid_m; i < hs * PROWS; i += T) {
@@ -620,7 +619,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 cc = PHRED_COLS - 1;
             }
             if (!v) continue;
-            atomicAdd(&t_phred[(uint64_t)(pos_base + pos) * 12 + cc], ((unsigned long long)v ^ sgn) - sgn);
+            atomicAdd(&t_phred[(uint64_t)(pos_base + pos) * 12 + cc], (unsigned long long)v);
             if (pos >= U - ean) atomicAdd(&t_ea_phred[(uint64_t)(P.ea_len - U + pos) * 12 + cc], (unsigned long long)v);
         }
     };
