@@ -97,6 +97,13 @@ template <int OFF> __device__ __forceinline__ uint32_t rd_b32(uint32_t a)
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
     return r;
 }
+typedef uint32_t sq_u32x4v __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ sq_u32x4v rd_b128(uint32_t a)   /* a + OFF: 16-byte aligned */
+{
+    sq_u32x4v r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+    return r;
+}
 __device__ __forceinline__ double rd_f64(uint32_t a)
 {
     double r;
@@ -114,13 +121,18 @@ template <int OFF> __device__ __forceinline__ sq_u32x2 rd_tr8(uint32_t a)
     asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
     return r;
 }
-/* c + (1 << byte J of w) */
+/* c + (1 << byte J of w) for bytes below 32 (the class codes: 0 .. 30).  A shift takes its amount from the low five bits of its
+   operand, so byte 0 needs no extraction and the others one v_lshrrev; v_lshl_add_u32 does the rest.  (Until round 5 this was
+   v_lshlrev_b32_sdwa + v_add_u32: gfx950 wants a wait state between an SDWA instruction and whatever uses its result, hipcc put
+   an s_nop behind every pair, and an s_nop costs a wave as much as an instruction: 120 issue slots per span for 40 cells, now 70.) */
 template <int J> __device__ __forceinline__ uint32_t add_one_shl_byte(uint32_t w, uint32_t one, uint32_t c)
 {
-    uint32_t t; /* one statement: left to itself hipcc collects the shifted ones of a whole round in registers */
-    asm volatile("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_%4 src1_sel:DWORD\n\t"
-                 "v_add_u32 %1, %0, %1"
-                 : "=&v"(t), "+v"(c) : "v"(w), "v"(one), "i"(J));
+    /* plain C, not asm: behind an asm statement whose result the next instruction uses hipcc puts an s_nop (it cannot know
+       what the statement holds; gfx950 wants a wait state behind SDWA and transcendental results), and these statements are
+       chains on one counter.  The empty statement keeps the order: left to itself hipcc collects the shifted ones of a whole
+       round in registers */
+    c = (one << ((J ? w >> (8 * J) : w) & 31u)) + c;
+    asm volatile("" :: "v"(c));   /* (an INPUT only: a statement that defines c would get an s_nop in front of c's next use) */
     return c;
 }
 /* byte J of w, times 2 */
@@ -858,10 +870,21 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             sq_u32x2 ts[NW], tq[NW];   /* the 8 rows' class codes / qualities at the lane's position of window w */
             if constexpr (DS) ts[0] = rd_tr8<0>(trb);
             if constexpr (DQ) tq[0] = rd_tr8<(int)QOFF>(trb);
+            /* The chain's quality bytes: a group of four steps of the quad's four chains is the 16 bytes at 16 G of the row --
+               ONE ds_read_b128 (all four lanes the same address), lane c takes byte c of each dword (a v_bfe by 8 c).  Until
+               round 5: four ds_read_u8 per group.  The kernel sits at its LDS pipe (SQ_INSTS_LDS x ~ 5 cycles = its run time,
+               DESIGN 5.0): 30 LDS instructions less per span for 40 vector ones more. */
+            const uint32_t sh8 = co << 3;
+            auto chain_byte8 = [&](uint32_t w) { return __builtin_amdgcn_ubfe(w, sh8, 8) << 3; };   /* byte c of w, times 8: its error rate's address */
+            auto load_group = [&](auto gc, auto Gc) {   /* qc[4 g .. 4 g + 3] = the dwords of group G */
+                constexpr int g = decltype(gc)::value, G = decltype(Gc)::value;
+                const sq_u32x4v v = rd_b128<16 * G>(qual_row);
+                qc[4 * g] = v.x; qc[4 * g + 1] = v.y; qc[4 * g + 2] = v.z; qc[4 * g + 3] = v.w;
+            };
             if constexpr (DQ)
-                static_for<0, 4 * CG>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr (i < KR4) qc[i] = rd_u8<4 * i>(qp);
+                static_for<0, CG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g < KRG) load_group(gc, std::integral_constant<int, g>{});
                 });
             static_for<0, S>([&](auto sc) {
                 constexpr int sI = decltype(sc)::value;
@@ -918,7 +941,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                     wait_lgkm<cap(SA + n_lq)>();
                     static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
                 }
-                if constexpr (nC1) { d[0] = rd_f64(qc[0] << 3); d[1] = rd_f64(qc[1] << 3); d[2] = rd_f64(qc[2] << 3); d[3] = rd_f64(qc[3] << 3); }
+                if constexpr (nC1) { d[0] = rd_f64(chain_byte8(qc[0])); d[1] = rd_f64(chain_byte8(qc[1])); d[2] = rd_f64(chain_byte8(qc[2])); d[3] = rd_f64(chain_byte8(qc[3])); }
                 if constexpr (DS)
                     static_for<0, HI>([&](auto mc) {
                         constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
@@ -931,7 +954,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                         if constexpr (m < n_l) { tie(l[m]); inc_u32<128 * ((t * HI + m) / HALF)>(hpp + l[m], one); }
                     });
                 }
-                if constexpr (nC2) { d[4] = rd_f64(qc[4] << 3); d[5] = rd_f64(qc[5] << 3); d[6] = rd_f64(qc[6] << 3); d[7] = rd_f64(qc[7] << 3); }
+                if constexpr (nC2) { d[4] = rd_f64(chain_byte8(qc[4])); d[5] = rd_f64(chain_byte8(qc[5])); d[6] = rd_f64(chain_byte8(qc[6])); d[7] = rd_f64(chain_byte8(qc[7])); }
                 if constexpr (ADr) {   /* the second step: behind the first one are d[0..3], the increments, d[4..7] */
                     wait_lgkm<cap(nC1 + n_lq + nC2)>();
                     tie(e0);
@@ -957,13 +980,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 uint32_t cln = 0;
                 if constexpr (ADr && t + 1 < NR) cln = rd_b32<4 * (t + 1)>(abase);
                 if constexpr (DQ)
-                    static_for<0, 4 * CG>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        if constexpr (i < 4 * g_nx) qc[i] = rd_u8<4 * (4 * (t + 1) * CG + i)>(qp);
+                    static_for<0, CG>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        if constexpr (g < g_nx) load_group(gc, std::integral_constant<int, (t + 1) * CG + g>{});
                     });
                 constexpr int n_cln = ADr && t + 1 < NR ? 1 : 0;
                 if constexpr (ADr) {
-                    wait_lgkm<cap(TRN * n_nx + n_cln + 4 * g_nx)>();
+                    wait_lgkm<cap(TRN * n_nx + n_cln + g_nx)>();
                     tie(e1);
                     st[0] = e1;
                     if constexpr (proper) {
@@ -981,7 +1004,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                         }
                     }
                 }
-                wait_lgkm<cap(4 * g_nx)>();
+                wait_lgkm<cap(g_nx)>();
                 tie(cln);
                 cl[0] = cln;
                 static_for<0, NW>([&](auto wc) {
