@@ -26,8 +26,7 @@ def default_route_builds():
     out = []
     for nw in range(1, 9):
         out.append((nw, False, False, False, False))                   # QCMetrics alone, one read length: one wave for both streams
-        if nw <= 7:
-            out.append((nw, True, False, True, False))                 # + AdapterCounter: a wave per stream (8 windows: k_wide)
+        out.append((nw, True, False, True, False))                     # + AdapterCounter: a wave per stream
         # reads of many lengths: one wave for both streams where that build exists, else a wave per stream
         out.append((nw, False, True, nw == 6, False))
         out.append((nw, True, True, nw >= 6, False))

@@ -914,7 +914,9 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
-    if (ad && nw >= 8) return SQ_OK;   /* 225-256 positions with adapters: k_wide is 3-11 % ahead of the 8-wave build (scripts/bench_len.py; round 5 again: 932 / 918 / 950 against 839 / 895 / 908 Gbases/s at 240 / 250 / 256 bases, profiles/r5/exp_w6.txt); that build serves the sorted route */
+    /* (225-256 positions with adapters went to k_wide until round 5: the 8-window build ran 8 waves of ~ 190 registers and was 3-11 %
+       behind; at 98 registers it runs 12 and is 10-14 % ahead -- 1038 / 1038 / 1107 against 928 / 943 / 969 Gbases/s at 240 / 250 / 256
+       bases, scripts/exp_len2.sh -- on 1.2 x the algorithmic bytes instead of k_wide's 2.85 x) */
     bool split = sq_knobs().span_split && (ad || sq_knobs().span_split_qc);   /* QCMetrics alone: one wave for both streams was 2-3 % ahead (SQ_SPAN_SPLIT_QC=1: a wave per stream there too) */
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }

@@ -193,6 +193,10 @@ constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool 
     /* 225-256 positions (and 193-224 of the builds for sorted rows): 8 waves of up to 256 registers -- at 12
        waves these builds spilled, and a build that spills is not used (span_waves): such reads went to the round-1
        kernels without a word (tests/test_gpu_routes.py) */
+    /* (round 5: the builds' registers fell by a third when the chain's tail stopped reading bytes one by one -- the 8-window build
+       of a wave per stream from 195 to 98 --, so batches of one read length with a wave per stream are bounded by LDS now: 16
+       waves up to 7 windows (LDS takes 7 windows down to 14), 12 at 8) */
+    if (!lng && split && !seg) return nw >= 8 ? 12 : 16;
     if (!lng && (nw >= 8 || (nw == 7 && seg))) return 8;
     return nw <= (lng ? 6 : split ? (seg ? 4 : 5) : 3) ? 16 : 12;
 }
@@ -1116,14 +1120,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                padding entry of the table, +0.0 */
             if constexpr (DQ && !LONG) {
                 uint32_t lb[8], tb[4];
+                /* (three LDS reads instead of twelve: the eight steps are two groups of 16 bytes, lane c's byte of each dword; the
+                   1-4 tail qualities lie in the one dword at Lmain, a multiple of four) */
+                const sq_u32x4v g0 = *(SQ_LDS const sq_u32x4v *)(uintptr_t)(qual_row + 16 * KRG), g1 = *(SQ_LDS const sq_u32x4v *)(uintptr_t)(qual_row + 16 * (KRG + 1));
+                const uint32_t tw = lds_u32(qual_row + Lmain);
+                const uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) lb[j] = lds_u8(qp + 4 * (KR4 + j));
+                for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? chain_byte8(gw[j]) : SPAN_ERR_PAD << 3;
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) tb[j] = lds_u8(qual_row + Lmain + j);
-#pragma unroll
-                for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? lb[j] << 3 : SPAN_ERR_PAD << 3;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? tb[j] << 3 : SPAN_ERR_PAD << 3;
+                for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? ((tw >> (8 * j)) & 0xFFu) << 3 : SPAN_ERR_PAD << 3;
                 double le[8], te[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) le[j] = lds_f64(lb[j]);

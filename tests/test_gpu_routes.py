@@ -30,10 +30,10 @@ def test_qcmetrics_alone_is_one_wave_for_both_streams():
 
 
 @pytest.mark.parametrize("L,with_adapters,alone", [(224, "k_span<7,AD,uniform,split>", "k_span<7,QC,uniform,both>"),
-                                                   (250, "k_wide<AD>", "k_span<8,QC,uniform,both>")])
+                                                   (250, "k_span<8,AD,uniform,split>", "k_span<8,QC,uniform,both>")])
 def test_longer_illumina_reads(L, with_adapters, alone):
-    """reads of 161-224 bases with adapters and of up to 256 without take k_span; at 225-256 with adapters k_wide is
-    the faster one (scripts/bench_len.py)"""
+    """reads of up to 256 bases take k_span with and without adapters (225-256 with adapters went to k_wide until round 5:
+    at 12 waves per CU instead of 8 the 8-window build is 10-14 % ahead, scripts/exp_len2.sh)"""
     from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics, synth
     import numpy as np
     from tests.helpers import split_fastq
