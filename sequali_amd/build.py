@@ -38,7 +38,7 @@ def default_route_builds():
     names += ["k_ptspanILi%dEE" % nw for nw in range(1, 9)] + ["k_isz_spanILi%dEE" % nw for nw in range(1, 9)]
     # adapters of 14-25 characters (sq_span_w6.hip; the default since round 5): batches of one read length from 5 windows on (a wave
     # per stream), every window count the length-sorted route can meet (one wave for both streams up to 5 windows, a wave per stream beyond)
-    names += ["k_spanILi%dELb1ELb0ELi6ELb1ELb0ELb0ELi0EE" % nw for nw in range(5, 8)]
+    names += ["k_spanILi%dELb1ELb0ELi6ELb1ELb0ELb0ELi0EE" % nw for nw in range(5, 9)]
     names += ["k_spanILi%dELb1ELb1ELi6E%sELb0ELb0ELi0EE" % (nw, b(nw >= 6)) for nw in range(3, 9)]
     # batches of one read length of 225-256 bases with adapters, and adapters of 14-25 characters below 129 bases: the round-1 kernel
     names += ["6k_wideILb0EE", "6k_wideILb1EE"]

@@ -198,7 +198,7 @@ constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool 
        waves up to 7 windows (LDS takes 7 windows down to 14), 12 at 8) */
     if (!lng && split && !seg) return nw >= 8 ? 12 : 16;
     if (!lng && (nw >= 8 || (nw == 7 && seg))) return 8;
-    return nw <= (lng ? 6 : split ? (seg ? 4 : 5) : 3) ? 16 : 12;
+    return nw <= (lng ? 6 : split ? 5 : 3) ? 16 : 12;   /* (sorted rows, a wave per stream: 16 waves up to 5 windows since the registers allow it, round 5) */
 }
 
 #ifdef SQ_SPAN_PROBE

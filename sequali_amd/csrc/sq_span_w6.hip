@@ -42,13 +42,13 @@ bool spills_w6()
 
 }  // namespace
 
-/* is there a build for this shape (one wave for both streams: 3 .. 5 windows; a wave per stream: 3 .. 7 for batches of one
-   read length, 3 .. 8 for sorted rows), and does it keep its registers */
+/* is there a build for this shape (one wave for both streams: 3 .. 5 windows; a wave per stream: 3 .. 8), and does it keep its
+   registers */
 bool sq_span_w6_exists(int nw, bool seg, bool split)
 {
     if (nw < 3) return false;
     if (!split) return nw <= SPAN_NW_AD;
-    return nw <= (seg ? 8 : 7);
+    return nw <= 8;
 }
 
 bool sq_span_w6_spills(int nw, bool seg, bool split)
@@ -57,7 +57,7 @@ bool sq_span_w6_spills(int nw, bool seg, bool split)
 #define W6_CASE(N, S, P) if (nw == N && seg == S && split == P) return spills_w6<N, S, P>();
     W6_CASE(3, false, false) W6_CASE(4, false, false) W6_CASE(5, false, false)
     W6_CASE(3, true, false) W6_CASE(4, true, false) W6_CASE(5, true, false)
-    W6_CASE(3, false, true) W6_CASE(4, false, true) W6_CASE(5, false, true) W6_CASE(6, false, true) W6_CASE(7, false, true)
+    W6_CASE(3, false, true) W6_CASE(4, false, true) W6_CASE(5, false, true) W6_CASE(6, false, true) W6_CASE(7, false, true) W6_CASE(8, false, true)
     W6_CASE(3, true, true) W6_CASE(4, true, true) W6_CASE(5, true, true) W6_CASE(6, true, true) W6_CASE(7, true, true) W6_CASE(8, true, true)
 #undef W6_CASE
     return true;
@@ -68,7 +68,7 @@ int sq_span_launch_w6(int nw, bool seg, bool split, sq_ctx *ctx, const PassParam
 #define W6_CASE(N, S, Q) if (nw == N && seg == S && split == Q) return launch_w6<N, S, Q>(ctx, P, n_ad, waves, lds, grid);
     W6_CASE(3, false, false) W6_CASE(4, false, false) W6_CASE(5, false, false)
     W6_CASE(3, true, false) W6_CASE(4, true, false) W6_CASE(5, true, false)
-    W6_CASE(3, false, true) W6_CASE(4, false, true) W6_CASE(5, false, true) W6_CASE(6, false, true) W6_CASE(7, false, true)
+    W6_CASE(3, false, true) W6_CASE(4, false, true) W6_CASE(5, false, true) W6_CASE(6, false, true) W6_CASE(7, false, true) W6_CASE(8, false, true)
     W6_CASE(3, true, true) W6_CASE(4, true, true) W6_CASE(5, true, true) W6_CASE(6, true, true) W6_CASE(7, true, true) W6_CASE(8, true, true)
 #undef W6_CASE
     sq_set_error("k_span: no build with a six-dword restart for %d windows", nw);
