@@ -42,6 +42,7 @@ static void knobs_load()
     k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
     k.span_split_qc = num("SQ_SPAN_SPLIT_QC", 0) != 0;
     k.span_w6 = num("SQ_SPAN_W6", -1);
+    k.span_short = flag("SQ_SPAN_SHORT");
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
     k.pt_fused = num("SQ_PT_FUSED", 1);
     k.span_waves = num("SQ_SPAN_WAVES", 0);

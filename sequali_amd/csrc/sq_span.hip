@@ -914,6 +914,9 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     const uint32_t U = P.uniform_len;
     if (!U || U > 32 * SPAN_NW_MAX || P.n < SPAN_R) return SQ_OK;
     const int nw = (int)((U + 31) / 32);
+    /* up to 64 positions with adapters: k_wide (64 rows x 64 bytes per visit: a short read is one or two visits) is 22 % ahead at 50
+       bases (766 against 628 Gbases/s on 25 M reads, scripts/bench_len_dev.py, round 5), 2 % at 75, level from 100 on */
+    if (ad && nw <= 2 && !sq_knobs().span_short && !span_needs_w6(P, ad)) return SQ_OK;   /* (SQ_SPAN_SHORT=1: k_span all the same) */
     /* (225-256 positions with adapters went to k_wide until round 5: the 8-window build ran 8 waves of ~ 190 registers and was 3-11 %
        behind; at 98 registers it runs 12 and is 10-14 % ahead -- 1038 / 1038 / 1107 against 928 / 943 / 969 Gbases/s at 240 / 250 / 256
        bases, scripts/exp_len2.sh -- on 1.2 x the algorithmic bytes instead of k_wide's 2.85 x) */

@@ -80,9 +80,11 @@ def test_adapter_ending_on_every_quarter_seam(U, route):
     arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
     gq, ga = QCMetrics(), AdapterCounter(probes)
     env = {"uniform": {}, "sorted": {"SQ_SPAN_SORTED": "1"}, "unsplit": {"SQ_SPAN_SPLIT": "0"}}[route]
+    nw = (U + 31) // 32
+    if nw <= 2:
+        env = dict(env, SQ_SPAN_SHORT="1")   # (batches of one read length of up to 64 bases take k_wide by default since round 5: the k_span builds are what is tested here)
     from tests.test_gpu_vs_oracle import _route_of
     r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush())))
-    nw = (U + 31) // 32
     if route == "uniform":
         assert r.split("+")[0] == f"k_span<{nw},AD,uniform,split>", r
     elif route == "sorted":

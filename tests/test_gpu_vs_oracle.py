@@ -491,8 +491,8 @@ def _uniform_route(U, with_adapters):
     nw = (U + 31) // 32
     if U > 256:
         return None      # the round-1 kernels, by what fits their LDS
-    if with_adapters:     # (225-256 bases with adapters: k_wide until round 5)
-        return f"k_span<{nw},AD,uniform,split>"
+    if with_adapters:     # (225-256 bases with adapters: k_wide until round 5; up to 64 bases: k_wide since round 5)
+        return f"k_span<{nw},AD,uniform,split>" if nw > 2 else "k_wide<AD>"
     return f"k_span<{nw},QC,uniform,both>"
 
 
