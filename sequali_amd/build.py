@@ -25,7 +25,7 @@ def default_route_builds():
     b = lambda x: "Lb1" if x else "Lb0"   # noqa: E731
     out = []
     for nw in range(1, 9):
-        out.append((nw, False, False, False, False))                   # QCMetrics alone, one read length: one wave for both streams
+        out.append((nw, False, False, nw >= 6, False))                 # QCMetrics alone, one read length: one wave for both streams, from 6 windows on a wave per stream (round 5)
         out.append((nw, True, False, True, False))                     # + AdapterCounter: a wave per stream
         # reads of many lengths: one wave for both streams where that build exists, else a wave per stream
         out.append((nw, False, True, nw == 6, False))

@@ -40,7 +40,7 @@ static void knobs_load()
     k.span_radix = flag("SQ_SPAN_RADIX");
     k.span_sorted_split = num("SQ_SPAN_SORTED_SPLIT", 0) != 0;
     k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
-    k.span_split_qc = num("SQ_SPAN_SPLIT_QC", 0) != 0;
+    k.span_split_qc = (int)num("SQ_SPAN_SPLIT_QC", -1);
     k.span_w6 = num("SQ_SPAN_W6", -1);
     k.span_short = flag("SQ_SPAN_SHORT");
     k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");

@@ -56,7 +56,7 @@ struct SqKnobs {
     int span_sorted = -1, span_waves = 0, span_probe = -1;
     int span_w6 = -1;          /* SQ_SPAN_W6: adapters of 14 .. 25 characters through k_span (sq_span_w6.hip) instead of k_wide / k_pass.  -1 (default, measured in round 5, scripts/exp_w6.sh): batches of one read length from 129 bases on (914 / 910 / 1029 against k_wide's 876 / 830 / 901 Gbases/s at 150 / 200 / 224 bases; at 100 bases k_wide's 776 against 694) and every length-sorted batch (the alternative there is k_pass); 0: never; 1: wherever a build exists */
     bool span_short = false;   /* SQ_SPAN_SHORT: k_span also for batches of one read length of up to 64 bases with adapters (default: k_wide, 22 % ahead at 50 bases) */
-    bool span_split_qc = false;   /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream too */
+    int span_split_qc = -1;    /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream.  -1 (default, measured in round 5, profiles/r5/exp_split_qc.txt): from 6 windows (161 bases) on, where one wave for both streams holds 8 waves a CU (1218 / 1290 against 1066 / 1145 Gbases/s at 200 / 250 bases; at 100 / 150 bases one wave for both is 2-4 % ahead); 0: never; 1: always */
     bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
     bool span_sorted_split = false;   /* SQ_SPAN_SORTED_SPLIT: the length-sorted route with a wave per stream */
     bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */

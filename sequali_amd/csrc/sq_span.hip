@@ -920,7 +920,11 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     /* (225-256 positions with adapters went to k_wide until round 5: the 8-window build ran 8 waves of ~ 190 registers and was 3-11 %
        behind; at 98 registers it runs 12 and is 10-14 % ahead -- 1038 / 1038 / 1107 against 928 / 943 / 969 Gbases/s at 240 / 250 / 256
        bases, scripts/exp_len2.sh -- on 1.2 x the algorithmic bytes instead of k_wide's 2.85 x) */
-    bool split = sq_knobs().span_split && (ad || sq_knobs().span_split_qc);   /* QCMetrics alone: one wave for both streams was 2-3 % ahead (SQ_SPAN_SPLIT_QC=1: a wave per stream there too) */
+    /* QCMetrics alone: a wave per stream from 6 windows on (the chain reads 16 bytes at a time and the builds hold ~ 100 registers since
+       round 5: 12 waves a CU against the 8 of one wave for both streams -- 1218 / 1290 against 1066 / 1145 Gbases/s at 200 / 250 bases;
+       up to 5 windows both run 16 waves and one wave for both streams is 2-4 % ahead, profiles/r5/exp_split_qc.txt) */
+    const int sqc = sq_knobs().span_split_qc;
+    bool split = sq_knobs().span_split && (ad || sqc > 0 || (sqc < 0 && nw >= 6));
     int waves = span_waves(P, nw, U, ad, n_ad, false, split);
     if (!waves && split) { split = false; waves = span_waves(P, nw, U, ad, n_ad, false, false); }
     if (!waves) return SQ_OK;

@@ -493,7 +493,7 @@ def _uniform_route(U, with_adapters):
         return None      # the round-1 kernels, by what fits their LDS
     if with_adapters:     # (225-256 bases with adapters: k_wide until round 5; up to 64 bases: k_wide since round 5)
         return f"k_span<{nw},AD,uniform,split>" if nw > 2 else "k_wide<AD>"
-    return f"k_span<{nw},QC,uniform,both>"
+    return f"k_span<{nw},QC,uniform,{'split' if nw >= 6 else 'both'}>"
 
 
 @pytest.mark.parametrize("U", [1, 3, 4, 5, 27, 31, 32, 33, 63, 64, 65, 97, 150, 151, 161, 176, 192, 193, 200, 224, 225, 250, 251, 256, 512])
@@ -525,6 +525,8 @@ def test_uniform_length_kernels_every_alignment(U):
     rq.add(buf, metas)
     ra.add(buf, metas)
     cases = [(False, {}),                                        # QCMetrics alone: k_span (records through LDS by LDS-DMA; k_ring from 257 positions on)
+             (False, {"SQ_SPAN_SPLIT_QC": "0"}),                 # QCMetrics alone: k_span, one wave for both streams (the default up to 160 positions)
+             (False, {"SQ_SPAN_SPLIT_QC": "1"}),                 # ... a wave per stream (the default from 161 on)
              (False, {"SQ_SPAN": "0"}),                          # QCMetrics alone: k_ring
              (False, {"SQ_WIDE": "1"}),                          # QCMetrics alone: k_wide
              (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
