@@ -38,6 +38,37 @@ __device__ __forceinline__ uint32_t cls6_of_dword(uint32_t w)
     return __builtin_amdgcn_perm(lut, 0x18181818u, 0x07060504u - ne4);
 }
 
+/* The same four class codes for the bytes sequencers write -- A C G T N in either case, and the bytes 0x00 / 0x20 --, one
+ * v_perm instead of ten instructions; cls6_unusual says whether a dword holds anything else (an IUPAC letter, a dot, a byte
+ * >= 0x80): then cls6_of_dword is the answer.  For a byte b with idx = b & 7: A C G T sit at 1 3 7 4 and N at 6; `want` is
+ * the upper-case letter idx stands for (0 for the others, which the bytes 0x00 and 0x20 "match": class N either way). */
+__device__ __forceinline__ uint32_t cls6_usual(uint32_t w)
+{
+    return __builtin_amdgcn_perm(0x0C181812u, 0x06180018u, w & 0x07070707u);
+}
+__device__ __forceinline__ uint32_t cls6_unusual(uint32_t w)   /* != 0: some byte of w is not of the usual ones */
+{
+    const uint32_t want = __builtin_amdgcn_perm(0x474E0054u, 0x43004100u, w & 0x07070707u);
+    return (w ^ want) & 0xDFDFDFDFu;
+}
+/* what QCMetrics counts per read besides the classes (:1997-2060): 0x01 for C / G, 0x10 for a base that is none of A C G T,
+ * per byte, from the byte's idx (usual bytes) or from the selector cls6_of_dword ends on (any byte) */
+__device__ __forceinline__ uint32_t gcn_usual(uint32_t w)
+{
+    return __builtin_amdgcn_perm(0x01101000u, 0x01100010u, w & 0x07070707u);
+}
+__device__ __forceinline__ uint32_t cls6_gcn_of_dword(uint32_t w, uint32_t *gcn)
+{
+    const uint32_t idx = w & 0x07070707u;
+    const uint32_t lut = __builtin_amdgcn_perm(0x0C181812u, 0x06180018u, idx);
+    const uint32_t flg = __builtin_amdgcn_perm(0x01101000u, 0x01100010u, idx);
+    const uint32_t want = __builtin_amdgcn_perm(0x47000054u, 0x43004100u, idx);
+    const uint32_t d = (w & 0xDFDFDFDFu) ^ want;
+    const uint32_t ne4 = ((d + 0x7F7F7F7Fu) & 0x80808080u) >> 5;
+    *gcn = __builtin_amdgcn_perm(flg, 0x10101010u, 0x07060504u - ne4);
+    return __builtin_amdgcn_perm(lut, 0x18181818u, 0x07060504u - ne4);
+}
+
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(SQ_LDS const uint8_t *)(uintptr_t)a; }
 __device__ __forceinline__ void lds_store_u32(uint32_t a, uint32_t v) { *(SQ_LDS uint32_t *)(uintptr_t)a = v; }
 __device__ __forceinline__ void lds_add(uint32_t a, uint32_t v)
@@ -572,7 +603,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     };
 
     uint32_t Lmain = 4 * ((U - 1) / 4), nsteps = Lmain / 4; /* _qcmodule.c:2062,2068 */
-    uint32_t npad = SB - U;                                  /* padding positions of a row */
     const uint32_t h = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31;
     uint32_t cnt[NW];
 #pragma unroll
@@ -765,7 +795,19 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
            (1) class codes: lane c of a quad takes dwords c, c + 4, ... of its read's sequence (8 rows
            x 4 lanes of an instruction in 32 banks), writes the codes back in place (phase H and the
            automaton read them) and counts G/C and non-ACGT bases */
-        uint32_t gacc = 0, nacc = 0;
+        /* G/C bases (low nibble) and bases that are none of A C G T (high nibble) of the lane's dwords, per byte lane; padding
+           counts as nothing.  A nibble holds 15: a second register from the 16th dword on */
+        constexpr int NF = (2 * NW + 14) / 15;
+        uint32_t gacc = 0, nacc = 0;   /* LONG: the same per byte lane as 4 x / 8 x a count, padding counted in both */
+        uint32_t facc[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++) facc[k] = 0;
+        auto gcn_sum = [&](const uint32_t (&f)[NF]) {   /* the lane's G/C count | its count of other bases << 16 */
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < NF; k++) { lo = sum_bytes(f[k] & 0x0F0F0F0Fu, lo); hi = sum_bytes((f[k] >> 4) & 0x0F0F0F0Fu, hi); }
+            return lo | (hi << 16);
+        };
         if constexpr (DS) {
             const uint32_t cb = seq_row + 4 * c;
             uint32_t Uv = U, cv = c; /* opaque: hipcc would keep the padding masks of all 2 NW dwords in registers across spans */
@@ -776,25 +818,60 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             /* LONG: every row has an end of its own, but the rows that end inside their segment are the
                last ones of a stretch (the reads are sorted by length): most spans hold full rows only */
             const bool ragged_rows = LONG && __builtin_amdgcn_ballot_w64(urow < U) != 0;
-            auto classes = [&](auto ragged_c) {
-#pragma unroll
-                for (int t = 0; t < 2 * NW; t++) {
-                    uint32_t cl = cls6_of_dword(raw[t]);
-                    if constexpr (LONG) {
-                        if constexpr (decltype(ragged_c)::value) {
-                            const uint32_t p0 = 16 * t + 4 * cv;
-                            cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
-                        }
-                    } else if (16u * t + 16 > Uv) { /* dwords that reach behind the end of the reads */
-                        const uint32_t p0 = 16 * t + 4 * cv;
-                        cl = pad_tail(cl, p0 < Uv ? (int)min(4u, Uv - p0) : 0, CLS6_PAD4);
-                    }
-                    lds_store_u32(cb + 16 * t, cl);
-                    gacc += cl & 0x04040404u;                 /* C, G and padding */
-                    nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
+            /* valid bytes of dword t of the lane (4: all; what lies behind the end of a read is text of the record, not bases) */
+            auto valid_of = [&](int t, auto ragged_c) -> int {
+                const uint32_t p0 = 16 * t + 4 * cv;
+                if constexpr (LONG) {
+                    if constexpr (decltype(ragged_c)::value) return p0 < urow ? (int)min(4u, urow - p0) : 0;
+                    return 4;
+                } else {
+                    if (16u * t + 16 > Uv) return p0 < Uv ? (int)min(4u, Uv - p0) : 0;   /* dwords that reach behind the end of the reads */
+                    return 4;
                 }
             };
-            if (ragged_rows) classes(std::true_type{}); else classes(std::false_type{});
+            auto classes = [&](auto ragged_c, auto exact_c) {
+#pragma unroll
+                for (int t = 0; t < 2 * NW; t++) {
+                    uint32_t cl, fl;
+                    if constexpr (decltype(exact_c)::value) cl = cls6_gcn_of_dword(lds_u32(cb + 16 * t), &fl);   /* (read again: this path holds no registers the usual one lacks) */
+                    else { cl = cls6_usual(raw[t]); fl = gcn_usual(raw[t]); }
+                    if (LONG ? decltype(ragged_c)::value : 16u * t + 16 > Uv) {
+                        const int nvalid = valid_of(t, ragged_c);
+                        cl = pad_tail(cl, nvalid, CLS6_PAD4);
+                        fl = pad_tail(fl, nvalid, 0);
+                    }
+                    lds_store_u32(cb + 16 * t, cl);
+                    facc[t / 15] += fl;
+                }
+            };
+            /* Is there a byte in the wave's rows that a sequencer does not write?  (Nearly never: then every dword is one v_perm
+               for the classes and one for the counts instead of cls6_of_dword's ten instructions and six for the counts.) */
+            auto unusual = [&](auto ragged_c) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int t = 0; t < 2 * NW; t++) {
+                    uint32_t x = cls6_unusual(raw[t]);
+                    if (LONG ? decltype(ragged_c)::value : 16u * t + 16 > Uv) x = pad_tail(x, valid_of(t, ragged_c), 0);
+                    bad |= x;
+                }
+                return __builtin_amdgcn_ballot_w64(bad != 0 && q < nv) != 0;
+            };
+            if constexpr (LONG) {
+                /* (the builds for long reads keep cls6_of_dword for every dword: two more code paths do not fit their registers) */
+                auto classes_long = [&](auto ragged_c) {
+#pragma unroll
+                    for (int t = 0; t < 2 * NW; t++) {
+                        uint32_t cl = cls6_of_dword(raw[t]);
+                        if constexpr (decltype(ragged_c)::value) cl = pad_tail(cl, valid_of(t, ragged_c), CLS6_PAD4);
+                        lds_store_u32(cb + 16 * t, cl);
+                        gacc += cl & 0x04040404u;                 /* C, G and padding */
+                        nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
+                    }
+                };
+                if (ragged_rows) classes_long(std::true_type{}); else classes_long(std::false_type{});
+            } else {
+                if (unusual(std::false_type{})) classes(std::false_type{}, std::true_type{}); else classes(std::false_type{}, std::false_type{});
+            }
             if constexpr (LONG && AD) {   /* the 12 bases in front of the segment: lanes 1 .. 3 of the quad, a dword each */
                 if (cv > 0) {
                     const uint32_t a = seq_row - 16 + 4 * cv;
@@ -805,8 +882,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 if (q >= nv) {
 #pragma unroll
                     for (int t = 0; t < 2 * NW; t++) lds_store_u32(cb + 16 * t, CLS6_PAD4);
-                    gacc = 2 * NW * 0x04040404u;
-                    nacc = 2 * NW * 0x08080808u;
                 }
             }
         }
@@ -1145,15 +1220,15 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             total = ((acc + quad_bcast_f64<0x55>(acc)) + quad_bcast_f64<0xAA>(acc)) + quad_bcast_f64<0xFF>(acc); /* :2098-2099 (lane c = 0) */
             total += tail0; total += tail1; total += tail2; total += tail3; /* :2100-2112 */
         }
-        uint32_t gsum = 0, nsum = 0;
+        uint32_t gn = 0;   /* the read's G/C bases | its bases that are none of A C G T << 16 */
         if constexpr (DS && !LONG) {
-            gsum = sum_bytes(gacc, 0); nsum = sum_bytes(nacc, 0);
-            gsum += quad_bcast<0xB1>(gsum); nsum += quad_bcast<0xB1>(nsum); /* quad_perm [1,0,3,2] */
-            gsum += quad_bcast<0x4E>(gsum); nsum += quad_bcast<0x4E>(nsum); /* quad_perm [2,3,0,1] */
+            gn = gcn_sum(facc);
+            gn += quad_bcast<0xB1>(gn); /* quad_perm [1,0,3,2] */
+            gn += quad_bcast<0x4E>(gn); /* quad_perm [2,3,0,1] */
         }
         if (!LONG && c == 0 && q < nv) {
             if constexpr (DS) {
-                const uint32_t gc_cnt = (gsum >> 2) - npad, acgt_cnt = SB - (nsum >> 3);
+                const uint32_t gc_cnt = gn & 0xFFFFu, acgt_cnt = U - (gn >> 16);
                 if (acgt_cnt > 0) atomicAdd(&l_gc[gc_percent(gc_cnt, acgt_cnt)], 1u);
             }
             if constexpr (DQ) {
@@ -1242,7 +1317,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         U = g.U;
         Lmain = 4 * ((U - 1) / 4);
         nsteps = Lmain / 4;
-        npad = SB - U;
         s = max((uint64_t)g.span0, c_lo) + my_seq;
         s_end = min((uint64_t)g.span0 + g.nspans, c_hi);
         s_last = (uint64_t)g.span0 + g.nspans - 1;

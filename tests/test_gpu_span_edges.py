@@ -340,3 +340,65 @@ def test_adapters_of_14_to_25_characters_on_every_quarter_seam(U, route):
             assert "w6" not in r and "k_span<" not in r.split("+")[0], r     # k_wide / k_pass as before
         compare_qc(rq, gq, metas, arr)
         assert _compare_adapters(ga, ra) >= 3 * len(ends)
+
+
+@pytest.mark.parametrize("U", [150, 33, 97, 200, 250])
+@pytest.mark.parametrize("route", ["uniform", "sorted", "unsplit", "pertile"])
+def test_bases_a_sequencer_does_not_write(U, route):
+    """k_span classifies the bytes sequencers write (A C G T N, either case) with one v_perm per dword and takes
+    cls6_of_dword (any byte, NUCLEOTIDE_TO_INDEX :1748-1763) only for a span that holds something else: reads of the
+    usual letters, reads with ONE other byte (first base, last base, next to a lane seam; the neighbours of the letters
+    in the low three bits -- Q ! 1 for A, S # for C, W ' for G, D $ for T, F & for N --, IUPAC codes, '.', '-', '*'),
+    reads of arbitrary printable bytes, mixed so that spans of 16 reads hold none, one and many of them; the text
+    behind a read's last base (newline, '+', qualities) must not count as unusual, nor as anything else"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(7 * U + len(route))
+    usual = np.frombuffer(b"ACGTNacgtn", np.uint8)
+    odd = np.frombuffer(b"Q!1S#W'D$F&RYKMBVHUX.-*@`~0", np.uint8)
+    probes = [A12[:min(U, 12)], "GGNCA"[:min(U, 5)]]
+    names, seqs, quals = [], [], []
+    n = 16 * 36 + 5
+    qs = _quarter(U)
+    for i in range(n):
+        L = U if route != "sorted" or i % 5 else max(1, U - 1 - i % 9)
+        block = (i // 16) % 4          # spans: all usual / one odd byte in one read / one odd byte in some reads / anything
+        s = rng.choice(usual, size=L, p=[.2, .2, .2, .2, .02, .04, .04, .04, .04, .02])
+        if block == 1 and i % 16 == 5 or block == 2 and rng.random() < 0.4:
+            at = [0, L - 1, min(L - 1, qs - 1), min(L - 1, qs), int(rng.integers(0, L))][int(rng.integers(0, 5))]
+            s[at] = odd[int(rng.integers(0, len(odd)))]
+        elif block == 3:
+            s = rng.integers(33, 127, size=L).astype(np.uint8)
+        s = s.tobytes().decode()
+        if L >= 12 and i % 4 == 0:
+            at = int(rng.integers(0, L - 11))
+            s = s[:at] + A12 + s[at + 12:]
+        names.append(f"M:1:F:1:{1101 + i // 200}:5:{i}" if route == "pertile" else "r" * (1 + i % 50))
+        seqs.append(s)
+        quals.append((rng.integers(0, 42, size=L) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra, rp = oracle.QCMetrics(), oracle.AdapterCounter(probes), oracle.PerTileQuality()
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq, ga, gp = QCMetrics(), AdapterCounter(probes), PerTileQuality()
+    env = {"uniform": {}, "sorted": {"SQ_SPAN_SORTED": "1"}, "unsplit": {"SQ_SPAN_SPLIT": "0"}, "pertile": {}}[route]
+    if (U + 31) // 32 <= 2:
+        env = dict(env, SQ_SPAN_SHORT="1")
+    from tests.test_gpu_vs_oracle import _route_of
+    if route == "pertile":
+        rp.add(buf, metas)
+        r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, None, gp).add_record_array(arr), gq.flush())))
+        assert "QCPT" in r, r
+    else:
+        r = _route_of(lambda: with_env(env, lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush())))
+        if route != "unsplit" or (U + 31) // 32 <= 5:   # (one wave for both streams with the automaton: up to 5 windows)
+            assert r.startswith("k_span") and "k_span<" in r, r
+    compare_qc(rq, gq, metas, arr)
+    if route == "pertile":
+        rt, gt = rp.get_tile_counts(), gp.get_tile_counts()
+        assert [t for t, _, _ in gt] == [t for t, _, _ in rt]
+        for (t, e, cnt), (_, er, cr) in zip(gt, rt):
+            np.testing.assert_allclose(np.array(e), er, rtol=1e-6, err_msg=f"tile {t}")
+            np.testing.assert_array_equal(u64(cnt), cr, err_msg=f"tile {t}")
+    else:
+        _compare_adapters(ga, ra)
