@@ -479,6 +479,13 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     __syncthreads();
 
     const uint32_t q = (uint32_t)lane >> 2, c = (uint32_t)lane & 3;
+    /* which bytes of the lane's last two sequence dwords (j = 0, 1: dword 2 NW - 2 + j; positions 16 (2 NW - 2 + j) + 4 c ..)
+       are bases of a read of U_ positions: behind the end of a read lies text of the record */
+    auto tail_keep = [](uint32_t U_, uint32_t c_, int j) {
+        const uint32_t p0 = 16 * (2 * NW - 2 + j) + 4 * c_;
+        const uint32_t nvalid = p0 < U_ ? min(4u, U_ - p0) : 0u;
+        return nvalid >= 4 ? 0xFFFFFFFFu : (1u << (8 * nvalid)) - 1u;
+    };
     /* DMA: piece i = 64 k + lane of a slot is 16 bytes of row i / PR: of its sequence (the first
        2 NW pieces), of its qualities (the next 2 NW; SPLIT: the stream the wave's role names), or
        the unused last one; where a row's streams start (relative to the span's first record) is
@@ -810,7 +817,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         };
         if constexpr (DS) {
             const uint32_t cb = seq_row + 4 * c;
-            uint32_t Uv = U, cv = c; /* opaque: hipcc would keep the padding masks of all 2 NW dwords in registers across spans */
+            uint32_t Uv = U, cv = c; /* opaque: what is made of them is made per span, not kept across the spans */
             if constexpr (LONG) asm volatile("" : "+v"(cv)); else asm volatile("" : "+s"(Uv), "+v"(cv));
             uint32_t raw[2 * NW];
 #pragma unroll
@@ -818,27 +825,25 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             /* LONG: every row has an end of its own, but the rows that end inside their segment are the
                last ones of a stretch (the reads are sorted by length): most spans hold full rows only */
             const bool ragged_rows = LONG && __builtin_amdgcn_ballot_w64(urow < U) != 0;
-            /* valid bytes of dword t of the lane (4: all; what lies behind the end of a read is text of the record, not bases) */
-            auto valid_of = [&](int t, auto ragged_c) -> int {
-                const uint32_t p0 = 16 * t + 4 * cv;
-                if constexpr (LONG) {
-                    if constexpr (decltype(ragged_c)::value) return p0 < urow ? (int)min(4u, urow - p0) : 0;
-                    return 4;
-                } else {
-                    if (16u * t + 16 > Uv) return p0 < Uv ? (int)min(4u, Uv - p0) : 0;   /* dwords that reach behind the end of the reads */
-                    return 4;
-                }
-            };
-            auto classes = [&](auto ragged_c, auto exact_c) {
+            /* Behind the end of a read lies text of the record, not bases: U > 32 (NW - 1), so only the lane's last two dwords can
+               reach there; `keep` masks their bytes that are bases (LONG: every row has an end of its own, see below) */
+            uint32_t keep[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+            if constexpr (!LONG) {   /* (made per span, from the opaque copies.  Kept in registers across the spans they would save 1 % -- and the builds of one
+                                        wave for both streams with 1-2 windows then report NaN error sums for reads whose second-last dword is
+                                        partly padding, for a reason the listing does not show: profiles/r5/exp_late_kernel_ab.txt) */
+                keep[0] = tail_keep(Uv, cv, 0);
+                keep[1] = tail_keep(Uv, cv, 1);
+            }
+            auto classes = [&](auto exact_c) {
 #pragma unroll
                 for (int t = 0; t < 2 * NW; t++) {
                     uint32_t cl, fl;
                     if constexpr (decltype(exact_c)::value) cl = cls6_gcn_of_dword(lds_u32(cb + 16 * t), &fl);   /* (read again: this path holds no registers the usual one lacks) */
                     else { cl = cls6_usual(raw[t]); fl = gcn_usual(raw[t]); }
-                    if (LONG ? decltype(ragged_c)::value : 16u * t + 16 > Uv) {
-                        const int nvalid = valid_of(t, ragged_c);
-                        cl = pad_tail(cl, nvalid, CLS6_PAD4);
-                        fl = pad_tail(fl, nvalid, 0);
+                    if (t >= 2 * NW - 2) {
+                        const uint32_t k = keep[t - (2 * NW - 2) < 0 ? 0 : t - (2 * NW - 2)];
+                        cl = (cl & k) | (CLS6_PAD4 & ~k);
+                        fl &= k;
                     }
                     lds_store_u32(cb + 16 * t, cl);
                     facc[t / 15] += fl;
@@ -846,12 +851,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             };
             /* Is there a byte in the wave's rows that a sequencer does not write?  (Nearly never: then every dword is one v_perm
                for the classes and one for the counts instead of cls6_of_dword's ten instructions and six for the counts.) */
-            auto unusual = [&](auto ragged_c) {
+            auto unusual = [&]() {
                 uint32_t bad = 0;
 #pragma unroll
                 for (int t = 0; t < 2 * NW; t++) {
                     uint32_t x = cls6_unusual(raw[t]);
-                    if (LONG ? decltype(ragged_c)::value : 16u * t + 16 > Uv) x = pad_tail(x, valid_of(t, ragged_c), 0);
+                    if (t >= 2 * NW - 2) x &= keep[t - (2 * NW - 2) < 0 ? 0 : t - (2 * NW - 2)];
                     bad |= x;
                 }
                 return __builtin_amdgcn_ballot_w64(bad != 0 && q < nv) != 0;
@@ -862,7 +867,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
 #pragma unroll
                     for (int t = 0; t < 2 * NW; t++) {
                         uint32_t cl = cls6_of_dword(raw[t]);
-                        if constexpr (decltype(ragged_c)::value) cl = pad_tail(cl, valid_of(t, ragged_c), CLS6_PAD4);
+                        if constexpr (decltype(ragged_c)::value) {
+                            const uint32_t p0 = 16 * t + 4 * cv;
+                            cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
+                        }
                         lds_store_u32(cb + 16 * t, cl);
                         gacc += cl & 0x04040404u;                 /* C, G and padding */
                         nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
@@ -870,7 +878,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 };
                 if (ragged_rows) classes_long(std::true_type{}); else classes_long(std::false_type{});
             } else {
-                if (unusual(std::false_type{})) classes(std::false_type{}, std::true_type{}); else classes(std::false_type{}, std::false_type{});
+                if (unusual()) classes(std::true_type{}); else classes(std::false_type{});
             }
             if constexpr (LONG && AD) {   /* the 12 bases in front of the segment: lanes 1 .. 3 of the quad, a dword each */
                 if (cv > 0) {
