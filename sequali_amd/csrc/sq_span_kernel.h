@@ -483,9 +483,23 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
        are bases of a read of U_ positions: behind the end of a read lies text of the record */
     auto tail_keep = [](uint32_t U_, uint32_t c_, int j) {
         const uint32_t p0 = 16 * (2 * NW - 2 + j) + 4 * c_;
-        const uint32_t nvalid = p0 < U_ ? min(4u, U_ - p0) : 0u;
+        const uint32_t left = U_ - p0;   /* (mod 2^32) */
+        const uint32_t nvalid = p0 < U_ ? (left > 4u ? 4u : left) : 0u;
         return nvalid >= 4 ? 0xFFFFFFFFu : (1u << (8 * nvalid)) - 1u;
     };
+    /* One read length, no PerTileQuality riding: the two masks are made once, from an OPAQUE copy of U.  Written as
+       `p0 < U ? min(4u, U - p0) : 0u` with the kernel's own U, hipcc (ROCm 7.2) concludes that p0 < U holds for every
+       lane -- U > 44 at two windows -- and deletes the tests U - 1 > 35 / 39 / 43 that guard the chain's last steps far below:
+       k_span<1|2,QC,uniform,both> then summed the error rates of the text behind a short read's qualities (NaN: 'Not a
+       valid phred character' for every read of 1-15 and 33-47 bases; profiles/r5/exp_late_kernel_ab.txt, item 4).  The
+       padding code always worked on opaque copies; now the reason is known. */
+    uint32_t keep_u0 = 0xFFFFFFFFu, keep_u1 = 0xFFFFFFFFu;
+    if constexpr (!SEG && !PT && !LONG) {
+        uint32_t Uo = U;
+        asm volatile("" : "+s"(Uo));
+        keep_u0 = tail_keep(Uo, c, 0);
+        keep_u1 = tail_keep(Uo, c, 1);
+    }
     /* DMA: piece i = 64 k + lane of a slot is 16 bytes of row i / PR: of its sequence (the first
        2 NW pieces), of its qualities (the next 2 NW; SPLIT: the stream the wave's role names), or
        the unused last one; where a row's streams start (relative to the span's first record) is
@@ -827,10 +841,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             const bool ragged_rows = LONG && __builtin_amdgcn_ballot_w64(urow < U) != 0;
             /* Behind the end of a read lies text of the record, not bases: U > 32 (NW - 1), so only the lane's last two dwords can
                reach there; `keep` masks their bytes that are bases (LONG: every row has an end of its own, see below) */
-            uint32_t keep[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-            if constexpr (!LONG) {   /* (made per span, from the opaque copies.  Kept in registers across the spans they would save 1 % -- and the builds of one
-                                        wave for both streams with 1-2 windows then report NaN error sums for reads whose second-last dword is
-                                        partly padding, for a reason the listing does not show: profiles/r5/exp_late_kernel_ab.txt) */
+            uint32_t keep[2] = {keep_u0, keep_u1};
+            if constexpr (!LONG && (SEG || PT)) {   /* a length per stretch / no register to spare across the spans: made per span */
                 keep[0] = tail_keep(Uv, cv, 0);
                 keep[1] = tail_keep(Uv, cv, 1);
             }
@@ -869,7 +881,8 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                         uint32_t cl = cls6_of_dword(raw[t]);
                         if constexpr (decltype(ragged_c)::value) {
                             const uint32_t p0 = 16 * t + 4 * cv;
-                            cl = pad_tail(cl, p0 < urow ? (int)min(4u, urow - p0) : 0, CLS6_PAD4);
+                            const uint32_t left = urow - p0;   /* (mod 2^32; spelled out: see tail_keep) */
+                            cl = pad_tail(cl, p0 < urow ? (int)(left > 4u ? 4u : left) : 0, CLS6_PAD4);
                         }
                         lds_store_u32(cb + 16 * t, cl);
                         gacc += cl & 0x04040404u;                 /* C, G and padding */
