@@ -820,6 +820,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
            counts as nothing.  A nibble holds 15: a second register from the 16th dword on */
         constexpr int NF = (2 * NW + 14) / 15;
         uint32_t gacc = 0, nacc = 0;   /* LONG: the same per byte lane as 4 x / 8 x a count, padding counted in both */
+        bool long_usual = false;       /* LONG: the span took the short way (its counts are in facc) */
         uint32_t facc[NF];
 #pragma unroll
         for (int k = 0; k < NF; k++) facc[k] = 0;
@@ -874,7 +875,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 return __builtin_amdgcn_ballot_w64(bad != 0 && q < nv) != 0;
             };
             if constexpr (LONG) {
-                /* (the builds for long reads keep cls6_of_dword for every dword: two more code paths do not fit their registers) */
+                /* (the builds for long reads keep cls6_of_dword for spans with rows that end inside the segment: all four code paths do not fit their registers) */
                 auto classes_long = [&](auto ragged_c) {
 #pragma unroll
                     for (int t = 0; t < 2 * NW; t++) {
@@ -889,7 +890,21 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                         nacc += cl & (cl >> 1) & 0x08080808u;     /* N and padding */
                     }
                 };
-                if (ragged_rows) classes_long(std::true_type{}); else classes_long(std::false_type{});
+                /* a span of full segments (nearly all of them: the reads are sorted by length) whose rows hold the usual letters
+                   only: the two v_perms of the other builds; the counts go to facc */
+                if (!ragged_rows) {
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int t = 0; t < 2 * NW; t++) bad |= cls6_unusual(raw[t]);
+                    long_usual = __builtin_amdgcn_ballot_w64(bad != 0) == 0;
+                }
+                if (long_usual) {
+#pragma unroll
+                    for (int t = 0; t < 2 * NW; t++) {
+                        lds_store_u32(cb + 16 * t, cls6_usual(raw[t]));
+                        facc[t / 15] += gcn_usual(raw[t]);
+                    }
+                } else if (ragged_rows) classes_long(std::true_type{}); else classes_long(std::false_type{});
             } else {
                 if (unusual()) classes(std::true_type{}); else classes(std::false_type{});
             }
@@ -907,11 +922,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             }
         }
         if constexpr (DS && LONG) {   /* the read's G/C and A/C/G/T counts, a segment at a time (:1997-2049; the bin: k_long_gc_bins) */
-            uint32_t gs = sum_bytes(gacc, 0), ns = sum_bytes(nacc, 0);
-            gs += quad_bcast<0xB1>(gs); ns += quad_bcast<0xB1>(ns);
-            gs += quad_bcast<0x4E>(gs); ns += quad_bcast<0x4E>(ns);
+            /* G/C | other << 16 of the lane's dwords, padding counted in both (the short way meets none) */
+            uint32_t gn = long_usual ? gcn_sum(facc) : (sum_bytes(gacc, 0) >> 2) | ((sum_bytes(nacc, 0) >> 3) << 16);
+            gn += quad_bcast<0xB1>(gn);
+            gn += quad_bcast<0x4E>(gn);
             if (c == 0 && urow) {
-                const uint32_t gc_cnt = (gs >> 2) - (SB - urow), acgt_cnt = SB - (ns >> 3);
+                const uint32_t gc_cnt = (gn & 0xFFFFu) - (SB - urow), acgt_cnt = SB - (gn >> 16);
                 unsigned int *dst = P.long_gc + 2 * (uint64_t)rec_cur;
                 asm volatile("global_atomic_add %0, %1, off\n\tglobal_atomic_add %0, %2, off offset:4" :: "v"(dst), "v"(gc_cnt), "v"(acgt_cnt) : "memory");
             }

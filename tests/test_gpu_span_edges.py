@@ -402,3 +402,41 @@ def test_bases_a_sequencer_does_not_write(U, route):
             np.testing.assert_array_equal(u64(cnt), cr, err_msg=f"tile {t}")
     else:
         _compare_adapters(ga, ra)
+
+
+def test_long_reads_with_bases_a_sequencer_does_not_write():
+    """the same through k_span<LONG> (segments of long reads): spans of full segments with the usual letters take the short
+    way, a span with another byte or with a row that ends inside its segment cls6_of_dword"""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(77)
+    usual = np.frombuffer(b"ACGTNacgtn", np.uint8)
+    odd = np.frombuffer(b"Q!1S#W'D$F&RYKMBVHUX.-*@`~0", np.uint8)
+    probes = [A12, "GGNCA"]
+    names, seqs, quals = [], [], []
+    n = 4200   # (the long route sorts its reads by length: batches of 4096 reads and more)
+    for i in range(n):
+        L = int(rng.integers(300, 1500)) if i % 7 else int(rng.integers(257, 300)) if i % 14 else int(rng.integers(1500, 6000))
+        s = rng.choice(usual, size=L, p=[.2, .2, .2, .2, .02, .04, .04, .04, .04, .02])
+        if i % 3 == 0:
+            for at in ([0, L - 1, 255, 256, 257] + [int(x) for x in rng.integers(0, L, size=3)])[:int(rng.integers(1, 9))]:
+                s[min(at, L - 1)] = odd[int(rng.integers(0, len(odd)))]
+        elif i % 11 == 5:
+            s = rng.integers(33, 127, size=L).astype(np.uint8)
+        s = s.tobytes().decode()
+        if i % 4 == 0:
+            at = int(rng.integers(0, L - 11))
+            s = s[:at] + A12 + s[at + 12:]
+        names.append(f"read{i}")
+        seqs.append(s)
+        quals.append((rng.integers(0, 42, size=L) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+    gq, ga = QCMetrics(), AdapterCounter(probes)
+    from tests.test_gpu_vs_oracle import _route_of
+    r = _route_of(lambda: (FusedPass(gq, ga).add_record_array(arr), gq.flush()))
+    assert "long>" in r, r
+    compare_qc(rq, gq, metas, arr)
+    _compare_adapters(ga, ra)
