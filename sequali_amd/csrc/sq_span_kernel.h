@@ -183,6 +183,14 @@ __device__ __forceinline__ void add_f64_lds(uint32_t a, double v)
 {
     asm volatile("ds_add_f64 %0, %1" :: "v"(a), "v"(v) : "memory");
 }
+/* 16-bit half J of w, times 8 */
+template <int J> __device__ __forceinline__ uint32_t shl3_word_of(uint32_t w, uint32_t three)
+{
+    uint32_t t;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_%3"
+        : "=v"(t) : "v"(three), "v"(w), "i"(J));
+    return t;
+}
 /* byte J of w, times 8 */
 template <int J> __device__ __forceinline__ uint32_t shl3_byte_of(uint32_t w, uint32_t three)
 {
@@ -987,11 +995,17 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             if constexpr (DS) ts[0] = rd_tr8<0>(trb);
             if constexpr (DQ) tq[0] = rd_tr8<(int)QOFF>(trb);
             /* The chain's quality bytes: a group of four steps of the quad's four chains is the 16 bytes at 16 G of the row --
-               ONE ds_read_b128 (all four lanes the same address), lane c takes byte c of each dword (a v_bfe by 8 c).  Until
-               round 5: four ds_read_u8 per group.  The kernel sits at its LDS pipe (SQ_INSTS_LDS x ~ 5 cycles = its run time,
-               DESIGN 5.0): 30 LDS instructions less per span for 40 vector ones more. */
-            const uint32_t sh8 = co << 3;
-            auto chain_byte8 = [&](uint32_t w) { return __builtin_amdgcn_ubfe(w, sh8, 8) << 3; };   /* byte c of w, times 8: its error rate's address */
+               ONE ds_read_b128 (all four lanes the same address), lane c takes byte c of each dword.  Until round 5: four
+               ds_read_u8 per group (30 LDS instructions more per span for 40 vector ones less: 2 % slower). */
+            /* byte c of two dwords, times 8 (the addresses of their error rates), in three instructions: a v_perm puts byte c of
+               both into the halves of one register (selector bytes c, zero, 4 + c, zero), an SDWA shift makes an address of each
+               half.  (Until the end of round 5 a v_bfe and a shift per dword: + 1 % on the headline, same box.) */
+            const uint32_t selc = 0x0C040C00u + co * 0x00010001u, three_c = 3;
+            auto chain_pair8 = [&](uint32_t w0, uint32_t w1, uint32_t &a0, uint32_t &a1) {
+                const uint32_t p = __builtin_amdgcn_perm(w1, w0, selc);
+                a0 = shl3_word_of<0>(p, three_c);
+                a1 = shl3_word_of<1>(p, three_c);
+            };
             auto load_group = [&](auto gc, auto Gc) {   /* qc[4 g .. 4 g + 3] = the dwords of group G */
                 constexpr int g = decltype(gc)::value, G = decltype(Gc)::value;
                 const sq_u32x4v v = rd_b128<16 * G>(qual_row);
@@ -1057,7 +1071,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                     wait_lgkm<cap(SA + n_lq)>();
                     static_for<0, 4 * CG>([&](auto ic) { tie(qc[decltype(ic)::value]); });
                 }
-                if constexpr (nC1) { d[0] = rd_f64(chain_byte8(qc[0])); d[1] = rd_f64(chain_byte8(qc[1])); d[2] = rd_f64(chain_byte8(qc[2])); d[3] = rd_f64(chain_byte8(qc[3])); }
+                if constexpr (nC1) { uint32_t a0, a1, a2, a3; chain_pair8(qc[0], qc[1], a0, a1); chain_pair8(qc[2], qc[3], a2, a3); d[0] = rd_f64(a0); d[1] = rd_f64(a1); d[2] = rd_f64(a2); d[3] = rd_f64(a3); }
                 if constexpr (DS)
                     static_for<0, HI>([&](auto mc) {
                         constexpr int m = decltype(mc)::value, cell = t * HI + m, w = cell / HALF, k = cell % HALF;
@@ -1070,7 +1084,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                         if constexpr (m < n_l) { tie(l[m]); inc_u32<128 * ((t * HI + m) / HALF)>(hpp + l[m], one); }
                     });
                 }
-                if constexpr (nC2) { d[4] = rd_f64(chain_byte8(qc[4])); d[5] = rd_f64(chain_byte8(qc[5])); d[6] = rd_f64(chain_byte8(qc[6])); d[7] = rd_f64(chain_byte8(qc[7])); }
+                if constexpr (nC2) { uint32_t a4, a5, a6, a7; chain_pair8(qc[4], qc[5], a4, a5); chain_pair8(qc[6], qc[7], a6, a7); d[4] = rd_f64(a4); d[5] = rd_f64(a5); d[6] = rd_f64(a6); d[7] = rd_f64(a7); }
                 if constexpr (ADr) {   /* the second step: behind the first one are d[0..3], the increments, d[4..7] */
                     wait_lgkm<cap(nC1 + n_lq + nC2)>();
                     tie(e0);
@@ -1238,7 +1252,12 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                 const uint32_t tw = lds_u32(qual_row + Lmain);
                 const uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) lb[j] = KR4 + j < nsteps ? chain_byte8(gw[j]) : SPAN_ERR_PAD << 3;
+                for (uint32_t j = 0; j < 8; j += 2) {
+                    uint32_t a0, a1;
+                    chain_pair8(gw[j], gw[j + 1], a0, a1);
+                    lb[j] = KR4 + j < nsteps ? a0 : SPAN_ERR_PAD << 3;
+                    lb[j + 1] = KR4 + j + 1 < nsteps ? a1 : SPAN_ERR_PAD << 3;
+                }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) tb[j] = Lmain + j < U ? ((tw >> (8 * j)) & 0xFFu) << 3 : SPAN_ERR_PAD << 3;
                 double le[8], te[4];
