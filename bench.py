@@ -459,6 +459,8 @@ def main():
     device = f"cuda:{device_index}"
     scratch = []
     reduce_ms = []
+    reduce_events = []
+    lib_stream = [torch.cuda.ExternalStream(int(lib.sq_stream_handle(ctx)), device=device)] if use_dist else [None]
 
     def step(events=None):
         for b in batches:
@@ -468,7 +470,8 @@ def main():
                                               ad._h if ad else None, pt._h if pt else None))
             if events is not None:
                 events.stop()
-        _lib.synchronize()
+        if not use_dist:
+            _lib.synchronize()
         if use_dist:
             # the job's one exchange step: sum the count tables of all ranks over RCCL, as ONE
             # all-reduce over one flat buffer (on a copy, so that repeated steps keep accumulating
@@ -484,14 +487,20 @@ def main():
                 flat = torch.empty(sum(t.numel() for t in tables), dtype=torch.int64, device=device)
                 scratch.extend([tables, flat, list(flat.split([t.numel() for t in tables])), None])
             tables, flat, parts, _ = scratch
+            # The pass ran on the library's stream, the copy and the collective run on torch's: each waits for the other ON THE
+            # DEVICE (hipStreamWaitEvent both ways) -- the copy for the pass's kernels, the next pass for the copy -- so a
+            # step costs no host round trip; the barrier behind the timed steps waits for everything.  (Until round 5 three
+            # host-side synchronisations per step: ~ 1 ms of a 12 ms step.)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(lib_stream[0])
             torch._foreach_copy_(parts, tables)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             scratch[3] = sqdist._all_reduce(flat)   # in place over RCCL (through the host under gloo)
             ev1.record()
-            torch.cuda.synchronize()
+            lib_stream[0].wait_stream(cur)
             if events is not None:
-                reduce_ms.append(ev0.elapsed_time(ev1))   # the collective alone (it runs on torch's stream)
+                reduce_events.append((ev0, ev1))   # the collective alone (it runs on torch's stream); read behind the barrier
 
     def barrier():
         if use_dist:
@@ -511,6 +520,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launch_ms = events.durations_ms()
+    reduce_ms = [e0.elapsed_time(e1) for e0, e1 in reduce_events]
 
     job_bases = world * total_bases
     rank_ms = None
