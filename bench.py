@@ -199,6 +199,98 @@ def cpu_baseline(sample_reads: int, passes: int = 1):
                       f"QCMetrics+AdapterCounter on one thread (the reference's second thread only decompresses), {dt:.2f} s"}
 
 
+def _reference_module():
+    """the reference's own extension (oracle/_ref, compiled from its sources by oracle/Makefile), or None"""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref_dir, "_qc.abi3.so")):
+        return None
+    try:
+        if ref_dir not in sys.path:
+            sys.path.insert(0, ref_dir)
+        import _qc as ref
+        return ref
+    except Exception:
+        return None
+
+
+def cpu_baselines_other(only=None):
+    """The reference's C on one thread beside configs 3 and 4 and the six-module loop: bounded samples of the same
+    synthetic records (host generator: identical bytes), parsed by the reference's own FastqParser (not timed), fed
+    array by array as __main__.py:279-306 does."""
+    from sequali_amd import synth
+    ref = _reference_module()
+    if ref is None:
+        return {}
+    model, cores = host_cpu()
+    out = {}
+
+    def arrays_of(kind, n):
+        text, metas = synth.host_records(kind, 0, n)
+        return list(ref.FastqParser(io.BytesIO(text))), int(metas["sequence_length"].sum())
+
+    def entry(bases, dt, sample):
+        return {"value": round(bases / dt / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "reference",
+                "host_cpu": model, "host_cores": cores, "sample": sample + f", {dt:.2f} s"}
+
+    if only is None or "config3_paired" in only:
+        n = 1_000_000
+        (text1, metas1), (text2, metas2) = synth.host_records(synth.ILLUMINA, 0, n), synth.host_records(synth.ILLUMINA_R2, 0, n)
+        b1, b2 = int(metas1["sequence_length"].sum()), int(metas2["sequence_length"].sum())
+        p1, p2 = ref.FastqParser(io.BytesIO(text1)), ref.FastqParser(io.BytesIO(text2))
+        pairs = [(x, p2.read(len(x))) for x in p1]      # the mates' arrays cut at the same record counts, as the driver does
+        m1, m2, t1, t2, z = ref.QCMetrics(), ref.QCMetrics(), ref.PerTileQuality(), ref.PerTileQuality(), ref.InsertSizeMetrics()
+        t0 = time.perf_counter()
+        for x, y in pairs:
+            m1.add_record_array(x); t1.add_record_array(x)
+            m2.add_record_array(y); t2.add_record_array(y)
+            z.add_record_array_pair(x, y)
+        dt = time.perf_counter() - t0
+        assert z.total_reads == n and m1.number_of_reads == n
+        c3 = entry(b1 + b2, dt, f"first {n} pairs of the workload ({b1 + b2} bases), (QCMetrics + PerTileQuality) x 2 + "
+                   "InsertSizeMetrics on one thread")
+        for name in ("config3_paired", "config3_paired_by_tile", "config3_paired_five_calls_unfused"):
+            out[name] = c3
+        del pairs
+    if only is None or "config4_nanopore" in only:
+        n = 100_000
+        arrays, bases = arrays_of(synth.NANOPORE, n)
+        m, a = ref.QCMetrics(), ref.AdapterCounter(list(synth.NANOPORE_PROBES))
+        t0 = time.perf_counter()
+        for x in arrays:
+            m.add_record_array(x)
+            a.add_record_array(x)
+        dt = time.perf_counter() - t0
+        assert m.number_of_reads == n
+        out["config4_nanopore"] = entry(bases, dt, f"first {n} reads of the workload ({bases} bases), QCMetrics + AdapterCounter "
+                                        "(14 probes) on one thread")
+        del arrays
+    if only is None or "single_end_six_modules" in only:
+        n = 2_000_000
+        arrays, bases = arrays_of(synth.ILLUMINA, n)
+        mods = (ref.QCMetrics(), ref.AdapterCounter(list(synth.ILLUMINA_PROBES)), ref.PerTileQuality(),
+                ref.OverrepresentedSequences(), ref.NanoStats(),
+                ref.DedupEstimator(front_sequence_offset=64, back_sequence_offset=0))
+        t0 = time.perf_counter()
+        for x in arrays:
+            for mod in mods:
+                mod.add_record_array(x)
+        dt = time.perf_counter() - t0
+        assert mods[0].number_of_reads == n
+        out["single_end_six_modules"] = entry(bases, dt, f"first {n} reads of the workload ({bases} bases), the six single-end modules of "
+                                              "__main__.py:279-306 on one thread")
+        per = {}
+        for label, make in (("overrep_alone", lambda: ref.OverrepresentedSequences()),
+                            ("dedup_single_end", lambda: ref.DedupEstimator(front_sequence_offset=64, back_sequence_offset=0))):
+            mod = make()
+            t0 = time.perf_counter()
+            for x in arrays:
+                mod.add_record_array(x)
+            dt = time.perf_counter() - t0
+            per[label] = entry(bases, dt, f"first {n} reads of the workload ({bases} bases), the module alone on one thread")
+        out.update(per)
+    return out
+
+
 def other_configs(lib, ctx, steps, warmup, only=None):
     """BASELINE configs 3 and 4 and the ragged variant of config 2, each timed like the headline:
     records resident in HBM, `steps` passes behind `warmup`, HIP events on the library's stream
@@ -226,7 +318,7 @@ def other_configs(lib, ctx, steps, warmup, only=None):
         avg = sum(ms) / len(ms)
         achieved = algo / (avg * 1e-3) / 1e9
         return {"workload": workload, "value": round(bases / dt / 1e9, 3), "unit": "Gbases/s",
-                "ms_per_step": round(dt * 1e3, 3), "route": route,
+                "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": max(warmup, 1), "route": route,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBPS, 5), "kernel": kernel,
                              "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_step": int(algo)},
@@ -357,6 +449,129 @@ def other_configs(lib, ctx, steps, warmup, only=None):
             lambda f, passes: {"base_table_sum_ok": bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == bases * passes),
                                "phred_scores_sum_ok": bool(int(np.array(f.qc_metrics.phred_scores(), np.uint64).sum()) == n * passes)})
         del arr
+    # ---- the (a) modules the headline does not hold, alone and composed as the reference's driver loop composes them
+    #      (__main__.py:279-306): every one over the HBM-resident 100 M reads of config 2 (pairs: config 3's), algorithmic
+    #      bytes by SURVEY 8(d)'s per-module figures.  The estimator and the k-mer table are SETTLED when the timed passes
+    #      start (one warm-up pass over all records went through them: the fresh object's pass is `first_pass_ms`) ----
+    module_entries = ("single_end_six_modules", "overrep_alone", "dedup_single_end")
+    if any(wanted(e) for e in module_entries):
+        from sequali_amd import DedupEstimator, NanoStats, OverrepresentedSequences
+        n, per = 100_000_000, 25_000_000
+        batches = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
+        bases = sum(b._batch.total_bases for b in batches)
+        name_len = 36
+        ovr_bytes = (2 * 5 * 21) * (n // 8) + 40 * n          # <= 210 B per sampled read (1 in 8) + 40 B/read
+        dedup_bytes = 56 * n                                   # 16 B fingerprint + 40 B meta per read
+
+        def timed_first(make, step):
+            """(objects after one pass, ms of that first pass): what a fresh table / estimator costs"""
+            o = make()
+            _lib.synchronize()
+            t0 = time.perf_counter()
+            step(o)
+            _lib.synchronize()
+            return o, (time.perf_counter() - t0) * 1e3
+
+        if wanted("overrep_alone"):
+            def ovr_step(o):
+                for b in batches:
+                    o.add_record_array(b)
+            first = {}
+
+            def ovr_make():
+                o, first["ms"] = timed_first(OverrepresentedSequences, ovr_step)
+                return o
+            out["overrep_alone"] = run(
+                "overrep", f"{n} x 150 bp synthetic single-end reads, OverrepresentedSequences (defaults: every 8th read, 21-mers, 5 M uniques) "
+                "alone, records resident in HBM; the table holds its 5 M fragments when the timed passes start",
+                "k_overrep", (bases, n, ovr_bytes), ovr_make, ovr_step,
+                lambda o, passes: {"number_of_sequences_ok": bool(o.number_of_sequences == n * (passes + 1)),
+                                   "sampled_ok": bool(o.sampled_sequences == (n // 8) * (passes + 1)),
+                                   "table_full_ok": bool(o.collected_unique_fragments == o.max_unique_fragments)})
+            out["overrep_alone"]["first_pass_ms"] = round(first["ms"], 3)
+        if wanted("dedup_single_end"):
+            def dd_step(o):
+                for b in batches:
+                    o.add_record_array(b)
+            first = {}
+
+            def dd_make():
+                o, first["ms"] = timed_first(lambda: DedupEstimator(front_sequence_offset=64, back_sequence_offset=0), dd_step)
+                first["bits"] = o._modulo_bits
+                return o
+            out["dedup_single_end"] = run(
+                "dedup", f"{n} x 150 bp synthetic single-end reads, DedupEstimator (the CLI's single-end geometry: 8 + 8 bases, front offset 64, "
+                "back offset 0; 1 M fingerprints) alone, records resident in HBM; a settled estimator (one pass over all records in front)",
+                "k_dedup_hash (+ table lookups on the device, the insertion tail of the new fingerprints on the host)",
+                (bases, n, dedup_bytes), dd_make, dd_step,
+                lambda o, passes: {"tracked_ok": bool(0 < o.tracked_sequences <= 1_000_000),
+                                   "counts_sum_ok": bool(int(np.array(o.duplication_counts(), np.uint64).sum()) > 0)})
+            out["dedup_single_end"]["first_pass_ms"] = round(first["ms"], 3)
+            out["dedup_single_end"]["modulo_bits_after_first_pass"] = first["bits"]
+        if wanted("single_end_six_modules"):
+            def six_make():
+                return (FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)), PerTileQuality()),
+                        OverrepresentedSequences(), NanoStats(),
+                        DedupEstimator(front_sequence_offset=64, back_sequence_offset=0))
+
+            def six_step(o):
+                fused, ovr, nano, dd = o
+                for b in batches:      # __main__.py:279-306: metrics, adapters, per tile quality, overrepresented, nanostats, dedup
+                    fused.add_record_array(b); clear(fused)
+                    ovr.add_record_array(b)
+                    nano.add_record_array(b)
+                    dd.add_record_array(b)
+            first = {}
+
+            def six_make_settled():
+                o, first["ms"] = timed_first(six_make, six_step)
+                return o
+            out["single_end_six_modules"] = run(
+                "six", f"{n} x 150 bp synthetic single-end reads through the reference's driver loop (__main__.py:279-306): "
+                "FusedPass(QCMetrics, AdapterCounter, PerTileQuality) + OverrepresentedSequences + NanoStats + DedupEstimator per array of 25 M, "
+                "records resident in HBM (NanoStats skips at the first header that is not a nanopore one, as the reference does)",
+                "the kernels `route` names",
+                (bases, n, 2 * bases + (48 + name_len) * n + ovr_bytes + dedup_bytes), six_make_settled, six_step,
+                lambda o, passes: {
+                    "base_table_sum_ok": bool(int(np.array(o[0].qc_metrics.base_count_table(), np.uint64).sum()) == bases * (passes + 1)),
+                    "pertile_reads_ok": bool(o[0].per_tile_quality.number_of_reads == n * (passes + 1)),
+                    "overrep_sequences_ok": bool(o[1].number_of_sequences == n * (passes + 1)),
+                    "nanostats_skipped_ok": bool(o[2].skipped_reason is not None),
+                    "dedup_tracked_ok": bool(0 < o[3].tracked_sequences <= 1_000_000)})
+            out["single_end_six_modules"]["first_pass_ms"] = round(first["ms"], 3)
+        del batches
+    if wanted("dedup_paired") or wanted("insert_size_alone"):
+        from sequali_amd import DedupEstimator
+        n, per = 100_000_000, 25_000_000
+        r1 = [synth.device_array(synth.ILLUMINA, k * per, per) for k in range(n // per)]
+        r2 = [synth.device_array(synth.ILLUMINA_R2, k * per, per) for k in range(n // per)]
+        bases = sum(b._batch.total_bases for b in r1) + sum(b._batch.total_bases for b in r2)
+        if wanted("dedup_paired"):
+            def ddp_step(o):
+                for a, b in zip(r1, r2):
+                    o.add_record_array_pair(a, b)
+
+            def ddp_make():
+                o = DedupEstimator(front_sequence_offset=0, back_sequence_offset=0)
+                ddp_step(o)
+                return o
+            out["dedup_paired"] = run(
+                "dedup_paired", f"{n} x 150 bp synthetic pairs, DedupEstimator (the CLI's paired geometry: 8 bases of each mate at offset 0) alone, "
+                "records resident in HBM; a settled estimator",
+                "k_dedup_hash (+ table lookups on the device, the insertion tail of the new fingerprints on the host)",
+                (bases, n, (16 + 80) * n), ddp_make, ddp_step,
+                lambda o, passes: {"tracked_ok": bool(0 < o.tracked_sequences <= 1_000_000)})
+        if wanted("insert_size_alone"):
+            def isz_step(o):
+                for a, b in zip(r1, r2):
+                    o.add_record_array_pair(a, b)
+            out["insert_size_alone"] = run(
+                "insert_size", f"{n} x 150 bp synthetic pairs, InsertSizeMetrics alone, records resident in HBM",
+                "the kernels `route` names",
+                (bases, n, bases // 2 + (32 + 80) * n), InsertSizeMetrics, isz_step,   # SURVEY 8d: 1 B/base of read 1 + 32 B of read 2's ends + 80
+                lambda o, passes: {"insert_size_pairs_ok": bool(o.total_reads == n * passes),
+                                   "insert_sizes_sum_ok": bool(int(np.array(o.insert_sizes(), np.uint64).sum()) == n * passes)})
+        del r1, r2
     # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
     if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split"):
         import io
@@ -609,6 +824,12 @@ def main():
                     for name, b in (tj.get("other_configs_hbm_bytes_per_step") or {}).items():
                         if name in out["other_configs"] and "roofline" in out["other_configs"][name]:
                             out["other_configs"][name]["roofline"]["traffic"] = b
+                try:
+                    for name, base in cpu_baselines_other(set(out["other_configs"])).items():
+                        if name in out["other_configs"]:
+                            out["other_configs"][name]["cpu_baseline"] = base
+                except Exception as e:   # a report, never a reason to lose the line
+                    out["other_configs"]["cpu_baseline_error"] = repr(e)
             except Exception as e:   # never a reason to lose the headline
                 out["other_configs"] = {"error": repr(e)}
         if world == 1 and args.cpu_sample > 0:

@@ -339,6 +339,12 @@ uint64_t sq_dedup_hash_table_size(sq_dedup *d);
 uint64_t sq_dedup_tracked_sequences(sq_dedup *d);
 /* duplication_counts :4721: the non-zero counts in slot order */
 int64_t sq_dedup_duplication_counts(sq_dedup *d, uint64_t *out, size_t cap);
+/* The table (EstimatorEntry[], :4283-4299) lives in HBM: lookups, inserts (DedupEstimator_add_fingerprint :4426-4460)
+ * and rebuilds (DedupEstimator_increment_modulo :4383-4423) run as parallel steps over pieces of the stream of hashes
+ * and leave the reference's table, slot for slot.  A piece the steps must not take (see csrc/sq_ends.hip) goes through
+ * the reference's loop on a host copy; these two count the pieces either way (tests, bench.py). */
+uint64_t sq_dedup_device_pieces(sq_dedup *d);
+uint64_t sq_dedup_host_pieces(sq_dedup *d);
 
 /* ---- InsertSizeMetrics, _qcmodule.c:5456-5982 ------------------------------ */
 sq_insertsize *sq_insertsize_new(sq_ctx *ctx, int64_t max_adapters);  /* :5505 */

@@ -82,22 +82,54 @@ def _hipcc() -> str:
     return exe
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+def _sha(paths, extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
         os.path.join(HERE, "..", "include", "sqgpu.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def source_key(src: str) -> str:
+    """what an object file was made from: its source, every header, the flags.  Content, not mtimes: a library that
+    travelled with a snapshot of the tree (gpurun) or was checked out beside newer sources must not pass as current."""
+    return _sha([os.path.join(CSRC, src)] + _headers(), " ".join(FLAGS))
+
+
+def library_key() -> str:
+    return _sha([os.path.join(CSRC, src) for src in SOURCES] + _headers(), " ".join(FLAGS))
+
+
+def _read(path: str) -> str:
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
+KEYFILE = LIB + ".key"
+
+
+def _stale() -> bool:
+    return not os.path.exists(LIB) or _read(KEYFILE) != library_key()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compiles and links under a file lock, into temporary names that are renamed into place:
     ranks of one torchrun job that all find the library stale neither compile into the same
-    object files at once nor dlopen a half-written library."""
+    object files at once nor dlopen a half-written library.  A source is compiled again when the
+    hash of what it is made from differs from the one recorded beside its object file."""
     if not force and not _stale():
         return LIB
     import fcntl
+    import json
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -107,8 +139,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             return LIB
         tag = f".{os.getpid()}.tmp"
 
-        def compile_one(src: str) -> str:
+        def compile_one(src: str):
             obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            key, resfile = source_key(src), obj + ".res.json"
+            if not force and os.path.exists(obj) and _read(obj + ".key") == key and os.path.exists(resfile):
+                with open(resfile) as f:
+                    return obj, json.load(f)
             flags = FLAGS + ["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else \
                 ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]   # .cpp: host only
             cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj + tag]
@@ -120,6 +156,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and l.strip() not in ("^", "")
                                 and not l.lstrip().split("|")[0].strip().isdigit()), file=sys.stderr)
             os.replace(obj + tag, obj)
+            with open(resfile, "w") as f:
+                json.dump(res, f)
+            with open(obj + ".key", "w") as f:
+                f.write(key)
             return obj, res
 
         with ThreadPoolExecutor(max_workers=8) as pool:
@@ -128,7 +168,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
         resources = {}
         for _, res in done:
             resources.update(res)
-        import json
         with open(os.path.join(objdir, "resources.json"), "w") as f:
             json.dump(resources, f, indent=0, sort_keys=True)
         check_default_routes(resources)   # before the link: a library with a spilling default route is not made
@@ -137,6 +176,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
         os.replace(LIB + tag, LIB)
+        with open(KEYFILE, "w") as f:
+            f.write(library_key())
     return LIB
 
 

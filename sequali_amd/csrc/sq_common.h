@@ -110,8 +110,8 @@ struct sq_ctx {
     uint64_t *pinned_stats = nullptr; /* SQ_STATS_N words: k_batch_stats' read-back */
     /* grow-only device scratch buffers (sorting), reused across batches so that no
        hipFree (a device-wide sync) sits between launches */
-    void *scratch[32] = {};       /* 0-5: the fused pass (sorting, carries; 3 holds P.order while a pass runs); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split; 21: k_batch_stats; 22: workgroup shares of k_span<LONG>; 23: its reads per segment; 24-28: the paired pass (sq_pair.hip); 29-31: the DedupEstimator's lower bound (sq_dedup_shard_settle) */
-    size_t scratch_bytes[32] = {};
+    void *scratch[40] = {};       /* 0-5: the fused pass (sorting, carries; 3 holds P.order while a pass runs); 6-13: selections and DedupEstimator; 14-15: k_span over sorted reads; 16: k_isz_span; 18-20: the device-side FASTQ split; 21: k_batch_stats; 22: workgroup shares of k_span<LONG>; 23: its reads per segment; 24-28: the paired pass (sq_pair.hip); 29-31: the DedupEstimator's lower bound (sq_dedup_shard_settle); 32-39: the DedupEstimator's table steps (dedup_process) */
+    size_t scratch_bytes[40] = {};
     /* small host arrays an asynchronous copy reads from (segment tables, row starts): the last few calls' copies
        stay alive here, whatever HIP does with pageable sources */
     std::vector<uint8_t> host_keep[8];

@@ -1010,7 +1010,7 @@ __global__ void k_dedup_gather(const unsigned long long *idx, uint64_t n_keep,
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_keep;
          e += (uint64_t)gridDim.x * blockDim.x) {
         out_hash[e] = hashes[idx[e]];
-        out_special[e] = special ? special[idx[e]] : 0;
+        if (out_special) out_special[e] = special ? special[idx[e]] : 0;
     }
 }
 
@@ -1028,6 +1028,192 @@ __global__ void k_dedup_ctz_hist(const unsigned long long *sorted, uint64_t n, u
     __syncthreads();
     for (int i = threadIdx.x; i < 65; i += blockDim.x)
         if (l_hist[i]) atomicAdd(&hist[i], (unsigned long long)l_hist[i]);
+}
+
+/* ---- DedupEstimator's table in HBM (round 6) ---------------------------------------------------------------
+ *
+ * The reference's estimator (:4426-4460) is sequential: a hash that passes the mask is looked up by linear probing,
+ * counted if found, inserted into the first empty slot if not; an arrival that finds the table full rebuilds it
+ * first.  What of that is observable -- which hashes are stored, their counts AND their slots (duplication_counts()
+ * walks the table in slot order, :4736-4744) -- is reproduced by parallel steps, piece by piece of the stream:
+ *
+ *   k_dd_classify   every survivor of the piece (the hashes that pass the mask, in read order) is looked up in the
+ *                   table AS IT STOOD WHEN THE PIECE BEGAN: entries never move or leave between rebuilds, so what is
+ *                   found then is found when its turn comes, in the same slot
+ *   (sort)          the survivors not found, stably by hash: the first of several equal ones will insert, the
+ *                   others find it (they become its count)
+ *   k_dd_heads ...  which arrival fills the table (the stored count reaches max_stored at the need-th FIRST
+ *                   occurrence of a new hash); the survivor behind it is the one whose arrival rebuilds, and the
+ *                   piece ends in front of it
+ *   k_dd_insert     linear probing by PRIORITY (Shun & Blelloch, "Phase-concurrent hash tables for determinism",
+ *                   SPAA 2014: an element that meets one of lower priority takes its slot and the displaced one
+ *                   moves on): with the order of arrival as the priority and resident entries above all, the layout
+ *                   is the one sequential insertion in order of arrival leaves, whatever order the lanes run in.
+ *                   The slots hold TOKENS (0: a resident entry, 1 + rank of arrival, ~0: empty) while the lanes
+ *                   compete; k_dd_finalize writes hash and count where the tokens came to rest
+ *   k_dd_rebuild_*  DedupEstimator_increment_modulo (:4383-4423) the same way: the entries that pass the stricter
+ *                   mask into an empty table, priority = slot in the old one (the order the reference walks it)
+ *   k_dd_trigger    the arrival that caused the rebuild, placed with the OLD bit count -- one lane
+ *
+ * One thing a lookup at the piece's start cannot see: an entry placed by k_dd_trigger does not sit in the probe run
+ * of its own hash, so a later arrival of that hash finds it only if entries inserted meanwhile have closed the gap.
+ * Such an entry is tracked (`odd`); a piece in which its hash arrives without being found takes the host's
+ * sequential loop (dedup_host_piece) -- about one piece in twenty rebuilds on the synthetic reads.
+ */
+constexpr unsigned int DD_EMPTY = 0xFFFFFFFFu, DD_MISS = 0xFFFFFFFFu;
+
+/* survivors: sel[e] = index (relative to the piece) of the e-th hash that passes the mask */
+__global__ void k_dd_classify(const unsigned long long *hashes, const unsigned long long *sel, uint64_t n_sel,
+                              const unsigned long long *thash, const unsigned int *tcount, uint64_t bits,
+                              uint64_t mask, unsigned long long odd_hash, int odd_valid, unsigned int *slot_out,
+                              unsigned int *flags /* [0]: the odd entry's hash arrived and was not found */)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_sel; e += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = hashes[sel[e]];
+        unsigned int found = DD_MISS;
+        for (uint64_t i = (h >> bits) & mask;; i = (i + 1) & mask) {
+            if (tcount[i] == 0) break;
+            if (thash[i] == h) { found = (unsigned int)i; break; }
+        }
+        slot_out[e] = found;
+        if (found == DD_MISS && odd_valid && h == odd_hash) flags[0] = 1;
+    }
+}
+
+struct DedupIsMiss {
+    const unsigned int *slot;
+    __device__ bool operator()(const unsigned long long &e) const { return slot[e] == DD_MISS; }
+};
+
+/* miss[r] = survivor index e of the r-th survivor not found -> its hash (the sort's key) and r (the value) */
+__global__ void k_dd_miss_keys(const unsigned long long *hashes, const unsigned long long *sel, const unsigned long long *miss,
+                               uint64_t n_miss, unsigned long long *key, unsigned int *val)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_miss; r += (uint64_t)gridDim.x * blockDim.x) {
+        key[r] = hashes[sel[miss[r]]];
+        val[r] = (unsigned int)r;
+    }
+}
+
+/* sorted by hash (stable: equal hashes in order of arrival): first[r] = 1 for the first arrival of every new hash */
+__global__ void k_dd_heads(const unsigned long long *skey, const unsigned int *sval, uint64_t n_miss, unsigned int *first)
+{
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n_miss; j += (uint64_t)gridDim.x * blockDim.x)
+        first[sval[j]] = (j == 0 || skey[j - 1] != skey[j]) ? 1u : 0u;
+}
+
+/* pos = inclusive sum of first: out[0] = the r whose first occurrence is the need-th new hash */
+__global__ void k_dd_find_nth(const unsigned int *first, const unsigned int *pos, uint64_t n_miss, unsigned int need,
+                              unsigned long long *out)
+{
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_miss; r += (uint64_t)gridDim.x * blockDim.x)
+        if (first[r] && pos[r] == need) out[0] = r;
+}
+
+__global__ void k_dd_tok_init(const unsigned int *tcount, unsigned int *tok, uint64_t size)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size; i += (uint64_t)gridDim.x * blockDim.x)
+        tok[i] = tcount[i] ? 0u : DD_EMPTY;
+}
+
+/* the token v looks for its slot from slot i on: smaller tokens stay, a larger one (or none) gives way and moves on */
+__device__ __forceinline__ void dd_priority_insert(unsigned int *tok, uint64_t mask, uint64_t i, unsigned int v)
+{
+    for (;;) {
+        const unsigned int c = __hip_atomic_load(&tok[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < v) { i = (i + 1) & mask; continue; }
+        if (atomicCAS(&tok[i], c, v) != c) continue;   /* somebody else was faster: look at the slot again */
+        if (c == DD_EMPTY) return;
+        v = c;                                           /* the displaced token goes on from the next slot */
+        i = (i + 1) & mask;
+    }
+}
+
+/* found survivors in front of the piece's end: their entry's count; heads of the sorted misses: the count the new
+ * entry will have (its arrivals in front of the end) and the token's walk into the table */
+__global__ void k_dd_apply_found(const unsigned int *slot, uint64_t e_end, unsigned int *tcount)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < e_end; e += (uint64_t)gridDim.x * blockDim.x)
+        if (slot[e] != DD_MISS) atomicAdd(&tcount[slot[e]], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *skey, const unsigned int *sval, uint64_t n_miss,
+                            const unsigned long long *miss, uint64_t e_end, uint64_t bits, uint64_t mask,
+                            unsigned int *tok, unsigned int *new_count /* [n_miss], by rank */,
+                            unsigned long long *n_inserted)
+{
+    for (uint64_t base = blockIdx.x * 256ull; base < n_miss; base += gridDim.x * 256ull) {   /* every lane of a wave the same trips */
+        const uint64_t j = base + threadIdx.x;
+        bool mine = j < n_miss && (j == 0 || skey[j - 1] != skey[j]);
+        unsigned int r = 0;
+        if (mine) {
+            r = sval[j];
+            mine = miss[r] < e_end;                       /* the first arrival lies behind the end: so do all */
+        }
+        const unsigned long long b = __ballot(mine);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(n_inserted, (unsigned long long)__popcll(b));
+        if (!mine) continue;
+        unsigned int c = 0;
+        for (uint64_t k = j; k < n_miss && skey[k] == skey[j]; k++) c += miss[sval[k]] < e_end;
+        new_count[r] = c;
+        dd_priority_insert(tok, mask, (skey[j] >> bits) & mask, r + 1);
+    }
+}
+
+__global__ void k_dd_finalize(const unsigned int *tok, uint64_t size, const unsigned long long *key /* by rank */,
+                              const unsigned int *new_count, unsigned long long *thash, unsigned int *tcount)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned int t = tok[i];
+        if (t == 0 || t == DD_EMPTY) continue;
+        thash[i] = key[t - 1];
+        tcount[i] = new_count[t - 1];
+    }
+}
+
+/* DedupEstimator_increment_modulo :4383-4423: the old table's entries that pass the mask of new_bits bits */
+__global__ void __launch_bounds__(256) k_dd_rebuild_insert(const unsigned long long *thash, const unsigned int *tcount, uint64_t size,
+                                    uint64_t new_bits, unsigned int *tok, unsigned long long *kept)
+{
+    const unsigned long long ignore = (1ULL << new_bits) - 1;
+    for (uint64_t base = blockIdx.x * 256ull; base < size; base += gridDim.x * 256ull) {
+        const uint64_t i = base + threadIdx.x;
+        const bool mine = i < size && tcount[i] != 0 && (thash[i] & ignore) == 0;
+        const unsigned long long b = __ballot(mine);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(kept, (unsigned long long)__popcll(b));
+        if (mine) dd_priority_insert(tok, size - 1, (thash[i] >> new_bits) & (size - 1), (unsigned int)i + 1);
+    }
+}
+
+__global__ void k_dd_rebuild_finalize(const unsigned int *tok, uint64_t size, const unsigned long long *ohash,
+                                      const unsigned int *ocount, unsigned long long *nhash, unsigned int *ncount)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned int t = tok[i];
+        nhash[i] = t == DD_EMPTY ? 0ull : ohash[t - 1];
+        ncount[i] = t == DD_EMPTY ? 0u : ocount[t - 1];
+    }
+}
+
+/* the tail of DedupEstimator_add_fingerprint :4453-4459 for the arrival that rebuilt: the slot by the OLD bit count.
+ * out[0] = the hash, out[1] = 1 if it was inserted (0: found and counted) */
+__global__ void k_dd_trigger(const unsigned long long *hashes, const unsigned long long *sel, uint64_t e,
+                             uint64_t old_bits, uint64_t mask, unsigned long long *thash, unsigned int *tcount,
+                             unsigned long long *out)
+{
+    const unsigned long long h = hashes[sel[e]];
+    out[0] = h;
+    for (uint64_t i = (h >> old_bits) & mask;; i = (i + 1) & mask) {
+        if (tcount[i] == 0) { thash[i] = h; tcount[i] = 1; out[1] = 1; return; }
+        if (thash[i] == h) { tcount[i]++; out[1] = 0; return; }
+    }
+}
+
+/* hashes the host made for pairs shorter than the fingerprint, into the batch's hashes */
+__global__ void k_dd_patch(unsigned long long *hashes, const unsigned long long *pos, const unsigned long long *val, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        hashes[pos[i]] = val[i];
 }
 
 __global__ void k_iota(unsigned long long *p, uint64_t n)
@@ -1477,16 +1663,21 @@ struct sq_dedup {
     sq_ctx *ctx;
     uint64_t modulo_bits = 0, table_size, max_stored, stored = 0;
     uint64_t front_len, back_len, front_off, back_off;
+    /* The table lives in HBM (d_hash / d_count; round 6) and is copied to the host when somebody asks for it (getters,
+       export) or when a piece has to take the sequential loop; an estimator without a context (the head of a gather
+       merge in tests/test_dedup_gather_cpu.py) has the host's copy only.  host_valid / dev_valid: which copy is current */
     std::vector<uint64_t> hash;
     std::vector<uint32_t> count;
+    bool host_valid = true, dev_valid = false;
+    unsigned long long *d_hash = nullptr, *d_hash2 = nullptr;
+    unsigned int *d_count = nullptr, *d_count2 = nullptr, *d_tok = nullptr;
+    /* the one entry that may sit outside the probe run of its hash: the arrival that caused the last rebuild, if it was
+       inserted (placed with the old bit count, :4453) and still passes the mask */
+    uint64_t odd_hash = 0;
+    bool odd_valid = false;
+    uint64_t host_pieces = 0, device_pieces = 0;   /* pieces that took the sequential loop / the parallel steps */
     std::vector<uint8_t> store; /* the fingerprint buffer the reference reuses */
-    /* host side of a piece of survivors (dedup_tail): grow-only */
-    std::vector<unsigned long long> h_idx, h_hashes;
-    std::vector<unsigned char> h_special, h_state;
-    unsigned parallel_skip = 0; /* pieces that skip the parallel attempt after one was taken back */
-    /* the fingerprint store while a batch of pairs walks through the tail: short pairs come by in read order */
-    std::vector<uint8_t> run_store;
-    uint64_t run_prev = UINT64_MAX; /* the last short pair of this batch that went through */
+    std::vector<unsigned long long> h_hashes;   /* host side of a piece of survivors (dedup_host_piece): grow-only */
     /* deferred mode (a shard of a multi-GPU job): add_* only hashes; the hashes
        stay in HBM until sq_dedup_resolve() runs the insertion tail over them, after the
        state of the shard in front has been imported */
@@ -1548,16 +1739,62 @@ SQ_EXPORT sq_dedup *sq_dedup_new(sq_ctx *ctx, int64_t max_stored_fingerprints, i
 SQ_EXPORT void sq_dedup_free(sq_dedup *d)
 {
     if (!d) return;
-    if (d->d_stream) {
-        (void)hipStreamSynchronize(d->ctx->stream);
-        (void)hipFree(d->d_stream);
-    }
+    if (d->ctx && (d->d_stream || d->d_hash)) (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->d_stream) (void)hipFree(d->d_stream);
+    for (void *p : {(void *)d->d_hash, (void *)d->d_hash2, (void *)d->d_count, (void *)d->d_count2, (void *)d->d_tok})
+        if (p) (void)hipFree(p);
     delete d;
 }
 
 namespace {
 
-/* DedupEstimator_increment_modulo, _qcmodule.c:4382-4423 */
+/* the current table on the host (getters, export, the sequential loop) */
+int dedup_to_host(sq_dedup *d)
+{
+    if (d->host_valid) return SQ_OK;
+    SQ_HIP(hipMemcpyAsync(d->hash.data(), d->d_hash, d->table_size * 8, hipMemcpyDeviceToHost, d->ctx->stream));
+    SQ_HIP(hipMemcpyAsync(d->count.data(), d->d_count, d->table_size * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+    SQ_HIP(hipStreamSynchronize(d->ctx->stream));
+    d->host_valid = true;
+    return SQ_OK;
+}
+
+/* the current table in HBM (the parallel steps) */
+int dedup_to_device(sq_dedup *d)
+{
+    if (d->dev_valid) return SQ_OK;
+    if (!d->d_hash) {
+        SQ_HIP(hipMalloc((void **)&d->d_hash, d->table_size * 8));
+        SQ_HIP(hipMalloc((void **)&d->d_hash2, d->table_size * 8));
+        SQ_HIP(hipMalloc((void **)&d->d_count, d->table_size * 4));
+        SQ_HIP(hipMalloc((void **)&d->d_count2, d->table_size * 4));
+        SQ_HIP(hipMalloc((void **)&d->d_tok, d->table_size * 4));
+    }
+    SQ_HIP(hipMemcpyAsync(d->d_hash, d->hash.data(), d->table_size * 8, hipMemcpyHostToDevice, d->ctx->stream));
+    SQ_HIP(hipMemcpyAsync(d->d_count, d->count.data(), d->table_size * 4, hipMemcpyHostToDevice, d->ctx->stream));
+    SQ_HIP(hipStreamSynchronize(d->ctx->stream));   /* the vectors may change behind this call */
+    d->dev_valid = true;
+    return SQ_OK;
+}
+
+/* which entry of the host's table cannot be reached from the slot its hash starts at (an imported state does not
+ * say): walking the run in front of every entry back to an empty slot is the table's size times a short run */
+void dedup_find_odd(sq_dedup *d)
+{
+    const uint64_t mask = d->table_size - 1, bits = d->modulo_bits;
+    d->odd_valid = false;
+    for (uint64_t i = 0; i < d->table_size; i++) {
+        if (!d->count[i]) continue;
+        const uint64_t h = d->hash[i];
+        if (bits && (h & ((1ULL << bits) - 1))) continue;   /* does not pass the mask: never arrives again */
+        bool reachable = true;
+        for (uint64_t j = (h >> bits) & mask; j != i; j = (j + 1) & mask)
+            if (!d->count[j]) { reachable = false; break; }
+        if (!reachable) { d->odd_hash = h; d->odd_valid = true; }
+    }
+}
+
+/* DedupEstimator_increment_modulo, _qcmodule.c:4382-4423 (host copy) */
 void dedup_rebuild(sq_dedup *d)
 {
     const uint64_t bits = d->modulo_bits + 1, ignore = (1ULL << bits) - 1, mask = d->table_size - 1;
@@ -1579,16 +1816,21 @@ void dedup_rebuild(sq_dedup *d)
 }
 
 /* the tail of DedupEstimator_add_fingerprint, _qcmodule.c:4430-4459, quirks included
- * (the pre-rebuild bit count indexes the triggering hash) */
+ * (the pre-rebuild bit count indexes the triggering hash), on the host copy */
 inline void dedup_insert(sq_dedup *d, uint64_t h)
 {
     const uint64_t bits = d->modulo_bits;
     if (h & ((1ULL << bits) - 1)) return;
-    if (d->stored >= d->max_stored) dedup_rebuild(d);
+    bool rebuilt = false;
+    if (d->stored >= d->max_stored) { dedup_rebuild(d); rebuilt = true; d->odd_valid = false; }
     const uint64_t mask = d->table_size - 1;
     uint64_t i = (h >> bits) & mask;
     for (;;) {
-        if (d->count[i] == 0) { d->hash[i] = h; d->count[i] = 1; d->stored++; return; }
+        if (d->count[i] == 0) {
+            d->hash[i] = h; d->count[i] = 1; d->stored++;
+            if (rebuilt && (h & ((1ULL << d->modulo_bits) - 1)) == 0) { d->odd_hash = h; d->odd_valid = true; }
+            return;
+        }
         if (d->hash[i] == h) { d->count[i]++; return; }
         i = (i + 1) & mask;
     }
@@ -1625,143 +1867,253 @@ int pair_store_bytes(sq_dedup *d, sq_batch *b1, sq_batch *b2, uint64_t r, std::v
     return SQ_OK;
 }
 
-/* the sequential part: hashes [0,n) on the device, in read order, through the
- * estimator.  Only hashes that pass the mask in force at the start can matter; the mask
- * only ever gets stricter (H3). */
-int dedup_tail(sq_dedup *d, const unsigned long long *d_hashes, const unsigned char *d_special, uint64_t n,
-               sq_batch *b1, sq_batch *b2, uint64_t r_base = 0)
+/* One piece through the reference's loop on the host's copy of the table: survivors sel[0, n_sel) of `hashes` (both
+ * on the device), in order.  For estimators without a device table (deferred shards use the parallel steps too) and
+ * for the pieces the parallel steps must not take (the odd entry's hash arrived; SQ_DEDUP_SEQUENTIAL=1). */
+int dedup_host_piece(sq_dedup *d, const unsigned long long *d_hashes, const unsigned long long *d_sel, uint64_t n_sel)
 {
     sq_ctx *ctx = d->ctx;
-    DedupKeep keep{(1ULL << d->modulo_bits) - 1, d_hashes, d_special};
-    unsigned long long *d_idx = nullptr;
-    uint64_t n_keep = 0;
-    int rc = ordered_select(ctx, n, keep, &d_idx, &n_keep);
+    int rc = dedup_to_host(d);
     if (rc) return rc;
-    if (n_keep == 0) return SQ_OK;
-    /* host copies live in the estimator and only grow (a fresh 10 MB vector per batch is a
-       millisecond of page faults) */
-    std::vector<unsigned long long> &idx = d->h_idx, &hashes = d->h_hashes;
-    std::vector<unsigned char> &special = d->h_special;
-    if (idx.size() < n_keep) { idx.resize(n_keep); hashes.resize(n_keep); special.resize(n_keep); d->h_state.resize(n_keep); }
-    {
-        unsigned long long *d_kh = (unsigned long long *)sq_scratch(ctx, 10, n_keep * 8);
-        unsigned char *d_ks = (unsigned char *)sq_scratch(ctx, 11, n_keep);
-        if (!d_kh || !d_ks) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
-        hipLaunchKernelGGL(k_dedup_gather, dim3(blocks_for(n_keep)), dim3(256), 0, ctx->stream, d_idx,
-                           n_keep, d_hashes, d_special, d_kh, d_ks);
-        SQ_HIP(hipMemcpyAsync(idx.data(), d_idx, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SQ_HIP(hipMemcpyAsync(hashes.data(), d_kh, n_keep * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (d_special)
-            SQ_HIP(hipMemcpyAsync(special.data(), d_ks, n_keep, hipMemcpyDeviceToHost, ctx->stream));
-        else
-            memset(special.data(), 0, n_keep);
-        SQ_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    const uint64_t fp_len = d->front_len + d->back_len;
-    /* Most of a settled estimator's survivors are already in the table.  Counting those is
-       order-free as long as no rebuild can fall into this piece: lookups do not change the
-       table, an entry never moves between rebuilds, and a rebuild needs stored >= max_stored
-       when a hash arrives, which the inserts of this piece cannot reach if there are few
-       enough of them.  So host threads look every survivor up in the table as it stands and
-       count the ones they find at once (atomic adds); if stored + (survivors not found) stays
-       below max_stored that was right, and only the others walk through the sequential
-       insert, in order (the first of several equal new hashes inserts, the rest find it).
-       Otherwise the counts are taken back and the whole piece takes the sequential loop,
-       hash by hash.  A piece that had to be taken back makes the next few skip the attempt
-       (a young estimator meets mostly new hashes). */
-    uint8_t *state = d->h_state.data(); /* 1: counted in parallel */
-    memset(state, 0, n_keep);
-    const unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (d->parallel_skip) d->parallel_skip--;
-    else if (n_keep >= 32768 && n_threads > 1 && !sq_knobs().dedup_sequential) {
-        const uint64_t bits = d->modulo_bits, mask = d->table_size - 1;
-        const uint64_t per = (n_keep + n_threads - 1) / n_threads;
-        std::vector<uint64_t> missing(n_threads, 0);
-        auto in_parallel = [&](auto &&fn) {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < n_threads; t++)
-                pool.emplace_back([&, t]() { fn(t, t * per, std::min<uint64_t>(n_keep, (t + 1) * per)); });
-            for (auto &th : pool) th.join();
-        };
-        in_parallel([&](unsigned t, uint64_t lo, uint64_t hi) {
-            uint64_t miss = 0;
-            for (uint64_t e = lo; e < hi; e++) {
-                if (e + 8 < hi) {
-                    const uint64_t sn = (hashes[e + 8] >> bits) & mask;
-                    __builtin_prefetch(&d->count[sn]);
-                    __builtin_prefetch(&d->hash[sn]);
-                }
-                bool found = false;
-                if (!special[e]) {
-                    const uint64_t h = hashes[e];
-                    for (uint64_t i = (h >> bits) & mask;; i = (i + 1) & mask) {
-                        /* counts only grow here and never from 0: a slot that is empty stays empty */
-                        if (__atomic_load_n(&d->count[i], __ATOMIC_RELAXED) == 0) break;
-                        if (d->hash[i] == h) {
-                            __atomic_fetch_add(&d->count[i], 1u, __ATOMIC_RELAXED);
-                            found = true;
-                            break;
-                        }
-                    }
-                }
-                state[e] = found;
-                miss += !found;
-            }
-            missing[t] = miss;
-        });
-        uint64_t not_found = 0;
-        for (uint64_t m : missing) not_found += m;
-        if (d->stored + not_found >= d->max_stored) { /* a rebuild may fall into this piece: take it back */
-            in_parallel([&](unsigned, uint64_t lo, uint64_t hi) {
-                const uint64_t bits2 = d->modulo_bits, mask2 = d->table_size - 1;
-                for (uint64_t e = lo; e < hi; e++) {
-                    if (!state[e]) continue;
-                    const uint64_t h = hashes[e];
-                    for (uint64_t i = (h >> bits2) & mask2;; i = (i + 1) & mask2)
-                        if (d->hash[i] == h && __atomic_load_n(&d->count[i], __ATOMIC_RELAXED) != 0) {
-                            __atomic_fetch_sub(&d->count[i], 1u, __ATOMIC_RELAXED);
-                            break;
-                        }
-                    state[e] = 0;
-                }
-            });
-            d->parallel_skip = 4;
-            if (sq_knobs().dedup_debug) fprintf(stderr, "dedup piece: %llu kept, %llu new, taken back\n", (unsigned long long)n_keep, (unsigned long long)not_found);
-        } else if (sq_knobs().dedup_debug) {
-            fprintf(stderr, "dedup piece: %llu kept, %llu new, counted by threads\n", (unsigned long long)n_keep, (unsigned long long)not_found);
-        }
-    }
-    for (uint64_t e = 0; e < n_keep; e++) {
-        if (state[e]) continue;
-        if (e + 12 < n_keep) { /* the slot a hash lands in is known ahead: hide the table's cache misses */
-            const uint64_t hn = hashes[e + 12];
-            const uint64_t slot = (hn >> d->modulo_bits) & (d->table_size - 1);
+    if (d->h_hashes.size() < n_sel) d->h_hashes.resize(n_sel);
+    unsigned long long *d_kh = (unsigned long long *)sq_scratch(ctx, 10, n_sel * 8);
+    if (!d_kh) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    hipLaunchKernelGGL(k_dedup_gather, dim3(blocks_for(n_sel)), dim3(256), 0, ctx->stream, d_sel, n_sel, d_hashes,
+                       (const unsigned char *)nullptr, d_kh, (unsigned char *)nullptr);
+    SQ_HIP(hipMemcpyAsync(d->h_hashes.data(), d_kh, n_sel * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long *hashes = d->h_hashes.data();
+    for (uint64_t e = 0; e < n_sel; e++) {
+        if (e + 12 < n_sel) { /* the slot a hash lands in is known ahead: hide the table's cache misses */
+            const uint64_t slot = (hashes[e + 12] >> d->modulo_bits) & (d->table_size - 1);
             __builtin_prefetch(&d->count[slot]);
             __builtin_prefetch(&d->hash[slot]);
         }
-        const uint64_t r = r_base + idx[e];
-        uint64_t h = hashes[e];
-        if (special[e]) {
-            /* a pair shorter than the fingerprint: bytes of the store shine through (:4512-4516).  Every such pair
-               of the batch comes by here, in read order (the filter keeps them whatever the mask, the threads above
-               leave them alone), so the store is carried: a pair in front that did not come by is a long one and
-               rewrote all of it.  (Walking back from every short pair to the last long one is quadratic in a batch
-               of nothing but short pairs.) */
-            std::vector<uint8_t> w;
-            if (r != 0 && d->run_prev != r - 1) {
-                rc = pair_store_bytes(d, b1, b2, r - 1, w);
-                if (rc) return rc;
-                d->run_store = w;
-            }
-            uint64_t total = 0;
-            rc = pair_store_bytes(d, b1, b2, r, w, &total);
+        dedup_insert(d, hashes[e]);
+    }
+    d->dev_valid = false;
+    d->host_pieces++;
+    return SQ_OK;
+}
+
+/* the device's copy of a small result, behind everything queued on the stream */
+int dedup_read_back(sq_ctx *ctx, const void *d_src, void *dst, size_t bytes)
+{
+    SQ_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    return SQ_OK;
+}
+
+/* indices [0,n) whose hash passes a mask, in order, without materialising 0 .. n-1 first */
+template <typename Pred>
+int ordered_select_counting(sq_ctx *ctx, uint64_t n, Pred pred, int slot0, unsigned long long **d_out, uint64_t *count)
+{
+    size_t temp_bytes = 0;
+    *d_out = nullptr;
+    *count = 0;
+    if (n == 0) return SQ_OK;
+    unsigned long long *d_sel = (unsigned long long *)sq_scratch(ctx, slot0, n * 8);
+    unsigned long long *d_num = (unsigned long long *)sq_scratch(ctx, 8, 8);
+    if (!d_sel || !d_num) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    hipcub::CountingInputIterator<unsigned long long> it(0ull);
+    SQ_HIP(hipcub::DeviceSelect::If(nullptr, temp_bytes, it, d_sel, d_num, (int)n, pred, ctx->stream));
+    void *d_temp = sq_scratch(ctx, 9, temp_bytes ? temp_bytes : 8);
+    if (!d_temp) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+    SQ_HIP(hipcub::DeviceSelect::If(d_temp, temp_bytes, it, d_sel, d_num, (int)n, pred, ctx->stream));
+    SQ_HIP(hipMemcpyAsync(&ctx->pinned[16], d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SQ_HIP(hipStreamSynchronize(ctx->stream));
+    *count = ctx->pinned[16];
+    *d_out = d_sel;
+    return SQ_OK;
+}
+
+/* The stream of hashes [0,n) on the device, in read order, through the estimator (the header above k_dd_classify has
+ * the plan).  Only hashes that pass the mask in force can matter, and the mask only ever gets stricter (H3): a piece is
+ * filtered with the mask in force when it starts and ends in front of the arrival that rebuilds. */
+int dedup_process(sq_dedup *d, const unsigned long long *d_hashes, uint64_t n)
+{
+    sq_ctx *ctx = d->ctx;
+    const uint64_t T = d->table_size, tmask = T - 1;
+    const bool force_host = sq_knobs().dedup_sequential;
+    unsigned quick = 0;   /* pieces in a row that ended at their first survivors: hashes whose low bits are not spread */
+    int rc;
+    for (uint64_t off = 0; off < n;) {
+        const int64_t need = (int64_t)d->max_stored - (int64_t)d->stored;   /* new hashes until the table is full */
+        const uint64_t bits = d->modulo_bits;
+        /* about one read in 2^bits survives; behind `need` new ones the piece ends anyway */
+        const uint64_t want = (uint64_t)std::max<int64_t>(need, 0) * 5 / 4 + 65536;
+        const uint64_t piece = std::min<uint64_t>({n - off, want << std::min<uint64_t>(bits, 20), (uint64_t)1 << 30});
+        const unsigned long long *ph = d_hashes + off;
+        unsigned long long *d_sel = nullptr;
+        uint64_t n_sel = 0;
+        rc = ordered_select_counting(ctx, piece, DedupKeep{bits ? (1ULL << bits) - 1 : 0ull, ph, nullptr}, 7, &d_sel, &n_sel);
+        if (rc) return rc;
+        if (n_sel == 0) { off += piece; continue; }
+        if (force_host || quick > 16) {
+            rc = dedup_host_piece(d, ph, d_sel, n_sel);
             if (rc) return rc;
-            std::copy(w.begin(), w.end(), d->run_store.begin());
-            d->run_prev = r;
-            const uint8_t *sp = d->run_store.data();
-            h = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, total >> 6);
+            off += piece;
+            continue;
         }
-        dedup_insert(d, h);
+        rc = dedup_to_device(d);
+        if (rc) return rc;
+        unsigned long long *d_res = (unsigned long long *)sq_scratch(ctx, 32, 64);   /* 0: n-th first arrival, 1: inserted, 2: kept, 3-4: trigger, 5 (as u32): flags */
+        unsigned int *d_slot = (unsigned int *)sq_scratch(ctx, 33, n_sel * 4);
+        if (!d_res || !d_slot) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemsetAsync(d_res, 0, 64, ctx->stream));
+        uint64_t e_end = n_sel;       /* survivors [0, e_end) arrive while the table has room */
+        bool trigger = false;
+        unsigned long long *d_miss = nullptr, *d_key = nullptr, *d_skey = nullptr;
+        unsigned int *d_val = nullptr, *d_sval = nullptr, *d_newc = nullptr;
+        uint64_t n_miss = 0;
+        if (need <= 0) {              /* full already: the first survivor rebuilds */
+            e_end = 0;
+            trigger = true;
+        } else {
+            hipLaunchKernelGGL(k_dd_classify, dim3(blocks_for(n_sel)), dim3(256), 0, ctx->stream, ph, d_sel, n_sel, d->d_hash,
+                               d->d_count, bits, tmask, (unsigned long long)d->odd_hash, d->odd_valid ? 1 : 0, d_slot,
+                               (unsigned int *)(d_res + 5));
+            rc = ordered_select_counting(ctx, n_sel, DedupIsMiss{d_slot}, 34, &d_miss, &n_miss);
+            if (rc) return rc;
+            uint64_t res[8];
+            rc = dedup_read_back(ctx, d_res, res, sizeof res);
+            if (rc) return rc;
+            if ((unsigned int)res[5]) {   /* the odd entry's hash arrived and a lookup now cannot say what it will find then */
+                rc = dedup_host_piece(d, ph, d_sel, n_sel);
+                if (rc) return rc;
+                off += piece;
+                continue;
+            }
+            if (n_miss) {
+                d_key = (unsigned long long *)sq_scratch(ctx, 35, n_miss * 8);
+                d_skey = (unsigned long long *)sq_scratch(ctx, 36, n_miss * 8);
+                d_val = (unsigned int *)sq_scratch(ctx, 37, n_miss * 4 * 4);   /* val, sorted val, first / new counts, positions */
+                if (!d_key || !d_skey || !d_val) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+                d_sval = d_val + n_miss;
+                d_newc = d_val + 2 * n_miss;
+                unsigned int *d_pos = d_val + 3 * n_miss;
+                hipLaunchKernelGGL(k_dd_miss_keys, dim3(blocks_for(n_miss)), dim3(256), 0, ctx->stream, ph, d_sel, d_miss, n_miss,
+                                   d_key, d_val);
+                size_t temp_bytes = 0;
+                SQ_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_key, d_skey, d_val, d_sval, (int)n_miss, 0, 64, ctx->stream));
+                void *d_temp = sq_scratch(ctx, 38, temp_bytes ? temp_bytes : 8);
+                if (!d_temp) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+                SQ_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_key, d_skey, d_val, d_sval, (int)n_miss, 0, 64, ctx->stream));
+                if (n_miss >= (uint64_t)need) {   /* enough arrivals that were not found to fill the table, if enough of them are new */
+                    unsigned int *d_first = d_newc;   /* the counts are written behind this use */
+                    hipLaunchKernelGGL(k_dd_heads, dim3(blocks_for(n_miss)), dim3(256), 0, ctx->stream, d_skey, d_sval, n_miss, d_first);
+                    size_t scan_bytes = 0;
+                    SQ_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, d_first, d_pos, (int)n_miss, ctx->stream));
+                    void *d_scan = sq_scratch(ctx, 38, scan_bytes ? scan_bytes : 8);
+                    if (!d_scan) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+                    SQ_HIP(hipcub::DeviceScan::InclusiveSum(d_scan, scan_bytes, d_first, d_pos, (int)n_miss, ctx->stream));
+                    SQ_HIP(hipMemsetAsync(d_res, 0xFF, 8, ctx->stream));
+                    hipLaunchKernelGGL(k_dd_find_nth, dim3(blocks_for(n_miss)), dim3(256), 0, ctx->stream, d_first, d_pos, n_miss,
+                                       (unsigned int)need, d_res);
+                    /* d_miss[r]: the survivor that fills the table; the one behind it rebuilds */
+                    rc = dedup_read_back(ctx, d_res, res, 8);
+                    if (rc) return rc;
+                    if (res[0] != ~0ull) {
+                        unsigned long long e_fill = 0;
+                        rc = dedup_read_back(ctx, d_miss + res[0], &e_fill, 8);
+                        if (rc) return rc;
+                        if (e_fill + 1 < n_sel) { e_end = e_fill + 1; trigger = true; }
+                    }
+                    SQ_HIP(hipMemsetAsync(d_res, 0, 8, ctx->stream));
+                }
+            }
+            /* survivors [0, e_end): the found ones count, the first arrivals of new hashes take their slots */
+            hipLaunchKernelGGL(k_dd_apply_found, dim3(blocks_for(e_end)), dim3(256), 0, ctx->stream, d_slot, e_end, d->d_count);
+            if (n_miss) {
+                hipLaunchKernelGGL(k_dd_tok_init, dim3(blocks_for(T)), dim3(256), 0, ctx->stream, d->d_count, d->d_tok, T);
+                hipLaunchKernelGGL(k_dd_insert, dim3(blocks_for(n_miss)), dim3(256), 0, ctx->stream, d_skey, d_sval, n_miss, d_miss,
+                                   e_end, bits, tmask, d->d_tok, d_newc, d_res + 1);
+                hipLaunchKernelGGL(k_dd_finalize, dim3(blocks_for(T)), dim3(256), 0, ctx->stream, d->d_tok, T, d_key, d_newc,
+                                   d->d_hash, d->d_count);
+            }
+            d->host_valid = false;
+        }
+        uint64_t trig_at = 0;
+        if (trigger) {
+            /* DedupEstimator_increment_modulo, then the arrival itself by the old bit count */
+            SQ_HIP(hipMemsetAsync(d->d_tok, 0xFF, T * 4, ctx->stream));
+            hipLaunchKernelGGL(k_dd_rebuild_insert, dim3(blocks_for(T)), dim3(256), 0, ctx->stream, d->d_hash, d->d_count, T,
+                               bits + 1, d->d_tok, d_res + 2);
+            hipLaunchKernelGGL(k_dd_rebuild_finalize, dim3(blocks_for(T)), dim3(256), 0, ctx->stream, d->d_tok, T, d->d_hash,
+                               d->d_count, d->d_hash2, d->d_count2);
+            std::swap(d->d_hash, d->d_hash2);
+            std::swap(d->d_count, d->d_count2);
+            hipLaunchKernelGGL(k_dd_trigger, dim3(1), dim3(1), 0, ctx->stream, ph, d_sel, e_end, bits, tmask, d->d_hash, d->d_count,
+                               d_res + 3);
+            SQ_HIP(hipMemcpyAsync(&trig_at, d_sel + e_end, 8, hipMemcpyDeviceToHost, ctx->stream));
+            d->host_valid = false;
+        }
+        SQ_HIP(hipGetLastError());
+        uint64_t res[8];
+        rc = dedup_read_back(ctx, d_res, res, sizeof res);
+        if (rc) return rc;
+        d->device_pieces++;
+        if (!trigger) {
+            d->stored += res[1];
+            off += piece;
+            quick = 0;
+            continue;
+        }
+        d->modulo_bits = bits + 1;
+        d->stored = res[2] + res[4];
+        d->odd_hash = res[3];
+        d->odd_valid = res[4] != 0 && (res[3] & ((1ULL << (bits + 1)) - 1)) == 0;
+        quick = e_end < 4 ? quick + 1 : 0;
+        off += trig_at + 1;
+    }
+    return SQ_OK;
+}
+
+/* the hashes of pairs shorter than the fingerprint: bytes of the store shine through (:4512-4516), so they are made
+ * on the host, pair after pair in read order, the store carried from one to the next (a pair in front that is not a
+ * short one rewrote all of it), and written into the batch's hashes before anything looks at them.  Leaves the
+ * store as the batch's last pair leaves it. */
+int dedup_patch_short_pairs(sq_dedup *d, sq_batch *b1, sq_batch *b2, unsigned long long *d_hashes,
+                            const unsigned char *d_special, uint64_t n)
+{
+    sq_ctx *ctx = d->ctx;
+    const uint64_t fp_len = d->front_len + d->back_len;
+    unsigned long long *d_idx = nullptr;
+    uint64_t n_special = 0;
+    int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, &d_idx, &n_special);
+    if (rc) return rc;
+    std::vector<unsigned long long> idx(n_special), val(n_special);
+    if (n_special) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_special * 8, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> cur = d->store, w;
+    uint64_t prev = UINT64_MAX;
+    for (uint64_t e = 0; e < n_special; e++) {
+        const uint64_t r = idx[e];
+        if (r != 0 && prev != r - 1) { /* the pair in front rewrote the whole store */
+            rc = pair_store_bytes(d, b1, b2, r - 1, cur);
+            if (rc) return rc;
+            cur.resize(fp_len);
+        }
+        uint64_t total = 0;
+        rc = pair_store_bytes(d, b1, b2, r, w, &total);
+        if (rc) return rc;
+        std::copy(w.begin(), w.end(), cur.begin());
+        prev = r;
+        const uint8_t *sp = cur.data();
+        val[e] = murmur3_x64_64([&](uint64_t i) { return sp[i]; }, fp_len, total >> 6);
+    }
+    if (prev != n - 1) { /* the last pair rewrote the whole store */
+        rc = pair_store_bytes(d, b1, b2, n - 1, cur);
+        if (rc) return rc;
+        cur.resize(fp_len);
+    }
+    d->store = cur;
+    if (n_special) {
+        unsigned long long *d_pv = (unsigned long long *)sq_scratch(ctx, 10, 2 * n_special * 8);
+        if (!d_pv) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemcpyAsync(d_pv, idx.data(), n_special * 8, hipMemcpyHostToDevice, ctx->stream));
+        SQ_HIP(hipMemcpyAsync(d_pv + n_special, val.data(), n_special * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_dd_patch, dim3(blocks_for(n_special)), dim3(256), 0, ctx->stream, d_hashes, d_pv, d_pv + n_special, n_special);
+        SQ_HIP(hipStreamSynchronize(ctx->stream));   /* idx and val leave with this frame */
     }
     return SQ_OK;
 }
@@ -1847,23 +2199,8 @@ int dedup_run(sq_dedup *d, sq_batch *b1, sq_batch *b2)
     if (d->deferred) {
         rc = dedup_defer(d, b1, b2, d_hashes, d_special, n);
     } else {
-        /* in pieces: the mask only gets stricter, so every piece is filtered with the one in
-           force when it starts.  About max_stored << bits hashes go by before the next rebuild,
-           so that is the piece: a fresh estimator does not drag a whole batch through the host
-           at mask 0, a settled one takes the batch in one piece */
-        rc = SQ_OK;
-        d->run_store = d->store;
-        d->run_prev = UINT64_MAX;
-        for (uint64_t off = 0; off < n && rc == SQ_OK;) {
-            const uint64_t piece = std::min<uint64_t>(n - off, std::max<uint64_t>(d->max_stored, 1u << 16)
-                                                                   << std::min<uint64_t>(d->modulo_bits, 20));
-            rc = dedup_tail(d, d_hashes + off, d_special + off, piece, b1, b2, off);
-            off += piece;
-        }
-        if (rc == SQ_OK && b2) { /* carry the store into the next batch: the last pair's if it was a long one */
-            if (d->run_prev == n - 1) d->store = d->run_store;
-            else rc = pair_store_bytes(d, b1, b2, n - 1, d->store);
-        }
+        rc = b2 ? dedup_patch_short_pairs(d, b1, b2, d_hashes, d_special, n) : SQ_OK;
+        if (rc == SQ_OK) rc = dedup_process(d, d_hashes, n);
     }
     (void)hipStreamSynchronize(ctx->stream);
     return rc;
@@ -1907,9 +2244,13 @@ SQ_EXPORT int sq_dedup_flush(sq_dedup *d) { return sq_synchronize(d->ctx); }
 SQ_EXPORT uint64_t sq_dedup_modulo_bits(sq_dedup *d) { return d->modulo_bits; }
 SQ_EXPORT uint64_t sq_dedup_hash_table_size(sq_dedup *d) { return d->table_size; }
 SQ_EXPORT uint64_t sq_dedup_tracked_sequences(sq_dedup *d) { return d->stored; }
+/* pieces of the stream that went through the parallel steps on the device / through the host's sequential loop */
+SQ_EXPORT uint64_t sq_dedup_device_pieces(sq_dedup *d) { return d->device_pieces; }
+SQ_EXPORT uint64_t sq_dedup_host_pieces(sq_dedup *d) { return d->host_pieces; }
 
 SQ_EXPORT int64_t sq_dedup_duplication_counts(sq_dedup *d, uint64_t *out, size_t cap)
 {
+    if (dedup_to_host(d)) return SQ_ERR_HIP;
     size_t n = 0;
     for (uint64_t i = 0; i < d->table_size; i++) { /* :4736-4744 slot order */
         if (!d->count[i]) continue;
@@ -1950,9 +2291,8 @@ SQ_EXPORT int sq_dedup_resolve(sq_dedup *d)
         if (!d->store_known[i]) d->store[i] = d->store_in[i];
     d->store_known.assign(fp_len, d->deferred ? 0 : 1);
     d->store_in = d->store;
-    const uint64_t chunk = 1ull << 23;
-    for (uint64_t off = 0; off < d->stream_n; off += chunk) {
-        int rc = dedup_tail(d, d->d_stream + off, nullptr, std::min(chunk, d->stream_n - off), nullptr, nullptr);
+    if (d->stream_n) {
+        int rc = dedup_process(d, d->d_stream, d->stream_n);
         if (rc) return rc;
     }
     SQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1974,6 +2314,7 @@ SQ_EXPORT int sq_dedup_export_state(sq_dedup *d, void *out, size_t cap)
 {
     if (d->stream_n) { sq_set_error("sq_dedup_export_state: resolve the pending hashes first"); return SQ_ERR_VALUE; }
     if (cap < sq_dedup_state_bytes(d)) { sq_set_error("sq_dedup_export_state: destination too small"); return SQ_ERR_VALUE; }
+    if (int rc = dedup_to_host(d)) return rc;
     const uint64_t fp_len = d->front_len + d->back_len, pad = (fp_len + 7) / 8 * 8;
     uint8_t *p = (uint8_t *)out;
     const uint64_t head[5] = {DEDUP_MAGIC, d->modulo_bits, d->stored, d->table_size, fp_len};
@@ -2004,6 +2345,9 @@ SQ_EXPORT int sq_dedup_import_state(sq_dedup *d, const void *in, size_t len)
     d->store_in.assign(p, p + fp_len); p += pad;
     memcpy(d->hash.data(), p, d->table_size * 8); p += d->table_size * 8;
     memcpy(d->count.data(), p, d->table_size * 4);
+    d->host_valid = true;
+    d->dev_valid = false;
+    dedup_find_odd(d);
     if (!d->deferred || (d->stream_n == 0 && d->unresolved.empty() &&
                          std::find(d->store_known.begin(), d->store_known.end(), 1) == d->store_known.end()))
         d->store = d->store_in; /* nothing of this shard is pending: the store is the imported one */
@@ -2166,13 +2510,21 @@ SQ_EXPORT int sq_dedup_feed_hashes(sq_dedup *d, const uint64_t *hashes, size_t n
     if (d->stream_n || !d->unresolved.empty()) { sq_set_error("sq_dedup_feed_hashes: resolve the pending hashes first"); return SQ_ERR_VALUE; }
     if (store_after && store_len != fp_len) { sq_set_error("sq_dedup_feed_hashes: a store of %zu bytes, the estimator's has %llu", store_len, (unsigned long long)fp_len); return SQ_ERR_VALUE; }
     if (d->modulo_bits < filtered_bits) return SQ_DEDUP_FEED_TOO_STRICT;
-    for (size_t e = 0; e < n; e++) {
-        if (e + 12 < n) {
-            const uint64_t slot = (hashes[e + 12] >> d->modulo_bits) & (d->table_size - 1);
-            __builtin_prefetch(&d->count[slot]);
-            __builtin_prefetch(&d->hash[slot]);
+    if (d->ctx && n) {   /* the stream through the table in HBM */
+        unsigned long long *d_in = (unsigned long long *)sq_scratch(d->ctx, 39, n * 8);
+        if (!d_in) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
+        SQ_HIP(hipMemcpyAsync(d_in, hashes, n * 8, hipMemcpyHostToDevice, d->ctx->stream));
+        SQ_HIP(hipStreamSynchronize(d->ctx->stream));
+        if (int rc = dedup_process(d, d_in, n)) return rc;
+    } else {             /* an estimator without a device: the reference's loop */
+        for (size_t e = 0; e < n; e++) {
+            if (e + 12 < n) {
+                const uint64_t slot = (hashes[e + 12] >> d->modulo_bits) & (d->table_size - 1);
+                __builtin_prefetch(&d->count[slot]);
+                __builtin_prefetch(&d->hash[slot]);
+            }
+            dedup_insert(d, hashes[e]);
         }
-        dedup_insert(d, hashes[e]);
     }
     if (store_after) {
         d->store.assign(store_after, store_after + fp_len);

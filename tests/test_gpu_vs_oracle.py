@@ -229,15 +229,15 @@ def test_dedup_vs_oracle_rebuilds():
     np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
 
 
-def test_dedup_survivors_counted_by_host_threads():
-    """pieces of >= 32768 survivors are looked up and counted by host threads when no rebuild
-    can fall into them, and taken back and re-run hash by hash when one can: device-generated
-    batches that overlap by half (found and new hashes mixed), a table small enough to be
-    rebuilt several times, the same run forced through the sequential tail, and the oracle"""
+def test_dedup_found_and_new_hashes_mixed_device_and_host_pieces():
+    """The estimator's table in HBM (csrc/sq_ends.hip, dedup_process): device-generated batches that overlap by
+    half (found and new hashes mixed), a table small enough to be rebuilt several times -- through the parallel steps
+    on the device, the same run forced through the host's sequential loop (SQ_DEDUP_SEQUENTIAL=1), and the oracle"""
     from sequali_amd import DedupEstimator, synth
+    from sequali_amd._lib import lib
     kw = dict(max_stored_fingerprints=150_000, front_sequence_offset=0, back_sequence_offset=0)
-    # 140 k new hashes fit (nothing to take back), the next batch finds 40 k of them and brings
-    # 100 k new ones: counted, then taken back because the table would fill; then larger batches
+    # 140 k new hashes fit, the next batch finds 40 k of them and brings 100 k new ones: the table fills inside the
+    # batch; then larger batches
     spans = [(0, 140_000), (100_000, 140_000), (0, 300_000), (150_000, 300_000), (0, 300_000)]
     batches = [synth.device_array(synth.ILLUMINA, first, n) for first, n in spans]
     ref = oracle.DedupEstimator(**kw)
@@ -250,6 +250,8 @@ def test_dedup_survivors_counted_by_host_threads():
         assert got._modulo_bits == ref._modulo_bits >= 1
         assert got.tracked_sequences == ref.tracked_sequences
         np.testing.assert_array_equal(u64(got.duplication_counts()), ref.duplication_counts())
+        dev, host = lib().sq_dedup_device_pieces(got._h), lib().sq_dedup_host_pieces(got._h)
+        assert (dev == 0 and host > 0) if env else dev > 0
 
 
 def test_dedup_pairs_with_short_reads_stale_bytes():
