@@ -185,21 +185,47 @@ def test_pertile_reads_ordered_by_tile_are_walked_as_stored():
 
 
 def test_overrep_vs_oracle_with_cap_crossing():
+    """the cap is crossed inside a batch (the first 700 distinct fragments in sampled-read, staging-SLOT order stay)"""
     from sequali_amd import OverrepresentedSequences
     rng = np.random.default_rng(41)
     kw = dict(max_unique_fragments=700, sample_every=3, fragment_length=21)
     ref, got = oracle.OverrepresentedSequences(**kw), OverrepresentedSequences(**kw)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        for _ in range(4):
-            buf, metas, arr = random_batch(rng, 1500, 160, alphabet=b"ACGTACGTACGTACGTN")
-            ref.add(buf, metas)
-            got.add_record_array(arr)
+
+    def run():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(4):
+                buf, metas, arr = random_batch(rng, 1500, 160, alphabet=b"ACGTACGTACGTACGTN")
+                ref.add(buf, metas)
+                got.add_record_array(arr)
+                got.flush()
+    run()
     assert got.collected_unique_fragments == ref.collected_unique_fragments == 700
     assert got.total_fragments == ref.total_fragments
     assert got.sampled_sequences == ref.sampled_sequences
     assert got.sequence_counts() == ref.sequence_counts()
     assert got.overrepresented_sequences(0.001) == ref.overrepresented_sequences(0.001)
+
+
+@pytest.mark.parametrize("k,start,end,max_len,cap", [(21, 100, 100, 160, 5000), (5, 40, 40, 90, 300), (7, 20, 60, 400, 900),
+                                                     (3, 8, 40, 60, 64), (31, 100, 100, 1200, 2000), (4, 30, 34, 64, 200)])
+def test_overrep_fragment_geometries(k, start, end, max_len, cap):
+    """reads that repeat fragments inside themselves (short k-mers: a fragment twice in a read is counted once,
+    :3588-3608), more fragments from one end than from the other, up to 16 fragments a read, N and other letters, caps
+    crossed in the middle of a batch"""
+    from sequali_amd import OverrepresentedSequences
+    rng = np.random.default_rng(1000 * k + start)
+    kw = dict(max_unique_fragments=cap, sample_every=1, fragment_length=k, bases_from_start=start, bases_from_end=end)
+    ref, got = oracle.OverrepresentedSequences(**kw), OverrepresentedSequences(**kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):
+            buf, metas, arr = random_batch(rng, 2000, max_len, alphabet=b"ACGTACGTACGTACGTNacgtR")
+            ref.add(buf, metas)
+            got.add_record_array(arr)
+    assert got.collected_unique_fragments == ref.collected_unique_fragments
+    assert got.total_fragments == ref.total_fragments
+    assert got.sequence_counts() == ref.sequence_counts()
 
 
 def test_overrep_whole_read_fragments():
