@@ -716,12 +716,18 @@ class _Deferring:
         # (the first max_adapters remainders in pair order, :5570-5611) do (scripts/fuzz.py 200 11, iteration 192).  The
         # drain in progress gets to everything that is owed, in order.
         if getattr(self, "_draining", False):
+            if through is not None:      # the caller wants this block's work done: the drain in progress sees to it
+                self._owed_through = through       # before it returns (it may itself be limited to full blocks or to another block)
             return
         self._draining = True
         try:
             self._drain_entries(sealed_only, through)
+            while getattr(self, "_owed_through", None) is not None:
+                owed, self._owed_through = self._owed_through, None
+                self._drain_entries(False, owed)
         finally:
             self._draining = False
+            self._owed_through = None
 
     def _drain_entries(self, sealed_only: bool, through) -> None:
         while self._todo:

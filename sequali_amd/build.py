@@ -41,7 +41,7 @@ def default_route_builds():
     names += ["k_spanILi%dELb1ELb0ELi6ELb1ELb0ELb0ELi0EE" % nw for nw in range(5, 9)]
     names += ["k_spanILi%dELb1ELb1ELi6E%sELb0ELb0ELi0EE" % (nw, b(nw >= 6)) for nw in range(3, 9)]
     # batches of one read length of 225-256 bases with adapters, and adapters of 14-25 characters below 129 bases: the round-1 kernel
-    names += ["6k_wideILb0EE", "6k_wideILb1EE"]
+    names += ["6k_wideILb1EE"]
     return names
 
 

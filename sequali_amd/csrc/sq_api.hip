@@ -35,35 +35,18 @@ static void knobs_load()
     auto num = [](const char *name, int unset) { const char *v = getenv(name); return v ? atoi(v) : unset; };
     k.span = num("SQ_SPAN", 1) != 0;
     k.span_split = num("SQ_SPAN_SPLIT", 1) != 0;
-    k.span_spills_ok = flag("SQ_SPAN_SPILLS_OK");
     k.span_sorted = num("SQ_SPAN_SORTED", -1);
-    k.span_radix = flag("SQ_SPAN_RADIX");
-    k.span_sorted_split = num("SQ_SPAN_SORTED_SPLIT", 0) != 0;
-    k.span_sync = num("SQ_SPAN_SYNC", 1) != 0;
     k.span_split_qc = (int)num("SQ_SPAN_SPLIT_QC", -1);
     k.span_w6 = num("SQ_SPAN_W6", -1);
     k.span_short = flag("SQ_SPAN_SHORT");
-    k.pt_prep_inline = flag("SQ_PT_PREP_INLINE");
     k.pt_fused = num("SQ_PT_FUSED", 1);
-    k.span_waves = num("SQ_SPAN_WAVES", 0);
-    k.span_probe = num("SQ_SPAN_PROBE", -1);
-    k.span_stamps = flag("SQ_SPAN_STAMPS");
-    k.wide = num("SQ_WIDE", -1);
     k.no_wide = flag("SQ_NO_WIDE");
     k.ring = flag("SQ_RING");
     k.no_ring = flag("SQ_NO_RING");
-    k.no_split = flag("SQ_NO_SPLIT");
     k.no_ptq = flag("SQ_NO_PTQ");
-    k.pt_sort = flag("SQ_PT_SORT");
-    k.pt_stored = flag("SQ_PT_STORED");
     k.no_segments = flag("SQ_NO_SEGMENTS");
     k.long_spans = num("SQ_LONG", 1) != 0;
-    k.long_nw = num("SQ_LONG_NW", 8);
-    k.long_stretch_cost = num("SQ_LONG_STRETCH_COST", 16);
-    k.lds_pad = num("SQ_LDS_PAD", 0);
-    k.probe_mode = num("SQ_PROBE_MODE", -1);
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
-    k.dedup_debug = flag("SQ_DEDUP_DEBUG");
     g_knobs = k;
     g_knobs_loaded = true;
 }

@@ -39,38 +39,32 @@ void sq_set_error(const char *fmt, ...);
         }                                                                               \
     } while (0)
 
-/* Route selection and experiment switches, read from the environment ONCE (first use) or when
- * sq_knobs_reload() is called (the tests flip a switch, reload, run, flip it back): the
- * dispatchers consult this struct, never getenv().  Defaults = what production runs.
- *   SQ_SPAN=0         no k_span / k_ptspan / k_isz_span: the round-1 kernels (cross-checks)
- *   SQ_SPAN_SPLIT=0   k_span with one wave for both streams of a span (round 2)
- *   SQ_SPAN_SYNC=0    a wave per stream without the tie between the two waves of a pair
- *   SQ_SPAN_SORTED    1 / 0: force / forbid the length-sorted k_span route for ragged batches
- *   SQ_SPAN_WAVES     cap on k_span's waves per workgroup (occupancy experiments)
- *   SQ_WIDE / SQ_NO_WIDE / SQ_RING / SQ_NO_RING   force / forbid k_wide, k_ring
- *   SQ_NO_SPLIT       QCMetrics + PerTileQuality in one k_pass instead of two kernels
- *   SQ_NO_PTQ, SQ_PT_SORT, SQ_PT_STORED, SQ_NO_SEGMENTS, SQ_LDS_PAD, SQ_DEDUP_SEQUENTIAL,
- *   SQ_DEDUP_DEBUG, SQ_LONG=0 (no k_long: k_read_sums + k_seg)  experiment switches */
+/* Route selection switches, read from the environment ONCE (first use) or when sq_knobs_reload() is called (the tests
+ * flip a switch, reload, run, flip it back): the dispatchers consult this struct, never getenv().  Defaults = what
+ * production runs.  Every switch names a kernel that is the DEFAULT for some shape of batch (tests/test_gpu_routes.py)
+ * and exists so that the tests can send batches of any size through it (round 6 took out the experiment switches):
+ *   SQ_SPAN=0           no k_span / k_ptspan / k_isz_span: the kernels behind them (k_wide, k_ring, k_pass, k_ptq, k_seg)
+ *   SQ_SPAN_SPLIT=0     k_span with one wave for both streams of a span
+ *   SQ_SPAN_SPLIT_QC    0 / 1: QCMetrics alone never / always with a wave per stream (default: from 161 bases on)
+ *   SQ_SPAN_SHORT=1     k_span also for batches of one read length of up to 64 bases with adapters (default: k_wide)
+ *   SQ_SPAN_SORTED      1 / 0: force / forbid the length-sorted k_span route for ragged batches
+ *   SQ_SPAN_W6          0 / 1: adapters of 14 .. 25 characters never / wherever a build exists through k_span
+ *   SQ_NO_WIDE, SQ_RING, SQ_NO_RING   k_pass instead of k_wide / k_ring; k_ring also with the automaton
+ *   SQ_NO_PTQ           PerTileQuality alone through k_pass
+ *   SQ_PT_FUSED         0: PerTileQuality and InsertSizeMetrics in passes of their own; 2: only the tile ids from the pass
+ *   SQ_LONG=0, SQ_NO_SEGMENTS   long reads: k_seg instead of k_span<LONG>; stripes of k_pass instead of segments
+ *   SQ_DEDUP_SEQUENTIAL DedupEstimator: every piece through the host's sequential loop */
 struct SqKnobs {
-    bool span = true, span_split = true, span_spills_ok = false;   /* SQ_SPAN_SPILLS_OK: use a k_span build that spills (experiments) */
-    int span_sorted = -1, span_waves = 0, span_probe = -1;
+    bool span = true, span_split = true;
+    int span_sorted = -1;
     int span_w6 = -1;          /* SQ_SPAN_W6: adapters of 14 .. 25 characters through k_span (sq_span_w6.hip) instead of k_wide / k_pass.  -1 (default, measured in round 5, scripts/exp_w6.sh): batches of one read length from 129 bases on (914 / 910 / 1029 against k_wide's 876 / 830 / 901 Gbases/s at 150 / 200 / 224 bases; at 100 bases k_wide's 776 against 694) and every length-sorted batch (the alternative there is k_pass); 0: never; 1: wherever a build exists */
     bool span_short = false;   /* SQ_SPAN_SHORT: k_span also for batches of one read length of up to 64 bases with adapters (default: k_wide, 22 % ahead at 50 bases) */
     int span_split_qc = -1;    /* SQ_SPAN_SPLIT_QC: QCMetrics alone with a wave per stream.  -1 (default, measured in round 5, profiles/r5/exp_split_qc.txt): from 6 windows (161 bases) on, where one wave for both streams holds 8 waves a CU (1218 / 1290 against 1066 / 1145 Gbases/s at 200 / 250 bases; at 100 / 150 bases one wave for both is 2-4 % ahead); 0: never; 1: always */
-    bool span_sync = true;     /* SQ_SPAN_SYNC=0: the two waves of a pair run free (see PassParams::span_sync) */
-    bool span_sorted_split = false;   /* SQ_SPAN_SORTED_SPLIT: the length-sorted route with a wave per stream */
-    bool span_radix = false;   /* SQ_SPAN_RADIX: the rows of a ragged batch by a radix sort of keys (round 2) although the batch knows its lengths */
-    bool span_stamps = false;
-    int wide = -1;             /* SQ_WIDE: -1 unset, else its value */
-    bool no_wide = false, ring = false, no_ring = false, no_split = false;
-    bool no_ptq = false, pt_sort = false, pt_stored = false, no_segments = false;
+    bool no_wide = false, ring = false, no_ring = false;
+    bool no_ptq = false, no_segments = false;
     int pt_fused = 1;          /* SQ_PT_FUSED: 1 (default since round 5: tests/test_gpu_pair.py is green on a GPU): PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan */
-    bool pt_prep_inline = false;   /* SQ_PT_PREP_INLINE: PerTileQuality's pass over the headers on the work stream (round 2) */
     bool long_spans = true;
-    int long_stretch_cost = 16;   /* SQ_LONG_STRETCH_COST: what a new segment costs a workgroup of k_span<LONG>, in spans (0: equal shares of spans) */
-    int long_nw = 8;           /* SQ_LONG_NW: 4 or 8 windows of 32 positions per segment of k_span<LONG> */
-    int lds_pad = 0, probe_mode = -1;
-    bool dedup_sequential = false, dedup_debug = false;
+    bool dedup_sequential = false;
 };
 const SqKnobs &sq_knobs();
 

@@ -1087,16 +1087,16 @@ struct DedupIsMiss {
 
 /* miss[r] = survivor index e of the r-th survivor not found -> its hash (the sort's key) and r (the value) */
 __global__ void k_dd_miss_keys(const unsigned long long *hashes, const unsigned long long *sel, const unsigned long long *miss,
-                               uint64_t n_miss, unsigned long long *key, unsigned int *val)
+                               uint64_t n_miss, unsigned long long *key, unsigned long long *val)
 {
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_miss; r += (uint64_t)gridDim.x * blockDim.x) {
         key[r] = hashes[sel[miss[r]]];
-        val[r] = (unsigned int)r;
+        val[r] = r;
     }
 }
 
 /* sorted by hash (stable: equal hashes in order of arrival): first[r] = 1 for the first arrival of every new hash */
-__global__ void k_dd_heads(const unsigned long long *skey, const unsigned int *sval, uint64_t n_miss, unsigned int *first)
+__global__ void k_dd_heads(const unsigned long long *skey, const unsigned long long *sval, uint64_t n_miss, unsigned int *first)
 {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n_miss; j += (uint64_t)gridDim.x * blockDim.x)
         first[sval[j]] = (j == 0 || skey[j - 1] != skey[j]) ? 1u : 0u;
@@ -1137,7 +1137,7 @@ __global__ void k_dd_apply_found(const unsigned int *slot, uint64_t e_end, unsig
         if (slot[e] != DD_MISS) atomicAdd(&tcount[slot[e]], 1u);
 }
 
-__global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *skey, const unsigned int *sval, uint64_t n_miss,
+__global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *skey, const unsigned long long *sval, uint64_t n_miss,
                             const unsigned long long *miss, uint64_t e_end, uint64_t bits, uint64_t mask,
                             unsigned int *tok, unsigned int *new_count /* [n_miss], by rank */,
                             unsigned long long *n_inserted)
@@ -1147,7 +1147,7 @@ __global__ void __launch_bounds__(256) k_dd_insert(const unsigned long long *ske
         bool mine = j < n_miss && (j == 0 || skey[j - 1] != skey[j]);
         unsigned int r = 0;
         if (mine) {
-            r = sval[j];
+            r = (unsigned int)sval[j];
             mine = miss[r] < e_end;                       /* the first arrival lies behind the end: so do all */
         }
         const unsigned long long b = __ballot(mine);
@@ -1216,44 +1216,11 @@ __global__ void k_dd_patch(unsigned long long *hashes, const unsigned long long 
         hashes[pos[i]] = val[i];
 }
 
-__global__ void k_iota(unsigned long long *p, uint64_t n)
-{
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x)
-        p[i] = i;
-}
-
 int blocks_for(uint64_t n, int cap = 16384)
 {
     uint64_t b = (n + 255) / 256;
     if (b > (uint64_t)cap) b = cap;
     return (int)(b ? b : 1);
-}
-
-/* indices [0,n) for which pred holds, in order, on the device; count on the host.  The result
- * lives in the context's scratch (valid until the next call): a hipMalloc / hipFree pair per
- * array and batch costs more than the selection */
-template <typename Pred>
-int ordered_select(sq_ctx *ctx, uint64_t n, Pred pred, unsigned long long **d_out, uint64_t *count)
-{
-    size_t temp_bytes = 0;
-    *d_out = nullptr;
-    *count = 0;
-    if (n == 0) return SQ_OK;
-    unsigned long long *d_in = (unsigned long long *)sq_scratch(ctx, 6, n * 8);
-    unsigned long long *d_sel = (unsigned long long *)sq_scratch(ctx, 7, n * 8);
-    unsigned long long *d_num = (unsigned long long *)sq_scratch(ctx, 8, 8);
-    if (!d_in || !d_sel || !d_num) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
-    hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_in, n);
-    SQ_HIP(hipcub::DeviceSelect::If(nullptr, temp_bytes, d_in, d_sel, d_num, (int)n, pred, ctx->stream));
-    void *d_temp = sq_scratch(ctx, 9, temp_bytes ? temp_bytes : 8);
-    if (!d_temp) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
-    SQ_HIP(hipcub::DeviceSelect::If(d_temp, temp_bytes, d_in, d_sel, d_num, (int)n, pred, ctx->stream));
-    SQ_HIP(hipMemcpyAsync(&ctx->pinned[16], d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SQ_HIP(hipStreamSynchronize(ctx->stream));
-    *count = ctx->pinned[16];
-    *d_out = d_sel;
-    return SQ_OK;
 }
 
 } // namespace
@@ -1904,9 +1871,11 @@ int dedup_read_back(sq_ctx *ctx, const void *d_src, void *dst, size_t bytes)
     return SQ_OK;
 }
 
-/* indices [0,n) whose hash passes a mask, in order, without materialising 0 .. n-1 first */
+/* indices [0,n) for which pred holds, in order, on the device (a counting iterator: 0 .. n-1 is never written out);
+ * the count on the host.  The result lives in the context's scratch slot `slot0` (valid until the next call that
+ * names it): a hipMalloc / hipFree pair per array and batch costs more than the selection */
 template <typename Pred>
-int ordered_select_counting(sq_ctx *ctx, uint64_t n, Pred pred, int slot0, unsigned long long **d_out, uint64_t *count)
+int ordered_select(sq_ctx *ctx, uint64_t n, Pred pred, int slot0, unsigned long long **d_out, uint64_t *count)
 {
     size_t temp_bytes = 0;
     *d_out = nullptr;
@@ -1946,7 +1915,7 @@ int dedup_process(sq_dedup *d, const unsigned long long *d_hashes, uint64_t n)
         const unsigned long long *ph = d_hashes + off;
         unsigned long long *d_sel = nullptr;
         uint64_t n_sel = 0;
-        rc = ordered_select_counting(ctx, piece, DedupKeep{bits ? (1ULL << bits) - 1 : 0ull, ph, nullptr}, 7, &d_sel, &n_sel);
+        rc = ordered_select(ctx, piece, DedupKeep{bits ? (1ULL << bits) - 1 : 0ull, ph, nullptr}, 7, &d_sel, &n_sel);
         if (rc) return rc;
         if (n_sel == 0) { off += piece; continue; }
         if (force_host || quick > 16) {
@@ -1964,7 +1933,8 @@ int dedup_process(sq_dedup *d, const unsigned long long *d_hashes, uint64_t n)
         uint64_t e_end = n_sel;       /* survivors [0, e_end) arrive while the table has room */
         bool trigger = false;
         unsigned long long *d_miss = nullptr, *d_key = nullptr, *d_skey = nullptr;
-        unsigned int *d_val = nullptr, *d_sval = nullptr, *d_newc = nullptr;
+        unsigned long long *d_val = nullptr, *d_sval = nullptr;
+        unsigned int *d_newc = nullptr;
         uint64_t n_miss = 0;
         if (need <= 0) {              /* full already: the first survivor rebuilds */
             e_end = 0;
@@ -1973,7 +1943,7 @@ int dedup_process(sq_dedup *d, const unsigned long long *d_hashes, uint64_t n)
             hipLaunchKernelGGL(k_dd_classify, dim3(blocks_for(n_sel)), dim3(256), 0, ctx->stream, ph, d_sel, n_sel, d->d_hash,
                                d->d_count, bits, tmask, (unsigned long long)d->odd_hash, d->odd_valid ? 1 : 0, d_slot,
                                (unsigned int *)(d_res + 5));
-            rc = ordered_select_counting(ctx, n_sel, DedupIsMiss{d_slot}, 34, &d_miss, &n_miss);
+            rc = ordered_select(ctx, n_sel, DedupIsMiss{d_slot}, 34, &d_miss, &n_miss);
             if (rc) return rc;
             uint64_t res[8];
             rc = dedup_read_back(ctx, d_res, res, sizeof res);
@@ -1987,11 +1957,11 @@ int dedup_process(sq_dedup *d, const unsigned long long *d_hashes, uint64_t n)
             if (n_miss) {
                 d_key = (unsigned long long *)sq_scratch(ctx, 35, n_miss * 8);
                 d_skey = (unsigned long long *)sq_scratch(ctx, 36, n_miss * 8);
-                d_val = (unsigned int *)sq_scratch(ctx, 37, n_miss * 4 * 4);   /* val, sorted val, first / new counts, positions */
+                d_val = (unsigned long long *)sq_scratch(ctx, 37, n_miss * 3 * 8);   /* ranks, sorted ranks; first arrivals / new counts, positions */
                 if (!d_key || !d_skey || !d_val) { sq_set_error("out of device memory"); return SQ_ERR_MEMORY; }
                 d_sval = d_val + n_miss;
-                d_newc = d_val + 2 * n_miss;
-                unsigned int *d_pos = d_val + 3 * n_miss;
+                d_newc = (unsigned int *)(d_val + 2 * n_miss);
+                unsigned int *d_pos = d_newc + n_miss;
                 hipLaunchKernelGGL(k_dd_miss_keys, dim3(blocks_for(n_miss)), dim3(256), 0, ctx->stream, ph, d_sel, d_miss, n_miss,
                                    d_key, d_val);
                 size_t temp_bytes = 0;
@@ -2080,7 +2050,7 @@ int dedup_patch_short_pairs(sq_dedup *d, sq_batch *b1, sq_batch *b2, unsigned lo
     const uint64_t fp_len = d->front_len + d->back_len;
     unsigned long long *d_idx = nullptr;
     uint64_t n_special = 0;
-    int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, &d_idx, &n_special);
+    int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, 7, &d_idx, &n_special);
     if (rc) return rc;
     std::vector<unsigned long long> idx(n_special), val(n_special);
     if (n_special) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_special * 8, hipMemcpyDeviceToHost));
@@ -2136,7 +2106,7 @@ int dedup_defer(sq_dedup *d, sq_batch *b1, sq_batch *b2, const unsigned long lon
         const uint64_t fp_len = d->front_len + d->back_len;
         unsigned long long *d_idx = nullptr;
         uint64_t n_special = 0;
-        int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, &d_idx, &n_special);
+        int rc = ordered_select(ctx, n, DedupSpecialOnly{d_special}, 7, &d_idx, &n_special);
         if (rc) return rc;
         std::vector<unsigned long long> idx(n_special);
         if (n_special) SQ_HIP(hipMemcpy(idx.data(), d_idx, n_special * 8, hipMemcpyDeviceToHost));
@@ -2469,7 +2439,7 @@ SQ_EXPORT int64_t sq_dedup_shard_passing(sq_dedup *d, uint64_t bits, uint64_t *o
             const unsigned long long *d_hashes = d->d_stream + off;
             unsigned long long *d_idx = nullptr;
             uint64_t n_keep = 0;
-            int rc = ordered_select(ctx, n, DedupKeep{(1ULL << bits) - 1, d_hashes, nullptr}, &d_idx, &n_keep);
+            int rc = ordered_select(ctx, n, DedupKeep{(1ULL << bits) - 1, d_hashes, nullptr}, 7, &d_idx, &n_keep);
             if (rc) return rc;
             if (!n_keep) continue;
             unsigned long long *d_kh = (unsigned long long *)sq_scratch(ctx, 10, n_keep * 8);

@@ -127,7 +127,6 @@ int sq_span_launch_pt(sq_ctx *ctx, const PassParams &P, int pair, uint64_t *done
     int waves = span_max_waves(nw, false, false, false, true);
     while (waves >= 4 && span_lds_layout(nw, U, 0, 0, 0, waves, false, false, false, pair == 2).total > 160 * 1024) waves--;
     if (waves < 4) return SQ_OK;
-    if (sq_knobs().span_waves > 0) waves = std::max(1, std::min(waves, sq_knobs().span_waves));
     const size_t lds = span_lds_layout(nw, U, 0, 0, 0, waves, false, false, false, pair == 2).total;
     PassParams C = P;
     C.n = (P.n / SPAN_R) * SPAN_R;

@@ -29,7 +29,6 @@ struct PassParams {
     uint32_t ea_in_lds;
     uint32_t uniform_len;     /* != 0: every record of the batch has this length (<= lds_len) */
     const double *thresholds; /* [94], see phred_thresholds() */
-    uint32_t span_sync;        /* k_span, a wave per stream: the two waves of a pair stay within a span of each other (SQ_SPAN_SYNC) */
     const uint32_t *span_bounds;   /* k_span over sorted rows: first span of every workgroup's stretch ([grid + 1]); NULL: equal shares */
     const double *thr_sum;    /* [257][96]: row U = the same thresholds for the SUM of the error rates of a read of U bases (phred_sum_thresholds()) */
     unsigned long long *qc_first_bad;

@@ -1401,124 +1401,6 @@ __global__ void __launch_bounds__(RING_THREADS, 4) k_ring(PassParams P)
         if (l_ps[i]) atomicAdd(&P.qc_ps[i], (unsigned long long)l_ps[i]);
 }
 
-#ifdef SQ_PROBE
-/* memory-pattern probe (experiments only): a wave visits its 64 reads BPR bytes per row and
-   stream at a time, one visit of loads in flight ahead of the one being consumed; FLAT: the
-   same bytes as one linear stream */
-template <int BPR>
-__global__ void __launch_bounds__(256, 4) k_probe(PassParams P, unsigned long long *sink)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int LPR = BPR / 16, RPI = 64 / LPR, ITS = 64 / RPI;
-    const uint32_t U = P.uniform_len;
-    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
-    uint32_t acc = 0;
-    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
-        const sq_meta m = P.metas[g * 64 + lane];
-        const unsigned long long soff = m.record_start + m.sequence_offset, qoff = m.record_start + m.qualities_offset;
-        unsigned long long so[ITS], qo[ITS];
-#pragma unroll
-        for (int it = 0; it < ITS; it++) {
-            const int row = it * RPI + lane / LPR;
-            so[it] = __shfl(soff, row) + (lane % LPR) * 16;
-            qo[it] = __shfl(qoff, row) + (lane % LPR) * 16;
-        }
-        uint4 a[ITS], b[ITS], a2[ITS], b2[ITS];
-        auto fetch = [&](uint32_t v, uint4 (&x)[ITS], uint4 (&y)[ITS]) {
-#pragma unroll
-            for (int it = 0; it < ITS; it++) {
-                x[it] = make_uint4(0, 0, 0, 0); y[it] = x[it];
-                if (v * BPR + (lane % LPR) * 16 < U) {
-                    x[it] = *(const uint4 *)(P.buf + so[it] + v * BPR);
-                    y[it] = *(const uint4 *)(P.buf + qo[it] + v * BPR);
-                }
-            }
-        };
-        const uint32_t nv = (U + BPR - 1) / BPR;
-        fetch(0, a, b);
-        for (uint32_t v = 0; v < nv; v++) {
-            if (v + 1 < nv) fetch(v + 1, a2, b2);
-#pragma unroll
-            for (int it = 0; it < ITS; it++) acc ^= a[it].x ^ a[it].y ^ a[it].z ^ a[it].w ^ b[it].x ^ b[it].y ^ b[it].z ^ b[it].w;
-#pragma unroll
-            for (int it = 0; it < ITS; it++) { a[it] = a2[it]; b[it] = b2[it]; }
-        }
-    }
-    if (acc == 0x12345679u) sink[0] = acc;
-}
-/* lane = row: every lane streams its own read, BPV bytes per stream and visit */
-template <int BPV>
-__global__ void __launch_bounds__(256, 4) k_probe_row(PassParams P, unsigned long long *sink)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int K = BPV / 16;
-    const uint32_t U = P.uniform_len;
-    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
-    uint32_t acc = 0;
-    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
-        const sq_meta m = P.metas[g * 64 + lane];
-        const uint8_t *sp = P.buf + m.record_start + m.sequence_offset, *qp = P.buf + m.record_start + m.qualities_offset;
-        uint4 a[K], b[K], a2[K], b2[K];
-        auto fetch = [&](uint32_t v, uint4 (&x)[K], uint4 (&y)[K]) {
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                x[k] = make_uint4(0, 0, 0, 0); y[k] = x[k];
-                if (v * BPV + k * 16 < U) {
-                    x[k] = *(const uint4 *)(sp + v * BPV + k * 16);
-                    y[k] = *(const uint4 *)(qp + v * BPV + k * 16);
-                }
-            }
-        };
-        const uint32_t nv = (U + BPV - 1) / BPV;
-        fetch(0, a, b);
-        for (uint32_t v = 0; v < nv; v++) {
-            if (v + 1 < nv) fetch(v + 1, a2, b2);
-#pragma unroll
-            for (int k = 0; k < K; k++) acc ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w ^ b[k].x ^ b[k].y ^ b[k].z ^ b[k].w;
-#pragma unroll
-            for (int k = 0; k < K; k++) { a[k] = a2[k]; b[k] = b2[k]; }
-        }
-    }
-    if (acc == 0x12345679u) sink[0] = acc;
-}
-__global__ void __launch_bounds__(256, 4) k_probe_flat(const uint4 *buf, uint64_t n16, unsigned long long *sink)
-{
-    uint32_t acc = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
-    }
-    for (; i < n16; i += stride) { const uint4 a = buf[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
-    if (acc == 0x12345679u) sink[0] = acc;
-}
-/* flat stream in wave-private contiguous spans of 64 records (what a wave of a row-streaming
-   kernel would read) */
-__global__ void __launch_bounds__(256, 4) k_probe_span(PassParams P, unsigned long long *sink)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t ngroups = P.n / 64, n_waves = (uint64_t)gridDim.x * 4, wave_id = (uint64_t)blockIdx.x * 4 + wave;
-    uint32_t acc = 0;
-    for (uint64_t g = wave_id; g < ngroups; g += n_waves) {
-        const unsigned long long first = P.metas[g * 64].record_start;
-        const sq_meta ml = P.metas[g * 64 + 63];
-        const unsigned long long end = ml.record_start + ml.qualities_offset + ml.sequence_length;
-        const unsigned long long a0 = first & ~15ull;
-        for (unsigned long long o = a0 + (unsigned long long)lane * 16; o < end; o += 4 * 1024) {
-            uint4 x[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                x[k] = make_uint4(0, 0, 0, 0);
-                if (o + k * 1024 < end) x[k] = *(const uint4 *)(P.buf + o + k * 1024);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
-        }
-    }
-    if (acc == 0x12345679u) sink[0] = acc;
-}
-#endif
 
 /* ---- k_wide: batches of one read length, 64 bytes per row and visit ----
  * What bounds the fused pass on short reads is how the memory system takes the gather: a wave
@@ -2893,7 +2775,7 @@ int pertile_prepare(sq_pertile *p, sq_batch *b, bool *active)
        object's call before (they read the slots) and for the batch's upload if that is still on its way. */
     const bool tiles_ready = p->tiles_ready;   /* QCMetrics' pass over this batch has parsed the headers (on ctx->stream) */
     p->tiles_ready = false;
-    hipStream_t S = sq_knobs().pt_prep_inline || tiles_ready ? ctx->stream : ctx->prep_stream;
+    hipStream_t S = tiles_ready ? ctx->stream : ctx->prep_stream;
     if (S != ctx->stream) {
         if (p->used) SQ_HIP(hipStreamWaitEvent(S, p->used, 0));
         if (b->ready) SQ_HIP(hipStreamWaitEvent(S, b->ready, 0));
@@ -2995,7 +2877,7 @@ SQ_EXPORT int sq_fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter
        adapters too: 2.5 + 1.5 ms per 25 M reads against 7.0 for k_pass<QC,PT> */
     if (m && p && !p->skipped && b->slack && b->n >= 4096 && b->min_length == b->max_length &&
         b->max_length > 0 && b->max_length <= LDS_HIST_MAX && !K.no_wide && !K.ring &&
-        !K.no_split && (a || (b->max_length <= 32u * SPAN_NW_MAX && K.span))) {
+        (a || (b->max_length <= 32u * SPAN_NW_MAX && K.span))) {
         /* without the adapters: PerTileQuality rides in QCMetrics' pass (sq_pair.hip) -- the tile ids from the header
            bytes the pass fetches anyway, and, while the reads come tile by tile, the table itself */
         bool pt_done = false;
@@ -3077,7 +2959,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
     const bool span_sorted =
         m && !pt_active && !stripes && !P.uniform_len && b->slack && b->min_length >= 1 && b->n < (1ull << 31) &&
         (!a || a->groups[0].states <= DFA_LDS_MAX_STATES) && b->max_length <= 32u * (a ? (K.span_split ? SPAN_NW_AD_SPLIT : SPAN_NW_AD) : SPAN_NW_MAX) &&
-        K.span && !K.ring && !K.no_ring && !K.no_wide && K.wide < 0 &&
+        K.span && !K.ring && !K.no_ring && !K.no_wide &&
         (K.span_sorted >= 0 ? K.span_sorted != 0 : b->n >= 65536);
     /* PerTileQuality alone on a batch of one read length whose table fits LDS: k_ptspan streams the
        batch as it lies (no sort by tile) */
@@ -3099,7 +2981,7 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                takes a contiguous run of groups, and nearly every group is of one tile).  Only a
                batch whose tiles are mixed (on average fewer than 256 reads between two changes)
                is walked in tile-sorted order, which costs the sort and makes every load a gather */
-            if (!ptspan && (K.pt_sort || ((uint64_t)p->tile_changes * 256 > b->n && !K.pt_stored)))
+            if (!ptspan && (uint64_t)p->tile_changes * 256 > b->n)
                 P.order = sorted_order(ctx, b, p->d_slots, (uint32_t)p->n_slots);
             P.blocked = P.order != nullptr; /* stored order: waves move through the batch together */
         }
@@ -3139,21 +3021,6 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             SQ_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
-#ifdef SQ_PROBE
-    if (K.probe_mode >= 0) {
-        unsigned long long *sink = (unsigned long long *)sq_scratch(ctx, 0, 64);
-        const int mode = K.probe_mode, grid = ctx->num_cus * 4;
-        if (mode == 32) hipLaunchKernelGGL((k_probe<32>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        else if (mode == 64) hipLaunchKernelGGL((k_probe<64>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        else if (mode == 128) hipLaunchKernelGGL((k_probe<128>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        else if (mode == 33) hipLaunchKernelGGL((k_probe_row<32>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        else if (mode == 65) hipLaunchKernelGGL((k_probe_row<64>), dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        else if (mode == 1) hipLaunchKernelGGL(k_probe_flat, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)P.buf, (uint64_t)(b->buf_len / 16), sink);
-        else hipLaunchKernelGGL(k_probe_span, dim3(grid), dim3(256), 0, ctx->stream, P, sink);
-        SQ_HIP(hipGetLastError());
-        return SQ_OK;
-    }
-#endif
     /* PerTileQuality alone on a batch of one read length: k_ptq for the full groups, k_pass for
        a trailing partial one (SQ_NO_PTQ=1: k_pass for all) */
     bool ptq_done = false;
@@ -3230,9 +3097,6 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             if (ad && dfa_lds && a->groups[gi].count * hist_stride(32u * (((uint32_t)b->max_length + 31) / 32)) * 4 <= 8192)
                 S.ad_lds = (uint32_t)a->groups[gi].count;
             uint64_t covered = 0;
-#ifdef SQ_SPAN_PROBE
-            if (K.span_probe >= 0) S.blocked = (uint32_t)K.span_probe;   /* timing builds: DMA alone, counting alone (wrong tables) */
-#endif
             int rc = sq_span_launch_sorted(ctx, S, ad, ad ? (uint32_t)a->groups[gi].count : 0, (uint32_t)b->min_length, (uint32_t)b->max_length,
                                            S.n == b->n && S.metas == b->d_metas && b->len_hist.size() == SQ_LEN_BINS ? b->len_hist.data() : nullptr, &covered);
             if (rc) return rc;
@@ -3240,10 +3104,9 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
         }
         PassParams Pfull = P;
         const bool uniform_fast = qc && !pt && P.uniform_len && !P.order && b->n >= 64 && (!ad || dfa_lds);
-        const bool wide_set = K.wide >= 0;
         const size_t wlds = wide_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
         const bool wide = uniform_fast && b->slack && wlds <= 160 * 1024 && !K.no_wide &&
-                          (ad ? !K.ring : K.wide > 0);
+                          ad && !K.ring;
         const size_t rlds = ring_lds_bytes(P.uniform_len, ad, states, ad ? P.ad_lds : 0);
         const bool ring = uniform_fast && !wide && rlds <= 160 * 1024 && !K.no_ring &&
                           (!ad || K.ring);
@@ -3252,11 +3115,8 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
              Gbases/s at 150 against k_ring's 1020), with the automaton up to 160 (1015 against
              k_wide's 1000; adapters of up to 13 characters).  SQ_SPAN=0: the other two. */
         bool span_done = false;
-        if (uniform_fast && b->slack && K.span && !K.ring && !K.no_ring && !K.no_wide && !wide_set) {
+        if (uniform_fast && b->slack && K.span && !K.ring && !K.no_ring && !K.no_wide) {
             uint64_t covered = 0;
-#ifdef SQ_SPAN_PROBE
-            if (K.span_probe >= 0) P.blocked = (uint32_t)K.span_probe;
-#endif
             int rc = SQ_OK;
             if (ride && !ad && !R.launched) {
                 PassParams C = P;
@@ -3269,9 +3129,6 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
                 if (pair) pair->covered = covered;
             }
             if (!rc && !covered) rc = sq_span_launch(ctx, P, ad, ad ? (uint32_t)a->groups[gi].count : 0, &covered);
-#ifdef SQ_SPAN_PROBE
-            P.blocked = 0;
-#endif
             if (rc) return rc;
             if (covered == b->n) continue;
             if (covered) {
@@ -3287,14 +3144,12 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             static bool wattr = false;
             if (!wattr) {
                 SQ_HIP(hipFuncSetAttribute((const void *)k_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                SQ_HIP(hipFuncSetAttribute((const void *)k_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 wattr = true;
             }
             const uint64_t want = (C.n / 64 + WIDE_WAVES - 1) / WIDE_WAVES;
             const int wgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cus));
-            sq_route(ctx, "k_wide<%s>", ad ? "AD" : "QC");
-            if (ad) hipLaunchKernelGGL((k_wide<true>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
-            else hipLaunchKernelGGL((k_wide<false>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
+            sq_route(ctx, "k_wide<AD>");   /* (QCMetrics alone never comes here: k_span, behind it k_ring) */
+            hipLaunchKernelGGL((k_wide<true>), dim3(wgrid), dim3(WIDE_THREADS), wlds, ctx->stream, C);
             SQ_HIP(hipGetLastError());
             if (C.n == b->n) continue;
             P.metas = b->d_metas + C.n;
@@ -3323,7 +3178,6 @@ static int fused_add_batch(sq_batch *b, sq_qcmetrics *m, sq_adaptercounter *a, s
             P.n = b->n - C.n;
         }
         size_t lds = pass_lds_bytes(qc, qc ? P.lds_len : 0, qc ? ea_rows : 0, dfa_lds, states, ad ? P.ad_lds : 0, pt ? P.lds_len : 0);
-        lds += (size_t)K.lds_pad; /* occupancy experiments */
         int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
         if (qc && segments) {
             /* (1) what is sequential per read; where k_span<LONG> takes the per-position pass it counts G/C per
@@ -3452,7 +3306,7 @@ SQ_EXPORT int sq_paired_add_batches(sq_batch *b1, sq_batch *b2, sq_qcmetrics *m1
     const SqKnobs &K = sq_knobs();
     auto side = [](sq_batch *b, sq_qcmetrics *m, sq_pertile *p) -> int { return (m || p) ? sq_fused_add_batch(b, m, nullptr, p) : SQ_OK; };
     auto uniform = [](const sq_batch *b) { return b->slack && b->n >= 4096 && b->min_length == b->max_length && b->max_length >= 16 && b->max_length <= 32u * SPAN_NW_MAX; };
-    const bool fuse = K.pt_fused == 1 && K.span && !K.no_split && !K.no_wide && !K.ring && m1 && p1 && m2 && p2 && z && !p1->skipped && !p2->skipped &&
+    const bool fuse = K.pt_fused == 1 && K.span && !K.no_wide && !K.ring && m1 && p1 && m2 && p2 && z && !p1->skipped && !p2->skipped &&
                       b1->n == b2->n && uniform(b1) && uniform(b2) && b1->n < (1ull << 32);
     if (!fuse) {
         int rc = side(b1, m1, p1);

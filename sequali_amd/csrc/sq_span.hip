@@ -43,32 +43,10 @@
 
 namespace {
 
-/* probe builds (-DSQ_SPAN_PROBE, SQ_SPAN_STAMPS=1): what the launch just issued spent per span and wave */
-static void span_print_stamps(sq_ctx *ctx, int nw)
-{
-#ifdef SQ_SPAN_PROBE
-    if (!sq_knobs().span_stamps) return;
-    unsigned long long h[16];
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_span_stamps), sizeof h);
-    const double all = (double)(h[3] + h[5]);
-    fprintf(stderr, "k_span<%d> stamps per span and wave (cycles): wait %.0f issue %.0f counting %.0f (%llu spans; both streams, or the bases) %.0f (%llu spans, the qualities)\n",
-            nw, (double)h[0] / all, (double)h[1] / all, h[3] ? (double)h[2] / h[3] : 0.0, h[3], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
-    fprintf(stderr, "  phases (class codes, rounds, matches + tails, per read, hits + flush): bases / both %.0f %.0f %.0f %.0f %.0f; qualities %.0f %.0f %.0f %.0f %.0f\n",
-            h[6] / (double)(h[3] ? h[3] : 1), h[7] / (double)(h[3] ? h[3] : 1), h[8] / (double)(h[3] ? h[3] : 1), h[9] / (double)(h[3] ? h[3] : 1), h[10] / (double)(h[3] ? h[3] : 1),
-            h[11] / (double)(h[5] ? h[5] : 1), h[12] / (double)(h[5] ? h[5] : 1), h[13] / (double)(h[5] ? h[5] : 1), h[14] / (double)(h[5] ? h[5] : 1), h[15] / (double)(h[5] ? h[5] : 1));
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_span_stamps), z, sizeof z);
-#else
-    (void)ctx; (void)nw;
-#endif
-}
-
 template <int NW, bool SEG, bool SPLIT>
 int launch_nw(sq_ctx *ctx, const PassParams &P0, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
 {
     PassParams P = P0;
-    P.span_sync = sq_knobs().span_sync;
     static bool attr = false;
     constexpr bool HAS_AD = NW <= (SPLIT ? SPAN_NW_AD_SPLIT : SPAN_NW_AD);
     if (!attr) {
@@ -157,15 +135,14 @@ int span_waves(const PassParams &P, int nw, uint32_t U, bool ad, uint32_t n_ad, 
     if (span_needs_w6(P, ad)) {
         const int w6 = sq_knobs().span_w6;
         if (w6 == 0 || (w6 < 0 && !seg && nw < 5) || (P.ad_maxlen + 2) / 4 > 6 || !sq_span_w6_exists(nw, seg, split)) return 0;
-        if (!sq_knobs().span_spills_ok && sq_span_w6_spills(nw, seg, split)) return 0;
-    } else if (!sq_knobs().span_spills_ok &&
+        if (sq_span_w6_spills(nw, seg, split)) return 0;
+    } else if (
         (seg ? (split ? span_build_spills_any<true, true>(nw, ad) : span_build_spills_any<true, false>(nw, ad))
              : (split ? span_build_spills_any<false, true>(nw, ad) : span_build_spills_any<false, false>(nw, ad)))) return 0;
     const int step = split ? 2 : 1;
     int waves = span_max_waves(nw, split, seg);   /* as many as LDS takes */
     while (waves >= 4 && span_lds_layout(nw, U, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, ad ? P.ad_lds : 0, waves, seg, split).total > 160 * 1024) waves -= step;
     if (waves < 4) return 0;
-    if (sq_knobs().span_waves > 0) waves = std::max(step, std::min(waves, sq_knobs().span_waves / step * step));
     return waves;
 }
 
@@ -728,7 +705,6 @@ template <int NW>
 int launch_long(sq_ctx *ctx, const PassParams &C0, bool ad, uint32_t n_ad, int waves, size_t lds, int grid)
 {
     PassParams C = C0;
-    C.span_sync = sq_knobs().span_sync;
     static bool attr = false;
     if (!attr) {
         SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, true, SPAN_W4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -745,7 +721,7 @@ int launch_long(sq_ctx *ctx, const PassParams &C0, bool ad, uint32_t n_ad, int w
 static int long_waves(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_len, int *nw_out)
 {
     const uint64_t n = P.n;
-    const int nw = sq_knobs().long_nw == 4 ? 4 : sq_knobs().long_nw == 6 ? 6 : 8;   /* windows of 32 positions per segment (SQ_LONG_NW) */
+    const int nw = 8;   /* windows of 32 positions per segment (4 and 6 measured slower in round 3) */
     const uint32_t LSEG = 32 * (uint32_t)nw;
     *nw_out = nw;
     if (!P.order || n < SPAN_R || n >= (1ull << 31) || !max_len || max_len >= (1u << 24) || P.buf_len >= (1ull << 40) || P.ea_len > 512) return 0;
@@ -753,7 +729,6 @@ static int long_waves(const PassParams &P, bool ad, uint32_t n_ad, uint32_t max_
     int waves = span_max_waves(nw, true, true, true);
     while (waves >= 4 && span_lds_layout(nw, LSEG, ad ? SPAN_STATES(P) : 0, ad ? n_ad : 0, 0, waves, true, true, true).total > 160 * 1024) waves -= 2;
     if (waves < 4) return 0;
-    if (sq_knobs().span_waves > 0) waves = std::max(2, std::min(waves, sq_knobs().span_waves / 2 * 2));
     return waves;
 }
 
@@ -861,15 +836,15 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
        workgroup that meets a new segment flushes, merges its histograms and restarts its DMA pipeline (what a
        dozen spans cost it), and the segments far into the reads hold a few spans each -- with equal shares
        the last workgroup of config 4 went through 155 of them, the others through 1-18, and the launch waited
-       for it: 9.65 ms, 7.85 with shares of equal COST (spans + SQ_LONG_STRETCH_COST per segment met; 12 and
+       for it: 9.65 ms, 7.85 with shares of equal COST (spans + 16 per segment met; 12 and
        more all measure the same). */
     std::vector<uint32_t> nspans_of;
     for (const SpanSeg &g : segs) nspans_of.push_back(g.nspans);
-    const std::vector<uint32_t> bounds = span_cost_shares(nspans_of, grid, (double)sq_knobs().long_stretch_cost);
+    const std::vector<uint32_t> bounds = span_cost_shares(nspans_of, grid, 16.0);
     uint32_t *d_bounds = (uint32_t *)sq_scratch(ctx, 22, bounds.size() * 4);
     if (!d_bounds) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
     SQ_HIP(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    C.span_bounds = sq_knobs().long_stretch_cost > 0 ? d_bounds : nullptr;
+    C.span_bounds = d_bounds;
     static bool attr = false;
     if (!attr) {
         SQ_HIP(hipFuncSetAttribute((const void *)k_long_ea, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -878,10 +853,8 @@ int sq_span_launch_long(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad
     C.long_gc = (unsigned int *)sq_scratch(ctx, 16, n * 8);
     if (!C.long_gc) { sq_set_error("out of device memory for the segments of long reads"); return SQ_ERR_MEMORY; }
     SQ_HIP(hipMemsetAsync(C.long_gc, 0, n * 8, ctx->stream));
-    int rc = nw == 4 ? launch_long<4>(ctx, C, ad, n_ad, waves, lds, grid) : nw == 6 ? launch_long<6>(ctx, C, ad, n_ad, waves, lds, grid)
-                                                                       : launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
+    int rc = launch_long<8>(ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
-    span_print_stamps(ctx, nw);
     rc = sq_span_long_followups(ctx, P);
     if (rc) return rc;
     SQ_HIP(hipGetLastError());
@@ -937,7 +910,6 @@ int sq_span_launch(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_ad, uin
     int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(nw, false, split, ctx, C, n_ad, waves, lds, grid)
                                   : split ? launch_any<false, true>(nw, ctx, C, ad, n_ad, waves, lds, grid) : launch_any<false, false>(nw, ctx, C, ad, n_ad, waves, lds, grid);
     if (rc) return rc;
-    span_print_stamps(ctx, nw);
     *done = C.n;
     return SQ_OK;
 }
@@ -954,8 +926,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     const uint64_t n = P.n;
     /* one wave for both streams: with rows gathered from all over the buffer a wave per stream measures the same
        (676-707 against 699-715 Gbases/s), and its 4-window build sits at exactly 128 registers -- a spill there
-       sent the whole route to the other build without a word (SQ_SPAN_SORTED_SPLIT=1: a wave per stream) */
-    const bool prefer_split = sq_knobs().span_split && sq_knobs().span_sorted_split;
+       sent the whole route to the other build without a word; profiles/r5/exp_sorted_split.txt) */
     if (!max_len || max_len > 32u * SPAN_NW_MAX || n < SPAN_R || n >= (1ull << 31)) return SQ_OK;
     /* every window count of the batch must be one the kernel takes, in one build or the other (each launch has its
        own: reads of 161-224 bases with adapters exist as a wave per stream only, the 4-window build of a wave per
@@ -966,7 +937,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         /* the build the default dispatch names for this window count (sequali_amd/build.py::default_route_builds fails
            the build when one of them spills): one wave for both streams, except where that build does not exist (the
            automaton beyond 5 windows) or does not fit its registers (6 windows for sorted rows) */
-        const bool first = prefer_split || (ad ? nw > SPAN_NW_AD : nw == 6);
+        const bool first = ad ? nw > SPAN_NW_AD : nw == 6;
         for (const bool sp : {first, !first}) {
             if (found || (sp && !sq_knobs().span_split)) continue;
             if (span_waves(P, nw, 32 * nw, ad, n_ad, true, sp)) { split_of[nw] = sp; found = true; }
@@ -975,7 +946,7 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
     }
     SpanRow *rows_out = (SpanRow *)sq_scratch(ctx, 15, n * sizeof(SpanRow));
     std::vector<uint64_t> longer((size_t)max_len + 1);   /* longer[w] = how many reads are longer than w */
-    if (len_hist && !sq_knobs().span_radix) {
+    if (len_hist) {
         /* the counts per length came with the batch: the rows go to their places in one pass (k_span_scatter) */
         uint64_t sum = 0;
         for (uint32_t w = max_len; w > 0; w--) { longer[w] = sum; sum += len_hist[w]; }
@@ -1055,7 +1026,6 @@ int sq_span_launch_sorted(sq_ctx *ctx, const PassParams &P, bool ad, uint32_t n_
         int rc = span_needs_w6(C, ad) ? sq_span_launch_w6(l.nw, true, split, ctx, C, n_ad, l.waves, lds, grid)
                                       : split ? launch_any<true, true>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid) : launch_any<true, false>(l.nw, ctx, C, ad, n_ad, l.waves, lds, grid);
         if (rc) return rc;
-        span_print_stamps(ctx, l.nw);
         seg_off += l.segs.size();
     }
     *done = n;

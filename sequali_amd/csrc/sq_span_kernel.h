@@ -240,12 +240,7 @@ constexpr int span_max_waves(int nw, bool split = false, bool seg = false, bool 
     return nw <= (lng ? 6 : split ? 5 : 3) ? 16 : 12;   /* (sorted rows, a wave per stream: 16 waves up to 5 windows since the registers allow it, round 5) */
 }
 
-#ifdef SQ_SPAN_PROBE
-__device__ unsigned long long g_span_stamps[6 + 10]; /* cycles summed over waves: top wait, DMA issue, counting; spans; SPLIT: counting and spans of the quality role */
-#define SPAN_STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
-/* phases inside a span: cycles since the stamp before go to ph[5 * (quality role) + k] */
-#define SPAN_PHASE(k) do { SPAN_STAMP(tq_); ph[(DS ? 0 : 5) + (k)] += tq_ - tp; tp = tq_; } while (0)
-#elif defined(SQ_SPAN_MARK)   /* comments in the ISA listing (hipcc -S): instructions per phase can be counted */
+#if defined(SQ_SPAN_MARK)   /* comments in the ISA listing (hipcc -S): instructions per phase can be counted */
 #define SPAN_PHASE(k) do { asm volatile("; SPAN_PHASE " #k ::: "memory"); } while (0)
 #else
 #define SPAN_PHASE(k) do { } while (0)
@@ -375,9 +370,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     static_assert(PAIR == 0 || PT, "the passes over pairs are builds of the pass that carries PerTileQuality");
     static_assert(!LONG || (SEG && SPLIT), "segments of long reads come as sorted rows, a wave per stream");
     static_assert(!PT || (!AD && !SEG && !SPLIT && !LONG), "PerTileQuality rides with QCMetrics alone on batches of one read length, one wave for both streams");
-#ifdef SQ_SPAN_PROBE
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, a_wait = 0, a_issue = 0, a_comp = 0, a_spans = 0, a_compq = 0, a_spansq = 0, ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp = 0, tq_ = 0;
-#endif
     /* Row r of a slot: sequence at r * ROWB, qualities at r * ROWB + QOFF (SPLIT: the slot holds
        one of the two streams, at r * ROWB).  A row is an odd number of 16-byte pieces (the last one
        is never loaded) and a lane's quarter an odd number of dwords, so that the 32 lanes of an LDS
@@ -752,9 +744,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         const uint32_t nv = SEG && s == s_last ? last_rows : SPAN_R;   /* rows q >= nv are filler */
         const uint32_t seq_row = sa + q * ROWB + PRE, qual_row = seq_row + QOFF;
         const uint32_t urow = LONG ? (q < nv ? urow_cur : 0u) : 0u;   /* LONG: positions of this row inside the segment */
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(tp);
-#endif
 
         if constexpr (PAIR == 1) {
             /* the first and the last 16 bases of the row, raw (the scan of read 1's pass compares raw bytes, :5699-5703): lanes
@@ -1400,13 +1389,7 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     }
     while (s < s_end) {
         /* the span in slot `cur` has landed, and so have the metas of the one after it */
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t0);
-#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t1);
-#endif
         if constexpr (PT) {   /* the header bytes of this span have arrived too */
             asm volatile("" : "+v"(name_next), "+v"(nlen_next));
             name_cur = name_next;
@@ -1417,11 +1400,9 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
                once they have drifted apart the line a record's sequence ends and its qualities begin in (and the
                span's metas) comes from memory twice -- 1.69 x the algorithmic bytes instead of 1.2 x.  A wave
                does not start span number k of its sequence before its partner has started number k - 1. */
-            if (P.span_sync) {
-                spans_done++;
-                *(volatile SQ_LDS uint32_t *)(uintptr_t)prog_mine = spans_done;   /* every lane the same word */
-                while (*(volatile SQ_LDS uint32_t *)(uintptr_t)prog_partner + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
-            }
+            spans_done++;
+            *(volatile SQ_LDS uint32_t *)(uintptr_t)prog_mine = spans_done;   /* every lane the same word */
+            while (*(volatile SQ_LDS uint32_t *)(uintptr_t)prog_partner + 1 < spans_done) __builtin_amdgcn_s_sleep(4);
         }
         if constexpr (PAIR == 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1474,22 +1455,10 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
             __builtin_amdgcn_sched_barrier(0);
         }
         if (s + stride < s_end) {
-#ifdef SQ_SPAN_PROBE
-            if (P.blocked & 4)      /* the DMA lands in a slot nobody reads (the last wave's, doubled up): counting runs on stale slots */
-                issue(lds_addr(smem + L.slots) + (W - 1) * 2 * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u), s + stride);
-            else if (!(P.blocked & 1))
-#endif
             issue(slot_base + (cur ^ 1) * SLOT, meta_base, role ^ (SPLIT ? 1u : 0u), s + stride);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the metas have been read: the next ones may land on them */
             if (s + 2 * stride < s_end) issue_meta(s + 2 * stride, meta_base);
         }
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t2);
-        if (P.blocked & 2) { cur ^= 1; s += stride; role ^= SPLIT ? 1u : 0u; a_wait += t1 - t0; a_issue += t2 - t1; a_spans++; continue; }
-#endif
-#ifdef SQ_SPAN_PROBE
-        if (SPLIT && (P.blocked & (role ? 16 : 8))) { /* 8: nothing is counted of the bases, 16: of the qualities */ } else
-#endif
         if constexpr (!SPLIT) body(std::true_type{}, std::true_type{});
         else if (role == 0) body(std::true_type{}, std::false_type{});
         else body(std::false_type{}, std::true_type{});
@@ -1497,11 +1466,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
         s += stride;
         rec_cur = rec_next;
         urow_cur = urow_next;
-#ifdef SQ_SPAN_PROBE
-        SPAN_STAMP(t3);
-        a_wait += t1 - t0; a_issue += t2 - t1;
-        if (SPLIT && role) { a_compq += t3 - t2; a_spansq++; } else { a_comp += t3 - t2; a_spans++; }
-#endif
         if constexpr (SPLIT) role ^= 1;
     }
     if constexpr (!SEG) break;
@@ -1513,14 +1477,6 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
     __syncthreads();
     seg_i++;
     }
-#ifdef SQ_SPAN_PROBE
-    if (lane == 0) {
-        atomicAdd(&g_span_stamps[0], a_wait); atomicAdd(&g_span_stamps[1], a_issue);
-        atomicAdd(&g_span_stamps[2], a_comp); atomicAdd(&g_span_stamps[3], a_spans);
-        atomicAdd(&g_span_stamps[4], a_compq); atomicAdd(&g_span_stamps[5], a_spansq);
-        for (int k = 0; k < 10; k++) atomicAdd(&g_span_stamps[6 + k], ph[k]);
-    }
-#endif
     if constexpr (PT) {
         if (pt_reads) pt_flush(pt_lo, pt_hi, pt_reads);
     }

@@ -17,7 +17,6 @@ template <int NW, bool SEG, bool SPLIT>
 int launch_w6(sq_ctx *ctx, const PassParams &P0, uint32_t n_ad, int waves, size_t lds, int grid)
 {
     PassParams P = P0;
-    P.span_sync = sq_knobs().span_sync;
     static bool attr = false;
     if (!attr) {
         SQ_HIP(hipFuncSetAttribute((const void *)k_span<NW, true, SEG, W6, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -329,26 +329,35 @@ def _dedup_gather(L, shards, base: int, counts: List[int], device, group=None):
     # 4. the head's tail: its own shard, then the others' survivors in shard order
     stop = total
     state = b""
+    failure = None
     if rank == 0:
-        hashes = np.ascontiguousarray(hashes.cpu().numpy()).view(np.uint64)
-        head = shards[0]
-        check(L.sq_dedup_resolve(head._h))
-        at = 0
-        for g in range(1, total):
-            n = int(sizes[g - 1])
-            part = np.ascontiguousarray(hashes[at:at + n])
-            after = np.ascontiguousarray(store_after[g])
-            rc = check(L.sq_dedup_feed_hashes(head._h, part.ctypes.data, n, int(filtered[g]), after.ctypes.data, fp_len))
-            if rc:          # SQ_DEDUP_FEED_TOO_STRICT: the relay takes it from here
-                stop = g
-                break
-            at += n
-        state = _dedup_export(L, head)
+        # the head works alone while the other ranks wait in the broadcast below: whatever it raises is caught, the
+        # others are told (stop = -1) and every rank raises -- a job that fails, not one that hangs
+        try:
+            hashes = np.ascontiguousarray(hashes.cpu().numpy()).view(np.uint64)
+            head = shards[0]
+            check(L.sq_dedup_resolve(head._h))
+            at = 0
+            for g in range(1, total):
+                n = int(sizes[g - 1])
+                part = np.ascontiguousarray(hashes[at:at + n])
+                after = np.ascontiguousarray(store_after[g])
+                rc = check(L.sq_dedup_feed_hashes(head._h, part.ctypes.data, n, int(filtered[g]), after.ctypes.data, fp_len))
+                if rc:          # SQ_DEDUP_FEED_TOO_STRICT: the relay takes it from here
+                    stop = g
+                    break
+                at += n
+            state = _dedup_export(L, head)
+        except Exception as e:   # noqa: BLE001 -- re-raised below, on every rank
+            failure, stop, state = e, -1, b""
     if _active(group):
         t = _wire(torch.tensor([stop], dtype=torch.int64, device=device), group)
         dist.broadcast(t, src=0, group=group)
         stop = int(t.item())
-        state = _broadcast_bytes(state, 0, device, group)
+        if stop >= 0:
+            state = _broadcast_bytes(state, 0, device, group)
+    if stop < 0:
+        raise RuntimeError("merge_dedup: the head's insertion tail failed on rank 0" + (f": {failure!r}" if failure is not None else "")) from failure
     for i, d in enumerate(shards):
         if 0 < base + i < stop:
             check(L.sq_dedup_shard_drop(d._h))
@@ -366,11 +375,12 @@ def merge_dedup(shards: Sequence, device=None, group=None, method: str = None) -
     its hashes with a mask it can prove the estimator has reached by then, the head runs one
     tail over what is left (sq_ends.hip "by gathering"; falls back to the relay for the
     rest when the proof's premise fails, and for the whole merge when some rank holds no shard).  Default: $SQ_DEDUP_MERGE,
-    else "gather" (since round 5: tests/test_gpu_shards.py ran both against one sequential run on a GPU)."""
+    else "relay": tests/test_gpu_shards.py runs both against one sequential run on a GPU, but with gloo ranks on ONE
+    device -- until a job of more than one rank has run the gather over RCCL, the relay stays the default."""
     import os
     from ._lib import check, lib
     L = lib()
-    method = method or os.environ.get("SQ_DEDUP_MERGE", "gather")
+    method = method or os.environ.get("SQ_DEDUP_MERGE", "relay")
     if method not in ("relay", "gather"):
         raise ValueError(f"merge_dedup: method {method!r} (relay or gather)")
     counts = _shard_counts(len(shards), device, group)

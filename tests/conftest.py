@@ -50,16 +50,21 @@ def _memory_watchdog(limit_gb: float, floor_gb: float) -> None:
     of twelve digits and memset an array of 2 TB.  The oracle refuses such ids now; this is the belt to
     those braces: a thread that ends the whole test process, loudly and with a non-zero code, once the resident
     memory of it and its children passes the limit ($SQ_TEST_RSS_LIMIT_GB, default 40; 0 = no watchdog) OR the
-    machine's MemAvailable falls below $SQ_TEST_MEM_FLOOR_GB (default 6) after having been above twice that.
-    Everything is read from /proc.  A runaway memset fills ~10 GB a second, the thread looks ten times a second."""
+    machine's MemAvailable falls below $SQ_TEST_MEM_FLOOR_GB (default 6) after having been above twice that WHILE this
+    tree itself holds more than a quarter of the limit (on a shared box somebody else's allocation is no reason to
+    end this run).  Everything is read from /proc; where /proc does not answer the run goes on without the watchdog,
+    with a warning.  A runaway memset fills ~10 GB a second, the thread looks ten times a second."""
     import threading
     import time
     me = os.getpid()
     page = os.sysconf("SC_PAGE_SIZE")
     saved_stderr = os.dup(2)
     if _resident_bytes_of_the_tree(me, page) <= 0:
-        raise RuntimeError("tests/conftest.py: /proc does not give this process's resident size; the memory "
-                           "watchdog cannot work here (set SQ_TEST_RSS_LIMIT_GB=0 to run without it)")
+        import warnings
+        warnings.warn("tests/conftest.py: /proc does not give this process's resident size: the test run goes on WITHOUT "
+                      "the memory watchdog (SQ_TEST_RSS_LIMIT_GB=0 silences this)", RuntimeWarning)
+        os.close(saved_stderr)
+        return
     armed_floor = _mem_available_bytes() > 2 * floor_gb * 2 ** 30
 
     def end(msg: str):
@@ -79,7 +84,7 @@ def _memory_watchdog(limit_gb: float, floor_gb: float) -> None:
                 end(f"{rss / 2 ** 30:.1f} GiB resident, limit {limit_gb:g} GiB (SQ_TEST_RSS_LIMIT_GB)")
             if armed_floor and floor_gb > 0:
                 avail = _mem_available_bytes()
-                if 0 <= avail < floor_gb * 2 ** 30:
+                if 0 <= avail < floor_gb * 2 ** 30 and rss > 0.25 * limit_gb * 2 ** 30:
                     end(f"MemAvailable {avail / 2 ** 30:.1f} GiB, floor {floor_gb:g} GiB (SQ_TEST_MEM_FLOOR_GB)")
             time.sleep(0.1)
     threading.Thread(target=watch, name="rss-watchdog", daemon=True).start()

@@ -404,3 +404,54 @@ def test_paired_pass_through_the_parsers_at_the_default_buffer_size():
         _compare_pertile(got[1], ref[1])
         _compare_pertile(got[3], ref[3])
         _compare_insert_sizes(got[4], ref[4])
+
+
+@pytest.mark.parametrize("bad_in", [1, 2])
+def test_an_invalid_phred_character_through_the_fused_passes(bad_in):
+    """A byte that is no phred character (:2073-2075, :2102-2105) in read 1 / in read 2 of a batch of pairs, through
+    PairedPass (k_span<QCPT_ends> / <QCPT_scan>) and through FusedPass(QCMetrics, None, PerTileQuality): the flush
+    raises the reference's ValueError and the QCMetrics object that met the byte holds what the reference's had counted
+    when it raised -- the reads in front of it and the part of the bad read in front of the byte's group of four."""
+    from sequali_amd import FastqRecordArrayView, FusedPass, InsertSizeMetrics, PairedPass, PerTileQuality, QCMetrics
+    rng = np.random.default_rng(90 + bad_in)
+    U, n, bad = 100, 16 * 300 + 7, 16 * 111 + 5
+    tiles = _runs(rng, n, [40, 300, 1000], [1101, 1102, 2205])
+    b1, m1 = _batch(rng, tiles, U)
+    b2, m2 = _batch(rng, tiles, U, name_of=lambda i, t: f"M0:7:FCX:{1 + i % 4}:{t}:{1000 + i}:{U} 2:N:0:ACGT")
+    bufs = {1: bytearray(b1), 2: bytearray(b2)}
+    metas = {1: m1, 2: m2}
+    mb = metas[bad_in][bad]
+    bufs[bad_in][int(mb["record_start"]) + int(mb["qualities_offset"]) + 57] = 0x7F
+    b1, b2 = bytes(bufs[1]), bytes(bufs[2])
+    ref, ref_metas = oracle.QCMetrics(), metas[bad_in].copy()
+    with pytest.raises(ValueError):
+        ref.add(b1 if bad_in == 1 else b2, ref_metas)
+
+    def check(q):
+        assert q.number_of_reads == ref.number_of_reads and q.max_length == ref.max_length
+        for name in ("base_count_table", "phred_count_table", "end_anchored_base_count_table",
+                     "end_anchored_phred_count_table", "gc_content", "phred_scores"):
+            np.testing.assert_array_equal(u64(getattr(q, name)()), getattr(ref, name)(), err_msg=name)
+
+    # the five calls of the driver loop as one
+    q1, p1, q2, p2, z = QCMetrics(), PerTileQuality(), QCMetrics(), PerTileQuality(), InsertSizeMetrics()
+    a1, a2 = FastqRecordArrayView._from_buffer(b1, m1.copy()), FastqRecordArrayView._from_buffer(b2, m2.copy())
+    bad_q = q1 if bad_in == 1 else q2
+
+    def paired():      # (arrays of this size are staged: the pass runs when somebody asks for the state)
+        PairedPass(q1, p1, q2, p2, z).add_record_array_pair(a1, a2)
+        with pytest.raises(ValueError, match="Not a valid phred character"):
+            bad_q.flush()
+    r = _route_of(paired)
+    assert "k_span<4,QCPT" in r, r
+    check(bad_q)
+    # QCMetrics + PerTileQuality of the bad mate alone
+    q, p = QCMetrics(), PerTileQuality()
+    arr = FastqRecordArrayView._from_buffer(b1 if bad_in == 1 else b2, metas[bad_in].copy())
+    def fused():
+        FusedPass(q, None, p).add_record_array(arr)
+        with pytest.raises(ValueError, match="Not a valid phred character"):
+            q.flush()
+    r = _route_of(fused)
+    assert r.split("+")[0] == "k_span<4,QCPT,uniform,both>", r
+    check(q)

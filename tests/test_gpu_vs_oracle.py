@@ -172,7 +172,7 @@ def test_pertile_reads_ordered_by_tile_are_walked_as_stored():
     rq.add(buf, metas)
     want = {t: (e, c) for t, e, c in rp.get_tile_counts()}
     assert len(want) == 2
-    for env in ({}, {"SQ_PT_SORT": "1"}):
+    for env in ({},):
         gq, gp = QCMetrics(), PerTileQuality()
         _with_env(env, lambda: (FusedPass(gq, None, gp).add_record_array(dev), gq.flush()))
         got = {t: (e, c) for t, e, c in gp.get_tile_counts()}
@@ -208,7 +208,7 @@ def test_overrep_vs_oracle_with_cap_crossing():
 
 
 @pytest.mark.parametrize("k,start,end,max_len,cap", [(21, 100, 100, 160, 5000), (5, 40, 40, 90, 300), (7, 20, 60, 400, 900),
-                                                     (3, 8, 40, 60, 64), (31, 100, 100, 1200, 2000), (4, 30, 34, 64, 200)])
+                                                     (3, 8, 40, 60, 64), (31, 100, 100, 1200, 2000), (5, 38, 42, 80, 200)]))
 def test_overrep_fragment_geometries(k, start, end, max_len, cap):
     """reads that repeat fragments inside themselves (short k-mers: a fragment twice in a read is counted once,
     :3588-3608), more fragments from one end than from the other, up to 16 fragments a read, N and other letters, caps
@@ -556,7 +556,6 @@ def test_uniform_length_kernels_every_alignment(U):
              (False, {"SQ_SPAN_SPLIT_QC": "0"}),                 # QCMetrics alone: k_span, one wave for both streams (the default up to 160 positions)
              (False, {"SQ_SPAN_SPLIT_QC": "1"}),                 # ... a wave per stream (the default from 161 on)
              (False, {"SQ_SPAN": "0"}),                          # QCMetrics alone: k_ring
-             (False, {"SQ_WIDE": "1"}),                          # QCMetrics alone: k_wide
              (False, {"SQ_NO_RING": "1"}),                       # QCMetrics alone: k_pass
              (True, {}),                                         # + AdapterCounter: k_span (k_wide from 161 positions on)
              (True, {"SQ_SPAN": "0"}),                           # k_wide
@@ -575,6 +574,51 @@ def test_uniform_length_kernels_every_alignment(U):
         route = _route_of(lambda: _with_env(env, run))
         if not env and _uniform_route(U, with_adapters):   # the default dispatch: the kernel DESIGN 4.1b names for this length, not a silent fallback
             assert route.split("+")[0] == _uniform_route(U, with_adapters), (U, with_adapters, route)
+        compare_qc(rq, gq, metas, arr)
+        if with_adapters:
+            for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
+                np.testing.assert_array_equal(u64(f), fr)
+                np.testing.assert_array_equal(u64(r), rr)
+
+
+_SWEEP_U = sorted(set(range(1, 65)) | {32 * k + d for k in range(2, 9) for d in (-2, -1, 0, 1, 2) if 32 * k + d <= 256})
+
+
+@pytest.mark.parametrize("U", _SWEEP_U)
+def test_k_span_every_length_up_to_64_and_around_every_window_border(U):
+    """k_span<NW, uniform> on EVERY read length from 1 to 64 and two either side of every multiple of 32 up to 256,
+    QCMetrics alone and with the adapters (SQ_SPAN_SHORT=1: up to 64 bases the default with adapters is k_wide).  The
+    padding masks of a batch of one read length are made from an opaque copy of U (sq_span_kernel.h, `keep_u0`): written
+    with the kernel's own U, hipcc (ROCm 7.2) dropped the guards of the f64 chains' last steps and every read of 1-15 and
+    33-47 bases summed the text behind its qualities (round 5) -- a sweep over a handful of lengths does not pin that."""
+    from sequali_amd import AdapterCounter, FastqRecordArrayView, FusedPass, QCMetrics
+    rng = np.random.default_rng(7000 + U)
+    n = 64 * 2 + 21
+    probes = ["ACGTACGTACGT"[:min(U, 12)], "GGGGG"[:min(U, 5)]]
+    names, seqs, quals = [], [], []
+    for i in range(n):
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=U, p=[.24, .24, .24, .24, .04]).tobytes().decode()
+        if U >= 12 and i % 3 == 0:
+            at = int(rng.integers(0, U - 11)) if i % 2 else U - 12
+            s = s[:at] + "ACGTACGTACGT" + s[at + 12:]
+        names.append("r" * (1 + i % 67))
+        seqs.append(s)
+        quals.append((rng.integers(0, 94, size=U) + 33).astype(np.uint8).tobytes().decode())
+    buf, metas = oracle.make_batch(names, seqs, quals)
+    rq, ra = oracle.QCMetrics(), oracle.AdapterCounter(probes)
+    rq.add(buf, metas)
+    ra.add(buf, metas)
+    nw = (U + 31) // 32
+    for with_adapters in (False, True):
+        arr = FastqRecordArrayView._from_buffer(buf, metas.copy())
+        gq, ga = QCMetrics(), AdapterCounter(probes)
+
+        def run():
+            (FusedPass(gq, ga) if with_adapters else gq).add_record_array(arr)
+            gq.flush()
+        route = _route_of(lambda: _with_env({"SQ_SPAN_SHORT": "1"}, run))
+        want = f"k_span<{nw},AD,uniform,split>" if with_adapters else f"k_span<{nw},QC,uniform,{'split' if nw >= 6 else 'both'}>"
+        assert route.split("+")[0] == want, (U, with_adapters, route)
         compare_qc(rq, gq, metas, arr)
         if with_adapters:
             for (_, f, r), (_, fr, rr) in zip(ga.get_counts(), ra.get_counts()):
@@ -695,7 +739,7 @@ def test_sorted_spans_two_million_trimmed_reads():
     gq, ga = QCMetrics(), AdapterCounter(probes)
     f = FusedPass(gq, ga)
     # rows in order by the batch's length counts (k_span_scatter) / by a radix sort of keys / the general k_pass / the four launches side by side
-    for env in ({}, {"SQ_SPAN_RADIX": "1"}, {"SQ_SPAN": "0"}):
+    for env in ({}, {"SQ_SPAN": "0"}):
         rq.add(buf, metas)
         ra.add(buf, metas)
         _with_env(env, lambda: (f.add_record_array(dev), gq.flush()))
@@ -972,7 +1016,7 @@ def test_config3_one_million_pairs(by_tile):
 
     # the default (PerTileQuality rides in QCMetrics' pass) / the passes of round 2 (the pass over the headers on a stream
     # of its own, beside the counting) / that pass on the work stream / the round-1 kernels
-    for env in ({}, {"SQ_PT_FUSED": "0"}, {"SQ_PT_FUSED": "0", "SQ_PT_PREP_INLINE": "1"}, {"SQ_SPAN": "0"}):
+    for env in ({}, {"SQ_PT_FUSED": "0"}, {"SQ_SPAN": "0"}):
         route = _route_of(lambda: _with_env(env, run))
         if not env:      # the default since round 5
             want = "k_span<5,QCPT,uniform,both>+k_pt_fold" if by_tile else "k_span<5,QCPT,uniform,both>+k_ptspan<5>"
