@@ -208,7 +208,7 @@ def test_overrep_vs_oracle_with_cap_crossing():
 
 
 @pytest.mark.parametrize("k,start,end,max_len,cap", [(21, 100, 100, 160, 5000), (5, 40, 40, 90, 300), (7, 20, 60, 400, 900),
-                                                     (3, 8, 40, 60, 64), (31, 100, 100, 1200, 2000), (5, 38, 42, 80, 200)]))
+                                                     (3, 8, 40, 60, 64), (31, 100, 100, 1200, 2000), (5, 38, 42, 80, 200)])
 def test_overrep_fragment_geometries(k, start, end, max_len, cap):
     """reads that repeat fragments inside themselves (short k-mers: a fragment twice in a read is counted once,
     :3588-3608), more fragments from one end than from the other, up to 16 fragments a read, N and other letters, caps
