@@ -1391,7 +1391,10 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         P.sample_base = done;
         P.rank_base = o->shard ? samples_before + done : done;
         P.n_samples = chunk;
-        hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, P); /* a workgroup counts hot fragments in LDS first: fewer, longer-lived ones */
+        /* a workgroup counts hot fragments in LDS first: fewer, longer-lived ones.  Twice the workgroups that fit at a time:
+           the pass is a chain of memory round trips per lane, and the second half fills the tail the first leaves
+           (20.2 -> 17.7 ms per 100 M reads; profiles/r6/exp_overrep.txt) */
+        hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, P);
         SQ_HIP(hipGetLastError());
         if (need_big) {
             SQ_HIP(hipStreamSynchronize(ctx->stream));
