@@ -1,16 +1,15 @@
 #!/bin/bash
-# Round-5 evidence (run on the GPU box, AFTER scripts/gpu_bisect_r5.sh has found what took round 4's boxes down and
-# tests/test_gpu_pair.py is green): kernel stats of the default bench.py and of the headline alone, then ONE
+# The round's evidence (run on the GPU box; ROUND=r6 by default): kernel stats of the default bench.py and of the headline alone, then ONE
 # configuration at a time (bench.py --configs NAME: several entries share kernels by name, so the counters of a
 # configuration are those of a run that holds nothing else): kernel stats, FETCH_SIZE and WRITE_SIZE (each counter in its
-# own --pmc pass), SQ counters for the headline and for config 3's new passes -> gpurun_out/r5/ (copy what is to be
-# judged to profiles/r5/).  Usage: bash scripts/profile_r5.sh [stats|headline|CONFIG ...]   (default: everything; the
+# own --pmc pass), SQ counters for the headline and for config 3's passes -> gpurun_out/$ROUND/ (copy what is to be
+# judged to profiles/$ROUND/).  Usage: [ROUND=r6] bash scripts/profile_configs.sh [stats|headline|CONFIG ...]   (default: everything; the
 # whole script is ~ 25 GPU-minutes)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r5
+OUT=$R/gpurun_out/${ROUND:-r6}
 mkdir -p $OUT
-WHAT="${@:-stats headline uniform_200bp uniform_250bp ragged_50_150 config3_paired config3_paired_by_tile config3_paired_five_calls_unfused config4_nanopore}"
+WHAT="${@:-stats headline uniform_200bp uniform_250bp ragged_50_150 config3_paired config3_paired_by_tile config4_nanopore single_end_six_modules overrep_alone dedup_single_end dedup_paired insert_size_alone}"
 SMALL="--steps 1 --warmup 1 --cpu-sample 0 --reads 25000000"
 stats() {   # $1: tag, rest: bench.py arguments
   tag=$1; shift
@@ -62,7 +61,7 @@ for f in glob.glob("cal_*/**/*counter_collection.csv", recursive=True):
 if cal.get("FETCH_SIZE"):
     per_byte = sum(cal["FETCH_SIZE"]) / len(cal["FETCH_SIZE"]) * 1024 / 8589934592.0
 tags = sorted({os.path.basename(d)[4:].rsplit("_", 1)[0] for d in glob.glob("pmc_*") if os.path.isdir(d)})
-traffic = {}
+traffic, passes_of = {}, {}
 with open("pmc_all.txt", "w") as out:
     out.write("per configuration (bench.py --configs NAME --steps 1 --warmup 1, 25 M-read batches): averages per launch of every kernel, one rocprofv3 --pmc pass per\\n"
               "counter set; FETCH_SIZE / WRITE_SIZE in KB (FETCH_SIZE of a linear stream = %.3f x its bytes); hbm bytes = FETCH_SIZE / that + WRITE_SIZE\\n\\n" % per_byte)
@@ -91,10 +90,12 @@ with open("pmc_all.txt", "w") as out:
                 total += hbm
                 out.write(f"    hbm bytes, all launches  {hbm:16.0f}\\n")
             out.write("\\n")
-        traffic[tag] = int(total / 2)   # two passes (one warm-up, one step) per run
-        out.write(f"     {tag}: hbm bytes per pass over the run's records (everything above, / 2 passes): {traffic[tag]}\\n\\n")
-json.dump({"csrc_sha": bench.csrc_sha(), "fetch_size_of_a_linear_stream_per_byte_read": round(per_byte, 4), "hbm_bytes_per_pass_by_run": traffic,
-           "note": "scripts/profile_r5.sh: one bench.py run per configuration (25 M-read batches; the headline's own batch is part of every run: subtract its "
+        passes = 3 if tag in ('single_end_six_modules', 'overrep_alone', 'dedup_single_end', 'dedup_paired') else 2   # one warm-up, one step; the settled modules: one more in front
+        traffic[tag] = int(total / passes)
+        passes_of[tag] = passes
+        out.write(f"     {tag}: hbm bytes per pass over the run's records (everything above, / the run's passes): {traffic[tag]}\\n\\n")
+json.dump({"csrc_sha": bench.csrc_sha(), "fetch_size_of_a_linear_stream_per_byte_read": round(per_byte, 4), "hbm_bytes_per_pass_by_run": traffic, "passes_by_run": passes_of,
+           "note": "scripts/profile_configs.sh: one bench.py run per configuration (25 M-read batches; the headline's own batch is part of every run: subtract its "
                    "kernel's bytes, listed under each run in pmc_all.txt); to be turned into profiles/traffic.json by hand once the numbers have been looked at"},
           open("traffic_by_run.json", "w"), indent=1)
 print(open("traffic_by_run.json").read())

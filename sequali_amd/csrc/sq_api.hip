@@ -47,6 +47,7 @@ static void knobs_load()
     k.no_segments = flag("SQ_NO_SEGMENTS");
     k.long_spans = num("SQ_LONG", 1) != 0;
     k.dedup_sequential = flag("SQ_DEDUP_SEQUENTIAL");
+    k.overrep_chain = flag("SQ_OVERREP_CHAIN");
     g_knobs = k;
     g_knobs_loaded = true;
 }

@@ -53,7 +53,8 @@ void sq_set_error(const char *fmt, ...);
  *   SQ_NO_PTQ           PerTileQuality alone through k_pass
  *   SQ_PT_FUSED         0: PerTileQuality and InsertSizeMetrics in passes of their own; 2: only the tile ids from the pass
  *   SQ_LONG=0, SQ_NO_SEGMENTS   long reads: k_seg instead of k_span<LONG>; stripes of k_pass instead of segments
- *   SQ_DEDUP_SEQUENTIAL DedupEstimator: every piece through the host's sequential loop */
+ *   SQ_DEDUP_SEQUENTIAL DedupEstimator: every piece through the host's sequential loop
+ *   SQ_OVERREP_CHAIN    OverrepresentedSequences: k_overrep instead of k_overrep_par */
 struct SqKnobs {
     bool span = true, span_split = true;
     int span_sorted = -1;
@@ -65,6 +66,7 @@ struct SqKnobs {
     int pt_fused = 1;          /* SQ_PT_FUSED: 1 (default since round 5: tests/test_gpu_pair.py is green on a GPU): PerTileQuality rides in QCMetrics' pass on batches of one read length (k_span<PT>, sq_pair.hip); 0: the passes of round 2 (k_tile_parse, k_span, k_ptspan); 2: tile ids from the pass, the table by k_ptspan */
     bool long_spans = true;
     bool dedup_sequential = false;
+    bool overrep_chain = false;   /* SQ_OVERREP_CHAIN: k_overrep (a lane's fragments one after the other: reads of more than 10 fragments, fragments of more than 24 bases) for every batch */
 };
 const SqKnobs &sq_knobs();
 

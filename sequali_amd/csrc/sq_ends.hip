@@ -195,6 +195,18 @@ __device__ void ovr_insert(const OvrParams &P, unsigned long long h, unsigned lo
                            unsigned long long &new_keys, unsigned int count = 1)
 {
     uint64_t i = h & P.table_mask;
+    if (P.mode == OVR_FULL) {   /* the table is closed (:3553): plain loads, see k_overrep_par */
+        const unsigned long long *keys = P.hashes;
+        for (;;) {
+            const unsigned long long cur = keys[i];
+            if (cur == 0) return;   /* new keys are dropped */
+            if (cur == h) {
+                if (((const unsigned int *)P.counts)[i] != 0) atomicAdd(&P.counts[i], count);   /* entries removed by the cap keep their key with a zero count */
+                return;
+            }
+            i = (i + 1) & P.table_mask;
+        }
+    }
     for (;;) {
         unsigned long long cur = __hip_atomic_load(&P.hashes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) {
@@ -298,6 +310,195 @@ __global__ void k_overrep(OvrParams P)
     if (threadIdx.x < OVR_CACHE && c_hash[threadIdx.x])
         ovr_insert(P, c_hash[threadIdx.x], c_rank[threadIdx.x], new_keys, c_count[threadIdx.x]);
     /* one atomic per wave, not per lane: they all go to the same address */
+    for (int off = 32; off > 0; off >>= 1) {
+        local_frags += __shfl_xor(local_frags, off);
+        new_keys += __shfl_xor(new_keys, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (local_frags) atomicAdd(P.total_fragments, local_frags);
+        if (new_keys) atomicAdd(P.n_unique, new_keys);
+    }
+}
+
+/* The same pass with a lane's memory requests IN FLIGHT TOGETHER (round 6).  k_overrep above is a chain of round trips
+ * per lane -- a fragment's three loads, its walk through a staging table that lives in scratch memory, its probe of the
+ * device table, then the next fragment -- and the counters say so (profiles/r6/pmc_k_overrep.txt: the waves wait three
+ * quarters of their time with 1.3 vector-memory instructions in flight per SIMD).  Here a lane asks for the bytes of
+ * ALL its fragments at once (up to OVR_PAR_F of up to 24 bases: the defaults are 10 of 21), makes their hashes in
+ * registers, drops a fragment that a fragment in front of it repeats (add_to_staging counts it once, :3588-3608), and
+ * -- when the table is closed, the state a run is in from its first few million reads on -- asks for the table slots
+ * of all of them at once as well.  The staging table itself is only re-enacted (an occupancy mask) where the SLOT
+ * order decides a rank (:3925-3930: the batch that crosses the cap, shards).  Everything else is k_overrep. */
+constexpr int OVR_PAR_F = 10;
+__device__ __forceinline__ long long kmer_of_words(unsigned long long w0, unsigned long long w1, unsigned long long w2, uint32_t k)
+{
+    uint64_t kmer = 0;
+    bool has_n = false, has_other = false;
+    const unsigned long long w[3] = {w0, w1, w2};
+#pragma unroll
+    for (uint32_t i = 0; i < 24; i++) {
+        if (i < k) {
+            const unsigned c = (unsigned)(w[i / 8] >> (8 * (i % 8))) & 0xFFu, cls = sq_base_class(c);
+            if (cls == 4) {
+                if ((c | 0x20u) == 'n') has_n = true; else has_other = true;
+            }
+            kmer = (kmer << 2) | (cls & 3);
+        }
+    }
+    if (has_other) return -1;
+    if (has_n) return -2;
+    uint64_t x = ~kmer;   /* reverse_complement_kmer :3634-3655 */
+    x = (x << 32) | (x >> 32);
+    x = ((x & 0xFFFF0000FFFF0000ULL) >> 16) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    x = ((x & 0xFF00FF00FF00FF00ULL) >> 8) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x & 0xF0F0F0F0F0F0F0F0ULL) >> 4) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x & 0xCCCCCCCCCCCCCCCCULL) >> 2) | ((x & 0x3333333333333333ULL) << 2);
+    const uint64_t rc = x >> (64 - 2 * k);
+    return (long long)(rc > kmer ? kmer : rc);
+}
+
+__global__ void __launch_bounds__(256) k_overrep_par(OvrParams P)
+{
+    __shared__ unsigned long long c_hash[OVR_CACHE], c_rank[OVR_CACHE];
+    __shared__ unsigned int c_count[OVR_CACHE];
+    for (uint32_t i = threadIdx.x; i < OVR_CACHE; i += blockDim.x) { c_hash[i] = 0; c_rank[i] = ~0ULL; c_count[i] = 0; }
+    __syncthreads();
+    unsigned long long local_frags = 0, new_keys = 0;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < P.n_samples;
+         s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = P.first_sample + (P.sample_base + s) * P.sample_every;
+        const sq_meta m = P.metas[r];
+        const long long L = m.sequence_length, k = P.k;
+        if (L < k) continue; /* still counted as sampled (:3837-3844) */
+        const uint8_t *seq = P.buf + m.record_start + m.sequence_offset, *buf_end = P.buf + P.buf_len;
+        const long long max_frag = (L + k - 1) / k, from_mid = max_frag / 2;
+        long long n_start = max_frag - from_mid, n_end = from_mid;
+        if (P.frags_start < n_start) n_start = P.frags_start;
+        if (P.frags_end < n_end) n_end = P.frags_end;
+        const int total = (int)(n_start + n_end);   /* <= OVR_PAR_F: the host sends other batches to k_overrep */
+        if (total == 0) continue;
+        uint32_t size = 1;   /* staging table of 2^ceil(log2(1.5 total)) slots (:3884) */
+        while (2 * size < 3 * (uint32_t)total) size <<= 1;
+        /* (1) every fragment's bytes */
+        unsigned long long w[OVR_PAR_F][3];
+#pragma unroll
+        for (int f = 0; f < OVR_PAR_F; f++) {
+            w[f][0] = w[f][1] = w[f][2] = 0;
+            if (f < total) {
+                const long long at = f < n_start ? f * k : L - n_end * k + (f - n_start) * k;
+                const uint8_t *p = seq + at;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (8 * j >= k) break;
+                    if (p + 8 * j + 8 <= buf_end) w[f][j] = sq_load_u64_unaligned(p + 8 * j);
+                    else for (int b = 0; b < 8 && p + 8 * j + b < buf_end; b++) w[f][j] |= (unsigned long long)p[8 * j + b] << (8 * b);
+                }
+            }
+        }
+        /* (2) their hashes; a fragment repeated inside the read is staged once */
+        unsigned long long h[OVR_PAR_F];
+        uint32_t keep = 0;   /* bit f: fragment f goes to the table */
+        bool warn = false;
+        unsigned long long valid = 0;
+#pragma unroll
+        for (int f = 0; f < OVR_PAR_F; f++) {
+            h[f] = 0;
+            if (f < total) {
+                const long long km = kmer_of_words(w[f][0], w[f][1], w[f][2], (uint32_t)k);
+                if (km == -1) warn = true;
+                if (km >= 0) {
+                    valid++;
+                    h[f] = wanghash64((uint64_t)km);   /* 0: indistinguishable from an empty slot (:3597) */
+                    bool dup = h[f] == 0;
+#pragma unroll
+                    for (int g = 0; g < f; g++) dup |= h[g] == h[f];
+                    if (!dup) keep |= 1u << f;
+                }
+            }
+        }
+        local_frags += valid;
+        if (warn) {
+            atomicAdd(P.warn_count, 1ULL);
+            atomicMax(P.warn_last, (long long)(P.record_base + r));
+        }
+        /* (3) where ranks matter: the staging slot of every kept fragment, in fragment order (add_to_staging's probing) */
+        uint32_t slot_of[OVR_PAR_F];
+#pragma unroll
+        for (int f = 0; f < OVR_PAR_F; f++) slot_of[f] = 0;
+        if (P.mode >= OVR_CROSSING) {
+            unsigned long long occ = 0;
+#pragma unroll
+            for (int f = 0; f < OVR_PAR_F; f++) {
+                if (!((keep >> f) & 1u)) continue;
+                const uint32_t pos = (uint32_t)h[f] & (size - 1);
+                const unsigned long long both = occ | (occ << size);
+                const uint32_t z = (uint32_t)__ffsll((long long)~(both >> pos)) - 1u;
+                slot_of[f] = (pos + z) & (size - 1);
+                occ |= 1ull << slot_of[f];
+            }
+        }
+        /* (4) the workgroup's entries for fragments that come again and again; what they do not take goes to the table.
+           (Not while the table is closed: there the entries are kept for what is FOUND, below.) */
+        uint32_t dev = P.mode == OVR_FULL ? keep : 0;   /* bit f: fragment f is for the device table */
+#pragma unroll
+        for (int f = 0; f < OVR_PAR_F; f++) {
+            if (P.mode == OVR_FULL || !((keep >> f) & 1u)) continue;
+            const unsigned long long rank = ((P.rank_base + s) << 24) | slot_of[f];
+            const uint32_t e = (uint32_t)(h[f] >> 24) & (OVR_CACHE - 1);
+            const unsigned long long cur = atomicCAS(&c_hash[e], 0ULL, h[f]);
+            if (cur == 0 || cur == h[f]) {
+                atomicAdd(&c_count[e], 1u);
+                atomicMin(&c_rank[e], rank);
+            } else {
+                dev |= 1u << f;
+            }
+        }
+        if (P.mode == OVR_FULL) {
+            /* The table is closed (:3553): look-ups only -- the first slot of every fragment asked for at once.  PLAIN loads:
+               nobody writes a key any more, and a count is zero (an entry the cap removed) or not for the whole launch, so
+               the XCD's L2 may answer.  The agent-scope loads ovr_insert needs beside concurrent inserts go past it to
+               memory, one transaction per probe: 24 of this pass's 27 ms per 100 M reads (profiles/r6/exp_overrep.txt) */
+            const unsigned long long *keys = P.hashes;
+            const unsigned int *cnts = P.counts;
+            unsigned long long cur[OVR_PAR_F];
+#pragma unroll
+            for (int f = 0; f < OVR_PAR_F; f++) {
+                cur[f] = 0;
+                if ((dev >> f) & 1u) cur[f] = keys[h[f] & P.table_mask];
+            }
+#pragma unroll
+            for (int f = 0; f < OVR_PAR_F; f++) {
+                if (!((dev >> f) & 1u)) continue;
+                uint64_t i = h[f] & P.table_mask;
+                unsigned long long c = cur[f];
+                while (c != 0 && c != h[f]) {
+                    i = (i + 1) & P.table_mask;
+                    c = keys[i];
+                }
+                /* entries removed by the cap keep their key with a zero count */
+                if (c == h[f] && cnts[i] != 0) {
+                    /* Found: one of the few fragments that come again and again (a poly-G tail, an adapter: a million
+                       arrivals of ONE table slot per 100 M reads).  An atomic add per arrival, all CUs on one address, was
+                       most of this pass's time (profiles/r6/exp_overrep.txt); the workgroup counts them in LDS -- the
+                       entries it keeps for the first hashes it meets while the table is open are, while it is closed,
+                       keyed by the table slot of what was found (ordinary fragments are not in the table and take none) */
+                    const uint32_t e = (uint32_t)(i * 0x9E3779B1u >> 20) & (OVR_CACHE - 1);
+                    const unsigned long long key = i + 1, was = atomicCAS(&c_hash[e], 0ULL, key);
+                    if (was == 0 || was == key) atomicAdd(&c_count[e], 1u);
+                    else atomicAdd(&P.counts[i], 1u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < OVR_PAR_F; f++)
+                if ((dev >> f) & 1u) ovr_insert(P, h[f], ((P.rank_base + s) << 24) | slot_of[f], new_keys);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < OVR_CACHE && c_hash[threadIdx.x]) {
+        if (P.mode == OVR_FULL) atomicAdd(&P.counts[c_hash[threadIdx.x] - 1], c_count[threadIdx.x]);   /* keyed by table slot + 1 */
+        else ovr_insert(P, c_hash[threadIdx.x], c_rank[threadIdx.x], new_keys, c_count[threadIdx.x]);
+    }
     for (int off = 32; off > 0; off >>= 1) {
         local_frags += __shfl_xor(local_frags, off);
         new_keys += __shfl_xor(new_keys, off);
@@ -1394,7 +1595,10 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         /* a workgroup counts hot fragments in LDS first: fewer, longer-lived ones.  Twice the workgroups that fit at a time:
            the pass is a chain of memory round trips per lane, and the second half fills the tail the first leaves
            (20.2 -> 17.7 ms per 100 M reads; profiles/r6/exp_overrep.txt) */
-        hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, P);
+        if (per_read <= (uint64_t)OVR_PAR_F && k <= 24 && !sq_knobs().overrep_chain)   /* every load of a lane in flight at once */
+            hipLaunchKernelGGL(k_overrep_par, dim3(blocks_for(chunk, ctx->num_cus * (mode == OVR_FULL ? 4 : 16))), dim3(256), 0, ctx->stream, P);   /* closed table: as many workgroups as fit at a time -- each brings every hot slot to the table once */
+        else
+            hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, P);
         SQ_HIP(hipGetLastError());
         if (need_big) {
             SQ_HIP(hipStreamSynchronize(ctx->stream));

@@ -184,8 +184,11 @@ def test_pertile_reads_ordered_by_tile_are_walked_as_stored():
         np.testing.assert_array_equal(u64(gq.base_count_table()), rq.base_count_table())
 
 
-def test_overrep_vs_oracle_with_cap_crossing():
-    """the cap is crossed inside a batch (the first 700 distinct fragments in sampled-read, staging-SLOT order stay)"""
+@pytest.mark.parametrize("env", [{}, {"SQ_OVERREP_CHAIN": "1"}], ids=["k_overrep_par", "k_overrep"])
+def test_overrep_vs_oracle_with_cap_crossing(env):
+    """the cap is crossed inside a batch (the first 700 distinct fragments in sampled-read, staging-SLOT order stay):
+    through k_overrep_par (a lane's loads in flight together, the staging slots re-enacted in registers) and through
+    k_overrep (a lane's fragments one after the other, the staging table itself)"""
     from sequali_amd import OverrepresentedSequences
     rng = np.random.default_rng(41)
     kw = dict(max_unique_fragments=700, sample_every=3, fragment_length=21)
@@ -199,7 +202,7 @@ def test_overrep_vs_oracle_with_cap_crossing():
                 ref.add(buf, metas)
                 got.add_record_array(arr)
                 got.flush()
-    run()
+    _with_env(env, run)
     assert got.collected_unique_fragments == ref.collected_unique_fragments == 700
     assert got.total_fragments == ref.total_fragments
     assert got.sampled_sequences == ref.sampled_sequences
