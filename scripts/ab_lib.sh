@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of experiment builds (scripts/build_exp.sh): the headline's launch time, three rounds.  usage: scripts/ab_lib.sh NAME [NAME ...]
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 if [ -n "$TESTS" ]; then for n in "$@"; do SQ_LIB=$PWD/scripts/build/libsqgpu_$n.so timeout 600 python -m pytest $TESTS -q -x -m gpu -p no:cacheprovider 2>&1 | tail -3 | sed "s/^/$n: /"; done; fi
 for i in 1 2 3; do
   for n in "$@"; do

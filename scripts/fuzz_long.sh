@@ -1,6 +1,6 @@
 #!/bin/bash
 # a long randomised differential run on one box: scripts/fuzz.py over several seeds, one line per seed
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 OUT=gpurun_out/fuzz
 mkdir -p $OUT
 : > $OUT/summary.txt
