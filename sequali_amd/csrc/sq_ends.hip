@@ -188,6 +188,7 @@ struct OvrParams {
     long long *warn_last;
     unsigned long long *big_staging; /* [n_samples][big_size] for reads with > 21 fragments */
     uint64_t big_size;
+    const uint32_t *occupied;        /* closed table: bit s = slot s holds a key (k_ovr_occupied); NULL: ask the table */
 };
 
 /* Sequence_duplication_insert_hash, _qcmodule.c:3542-3568, concurrent form */
@@ -320,33 +321,59 @@ __global__ void k_overrep(OvrParams P)
     }
 }
 
-/* The same pass with a lane's memory requests IN FLIGHT TOGETHER (round 6).  k_overrep above is a chain of round trips
- * per lane -- a fragment's three loads, its walk through a staging table that lives in scratch memory, its probe of the
- * device table, then the next fragment -- and the counters say so (profiles/r6/pmc_k_overrep.txt: the waves wait three
- * quarters of their time with 1.3 vector-memory instructions in flight per SIMD).  Here a lane asks for the bytes of
- * ALL its fragments at once (up to OVR_PAR_F of up to 24 bases: the defaults are 10 of 21), makes their hashes in
- * registers, drops a fragment that a fragment in front of it repeats (add_to_staging counts it once, :3588-3608), and
- * -- when the table is closed, the state a run is in from its first few million reads on -- asks for the table slots
- * of all of them at once as well.  The staging table itself is only re-enacted (an occupancy mask) where the SLOT
- * order decides a rank (:3925-3930: the batch that crosses the cap, shards).  Everything else is k_overrep. */
+/* The pass over a CLOSED table -- the state a run is in from its first few million reads on (:3553: new keys are dropped,
+ * what is found is counted) -- with a lane's memory requests IN FLIGHT TOGETHER (round 6).  k_overrep above is a chain of
+ * round trips per lane: a fragment's three loads, its walk through a staging table that lives in scratch memory, its probe of
+ * the device table, then the next fragment (profiles/r6/pmc_k_overrep.txt: the waves wait three quarters of their time with
+ * 1.3 vector-memory instructions in flight per SIMD).  Here a lane asks for the bytes of ALL its fragments at once (up to
+ * OVR_PAR_F of up to 24 bases: the defaults are 10 of 21), makes their hashes in registers, drops a fragment that a fragment
+ * in front of it repeats (add_to_staging counts it once, :3588-3608; the staging table's slot ORDER only decides ranks, and a
+ * closed table has none to give), asks a bitmap of the table's occupied slots (2 MB, L2-resident: seven probes in ten end
+ * there) and walks the probe runs of what is left together, a slot of every fragment per round.  What is found -- the few
+ * fragments that come again and again: a poly-G tail, an adapter, a million arrivals of ONE table slot per 100 M reads -- is
+ * counted per workgroup in LDS, by table slot, and reaches the table once per workgroup.
+ * Kept SMALL on purpose: the first version also carried the open table's modes and was 96 KB of code, more than the
+ * instruction cache two CUs share holds -- every change to it measured the same 2.8 ms per 25 M reads
+ * (profiles/r6/exp_overrep.txt). */
 constexpr int OVR_PAR_F = 10;
-__device__ __forceinline__ long long kmer_of_words(unsigned long long w0, unsigned long long w1, unsigned long long w2, uint32_t k)
+/* 8 bases -> 16 bits (A 0 C 1 G 2 T 3, either case; the first base most significant): (c >> 1) & 3 gives A 0 C 1 G 3 T 2, the
+   exclusive or with its own upper bit puts G and T right; three folds bring the eight fields together */
+__device__ __forceinline__ uint32_t ovr_pack8(unsigned long long w)
 {
-    uint64_t kmer = 0;
-    bool has_n = false, has_other = false;
+    unsigned long long t = (w >> 1) & 0x0303030303030303ULL;
+    t = (t ^ (t >> 1)) & 0x0303030303030303ULL;
+    t = ((t << 2) | (t >> 8)) & 0x000F000F000F000FULL;
+    t = ((t << 4) | (t >> 16)) & 0x000000FF000000FFULL;
+    return (uint32_t)(((t << 8) | (t >> 32)) & 0xFFFFULL);
+}
+/* bit 7 of every byte of x that is not zero */
+__device__ __forceinline__ unsigned long long ovr_nonzero_bytes(unsigned long long x)
+{
+    return (((x & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | x) & 0x8080808080808080ULL;
+}
+/* sequence_to_canonical_kmer (:3657-3694) for k <= 24 bases lying in three words: >= 0 the k-mer, -1 a byte outside ACGTN, -2 an N */
+__device__ __forceinline__ long long ovr_kmer_of_words(unsigned long long w0, unsigned long long w1, unsigned long long w2, uint32_t k)
+{
     const unsigned long long w[3] = {w0, w1, w2};
+    unsigned long long not_acgt = 0, is_n = 0;   /* bit 7 of byte j, word i: base 8 i + j of the fragment is none of A C G T / is an N */
+    uint64_t kmer = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 24; i++) {
-        if (i < k) {
-            const unsigned c = (unsigned)(w[i / 8] >> (8 * (i % 8))) & 0xFFu, cls = sq_base_class(c);
-            if (cls == 4) {
-                if ((c | 0x20u) == 'n') has_n = true; else has_other = true;
-            }
-            kmer = (kmer << 2) | (cls & 3);
-        }
+    for (int i = 0; i < 3; i++) {
+        const unsigned long long u = w[i] & 0xDFDFDFDFDFDFDFDFULL;
+        /* the letter a base's two bits stand for, beside the base itself: equal for A C G T in either case, else not */
+        unsigned long long t = (w[i] >> 1) & 0x0303030303030303ULL;
+        t = (t ^ (t >> 1)) & 0x0303030303030303ULL;
+        const uint32_t lo = __builtin_amdgcn_perm(0u, 0x54474341u, (uint32_t)t), hi = __builtin_amdgcn_perm(0u, 0x54474341u, (uint32_t)(t >> 32));
+        const unsigned long long letters = ((unsigned long long)hi << 32) | lo;
+        const int nb = (int)k - 8 * i;   /* bases of this word that belong to the fragment: its first min(8, nb) bytes */
+        const unsigned long long in = nb >= 8 ? ~0ULL : nb <= 0 ? 0ULL : ((1ULL << (8 * nb)) - 1);
+        not_acgt |= ovr_nonzero_bytes(u ^ letters) & in;
+        is_n |= ~ovr_nonzero_bytes(u ^ 0x4E4E4E4E4E4E4E4EULL) & 0x8080808080808080ULL & in;
+        kmer = (kmer << 16) | ovr_pack8(w[i]);
     }
-    if (has_other) return -1;
-    if (has_n) return -2;
+    if (not_acgt & ~is_n) return -1;
+    if (is_n) return -2;
+    kmer >>= 2 * (24 - k);
     uint64_t x = ~kmer;   /* reverse_complement_kmer :3634-3655 */
     x = (x << 32) | (x >> 32);
     x = ((x & 0xFFFF0000FFFF0000ULL) >> 16) | ((x & 0x0000FFFF0000FFFFULL) << 16);
@@ -359,52 +386,53 @@ __device__ __forceinline__ long long kmer_of_words(unsigned long long w0, unsign
 
 __global__ void __launch_bounds__(256) k_overrep_par(OvrParams P)
 {
-    __shared__ unsigned long long c_hash[OVR_CACHE], c_rank[OVR_CACHE];
+    __shared__ unsigned long long c_slot[OVR_CACHE];   /* table slot + 1 of what the entry counts (0: free) */
     __shared__ unsigned int c_count[OVR_CACHE];
-    for (uint32_t i = threadIdx.x; i < OVR_CACHE; i += blockDim.x) { c_hash[i] = 0; c_rank[i] = ~0ULL; c_count[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < OVR_CACHE; i += blockDim.x) { c_slot[i] = 0; c_count[i] = 0; }
     __syncthreads();
-    unsigned long long local_frags = 0, new_keys = 0;
+    unsigned long long local_frags = 0;
+    const unsigned long long *keys = P.hashes;
+    const unsigned int *cnts = P.counts;
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < P.n_samples;
          s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = P.first_sample + (P.sample_base + s) * P.sample_every;
         const sq_meta m = P.metas[r];
         const long long L = m.sequence_length, k = P.k;
         if (L < k) continue; /* still counted as sampled (:3837-3844) */
-        const uint8_t *seq = P.buf + m.record_start + m.sequence_offset, *buf_end = P.buf + P.buf_len;
+        const uint8_t *seq = P.buf + m.record_start + m.sequence_offset, *last8 = P.buf + P.buf_len - 8;
         const long long max_frag = (L + k - 1) / k, from_mid = max_frag / 2;
         long long n_start = max_frag - from_mid, n_end = from_mid;
         if (P.frags_start < n_start) n_start = P.frags_start;
         if (P.frags_end < n_end) n_end = P.frags_end;
         const int total = (int)(n_start + n_end);   /* <= OVR_PAR_F: the host sends other batches to k_overrep */
         if (total == 0) continue;
-        uint32_t size = 1;   /* staging table of 2^ceil(log2(1.5 total)) slots (:3884) */
-        while (2 * size < 3 * (uint32_t)total) size <<= 1;
-        /* (1) every fragment's bytes */
+        /* (1) every fragment's bytes: three words each (a word that would reach behind the buffer is taken from its last
+           eight bytes and shifted: what lies behind a fragment's k bases is never looked at) */
         unsigned long long w[OVR_PAR_F][3];
 #pragma unroll
         for (int f = 0; f < OVR_PAR_F; f++) {
             w[f][0] = w[f][1] = w[f][2] = 0;
             if (f < total) {
                 const long long at = f < n_start ? f * k : L - n_end * k + (f - n_start) * k;
-                const uint8_t *p = seq + at;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
+                    const uint8_t *p = seq + at + 8 * j;
                     if (8 * j >= k) break;
-                    if (p + 8 * j + 8 <= buf_end) w[f][j] = sq_load_u64_unaligned(p + 8 * j);
-                    else for (int b = 0; b < 8 && p + 8 * j + b < buf_end; b++) w[f][j] |= (unsigned long long)p[8 * j + b] << (8 * b);
+                    if (p <= last8) w[f][j] = sq_load_u64_unaligned(p);
+                    else if (p < last8 + 8) w[f][j] = sq_load_u64_unaligned(last8) >> (8 * (p - last8));
                 }
             }
         }
-        /* (2) their hashes; a fragment repeated inside the read is staged once */
+        /* (2) their hashes; a fragment repeated inside the read is counted once */
         unsigned long long h[OVR_PAR_F];
-        uint32_t keep = 0;   /* bit f: fragment f goes to the table */
+        uint32_t dev = 0;   /* bit f: fragment f asks the table */
         bool warn = false;
         unsigned long long valid = 0;
 #pragma unroll
         for (int f = 0; f < OVR_PAR_F; f++) {
             h[f] = 0;
             if (f < total) {
-                const long long km = kmer_of_words(w[f][0], w[f][1], w[f][2], (uint32_t)k);
+                const long long km = ovr_kmer_of_words(w[f][0], w[f][1], w[f][2], (uint32_t)k);
                 if (km == -1) warn = true;
                 if (km >= 0) {
                     valid++;
@@ -412,7 +440,7 @@ __global__ void __launch_bounds__(256) k_overrep_par(OvrParams P)
                     bool dup = h[f] == 0;
 #pragma unroll
                     for (int g = 0; g < f; g++) dup |= h[g] == h[f];
-                    if (!dup) keep |= 1u << f;
+                    if (!dup) dev |= 1u << f;
                 }
             }
         }
@@ -421,91 +449,59 @@ __global__ void __launch_bounds__(256) k_overrep_par(OvrParams P)
             atomicAdd(P.warn_count, 1ULL);
             atomicMax(P.warn_last, (long long)(P.record_base + r));
         }
-        /* (3) where ranks matter: the staging slot of every kept fragment, in fragment order (add_to_staging's probing) */
-        uint32_t slot_of[OVR_PAR_F];
-#pragma unroll
-        for (int f = 0; f < OVR_PAR_F; f++) slot_of[f] = 0;
-        if (P.mode >= OVR_CROSSING) {
-            unsigned long long occ = 0;
+        /* (3) the bitmap of occupied slots: PLAIN loads here and below -- nobody writes a key any more, and a count is zero
+           (an entry the cap removed) or not for the whole launch, so the XCD's L2 may answer */
+        {
+            uint32_t occ[OVR_PAR_F];
 #pragma unroll
             for (int f = 0; f < OVR_PAR_F; f++) {
-                if (!((keep >> f) & 1u)) continue;
-                const uint32_t pos = (uint32_t)h[f] & (size - 1);
-                const unsigned long long both = occ | (occ << size);
-                const uint32_t z = (uint32_t)__ffsll((long long)~(both >> pos)) - 1u;
-                slot_of[f] = (pos + z) & (size - 1);
-                occ |= 1ull << slot_of[f];
+                occ[f] = 0;
+                if ((dev >> f) & 1u) occ[f] = P.occupied[(h[f] & P.table_mask) >> 5];
             }
-        }
-        /* (4) the workgroup's entries for fragments that come again and again; what they do not take goes to the table.
-           (Not while the table is closed: there the entries are kept for what is FOUND, below.) */
-        uint32_t dev = P.mode == OVR_FULL ? keep : 0;   /* bit f: fragment f is for the device table */
 #pragma unroll
-        for (int f = 0; f < OVR_PAR_F; f++) {
-            if (P.mode == OVR_FULL || !((keep >> f) & 1u)) continue;
-            const unsigned long long rank = ((P.rank_base + s) << 24) | slot_of[f];
-            const uint32_t e = (uint32_t)(h[f] >> 24) & (OVR_CACHE - 1);
-            const unsigned long long cur = atomicCAS(&c_hash[e], 0ULL, h[f]);
-            if (cur == 0 || cur == h[f]) {
-                atomicAdd(&c_count[e], 1u);
-                atomicMin(&c_rank[e], rank);
-            } else {
-                dev |= 1u << f;
-            }
+            for (int f = 0; f < OVR_PAR_F; f++)
+                if (((dev >> f) & 1u) && !((occ[f] >> (h[f] & 31u)) & 1u)) dev &= ~(1u << f);
         }
-        if (P.mode == OVR_FULL) {
-            /* The table is closed (:3553): look-ups only -- the first slot of every fragment asked for at once.  PLAIN loads:
-               nobody writes a key any more, and a count is zero (an entry the cap removed) or not for the whole launch, so
-               the XCD's L2 may answer.  The agent-scope loads ovr_insert needs beside concurrent inserts go past it to
-               memory, one transaction per probe: 24 of this pass's 27 ms per 100 M reads (profiles/r6/exp_overrep.txt) */
-            const unsigned long long *keys = P.hashes;
-            const unsigned int *cnts = P.counts;
+        /* (4) the probe runs, together */
+        uint64_t at[OVR_PAR_F];
+#pragma unroll
+        for (int f = 0; f < OVR_PAR_F; f++) at[f] = h[f] & P.table_mask;
+        while (dev) {
             unsigned long long cur[OVR_PAR_F];
 #pragma unroll
             for (int f = 0; f < OVR_PAR_F; f++) {
                 cur[f] = 0;
-                if ((dev >> f) & 1u) cur[f] = keys[h[f] & P.table_mask];
+                if ((dev >> f) & 1u) cur[f] = keys[at[f]];
             }
 #pragma unroll
             for (int f = 0; f < OVR_PAR_F; f++) {
                 if (!((dev >> f) & 1u)) continue;
-                uint64_t i = h[f] & P.table_mask;
-                unsigned long long c = cur[f];
-                while (c != 0 && c != h[f]) {
-                    i = (i + 1) & P.table_mask;
-                    c = keys[i];
-                }
-                /* entries removed by the cap keep their key with a zero count */
-                if (c == h[f] && cnts[i] != 0) {
-                    /* Found: one of the few fragments that come again and again (a poly-G tail, an adapter: a million
-                       arrivals of ONE table slot per 100 M reads).  An atomic add per arrival, all CUs on one address, was
-                       most of this pass's time (profiles/r6/exp_overrep.txt); the workgroup counts them in LDS -- the
-                       entries it keeps for the first hashes it meets while the table is open are, while it is closed,
-                       keyed by the table slot of what was found (ordinary fragments are not in the table and take none) */
+                if (cur[f] != 0 && cur[f] != h[f]) { at[f] = (at[f] + 1) & P.table_mask; continue; }   /* somebody else's: on to the next slot */
+                dev &= ~(1u << f);
+                const uint64_t i = at[f];
+                if (cur[f] == h[f] && cnts[i] != 0) {   /* (entries removed by the cap keep their key with a zero count) */
                     const uint32_t e = (uint32_t)(i * 0x9E3779B1u >> 20) & (OVR_CACHE - 1);
-                    const unsigned long long key = i + 1, was = atomicCAS(&c_hash[e], 0ULL, key);
+                    const unsigned long long key = i + 1, was = atomicCAS(&c_slot[e], 0ULL, key);
                     if (was == 0 || was == key) atomicAdd(&c_count[e], 1u);
                     else atomicAdd(&P.counts[i], 1u);
                 }
             }
-        } else {
-#pragma unroll
-            for (int f = 0; f < OVR_PAR_F; f++)
-                if ((dev >> f) & 1u) ovr_insert(P, h[f], ((P.rank_base + s) << 24) | slot_of[f], new_keys);
         }
     }
     __syncthreads();
-    if (threadIdx.x < OVR_CACHE && c_hash[threadIdx.x]) {
-        if (P.mode == OVR_FULL) atomicAdd(&P.counts[c_hash[threadIdx.x] - 1], c_count[threadIdx.x]);   /* keyed by table slot + 1 */
-        else ovr_insert(P, c_hash[threadIdx.x], c_rank[threadIdx.x], new_keys, c_count[threadIdx.x]);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        local_frags += __shfl_xor(local_frags, off);
-        new_keys += __shfl_xor(new_keys, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (local_frags) atomicAdd(P.total_fragments, local_frags);
-        if (new_keys) atomicAdd(P.n_unique, new_keys);
+    if (threadIdx.x < OVR_CACHE && c_slot[threadIdx.x]) atomicAdd(&P.counts[c_slot[threadIdx.x] - 1], c_count[threadIdx.x]);
+    for (int off = 32; off > 0; off >>= 1) local_frags += __shfl_xor(local_frags, off);
+    if ((threadIdx.x & 63) == 0 && local_frags) atomicAdd(P.total_fragments, local_frags);
+}
+
+/* the closed table's occupied slots as bits (2 MB for the default table's 128 MB of keys: it stays in an XCD's L2) */
+__global__ void k_ovr_occupied(const unsigned long long *hashes, uint64_t table_size, uint32_t *bits)
+{
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < table_size / 32; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t m = 0;
+#pragma unroll 8
+        for (uint32_t b = 0; b < 32; b++) m |= (hashes[32 * w + b] != 0 ? 1u : 0u) << b;
+        bits[w] = m;
     }
 }
 
@@ -1435,6 +1431,8 @@ struct sq_overrep {
     uint64_t number_of_sequences = 0, sampled_sequences = 0;
     uint64_t table_size = 0;
     bool full = false;
+    uint32_t *d_occupied = nullptr;   /* the closed table's occupied slots as bits; made at the first launch on the closed table */
+    bool occupied_valid = false;
     unsigned long long *d_hashes = nullptr, *d_ranks = nullptr;
     unsigned int *d_counts = nullptr;
     unsigned long long *d_scalars = nullptr; /* [0] n_unique [1] total_fragments [2] warn_count [3] warn_last */
@@ -1491,7 +1489,7 @@ SQ_EXPORT void sq_overrep_free(sq_overrep *o)
 {
     if (!o) return;
     (void)hipStreamSynchronize(o->ctx->stream);
-    for (void *p : {(void *)o->d_hashes, (void *)o->d_counts, (void *)o->d_ranks, (void *)o->d_scalars})
+    for (void *p : {(void *)o->d_hashes, (void *)o->d_counts, (void *)o->d_ranks, (void *)o->d_scalars, (void *)o->d_occupied})
         if (p) (void)hipFree(p);
     delete o;
 }
@@ -1568,6 +1566,12 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
             P.hashes = o->d_hashes; P.counts = o->d_counts; P.table_mask = o->table_size - 1;
         } else if (o->full) {
             mode = OVR_FULL;
+            if (!o->occupied_valid && o->table_size >= 32) {   /* the keys do not change any more */
+                if (!o->d_occupied) SQ_HIP(hipMalloc((void **)&o->d_occupied, o->table_size / 8));
+                hipLaunchKernelGGL(k_ovr_occupied, dim3(blocks_for(o->table_size / 32)), dim3(256), 0, ctx->stream, o->d_hashes, o->table_size, o->d_occupied);
+                o->occupied_valid = true;
+            }
+            P.occupied = o->occupied_valid ? o->d_occupied : nullptr;
         } else {
             /* keys this launch can add at most; keep the open-addressing table under ~80 % */
             const uint64_t room_cap = o->max_unique - o->n_unique_host;
@@ -1595,8 +1599,8 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         /* a workgroup counts hot fragments in LDS first: fewer, longer-lived ones.  Twice the workgroups that fit at a time:
            the pass is a chain of memory round trips per lane, and the second half fills the tail the first leaves
            (20.2 -> 17.7 ms per 100 M reads; profiles/r6/exp_overrep.txt) */
-        if (per_read <= (uint64_t)OVR_PAR_F && k <= 24 && !sq_knobs().overrep_chain)   /* every load of a lane in flight at once */
-            hipLaunchKernelGGL(k_overrep_par, dim3(blocks_for(chunk, ctx->num_cus * (mode == OVR_FULL ? 4 : 16))), dim3(256), 0, ctx->stream, P);   /* closed table: as many workgroups as fit at a time -- each brings every hot slot to the table once */
+        if (mode == OVR_FULL && P.occupied && per_read <= (uint64_t)OVR_PAR_F && k <= 24 && !sq_knobs().overrep_chain)   /* the closed table: every load of a lane in flight at once */
+            hipLaunchKernelGGL(k_overrep_par, dim3(blocks_for(chunk, ctx->num_cus * 8)), dim3(256), 0, ctx->stream, P);
         else
             hipLaunchKernelGGL(k_overrep, dim3(blocks_for(chunk, ctx->num_cus * 16)), dim3(256), 0, ctx->stream, P);
         SQ_HIP(hipGetLastError());
@@ -1781,6 +1785,8 @@ SQ_EXPORT int sq_overrep_shard_install(sq_overrep *o, const uint64_t *d_hashes, 
     o->sampled_sequences = totals[1];
     o->n_unique_host = n;
     o->full = n >= o->max_unique;
+    o->occupied_valid = false;
+    if (o->d_occupied) { (void)hipFree(o->d_occupied); o->d_occupied = nullptr; }   /* (the table may have another size now) */
     o->shard = false;
     o->first_record = 0;
     return SQ_OK;
