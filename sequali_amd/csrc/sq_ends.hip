@@ -541,6 +541,24 @@ __global__ void k_ovr_kill(unsigned int *counts, const unsigned long long *slots
  * the first max_unique distinct hashes of the job in that order with all their
  * occurrences counted, so the merge is: candidates = every shard's first max_unique
  * keys -> first max_unique distinct of the union -> per-shard counts of those -> sum. */
+/* The table closes: the keys the cap removed (count 0) leave it.  They kept their slots while the batch that crossed the cap
+ * was being sorted out (a key with a zero count is "seen, not counted"), and the table had been filled up to four fifths for
+ * that batch: every probe of the closed table then walked runs of a dozen dead keys (profiles/r6/pmc_k_overrep_compact.txt:
+ * 492 vector-memory reads per wave and iteration where ten fragments need ten).  A fragment that meets a dead key and one
+ * that meets an empty slot are treated alike (:3553: not in the table, dropped), so the live keys alone, hashed into a fresh
+ * table -- three tenths full with the default cap -- give the same counts. */
+__global__ void k_ovr_compact(const unsigned long long *oh, const unsigned int *oc, uint64_t size, unsigned long long *nh, unsigned int *nc)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long h = oh[i];
+        const unsigned int c = oc[i];
+        if (!h || !c) continue;
+        uint64_t j = h & (size - 1);
+        while (atomicCAS(&nh[j], 0ULL, h) != 0ULL) j = (j + 1) & (size - 1); /* keys are distinct */
+        nc[j] = c;
+    }
+}
+
 __global__ void k_ovr_rehash(const unsigned long long *oh, const unsigned int *oc, const unsigned long long *orank,
                              uint64_t old_size, unsigned long long *nh, unsigned int *nc,
                              unsigned long long *nrank, uint64_t new_mask)
@@ -1645,7 +1663,25 @@ SQ_EXPORT int sq_overrep_add_batch(sq_overrep *o, sq_batch *b)
         } else {
             o->n_unique_host = n_after;
         }
-        if (!o->shard && o->n_unique_host >= o->max_unique) o->full = true;
+        if (!o->shard && o->n_unique_host >= o->max_unique && !o->full) {
+            o->full = true;
+            if (mode == OVR_CROSSING) {   /* dead keys in the table: out with them (k_ovr_compact) */
+                unsigned long long *nh = nullptr;
+                unsigned int *nc = nullptr;
+                SQ_HIP(hipMalloc((void **)&nh, o->table_size * 8));
+                SQ_HIP(hipMalloc((void **)&nc, o->table_size * 4));
+                SQ_HIP(hipMemsetAsync(nh, 0, o->table_size * 8, ctx->stream));
+                SQ_HIP(hipMemsetAsync(nc, 0, o->table_size * 4, ctx->stream));
+                hipLaunchKernelGGL(k_ovr_compact, dim3(blocks_for(o->table_size)), dim3(256), 0, ctx->stream, o->d_hashes, o->d_counts,
+                                   o->table_size, nh, nc);
+                SQ_HIP(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(o->d_hashes); (void)hipFree(o->d_counts);
+                o->d_hashes = nh; o->d_counts = nc;
+                P.hashes = nh; P.counts = nc;
+                if (o->d_ranks) { (void)hipFree(o->d_ranks); o->d_ranks = nullptr; }
+                o->occupied_valid = false;
+            }
+        }
     }
     return SQ_OK;
 }
