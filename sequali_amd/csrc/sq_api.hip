@@ -31,7 +31,8 @@ static bool g_knobs_loaded = false;
 static void knobs_load()
 {
     SqKnobs k;
-    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    /* (defined but empty or "0" is OFF: `for v in "" 1; do SQ_X=$v ...` compared a kernel with itself twice in round 6) */
+    auto flag = [](const char *name) { const char *v = getenv(name); return v != nullptr && *v != 0 && strcmp(v, "0") != 0; };
     auto num = [](const char *name, int unset) { const char *v = getenv(name); return v ? atoi(v) : unset; };
     k.span = num("SQ_SPAN", 1) != 0;
     k.span_split = num("SQ_SPAN_SPLIT", 1) != 0;
