@@ -573,25 +573,31 @@ def other_configs(lib, ctx, steps, warmup, only=None):
                                    "insert_sizes_sum_ok": bool(int(np.array(o.insert_sizes(), np.uint64).sum()) == n * passes)})
         del r1, r2
     # ---- end to end from host memory (not HBM resident: host / PCIe bound, never `value`) ----
-    if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split"):
+    if wanted("e2e_host_fastq_default_buffer") or wanted("e2e_pinned_64MiB_device_split") or wanted("e2e_host_fastq_default_buffer_six_modules"):
         import io
         from sequali_amd import FastqParser, PinnedReader
         n = 2_000_000
         text = synth.illumina_fastq(0, n)
 
-        def e2e(make_file, **parser_kw):
-            f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)))
+        def e2e(make_file, six=False, **parser_kw):
+            from sequali_amd import DedupEstimator, NanoStats, OverrepresentedSequences
+            f = FusedPass(QCMetrics(), AdapterCounter(list(synth.ILLUMINA_PROBES)), PerTileQuality() if six else None)
+            more = (OverrepresentedSequences(), NanoStats(), DedupEstimator(front_sequence_offset=64, back_sequence_offset=0)) if six else ()
             fobj = make_file()
             _lib.synchronize()
             t0 = time.perf_counter()
             arrays = 0
             for a in FastqParser(fobj, **parser_kw):
-                f.add_record_array(a)
+                f.add_record_array(a)      # __main__.py:279-306: one call per module and array
+                for mod in more:
+                    mod.add_record_array(a)
                 arrays += 1
             f.qc_metrics.flush()
+            ok = bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)
+            if six:
+                ok = ok and f.per_tile_quality.number_of_reads == n and more[0].number_of_sequences == n and more[2].tracked_sequences > 0
             _lib.synchronize()
             dt = time.perf_counter() - t0
-            ok = bool(int(np.array(f.qc_metrics.base_count_table(), np.uint64).sum()) == 150 * n)
             return dt, arrays, ok
 
         first_dt, _, _ = e2e(lambda: io.BytesIO(text))       # first pass: page-locks its 64 MiB staging blocks (they go to a pool)
@@ -601,11 +607,20 @@ def other_configs(lib, ctx, steps, warmup, only=None):
         out["e2e_host_fastq_default_buffer"] = {
             "workload": f"{n} x 150 bp FASTQ text in host memory (io.BytesIO) through FastqParser at its default 128 KiB ({arrays} arrays, "
                         "~380 reads each), QCMetrics + AdapterCounter called once per array as __main__.py:279-306 does; the parser's buffer logic "
-                        "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), one upload and one launch per block; file read, record "
-                        "split, upload and counting included",
+                        "runs in the C ABI over page-locked 64 MiB blocks (sq_feeder), whose worker threads read the BytesIO's buffer and note the "
+                        "line ends, one upload and one launch per block; file read, record split, upload and counting included",
             "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
             "first_pass_seconds": round(first_dt, 3), "seconds_of_three_passes": [round(r[0], 3) for r in runs],
             "checks": {"base_table_sum_ok": ok}}
+        if wanted("e2e_host_fastq_default_buffer_six_modules"):
+            e2e(lambda: io.BytesIO(text), six=True)
+            runs = [e2e(lambda: io.BytesIO(text), six=True) for _ in range(3)]
+            dt, arrays, ok = sorted(runs)[1]
+            out["e2e_host_fastq_default_buffer_six_modules"] = {
+                "workload": f"the same {n} reads and call pattern ({arrays} arrays at the default 128 KiB) with all six single-end modules of __main__.py:279-306 "
+                            "called once per array: FusedPass(QCMetrics, AdapterCounter, PerTileQuality), OverrepresentedSequences, NanoStats, DedupEstimator",
+                "value": round(150 * n / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+                "seconds_of_three_passes": [round(r[0], 3) for r in runs], "checks": {"tables_ok": all(r[2] for r in runs)}}
         big = dict(initial_buffersize=64 << 20, split_on_device=True)
         reader = PinnedReader(text)                            # the text in page-locked memory, as a file object
 

@@ -116,6 +116,13 @@ typedef struct sq_feed_array {
 sq_feeder *sq_feeder_new(sq_ctx *ctx, size_t read_in_size, size_t block_bytes);
 void sq_feeder_free(sq_feeder *f);
 /* where the caller's file.readinto() puts the next bytes, and how many fit (:1022-1030) */
+/* A source the feeder reads by itself instead of being fed (to be set before the first sq_feeder_next, which then never
+ * answers SQ_FEED_MORE): worker threads copy it into the staging blocks and note the line ends on their way, so that neither
+ * the read (readinto of FastqParser_create_record_array, :1040-1051) nor the newline search (the four memchr of a record,
+ * :1101-1139) run on the caller's thread.  `text` must stay valid and unchanged until sq_feeder_free; `fd` is a regular file,
+ * read with pread. */
+int sq_feeder_set_source_memory(sq_feeder *f, const uint8_t *text, size_t len);
+int sq_feeder_set_source_fd(sq_feeder *f, int fd, uint64_t offset, uint64_t len);
 uint8_t *sq_feeder_fill(sq_feeder *f, size_t *room);
 int sq_feeder_filled(sq_feeder *f, size_t n);
 /* FastqParser_create_record_array :964-1184 (min 1, max SIZE_MAX: __next__; n, n: read(n)).

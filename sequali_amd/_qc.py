@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import array
 import ctypes as C
+import io
 import sys
 import os
 import warnings
@@ -468,6 +469,46 @@ class _Feeder:
             lib().sq_feeder_release(self.h, block_id)
 
 
+_USE_SOURCE = os.environ.get("SQ_FEEDER_SOURCE", "1") != "0"   # 0: every file object is read through its readinto()
+
+
+def _feeder_source(f: "_Feeder", fileobj):
+    """Lets the feeder read `fileobj` by itself where that is the same bytes (sq_feeder_set_source_*: worker threads copy
+    the text into the staging blocks and note the line ends on their way -- neither readinto() nor the newline search run
+    on the thread of the caller's loop): an io.BytesIO (its buffer, from its position on) and a plain buffered binary
+    file (its descriptor, by pread).  Returns what must stay alive while the feeder reads, or None: the file object is
+    read through readinto() as the reference does (_qcmodule.c:1040-1051).  The file object's own position is left at
+    its end either way once the parser has seen everything."""
+    if not _USE_SOURCE or f.h is None:
+        return None
+    try:
+        if type(fileobj) is io.BytesIO:
+            pos = fileobj.tell()
+            data = fileobj.getvalue()             # the bytes object it was made from, not a copy (getbuffer() un-shares it: a copy of everything)
+            n = len(data) - pos
+            if n <= 0:
+                return None
+            addr = C.cast(C.c_char_p(data), C.c_void_p).value
+            if lib().sq_feeder_set_source_memory(f.h, addr + pos, n) != 0:
+                return None
+            fileobj.seek(0, 2)
+            return (fileobj, data)                # `data` stays alive and is immutable: the workers read from it
+        if type(fileobj) is io.BufferedReader and type(getattr(fileobj, "raw", None)) is io.FileIO:
+            st = os.fstat(fileobj.fileno())
+            import stat as _stat
+            if not _stat.S_ISREG(st.st_mode):
+                return None
+            pos = fileobj.tell()
+            n = st.st_size - pos
+            if n <= 0 or lib().sq_feeder_set_source_fd(f.h, fileobj.fileno(), pos, n) != 0:
+                return None
+            fileobj.seek(0, 2)
+            return (fileobj,)
+    except (OSError, ValueError, BufferError, TypeError):
+        pass
+    return None
+
+
 class _FeedArrayInfo(C.Structure):
     _fields_ = [("block_id", C.c_uint64), ("byte_start", C.c_uint64), ("byte_len", C.c_uint64),
                 ("first_record", C.c_uint64), ("n_records", C.c_uint64)]
@@ -870,6 +911,7 @@ class FastqParser:
         self._token = _Source()      # arrays of one parser are staged together
         self._dev_left, self._dev_hold = 0, None   # split_on_device: leftover bytes, page-locked buffer
         self._feeder: Optional[_Feeder] = None
+        self._source = None
         self._blk: Optional[_FeedBlock] = None
         # extension: iterate with the record split done on the GPU (sq_batch_from_fastq);
         # the text is uploaded once and the metas never exist on the host unless a
@@ -901,6 +943,7 @@ class FastqParser:
         f = self._feeder
         if f is None:
             f = self._feeder = _Feeder(self._read_in_size)
+            self._source = _feeder_source(f, self._file)    # the feeder may read the file by itself (worker threads)
         info = _FeedArrayInfo()
         room = C.c_size_t(0)
         while True:

@@ -154,56 +154,14 @@ int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, 
     return n;
 }
 
-static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
-                          uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *first_high)
+/* The record loop itself (:1093-1171).  next_newline(from): the first newline at or behind `from` inside the range, or
+ * NULL -- the loop asks strictly left to right; finish_ascii(): called once, whichever way the loop ends. */
+template <class NextNewline, class FinishAscii>
+static int64_t record_loop(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                           uint64_t stats[SQ_STATS_N], NextNewline &&next_newline, FinishAscii &&finish_ascii)
 {
     const uint8_t *end = base + end_off;
     const uint8_t *rec = base + start;
-    /* the newlines of the range, in order: every call hands out the next one (NULL: there is none).
-       The record loop asks for them strictly left to right -- `from` is always one behind the
-       newline it got last -- so no position has to be compared */
-    uint32_t nl[2048];
-    size_t nl_count = 0, nl_next = 0;
-    const uint8_t *scan = rec;    /* everything in front of it has been scanned */
-    const uint8_t *chunk0 = rec;  /* nl[] holds offsets from here */
-    const uint8_t *ascii_lo = ascii_from == (size_t)-1 ? nullptr : base + ascii_from;
-    const uint8_t *high_at = nullptr;   /* the first byte >= 0x80 at or behind ascii_lo met so far */
-    auto refill = [&]() -> bool {       /* false: the range has no more newlines */
-        while (scan < end) {
-            size_t scanned = 0;
-            uint32_t high = UINT32_MAX;
-            chunk0 = scan;
-            nl_next = 0;
-            nl_count = sq_scan_newlines(scan, std::min<size_t>((size_t)(end - scan), (size_t)1 << 30), 0, nl, 2048, &scanned, &high);
-            if (high != UINT32_MAX && high_at == nullptr && ascii_lo) {
-                const uint8_t *h = scan + high;
-                if (h < ascii_lo) {   /* in front of the new bytes (checked by an earlier call): look again from there */
-                    const int64_t again = ascii_lo < scan + scanned ? sq_first_non_ascii_fast(ascii_lo, (size_t)(scan + scanned - ascii_lo)) : -1;
-                    h = again >= 0 ? ascii_lo + again : nullptr;
-                }
-                if (h) high_at = h;
-            }
-            scan += scanned;
-            if (nl_count) return true;
-        }
-        return false;
-    };
-    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
-        if (nl_next == nl_count && !refill()) return nullptr;
-        return chunk0 + nl[nl_next++];
-    };
-    /* what of the new bytes the scan has not seen (the loop ended on max_records, or on an error) */
-    auto finish_ascii = [&]() {
-        if (!ascii_lo || !first_high) return;
-        if (!high_at) {
-            const uint8_t *from = std::max(scan, ascii_lo);
-            if (from < end) {
-                const int64_t r = sq_first_non_ascii_fast(from, (size_t)(end - from));
-                if (r >= 0) high_at = from + r;
-            }
-        }
-        *first_high = high_at ? (int64_t)(high_at - base) : -1;
-    };
     int64_t n = 0;
     while ((size_t)n < cap) {
         if (rec + 2 >= end) break; /* :1094 */
@@ -262,6 +220,103 @@ static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_
     if (consumed) *consumed = (size_t)(rec - (base + start));
     finish_ascii();
     return n;
+}
+
+static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                          uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *first_high)
+{
+    const uint8_t *end = base + end_off;
+    /* the newlines of the range, in order: every call hands out the next one (NULL: there is none).
+       The record loop asks for them strictly left to right -- `from` is always one behind the
+       newline it got last -- so no position has to be compared */
+    uint32_t nl[2048];
+    size_t nl_count = 0, nl_next = 0;
+    const uint8_t *scan = base + start;    /* everything in front of it has been scanned */
+    const uint8_t *chunk0 = scan;          /* nl[] holds offsets from here */
+    const uint8_t *ascii_lo = ascii_from == (size_t)-1 ? nullptr : base + ascii_from;
+    const uint8_t *high_at = nullptr;   /* the first byte >= 0x80 at or behind ascii_lo met so far */
+    auto refill = [&]() -> bool {       /* false: the range has no more newlines */
+        while (scan < end) {
+            size_t scanned = 0;
+            uint32_t high = UINT32_MAX;
+            chunk0 = scan;
+            nl_next = 0;
+            nl_count = sq_scan_newlines(scan, std::min<size_t>((size_t)(end - scan), (size_t)1 << 30), 0, nl, 2048, &scanned, &high);
+            if (high != UINT32_MAX && high_at == nullptr && ascii_lo) {
+                const uint8_t *h = scan + high;
+                if (h < ascii_lo) {   /* in front of the new bytes (checked by an earlier call): look again from there */
+                    const int64_t again = ascii_lo < scan + scanned ? sq_first_non_ascii_fast(ascii_lo, (size_t)(scan + scanned - ascii_lo)) : -1;
+                    h = again >= 0 ? ascii_lo + again : nullptr;
+                }
+                if (h) high_at = h;
+            }
+            scan += scanned;
+            if (nl_count) return true;
+        }
+        return false;
+    };
+    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
+        if (nl_next == nl_count && !refill()) return nullptr;
+        return chunk0 + nl[nl_next++];
+    };
+    /* what of the new bytes the scan has not seen (the loop ended on max_records, or on an error) */
+    auto finish_ascii = [&]() {
+        if (!ascii_lo || !first_high) return;
+        if (!high_at) {
+            const uint8_t *from = std::max(scan, ascii_lo);
+            if (from < end) {
+                const int64_t r = sq_first_non_ascii_fast(from, (size_t)(end - from));
+                if (r >= 0) high_at = from + r;
+            }
+        }
+        *first_high = high_at ? (int64_t)(high_at - base) : -1;
+    };
+    return record_loop(base, start, end_off, metas, cap, consumed, stats, next_newline, finish_ascii);
+}
+
+/* sq_split_range_ascii over a range whose newlines are known already: `pieces` (sorted, back to back) cover [start,
+ * end_off) of `base` -- what the feeder's workers noted while they copied the text in (SqNlPiece, sq_feed.hip).  The same
+ * records, the same errors in the same order; the text itself is only looked at where a record is checked. */
+int64_t sq_split_range_indexed(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                               uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii, const SqNlPiece *pieces, size_t n_pieces)
+{
+    size_t k = 0, j = 0;   /* the next newline to hand out: entry j of piece k */
+    while (k < n_pieces && pieces[k].to <= start) k++;
+    if (k < n_pieces) j = (size_t)(std::lower_bound(pieces[k].nl, pieces[k].nl + pieces[k].n_nl, (uint32_t)start) - pieces[k].nl);
+    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
+        while (k < n_pieces) {
+            if (j < pieces[k].n_nl) {
+                const uint32_t at = pieces[k].nl[j];
+                if (at >= end_off) return nullptr;
+                j++;
+                return base + at;
+            }
+            k++;
+            j = 0;
+        }
+        return nullptr;
+    };
+    /* :1055-1067: the first byte >= 0x80 among the bytes [ascii_from, end_off) */
+    auto finish_ascii = [&]() {
+        if (!non_ascii) return;
+        *non_ascii = -1;
+        if (ascii_from == (size_t)-1) return;
+        for (size_t q = 0; q < n_pieces; q++) {
+            const SqNlPiece &pc = pieces[q];
+            if (pc.to <= ascii_from || pc.first_high == UINT32_MAX) continue;
+            if (pc.from >= end_off) break;
+            size_t at = pc.first_high;
+            if (at < ascii_from) {   /* the piece's first one lies in front of the new bytes: look again behind them */
+                const size_t hi = std::min(pc.to, end_off);
+                const int64_t r = ascii_from < hi ? sq_first_non_ascii_fast(base + ascii_from, hi - ascii_from) : -1;
+                if (r < 0) continue;
+                at = ascii_from + (size_t)r;
+            }
+            if (at < end_off) *non_ascii = (int64_t)at;
+            break;
+        }
+    };
+    return record_loop(base, start, end_off, metas, cap, consumed, stats, next_newline, finish_ascii);
 }
 
 SQ_EXPORT int64_t sq_fastq_split(const uint8_t *buf, size_t len, sq_meta *metas, size_t cap,

@@ -93,6 +93,16 @@ inline std::string sq_py_repr_ascii(const char *p, size_t n)
     return out;
 }
 
+/* What a worker of the parser's feeder has learnt about a stretch [from, to) of a staging block while it copied it in
+ * (sq_feed.hip): the offsets (in the block) of its newlines, ascending, and of its first byte >= 0x80 (UINT32_MAX: none).
+ * The record split takes its newlines from these instead of scanning the text again (sq_split_range_indexed). */
+struct SqNlPiece {
+    size_t from, to;
+    const uint32_t *nl;
+    size_t n_nl;
+    uint32_t first_high;
+};
+
 struct sq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -23,12 +23,20 @@
  * files, gzip streams).
  */
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "sq_common.h"
 #include <time.h>
+#include <unistd.h>
 
 int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end, sq_meta *metas, size_t cap, size_t *consumed,
                              uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii);
+int64_t sq_split_range_indexed(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
+                               uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii, const SqNlPiece *pieces, size_t n_pieces);
+size_t sq_scan_newlines(const uint8_t *p, size_t n, uint32_t base, uint32_t *out, size_t cap, size_t *scanned, uint32_t *high);   /* sq_hostsimd.cpp */
+int64_t sq_first_non_ascii_fast(const uint8_t *p, size_t n);
 
 namespace {
 
@@ -91,6 +99,18 @@ struct FeedBlock {
     hipEvent_t copied = nullptr;   /* the upload of the block has left pinned memory */
     bool in_flight = false;
     uint64_t stats[SQ_STATS_N] = {};   /* bases, longest read, longest name, longest record span, ~(shortest read) */
+    /* a feeder with a source of its own (sq_feeder_set_source_*): what its workers noted of the stretches they copied in,
+       in order of offset, back to back from 0; `used` is the end of the longest run of finished ones.  Touched under
+       sq_feeder::mu (a finished piece itself does not change any more) */
+    struct Piece {
+        size_t from = 0, to = 0;
+        std::vector<uint32_t> nl;
+        uint32_t first_high = UINT32_MAX;
+        bool done = false;
+    };
+    std::vector<Piece *> pieces;
+    size_t reserved = 0;    /* end of the last piece handed to a worker */
+    ~FeedBlock() { for (Piece *p : pieces) delete p; }
     uint8_t *pin() const { return (uint8_t *)text.p; }
     sq_meta *metas() const { return (sq_meta *)meta.p; }
 };
@@ -111,11 +131,107 @@ struct sq_feeder {
     size_t arr_len = 0;       /* bytes of the reference's buffer so far */
     size_t arr_first_record = 0;
     size_t need = 0;          /* bytes sq_feeder_fill must have room for */
+    /* A source the feeder reads by itself (sq_feeder_set_source_memory / _fd): worker threads copy the next stretches of
+       it into the open block, as far as the block has room, and note the newlines and the first byte >= 0x80 of what
+       they copy (FeedBlock::Piece); the record split takes its newlines from there (sq_split_range_indexed) and
+       sq_feeder_next never asks the caller for bytes.  Round 6: of the 85-95 ms a pass over 2 M reads through the
+       reference's call pattern took, 21-24 were the caller's readinto and 34-47 the newline scan, both on the one thread
+       that also runs the Python loop. */
+    bool has_source = false;
+    const uint8_t *src_mem = nullptr;
+    int src_fd = -1;
+    uint64_t src_off = 0, src_end = 0;   /* the next byte to hand to a worker; where the source ends */
+    bool src_failed = false;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_data;
+    std::vector<std::thread> workers;
+    int busy = 0;             /* workers copying right now */
+    bool stop = false, paused = false;
 };
 
 namespace {
 
 FeedBlock *open_block(sq_feeder *f) { return f->blocks.empty() || f->blocks.back()->sealed ? nullptr : f->blocks.back(); }
+
+constexpr size_t FEED_PIECE = (size_t)1 << 20;   /* what a worker copies at a time */
+
+/* a worker of a feeder with a source: the next stretch of the source into the open block, its newlines noted */
+void feed_worker(sq_feeder *f)
+{
+    std::unique_lock<std::mutex> lk(f->mu);
+    for (;;) {
+        FeedBlock *b = nullptr;
+        size_t n = 0;
+        for (;;) {
+            if (f->stop) return;
+            b = f->paused ? nullptr : open_block(f);
+            if (b && !f->src_failed && f->src_off < f->src_end && b->reserved < b->cap) {
+                n = (size_t)std::min<uint64_t>({(uint64_t)FEED_PIECE, (uint64_t)(b->cap - b->reserved), f->src_end - f->src_off});
+                break;
+            }
+            f->cv_work.wait(lk);
+        }
+        FeedBlock::Piece *pc = new FeedBlock::Piece();
+        pc->from = b->reserved;
+        pc->to = b->reserved + n;
+        b->reserved += n;
+        b->pieces.push_back(pc);
+        const uint64_t at = f->src_off;
+        f->src_off += n;
+        f->busy++;
+        lk.unlock();
+        uint8_t *dst = b->pin() + pc->from;
+        bool ok = true;
+        if (f->src_mem) {
+            memcpy(dst, f->src_mem + at, n);
+        } else {
+            size_t got = 0;
+            while (got < n) {
+                const ssize_t r = pread(f->src_fd, dst + got, n - got, (off_t)(at + got));
+                if (r <= 0) { ok = false; break; }   /* the file is shorter than it was, or an I/O error */
+                got += (size_t)r;
+            }
+        }
+        if (ok) {
+            pc->nl.reserve(n / 64 + 16);
+            size_t done = 0;
+            while (done < n) {
+                uint32_t tmp[2048], high = UINT32_MAX;
+                size_t scanned = 0;
+                const size_t k = sq_scan_newlines(dst + done, n - done, (uint32_t)(pc->from + done), tmp, 2048, &scanned, &high);
+                pc->nl.insert(pc->nl.end(), tmp, tmp + k);
+                if (high != UINT32_MAX && pc->first_high == UINT32_MAX) pc->first_high = high;
+                done += scanned;
+                if (!scanned) break;
+            }
+        }
+        lk.lock();
+        f->busy--;
+        if (!ok) f->src_failed = true;
+        pc->done = true;
+        /* the text is there up to the end of the longest run of finished pieces */
+        size_t used = b->used;
+        for (FeedBlock::Piece *q : b->pieces) {
+            if (q->to <= used) continue;
+            if (!q->done || q->from != used) break;
+            used = q->to;
+        }
+        b->used = used;
+        f->cv_data.notify_all();
+    }
+}
+
+/* nobody copies into the open block any more until feed_resume(): its `used` and `reserved` agree */
+void feed_pause(sq_feeder *f, std::unique_lock<std::mutex> &lk)
+{
+    f->paused = true;
+    while (f->busy) f->cv_data.wait(lk);
+}
+void feed_resume(sq_feeder *f)
+{
+    f->paused = false;
+    f->cv_work.notify_all();
+}
 
 FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
 {
@@ -148,6 +264,13 @@ void free_block(FeedBlock *b)
    leftover and what was read ahead) over to a new one that has room for `room` more bytes */
 int roll_block(sq_feeder *f, size_t room)
 {
+    std::unique_lock<std::mutex> lk(f->mu, std::defer_lock);
+    if (f->has_source) {   /* the workers leave the block alone while it is closed and its tail moves */
+        lk.lock();
+        feed_pause(f, lk);
+    }
+
+    struct Resume { sq_feeder *f; ~Resume() { if (f->has_source) feed_resume(f); } } resume{f};
     FeedBlock *o = open_block(f);
     const size_t carry = o ? o->used - f->pos : 0;
     if (o) {
@@ -158,6 +281,33 @@ int roll_block(sq_feeder *f, size_t room)
     if (!n) { sq_set_error("out of memory for a staging block"); return SQ_ERR_MEMORY; }
     if (carry) memcpy(n->pin(), o->pin() + f->pos, carry);
     n->used = carry;
+    if (f->has_source) {
+        n->reserved = carry;
+        if (carry) {   /* what the workers noted of the carried bytes comes along, as one piece */
+            FeedBlock::Piece *pc = new FeedBlock::Piece();
+            pc->from = 0;
+            pc->to = carry;
+            pc->done = true;
+            bool look_again = false;
+            for (const FeedBlock::Piece *q : o->pieces) {
+                if (q->to <= f->pos) continue;
+                for (uint32_t at : q->nl)
+                    if (at >= f->pos) pc->nl.push_back(at - (uint32_t)f->pos);
+                if (q->first_high != UINT32_MAX && pc->first_high == UINT32_MAX) {
+                    if (q->first_high >= f->pos) pc->first_high = q->first_high - (uint32_t)f->pos;
+                    else look_again = true;   /* the piece's first one stays behind: is there another in what moves? */
+                }
+            }
+            if (look_again && pc->first_high == UINT32_MAX) {
+                const int64_t r = sq_first_non_ascii_fast(n->pin(), carry);
+                if (r >= 0) pc->first_high = (uint32_t)r;
+            } else if (look_again) {
+                const int64_t r = sq_first_non_ascii_fast(n->pin(), pc->first_high);
+                if (r >= 0) pc->first_high = (uint32_t)r;
+            }
+            n->pieces.push_back(pc);
+        }
+    }
     f->logical_end -= o ? f->pos : 0;
     f->pos = 0;
     if (o && o->n_records == 0) {   /* nothing in it: not a block anyone will ask for */
@@ -197,13 +347,47 @@ SQ_EXPORT sq_feeder *sq_feeder_new(sq_ctx *ctx, size_t read_in_size, size_t bloc
 SQ_EXPORT void sq_feeder_free(sq_feeder *f)
 {
     if (!f) return;
+    if (!f->workers.empty()) {
+        { std::lock_guard<std::mutex> g(f->mu); f->stop = true; }
+        f->cv_work.notify_all();
+        for (std::thread &t : f->workers) t.join();
+    }
     for (FeedBlock *b : f->blocks) free_block(b);
     delete f;
+}
+
+/* The feeder reads its text by itself from here on: `len` bytes at `text` (memory the caller keeps valid and unchanged
+ * until sq_feeder_free -- a BytesIO's buffer, a mapping), or the bytes [offset, offset + len) of the regular file `fd`
+ * (pread: the descriptor's own position is neither used nor moved).  To be called before the first sq_feeder_next;
+ * sq_feeder_next then never answers SQ_FEED_MORE.  The arrays are those of the caller-fed feeder: the same windows of the
+ * same bytes. */
+static int feeder_start(sq_feeder *f)
+{
+    if (f->has_source || !f->blocks.empty()) { sq_set_error("sq_feeder_set_source: the parser has started already"); return SQ_ERR_VALUE; }
+    if (f->read_in >= ((size_t)1 << 30)) { sq_set_error("sq_feeder_set_source: buffers of 1 GiB and more are read by the caller"); return SQ_ERR_VALUE; }
+    f->has_source = true;
+    const unsigned hc = std::thread::hardware_concurrency();
+    unsigned n = std::max(1u, std::min(4u, hc > 1 ? hc - 1 : 1u));
+    if (f->src_end - f->src_off < ((uint64_t)4 << 20)) n = 1;   /* a few pieces: one worker (a parser over a few records should not start four threads) */
+    if (const char *v = getenv("SQ_FEED_WORKERS")) n = (unsigned)std::max(1, std::min(16, atoi(v)));   /* (experiments) */
+    for (unsigned i = 0; i < n; i++) f->workers.emplace_back(feed_worker, f);
+    return SQ_OK;
+}
+SQ_EXPORT int sq_feeder_set_source_memory(sq_feeder *f, const uint8_t *text, size_t len)
+{
+    f->src_mem = text; f->src_fd = -1; f->src_off = 0; f->src_end = len;
+    return feeder_start(f);
+}
+SQ_EXPORT int sq_feeder_set_source_fd(sq_feeder *f, int fd, uint64_t offset, uint64_t len)
+{
+    f->src_mem = nullptr; f->src_fd = fd; f->src_off = offset; f->src_end = offset + len;
+    return feeder_start(f);
 }
 
 /* Where the next bytes of the file go and how many of them fit (*room >= 1). */
 SQ_EXPORT uint8_t *sq_feeder_fill(sq_feeder *f, size_t *room)
 {
+    if (f->has_source) { sq_set_error("sq_feeder_fill: the feeder reads its source by itself"); *room = 0; return nullptr; }
     FeedBlock *b = open_block(f);
     /* read ahead in pieces of 16 buffers (1 MiB at least): a block that is sealed early -- a
        getter asked for its records -- carries little over to the next one */
@@ -219,6 +403,7 @@ SQ_EXPORT uint8_t *sq_feeder_fill(sq_feeder *f, size_t *room)
 /* n bytes were put where sq_feeder_fill pointed; 0: the file has ended. */
 SQ_EXPORT int sq_feeder_filled(sq_feeder *f, size_t n)
 {
+    if (f->has_source) { sq_set_error("sq_feeder_filled: the feeder reads its source by itself"); return SQ_ERR_VALUE; }
     FeedBlock *b = open_block(f);
     if (!b || n > b->cap - b->used) { sq_set_error("sq_feeder_filled: more bytes than there was room for"); return SQ_ERR_VALUE; }
     if (n == 0) f->file_eof = true;
@@ -257,7 +442,25 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         /* one readinto of the reference: the free part of a new buffer of read_in bytes, later read_in more */
         const size_t want = f->first ? (f->read_in > f->arr_len ? f->read_in - f->arr_len : 0) : f->read_in;
         if (want > 0) {
-            const size_t have = b->used - (f->pos + f->arr_len);
+            size_t used_now = b->used;
+            if (f->has_source) {   /* the workers bring the bytes: wait until this read's are there, the source is exhausted or the block is full */
+                std::unique_lock<std::mutex> lk(f->mu);
+                const size_t upto = f->pos + f->arr_len + want;
+                for (;;) {
+                    used_now = b->used;
+                    if (f->src_failed) {
+                        sq_set_error("the file could not be read to its end");
+                        f->in_array = false;
+                        return SQ_ERR_HIP;
+                    }
+                    const bool drained = f->src_off >= f->src_end && f->busy == 0 && b->used == b->reserved;
+                    if (drained) f->file_eof = true;
+                    if (used_now >= upto || drained || (b->reserved >= b->cap && f->busy == 0 && b->used == b->reserved)) break;
+                    f->cv_work.notify_all();
+                    f->cv_data.wait(lk);
+                }
+            }
+            const size_t have = used_now - (f->pos + f->arr_len);
             if (have < want && !f->file_eof) {
                 if (b->cap - (f->pos + f->arr_len) < want) {
                     /* the block ends inside this array: its arrays so far are sealed, this one starts the next block */
@@ -274,6 +477,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                     f->logical_end = 0;   /* of no use until this array is done */
                     f->arr_len = keep_len;
                 }
+                if (f->has_source) continue;   /* the new block fills by itself: this read again */
                 f->need = want - have;
                 return SQ_FEED_MORE;
             }
@@ -309,6 +513,16 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             memcpy(stats, b->stats, sizeof stats);
             int64_t bad = -1;
             const double t_split = feed_now();
+            if (f->has_source) {
+                std::vector<SqNlPiece> idx;
+                {
+                    std::lock_guard<std::mutex> g(f->mu);
+                    for (const FeedBlock::Piece *q : b->pieces)
+                        if (q->to > f->pos && q->from < f->pos + f->arr_len) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->nl.size(), q->first_high});
+                }
+                n = sq_split_range_indexed(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats, fresh_from, &bad,
+                                           idx.data(), idx.size());
+            } else
             n = sq_split_range_ascii(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats, fresh_from, &bad);
             g_feed_times[1] += feed_now() - t_split;
             if (non_ascii_error(bad)) return SQ_ERR_VALUE;
@@ -419,10 +633,14 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     b->min_length = fb->n_records ? ~fb->stats[4] : 0;
     b->len_hist.resize(SQ_LEN_BINS);
     for (int i = 0; i < SQ_LEN_BINS; i++) b->len_hist[i] = (uint32_t)fb->stats[5 + i];
-    if (hipMalloc((void **)&b->d_buf, b->buf_len + 64) != hipSuccess ||
-        hipMalloc((void **)&b->d_metas, (b->n ? b->n : 1) * sizeof(sq_meta)) != hipSuccess) {
+    /* text and metas from the context's pool (as sq_batch_from_fastq's): a hipMalloc / hipFree pair per block and array was 0.4 ms
+       of host time per block, and hipFree waits for the device */
+    b->pooled = true;
+    b->d_buf = (uint8_t *)sq_dev_get(ctx, b->buf_len + 64);
+    b->d_metas = b->d_buf ? (sq_meta *)sq_dev_get(ctx, (b->n ? b->n : 1) * sizeof(sq_meta)) : nullptr;
+    if (!b->d_buf || !b->d_metas) {
         sq_set_error("sq_feeder_upload: out of device memory");
-        if (b->d_buf) (void)hipFree(b->d_buf);
+        if (b->d_buf) sq_dev_put(ctx, b->d_buf);
         delete b;
         return nullptr;
     }
@@ -430,8 +648,8 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
         sq_set_error("sq_feeder_upload: %s: %s", what, hipGetErrorString(e));
         (void)hipStreamSynchronize(ctx->stream);   /* nothing may still be writing the blocks that go back */
         if (b->ready) (void)hipEventDestroy(b->ready);
-        (void)hipFree(b->d_buf);
-        (void)hipFree(b->d_metas);
+        sq_dev_put(ctx, b->d_buf);
+        sq_dev_put(ctx, b->d_metas);
         delete b;
         return nullptr;
     };
@@ -456,6 +674,8 @@ SQ_EXPORT void sq_feeder_debug_times(double *out, int reset)
 
 SQ_EXPORT void sq_feeder_release(sq_feeder *f, uint64_t block_id)
 {
+    std::unique_lock<std::mutex> lk(f->mu, std::defer_lock);
+    if (f->has_source) lk.lock();   /* the workers look at the list of blocks */
     for (size_t i = 0; i < f->blocks.size(); i++)
         if (f->blocks[i]->id == block_id && f->blocks[i]->sealed) {
             free_block(f->blocks[i]);
