@@ -1869,7 +1869,14 @@ class NanoStats(_Deferring):
         # in its metas (:5314): arrays that were not staged
         wb = arr._writeback() if arr._writeback is not None else None
         if wb is not None:
-            wb._drain()
+            # (a view of a staging block: what that QCMetrics owes THIS block, no further -- a full drain went on into the
+            # parser's open block and sealed it half full, every block of a six-module run: round 6)
+            blk = getattr(arr, "_blk", None)
+            blk = blk() if isinstance(blk, weakref.ReferenceType) else blk
+            if blk is not None:
+                wb._drain(through=blk)
+            else:
+                wb._drain()
         rc = lib().sq_nanostats_add_batch(self._handle, arr._device().handle)
         n = lib().sq_nanostats_last_warnings(self._handle, None, 0)
         if n:
