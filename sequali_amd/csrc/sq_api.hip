@@ -154,8 +154,10 @@ int64_t sq_split_range_ascii(const uint8_t *base, size_t start, size_t end_off, 
     return n;
 }
 
-/* The record loop itself (:1093-1171).  next_newline(from): the first newline at or behind `from` inside the range, or
- * NULL -- the loop asks strictly left to right; finish_ascii(): called once, whichever way the loop ends. */
+/* The record loop itself (:1093-1171).  next_newline(from, &after): the first newline at or behind `from` inside the range,
+ * or NULL -- the loop asks strictly left to right; `after`: the byte that follows that newline where the provider knows it,
+ * else 0 (the loop then looks at the text under the conditions it always did); finish_ascii(): called once, whichever
+ * way the loop ends. */
 template <class NextNewline, class FinishAscii>
 static int64_t record_loop(const uint8_t *base, size_t start, size_t end_off, sq_meta *metas, size_t cap, size_t *consumed,
                            uint64_t stats[SQ_STATS_N], NextNewline &&next_newline, FinishAscii &&finish_ascii)
@@ -163,30 +165,32 @@ static int64_t record_loop(const uint8_t *base, size_t start, size_t end_off, sq
     const uint8_t *end = base + end_off;
     const uint8_t *rec = base + start;
     int64_t n = 0;
+    uint8_t rec_first = 0, after = 0;   /* rec[0] where the newline in front of it brought it along */
     while ((size_t)n < cap) {
         if (rec + 2 >= end) break; /* :1094 */
-        if (rec[0] != '@') {
+        if ((rec_first ? rec_first : rec[0]) != '@') {
             sq_set_error("Record does not start with @ but with %c", rec[0]);
             finish_ascii();
             return SQ_ERR_VALUE;
         }
         const uint8_t *name = rec + 1;
-        const uint8_t *name_end = next_newline(name);
+        const uint8_t *name_end = next_newline(name, after);
         if (!name_end) break;
         const uint8_t *seq = name_end + 1;
-        const uint8_t *seq_end = next_newline(seq);
+        const uint8_t *seq_end = next_newline(seq, after);
         if (!seq_end) break;
         const uint8_t *plus = seq_end + 1;
-        if (plus < end && plus[0] != '+') {
+        if (plus < end && (after ? after : plus[0]) != '+') {
             sq_set_error("Record second header does not start with + but with %c", plus[0]);
             finish_ascii();
             return SQ_ERR_VALUE;
         }
-        const uint8_t *plus_end = next_newline(plus);
+        const uint8_t *plus_end = next_newline(plus, after);
         if (!plus_end) break;
         const uint8_t *qual = plus_end + 1;
-        const uint8_t *qual_end = next_newline(qual);
+        const uint8_t *qual_end = next_newline(qual, after);
         if (!qual_end) break;
+        rec_first = after;
         if (seq_end - seq != qual_end - qual) {
             sq_set_error("Record sequence and qualities do not have equal length, %s", sq_py_repr_ascii((const char *)name, name_end - name).c_str());   /* :1141-1146: %R */
             finish_ascii();
@@ -255,7 +259,8 @@ static int64_t split_core(const uint8_t *base, size_t start, size_t end_off, sq_
         }
         return false;
     };
-    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
+    auto next_newline = [&](const uint8_t *, uint8_t &after) -> const uint8_t * {
+        after = 0;
         if (nl_next == nl_count && !refill()) return nullptr;
         return chunk0 + nl[nl_next++];
     };
@@ -283,11 +288,13 @@ int64_t sq_split_range_indexed(const uint8_t *base, size_t start, size_t end_off
     size_t k = 0, j = 0;   /* the next newline to hand out: entry j of piece k */
     while (k < n_pieces && pieces[k].to <= start) k++;
     if (k < n_pieces) j = (size_t)(std::lower_bound(pieces[k].nl, pieces[k].nl + pieces[k].n_nl, (uint32_t)start) - pieces[k].nl);
-    auto next_newline = [&](const uint8_t *) -> const uint8_t * {
+    auto next_newline = [&](const uint8_t *, uint8_t &after) -> const uint8_t * {
+        after = 0;
         while (k < n_pieces) {
             if (j < pieces[k].n_nl) {
                 const uint32_t at = pieces[k].nl[j];
                 if (at >= end_off) return nullptr;
+                if ((size_t)at + 1 < end_off) after = pieces[k].after[j];   /* (behind the range's end nothing is looked at) */
                 j++;
                 return base + at;
             }

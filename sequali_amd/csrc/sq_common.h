@@ -94,11 +94,15 @@ inline std::string sq_py_repr_ascii(const char *p, size_t n)
 }
 
 /* What a worker of the parser's feeder has learnt about a stretch [from, to) of a staging block while it copied it in
- * (sq_feed.hip): the offsets (in the block) of its newlines, ascending, and of its first byte >= 0x80 (UINT32_MAX: none).
- * The record split takes its newlines from these instead of scanning the text again (sq_split_range_indexed). */
+ * (sq_feed.hip): the offsets (in the block) of its newlines, ascending, the byte that follows each of them (0: not noted
+ * -- it lies behind the stretch --, or it is a zero byte: look at the text), and the offset of its first byte >= 0x80
+ * (UINT32_MAX: none).  The record split takes its newlines from these instead of scanning the text again
+ * (sq_split_range_indexed), and the two characters it checks per record ('@', '+': each the byte behind a newline) too: the
+ * text was written by other cores and every look at it is a cache miss. */
 struct SqNlPiece {
     size_t from, to;
     const uint32_t *nl;
+    const uint8_t *after;
     size_t n_nl;
     uint32_t first_high;
 };

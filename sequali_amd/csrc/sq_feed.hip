@@ -105,6 +105,7 @@ struct FeedBlock {
     struct Piece {
         size_t from = 0, to = 0;
         std::vector<uint32_t> nl;
+        std::vector<uint8_t> after;   /* the byte behind each newline (0: it lies behind the piece, or is a zero byte) */
         uint32_t first_high = UINT32_MAX;
         bool done = false;
     };
@@ -204,6 +205,9 @@ void feed_worker(sq_feeder *f)
                 done += scanned;
                 if (!scanned) break;
             }
+            pc->after.resize(pc->nl.size());
+            const uint8_t *text = b->pin();
+            for (size_t i = 0; i < pc->nl.size(); i++) pc->after[i] = (size_t)pc->nl[i] + 1 < pc->to ? text[pc->nl[i] + 1] : 0;
         }
         lk.lock();
         f->busy--;
@@ -291,8 +295,8 @@ int roll_block(sq_feeder *f, size_t room)
             bool look_again = false;
             for (const FeedBlock::Piece *q : o->pieces) {
                 if (q->to <= f->pos) continue;
-                for (uint32_t at : q->nl)
-                    if (at >= f->pos) pc->nl.push_back(at - (uint32_t)f->pos);
+                for (size_t i = 0; i < q->nl.size(); i++)
+                    if (q->nl[i] >= f->pos) { pc->nl.push_back(q->nl[i] - (uint32_t)f->pos); pc->after.push_back(q->after[i]); }
                 if (q->first_high != UINT32_MAX && pc->first_high == UINT32_MAX) {
                     if (q->first_high >= f->pos) pc->first_high = q->first_high - (uint32_t)f->pos;
                     else look_again = true;   /* the piece's first one stays behind: is there another in what moves? */
@@ -518,7 +522,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                 {
                     std::lock_guard<std::mutex> g(f->mu);
                     for (const FeedBlock::Piece *q : b->pieces)
-                        if (q->to > f->pos && q->from < f->pos + f->arr_len) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->nl.size(), q->first_high});
+                        if (q->to > f->pos && q->from < f->pos + f->arr_len) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->after.data(), q->nl.size(), q->first_high});
                 }
                 n = sq_split_range_indexed(b->pin(), f->pos, f->pos + f->arr_len, b->metas() + b->n_records, cap, &consumed, stats, fresh_from, &bad,
                                            idx.data(), idx.size());
