@@ -469,6 +469,7 @@ class _Feeder:
             lib().sq_feeder_release(self.h, block_id)
 
 
+_MAX_RECORDS = (1 << 63) - 1
 _USE_SOURCE = os.environ.get("SQ_FEEDER_SOURCE", "1") != "0"   # 0: every file object is read through its readinto()
 
 
@@ -912,6 +913,7 @@ class FastqParser:
         self._dev_left, self._dev_hold = 0, None   # split_on_device: leftover bytes, page-locked buffer
         self._feeder: Optional[_Feeder] = None
         self._source = None
+        self._fast_next = None     # (sq_feeder_next, handle, byref(info), info) once the feeder reads the file itself
         self._blk: Optional[_FeedBlock] = None
         # extension: iterate with the record split done on the GPU (sq_batch_from_fastq);
         # the text is uploaded once and the metas never exist on the host unless a
@@ -922,7 +924,23 @@ class FastqParser:
         return self
 
     def __next__(self) -> FastqRecordArrayView:
-        arr = self._create_on_device() if self._split_on_device else self._create(1, sys.maxsize)
+        fast = self._fast_next
+        if fast is not None:        # the driver loop's case: the feeder reads the file itself, one foreign call per array
+            rc = fast[0](fast[1], 1, _MAX_RECORDS, fast[2])
+            if rc == 0:
+                info = fast[3]
+                n = info.n_records
+                blk = self._blk
+                if n and blk is not None and blk.block_id == info.block_id:
+                    starts = blk.starts
+                    starts.append(starts[-1] + n)
+                    return _FedArray(blk, len(starts) - 2, info.byte_start, info.byte_len, info.first_record, n)
+                arr = self._fed_array(info)      # a new block, or the end of the file
+            else:
+                check(rc)
+                arr = self._create(1, sys.maxsize)   # (SQ_FEED_MORE cannot come from a feeder with a source: kept for safety)
+        else:
+            arr = self._create_on_device() if self._split_on_device else self._create(1, sys.maxsize)
         if len(arr) == 0:
             raise StopIteration
         return arr
@@ -944,6 +962,9 @@ class FastqParser:
         if f is None:
             f = self._feeder = _Feeder(self._read_in_size)
             self._source = _feeder_source(f, self._file)    # the feeder may read the file by itself (worker threads)
+            if self._source is not None:
+                info = _FeedArrayInfo()
+                self._fast_next = (lib().sq_feeder_next, f.h, C.byref(info), info)
         info = _FeedArrayInfo()
         room = C.c_size_t(0)
         while True:
@@ -956,6 +977,10 @@ class FastqParser:
             got = self._file.readinto((C.c_char * room.value).from_address(p)) or 0
             check(lib().sq_feeder_filled(f.h, got))
         check(rc)
+        return self._fed_array(info)
+
+    def _fed_array(self, info) -> FastqRecordArrayView:
+        f = self._feeder
         if info.n_records == 0:
             return FastqRecordArrayView._from_buffer(b"", np.zeros(0, dtype=META_DTYPE))
         blk = self._blk
