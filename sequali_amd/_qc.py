@@ -433,6 +433,18 @@ class _Block:
         return v
 
 
+_LIVE_FEEDERS = weakref.WeakSet()   # at exit their workers are stopped while what they read from is still there
+
+
+def _stop_feeders() -> None:
+    for f in list(_LIVE_FEEDERS):
+        f.__del__()
+
+
+import atexit  # noqa: E402
+atexit.register(_stop_feeders)
+
+
 class _Feeder:
     """sq_feeder (csrc/sq_feed.hip): FastqParser's buffer logic over pinned staging blocks"""
 
@@ -446,15 +458,18 @@ class _Feeder:
         self.h = lib().sq_feeder_new(ctx, read_in_size, _STAGE_LIMIT)
         if not self.h:
             raise MemoryError(_lib.last_error())
+        self.source = None     # what the feeder's workers read from (kept alive until they have stopped: __del__)
         self.sealed: List[int] = []
+        _LIVE_FEEDERS.add(self)
 
     def __del__(self):
         try:
             if self.h:
-                lib().sq_feeder_free(self.h)
+                lib().sq_feeder_free(self.h)     # waits for the workers
         except Exception:
             pass
         self.h = None
+        self.source = None
 
     def retire(self, blk: "_FeedBlock") -> None:
         """a block has been closed: the oldest pinned copies go back to the pool.  A block that somebody
@@ -961,7 +976,10 @@ class FastqParser:
         f = self._feeder
         if f is None:
             f = self._feeder = _Feeder(self._read_in_size)
-            self._source = _feeder_source(f, self._file)    # the feeder may read the file by itself (worker threads)
+            # the feeder may read the file by itself (worker threads).  What they read from belongs to the FEEDER object: it must
+            # outlive sq_feeder_free, which waits for them (a parser dropped in the middle of a file let go of the BytesIO's bytes
+            # first, now and then, and a worker copied from freed memory)
+            self._source = f.source = _feeder_source(f, self._file)
             if self._source is not None:
                 info = _FeedArrayInfo()
                 self._fast_next = (lib().sq_feeder_next, f.h, C.byref(info), info)

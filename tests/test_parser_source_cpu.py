@@ -114,3 +114,15 @@ def test_the_switch_sends_every_file_object_through_readinto(monkeypatch):
     text = _text(np.random.default_rng(41), 2000, 100)
     p = FastqParser(io.BytesIO(text))
     assert sum(len(a) for a in p) == 2000 and p._source is None
+
+
+def test_a_parser_dropped_in_the_middle_of_its_file():
+    """The workers read from the BytesIO's bytes: those must outlive sq_feeder_free, which waits for the workers (they belong
+    to the feeder object).  A parser that let go of them first crashed now and then -- here: 300 parsers dropped after one
+    array of a text of several pieces."""
+    rng = np.random.default_rng(51)
+    text = _text(rng, 60_000, 300)
+    for i in range(300):
+        p = FastqParser(io.BytesIO(text), 128 * 1024)
+        assert len(next(p)) > 0
+        del p
