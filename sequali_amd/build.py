@@ -75,6 +75,47 @@ def check_default_routes(resources) -> None:
                            "\n".join(missing + spilling))
 
 
+# The f64 chains of k_span end in steps that exist for some read lengths only: scalar compares of U against constants guard them.
+# Round 5 met a build in which hipcc (ROCm 7.2.0, clang 22) had DROPPED three of them after reading a fact about U out of an
+# unrelated expression (every read of 1-15 and 33-47 bases summed the text behind its qualities); the sources now keep
+# U opaque there.  tests/test_gpu_vs_oracle.py sweeps every length on a GPU; this is the same question asked of the listing, where no
+# GPU is: the builds for batches of one read length of up to 64 bases must hold at least the compares the good build of this
+# compiler holds.  Another compiler: no verdict (its code may be right with other instructions).
+CHAIN_GUARDS = {"version": "7.2.", "min_scalar_compares": {1: 11, 2: 11}}   # k_span<NW, ., uniform>: s_cmp_gt_u32 + s_cmp_lt_u32
+
+
+def check_chain_guards(obj: str, hipcc: str) -> None:
+    import re
+    import tempfile
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    if "HIP version: " + CHAIN_GUARDS["version"] not in ver:
+        print("build.py: hipcc is not the ROCm %sx the chain-guard check knows: skipped" % CHAIN_GUARDS["version"], file=sys.stderr)
+        return
+    llvm = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin")
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, dev = os.path.join(tmp, "fat"), os.path.join(tmp, "dev.co")
+        r = subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], capture_output=True, text=True)
+        if r.returncode == 0:
+            r = subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev], capture_output=True, text=True)
+        if r.returncode != 0:
+            print("build.py: the device code of %s could not be taken out: chain-guard check skipped\n%s" % (obj, r.stderr), file=sys.stderr)
+            return
+        listing = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", dev], capture_output=True, text=True).stdout
+    bad = []
+    for body in re.split(r"\n(?=[0-9a-f]{16} <)", listing):
+        m = re.match(r"[0-9a-f]{16} <(\S*k_spanILi([12])ELb[01]ELb0ELi3E\S*)>", body)
+        if not m:
+            continue
+        n = body.count("s_cmp_gt_u32") + body.count("s_cmp_lt_u32")
+        if n < CHAIN_GUARDS["min_scalar_compares"][int(m.group(2))]:
+            bad.append("%s: %d scalar compares" % (m.group(1), n))
+    if bad:
+        raise RuntimeError("k_span builds for short reads have lost guards of their f64 chains (see build.py::CHAIN_GUARDS):\n" + "\n".join(bad))
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -171,6 +212,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with open(os.path.join(objdir, "resources.json"), "w") as f:
             json.dump(resources, f, indent=0, sort_keys=True)
         check_default_routes(resources)   # before the link: a library with a spilling default route is not made
+        check_chain_guards(os.path.join(objdir, "sq_span.o"), hipcc)
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag, *objs],
                            capture_output=True, text=True)
         if r.returncode != 0:
