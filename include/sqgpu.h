@@ -156,6 +156,9 @@ void sq_route_reset(sq_ctx *ctx);
 /* Diagnostics: seconds the process's feeders have spent moving to a new block, in the record split and in fresh
  * allocations of the page-locked pool, and the number of those allocations (out[0..3]); reset != 0: start again. */
 void sq_feeder_debug_times(double *out, int reset);
+/* Diagnostics: the context's pool of device blocks (texts and metas of record arrays): hipMalloc calls, hipFree calls,
+ * blocks idle in the pool, blocks of freed arrays still waiting for the kernels queued when they were freed (out[0..3]). */
+void sq_pool_counts(sq_ctx *ctx, uint64_t *out);
 
 /* page-locked host memory (uploads from it run at the bus rate); plain memory without a device */
 void *sq_host_alloc(size_t bytes, int *pinned);
@@ -231,6 +234,10 @@ void sq_qcmetrics_free(sq_qcmetrics *m);
 int sq_qcmetrics_add(sq_qcmetrics *m, const uint8_t *buf, size_t buf_len, sq_meta *metas, size_t n);
 int sq_qcmetrics_add_batch(sq_qcmetrics *m, sq_batch *b);
 int sq_qcmetrics_flush(sq_qcmetrics *m);
+/* Without waiting: the first call arms a poll (0); later calls: 0 = the passes queued when it was armed still run, 1 = they
+ * have ended and no invalid phred character is flagged (the batches handed in before the arming call are counted for good:
+ * the caller may free them; disarmed), -1 = a character is flagged (sq_qcmetrics_flush sees to it; disarmed). */
+int sq_qcmetrics_poll(sq_qcmetrics *m);
 /* Behind a flush that returned SQ_ERR_VALUE (an invalid phred character, _qcmodule.c:2102-2105:
  * the passes run whole batches and only flag the read).  A batch may hold the records of several
  * calls (small arrays are staged together); for every call's stretch [start, end) of it:

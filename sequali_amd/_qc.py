@@ -1234,6 +1234,7 @@ class QCMetrics(_Deferring):
             raise MemoryError(_lib.last_error())
         self._init_defer(h)
         self._pending: List[FastqRecordArrayView] = []
+        self._polled: Optional[int] = None     # arrays of _pending in front of the armed poll (_settle)
 
     def __del__(self):
         try:
@@ -1261,6 +1262,26 @@ class QCMetrics(_Deferring):
         self._pending.append(arr)
         if len(self._pending) > 64:
             self.flush()
+        elif len(self._pending) > 1:
+            self._settle()
+
+    def _settle(self) -> None:
+        """lets go of the arrays whose passes have ended without an invalid phred character -- found out without waiting
+        (sq_qcmetrics_poll).  A pending array holds its staging block's copy in HBM; until round 6 every block of a file
+        stayed there until the 65th came or somebody flushed, and each one was a fresh hipMalloc (exp_e2e_pool.txt)"""
+        r = lib().sq_qcmetrics_poll(self._handle)
+        if self._polled is None:
+            if r == 0:
+                self._polled = len(self._pending)    # armed behind the passes of that many arrays
+            return
+        if r == 0:
+            return
+        n, self._polled = self._polled, None
+        if r == 1:
+            done, self._pending = self._pending[:n], self._pending[n:]
+            self._written_back(done)
+            if self._pending and lib().sq_qcmetrics_poll(self._handle) == 0:
+                self._polled = len(self._pending)
 
     def add_read(self, read: FastqRecordView) -> None:
         view = _require_view(read)
@@ -1284,6 +1305,9 @@ class QCMetrics(_Deferring):
         self._drain()
         pending, self._pending = self._pending, []
         rc = lib().sq_qcmetrics_flush(self._handle)
+        if self._polled is not None:     # an armed poll ends here (the passes have ended: this call disarms it)
+            lib().sq_qcmetrics_poll(self._handle)
+            self._polled = None
         error = None
         if rc < 0:
             msg = _lib.last_error()
@@ -1311,7 +1335,14 @@ class QCMetrics(_Deferring):
             if error is None:
                 error = ValueError(msg)
             check(lib().sq_qcmetrics_flush(self._handle))    # the log of the handled batches ends here
-        for arr in pending:
+        self._written_back(pending)
+        if error is not None:
+            raise error
+
+    @staticmethod
+    def _written_back(arrays) -> None:
+        """accumulated_error_rate of arrays whose passes have ended (:2126)"""
+        for arr in arrays:
             blk = getattr(arr, "_blk", None)
             blk = blk() if blk is not None else None
             if blk is not None:
@@ -1325,8 +1356,6 @@ class QCMetrics(_Deferring):
                         child._metas["accumulated_error_rate"] = rates[r0:r1]
                         child._writeback = None
             arr._writeback = None
-        if error is not None:
-            raise error
 
     @property
     def number_of_reads(self) -> int:

@@ -102,12 +102,21 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     for (void *p : ctx->scratch)
         if (p) (void)hipFree(p);
     if (ctx->ahead.dev) sq_dev_put(ctx, ctx->ahead.dev);
+    sq_dev_reclaim(ctx, true);
     for (auto &f : ctx->pool_free) (void)hipFree(f.p);
     for (auto &f : ctx->pool_live) (void)hipFree(f.p);   /* batches that outlive their context hold dangling blocks: as before */
     delete ctx;
 }
 
 SQ_EXPORT const char *sq_last_route(sq_ctx *ctx) { return ctx->route.c_str(); }
+/* out[0..3]: hipMalloc and hipFree calls of the context's pool of device blocks so far, blocks idle in it, blocks waiting for their event */
+SQ_EXPORT void sq_pool_counts(sq_ctx *ctx, uint64_t *out)
+{
+    out[0] = ctx->pool_mallocs;
+    out[1] = ctx->pool_frees;
+    out[2] = ctx->pool_free.size();
+    out[3] = ctx->deferred.size();
+}
 SQ_EXPORT void sq_route_reset(sq_ctx *ctx) { ctx->route.clear(); }
 
 SQ_EXPORT int sq_synchronize(sq_ctx *ctx)
@@ -1072,6 +1081,20 @@ SQ_EXPORT sq_batch *sq_batch_from_bam(sq_ctx *ctx, const uint8_t *bam, size_t le
 SQ_EXPORT void sq_batch_free(sq_batch *b)
 {
     if (!b) return;
+    if (b->pooled && (b->owns || b->owns_metas)) {   /* the blocks go back behind what is queued on the stream, without waiting for it */
+        sq_ctx::Deferred d{b->owns ? (void *)b->d_buf : nullptr, (void *)b->d_metas, nullptr};
+        if (hipEventCreateWithFlags(&d.passed, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(d.passed, b->ctx->stream) == hipSuccess) {
+                b->ctx->deferred.push_back(d);
+                sq_dev_reclaim(b->ctx, false);
+                if (b->ready) (void)hipEventDestroy(b->ready);
+                delete b;
+                return;
+            }
+            (void)hipEventDestroy(d.passed);
+        }
+        (void)hipGetLastError();
+    }
     if (b->owns || b->owns_metas) (void)hipStreamSynchronize(b->ctx->stream);
     if (b->ready) (void)hipEventDestroy(b->ready);
     if (b->pooled) {

@@ -131,14 +131,45 @@ struct sq_ctx {
     struct DevBlock { void *p; size_t cap; };
     std::vector<DevBlock> pool_free, pool_live;
     size_t pool_free_bytes = 0;
+    /* blocks of batches that were freed while kernels on `stream` may still read them: they go back to the pool once the
+       event has passed (sq_batch_free used to wait for the stream: 0.25 ms of the caller's thread per staging block) */
+    struct Deferred { void *a, *b; hipEvent_t passed; };
+    std::vector<Deferred> deferred;
+    uint64_t pool_mallocs = 0, pool_frees = 0;   /* (sq_pool_counts) */
     /* FASTQ text uploaded ahead of the call that will split it (sq_batch_from_fastq_ahead) */
     struct Ahead { const uint8_t *host = nullptr; size_t len = 0; uint8_t *dev = nullptr; };
     Ahead ahead;
 };
 
+inline void sq_dev_put(sq_ctx *ctx, void *p);
+/* the deferred blocks whose event has passed go back to the pool; wait: all of them, waited for */
+inline void sq_dev_reclaim(sq_ctx *ctx, bool wait)
+{
+    size_t kept = 0;
+    for (size_t i = 0; i < ctx->deferred.size(); i++) {
+        sq_ctx::Deferred d = ctx->deferred[i];
+        if (wait) (void)hipEventSynchronize(d.passed);
+        else if (hipEventQuery(d.passed) != hipSuccess) {
+            (void)hipGetLastError();   /* hipErrorNotReady */
+            ctx->deferred[kept++] = d;
+            continue;
+        }
+        (void)hipEventDestroy(d.passed);
+        sq_dev_put(ctx, d.a);
+        sq_dev_put(ctx, d.b);
+    }
+    ctx->deferred.resize(kept);
+}
+
 /* a device block of at least `bytes` from the context's pool (sq_dev_put hands it back) */
 inline void *sq_dev_get(sq_ctx *ctx, size_t bytes)
 {
+    if (!ctx->deferred.empty()) {
+        sq_dev_reclaim(ctx, false);
+        bool fits = false;
+        for (const sq_ctx::DevBlock &f : ctx->pool_free) fits = fits || (f.cap >= bytes && f.cap <= 2 * bytes + (1 << 20));
+        if (!fits && !ctx->deferred.empty()) sq_dev_reclaim(ctx, true);   /* rather than a hipMalloc */
+    }
     size_t best = ctx->pool_free.size();
     for (size_t i = 0; i < ctx->pool_free.size(); i++)
         if (ctx->pool_free[i].cap >= bytes && ctx->pool_free[i].cap <= 2 * bytes + (1 << 20) &&
@@ -151,6 +182,7 @@ inline void *sq_dev_get(sq_ctx *ctx, size_t bytes)
         ctx->pool_free_bytes -= blk.cap;
     } else {
         blk.cap = (bytes + (bytes >> 4) + 0xFFFFF) & ~(size_t)0xFFFFF;   /* buffers of one parser differ by a leftover */
+        ctx->pool_mallocs++;
         if (hipMalloc(&blk.p, blk.cap) != hipSuccess) {
             /* give the pool's idle blocks back and try once more */
             for (auto &f : ctx->pool_free) (void)hipFree(f.p);
@@ -170,12 +202,22 @@ inline void sq_dev_put(sq_ctx *ctx, void *p)
         if (ctx->pool_live[i].p == p) {
             const sq_ctx::DevBlock blk = ctx->pool_live[i];
             ctx->pool_live.erase(ctx->pool_live.begin() + (long)i);
-            if (ctx->pool_free.size() >= 8 || ctx->pool_free_bytes + blk.cap > ((size_t)2 << 30)) {
+            /* the idle blocks that have lain longest make room: a pool full of sizes nobody asks for any more (another
+               parser's first small block, metas of arrays of another size) made every put a hipFree and every get a
+               hipMalloc -- 18 + 10 of them per pass over 11 staging blocks (profiles/r6/exp_e2e_pool.txt) */
+            if (blk.cap > ((size_t)2 << 30)) {
+                ctx->pool_frees++;
                 (void)hipFree(blk.p);
-            } else {
-                ctx->pool_free.push_back(blk);
-                ctx->pool_free_bytes += blk.cap;
+                return;
             }
+            while (!ctx->pool_free.empty() && (ctx->pool_free.size() >= 16 || ctx->pool_free_bytes + blk.cap > ((size_t)4 << 30))) {
+                ctx->pool_frees++;
+                ctx->pool_free_bytes -= ctx->pool_free.front().cap;
+                (void)hipFree(ctx->pool_free.front().p);
+                ctx->pool_free.erase(ctx->pool_free.begin());
+            }
+            ctx->pool_free.push_back(blk);
+            ctx->pool_free_bytes += blk.cap;
             return;
         }
     (void)hipFree(p);   /* not from the pool */

@@ -23,6 +23,7 @@
  * files, gzip streams).
  */
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -111,6 +112,15 @@ struct FeedBlock {
     };
     std::vector<Piece *> pieces;
     size_t reserved = 0;    /* end of the last piece handed to a worker */
+    /* the block's place in HBM, taken when the block is opened (a feeder with a source and a device): every piece goes up
+       as soon as its worker has it, the metas every 64 K records, on the feeder's copy stream -- when the block is sealed
+       all but its tail is there already (early_bad: a copy failed, sq_feeder_upload sends everything again) */
+    sq_ctx *ctx = nullptr;
+    hipStream_t early_stream = nullptr;
+    uint8_t *d_text = nullptr;
+    sq_meta *d_metas = nullptr;
+    size_t metas_sent = 0;
+    std::atomic<bool> early_bad{false};
     ~FeedBlock() { for (Piece *p : pieces) delete p; }
     uint8_t *pin() const { return (uint8_t *)text.p; }
     sq_meta *metas() const { return (sq_meta *)meta.p; }
@@ -148,6 +158,8 @@ struct sq_feeder {
     std::vector<std::thread> workers;
     int busy = 0;             /* workers copying right now */
     bool stop = false, paused = false;
+    hipStream_t copy_stream = nullptr;   /* the early uploads (FeedBlock::d_text); null: blocks go up when they are sealed */
+    hipEvent_t copy_done = nullptr;
 };
 
 namespace {
@@ -155,10 +167,12 @@ namespace {
 FeedBlock *open_block(sq_feeder *f) { return f->blocks.empty() || f->blocks.back()->sealed ? nullptr : f->blocks.back(); }
 
 constexpr size_t FEED_PIECE = (size_t)1 << 20;   /* what a worker copies at a time */
+constexpr size_t FEED_EARLY_METAS = (size_t)1 << 16;   /* records whose metas go up together */
 
 /* a worker of a feeder with a source: the next stretch of the source into the open block, its newlines noted */
 void feed_worker(sq_feeder *f)
 {
+    if (f->copy_stream) (void)hipSetDevice(f->ctx->device);
     std::unique_lock<std::mutex> lk(f->mu);
     for (;;) {
         FeedBlock *b = nullptr;
@@ -209,8 +223,14 @@ void feed_worker(sq_feeder *f)
             const uint8_t *text = b->pin();
             for (size_t i = 0; i < pc->nl.size(); i++) pc->after[i] = (size_t)pc->nl[i] + 1 < pc->to ? text[pc->nl[i] + 1] : 0;
         }
+        bool sent = true;
+        if (ok && b->d_text && hipMemcpyAsync(b->d_text + pc->from, dst, n, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            sent = false;
+        }
         lk.lock();
         f->busy--;
+        if (!sent) b->early_bad = true;
         if (!ok) f->src_failed = true;
         pc->done = true;
         /* the text is there up to the end of the longest run of finished pieces */
@@ -251,12 +271,32 @@ FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
     if (!b->text.p || !b->meta.p) { pool_put(b->text); pool_put(b->meta); delete b; return nullptr; }
     b->id = f->next_id++;
     b->stats[4] = 0;
+    if (f->copy_stream) {
+        b->ctx = f->ctx;
+        b->early_stream = f->copy_stream;
+        b->d_text = (uint8_t *)sq_dev_get(f->ctx, cap + 64);
+        b->d_metas = b->d_text ? (sq_meta *)sq_dev_get(f->ctx, b->meta_cap * sizeof(sq_meta)) : nullptr;   /* neither there: the block goes up when it is sealed */
+    }
     f->blocks.push_back(b);
     return b;
 }
 
+/* the block's early copies are given up (they have ended: nothing writes the device blocks that go back) */
+void drop_early(FeedBlock *b, bool metas_only)
+{
+    if (!b->d_text && !b->d_metas) return;
+    (void)hipStreamSynchronize(b->early_stream);
+    if (b->d_metas) sq_dev_put(b->ctx, b->d_metas);
+    b->d_metas = nullptr;
+    b->metas_sent = 0;
+    if (metas_only) return;
+    if (b->d_text) sq_dev_put(b->ctx, b->d_text);
+    b->d_text = nullptr;
+}
+
 void free_block(FeedBlock *b)
 {
+    drop_early(b, false);
     if (b->in_flight && b->copied) (void)hipEventSynchronize(b->copied);
     if (b->copied) (void)hipEventDestroy(b->copied);
     pool_put(b->text);
@@ -285,6 +325,10 @@ int roll_block(sq_feeder *f, size_t room)
     if (!n) { sq_set_error("out of memory for a staging block"); return SQ_ERR_MEMORY; }
     if (carry) memcpy(n->pin(), o->pin() + f->pos, carry);
     n->used = carry;
+    if (carry && n->d_text && hipMemcpyAsync(n->d_text, n->pin(), carry, hipMemcpyHostToDevice, n->early_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        n->early_bad = true;
+    }
     if (f->has_source) {
         n->reserved = carry;
         if (carry) {   /* what the workers noted of the carried bytes comes along, as one piece */
@@ -357,6 +401,8 @@ SQ_EXPORT void sq_feeder_free(sq_feeder *f)
         for (std::thread &t : f->workers) t.join();
     }
     for (FeedBlock *b : f->blocks) free_block(b);
+    if (f->copy_stream) { (void)hipStreamSynchronize(f->copy_stream); (void)hipStreamDestroy(f->copy_stream); }
+    if (f->copy_done) (void)hipEventDestroy(f->copy_done);
     delete f;
 }
 
@@ -370,6 +416,17 @@ static int feeder_start(sq_feeder *f)
     if (f->has_source || !f->blocks.empty()) { sq_set_error("sq_feeder_set_source: the parser has started already"); return SQ_ERR_VALUE; }
     if (f->read_in >= ((size_t)1 << 30)) { sq_set_error("sq_feeder_set_source: buffers of 1 GiB and more are read by the caller"); return SQ_ERR_VALUE; }
     f->has_source = true;
+    /* with a device: the blocks go up piece by piece as they fill (SQ_FEED_EARLY=0: when they are sealed, as for a
+       caller-fed feeder) */
+    const char *early = getenv("SQ_FEED_EARLY");
+    if (f->ctx && !(early && (early[0] == '0' || early[0] == 0))) {
+        if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&f->copy_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+            f->copy_stream = nullptr;
+        }
+    }
     const unsigned hc = std::thread::hardware_concurrency();
     unsigned n = std::max(1u, std::min(4u, hc > 1 ? hc - 1 : 1u));
     if (f->src_end - f->src_off < ((uint64_t)4 << 20)) n = 1;   /* a few pieces: one worker (a parser over a few records should not start four threads) */
@@ -536,6 +593,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             PinBuf bigger = pool_get(2 * b->meta_cap * sizeof(sq_meta), f->ctx != nullptr);
             if (!bigger.p) { sq_set_error("out of memory for the record table"); f->in_array = false; return SQ_ERR_MEMORY; }
             memcpy(bigger.p, b->meta.p, b->n_records * sizeof(sq_meta));
+            drop_early(b, true);   /* copies may still read the old table, and the one in HBM is as small */
             pool_put(b->meta);
             b->meta = bigger;
             b->meta_cap *= 2;
@@ -557,6 +615,14 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
             f->logical_end = f->pos + f->arr_len;
             f->pos += consumed;
             f->in_array = false;
+            if (b->d_metas && b->n_records - b->metas_sent >= FEED_EARLY_METAS) {   /* the metas of arrays handed out do not change any more */
+                if (hipMemcpyAsync(b->d_metas + b->metas_sent, b->metas() + b->metas_sent, (b->n_records - b->metas_sent) * sizeof(sq_meta),
+                                   hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    b->early_bad = true;
+                }
+                b->metas_sent = b->n_records;
+            }
             return SQ_OK;
         }
     }
@@ -640,16 +706,32 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     /* text and metas from the context's pool (as sq_batch_from_fastq's): a hipMalloc / hipFree pair per block and array was 0.4 ms
        of host time per block, and hipFree waits for the device */
     b->pooled = true;
-    b->d_buf = (uint8_t *)sq_dev_get(ctx, b->buf_len + 64);
-    b->d_metas = b->d_buf ? (sq_meta *)sq_dev_get(ctx, (b->n ? b->n : 1) * sizeof(sq_meta)) : nullptr;
+    const bool early = fb->d_text && !fb->early_bad;
+    size_t metas_there = 0;
+    if (early) {   /* the text is in HBM but for what is still on its way; so are the metas of all but the last arrays */
+        b->d_buf = fb->d_text;
+        fb->d_text = nullptr;
+        if (fb->d_metas) {
+            b->d_metas = fb->d_metas;
+            fb->d_metas = nullptr;
+            metas_there = fb->metas_sent;
+        } else
+            b->d_metas = (sq_meta *)sq_dev_get(ctx, (b->n ? b->n : 1) * sizeof(sq_meta));
+    } else {
+        drop_early(fb, false);
+        b->d_buf = (uint8_t *)sq_dev_get(ctx, b->buf_len + 64);
+        b->d_metas = b->d_buf ? (sq_meta *)sq_dev_get(ctx, (b->n ? b->n : 1) * sizeof(sq_meta)) : nullptr;
+    }
     if (!b->d_buf || !b->d_metas) {
         sq_set_error("sq_feeder_upload: out of device memory");
+        if (early) (void)hipStreamSynchronize(fb->early_stream);
         if (b->d_buf) sq_dev_put(ctx, b->d_buf);
         delete b;
         return nullptr;
     }
     auto fail = [&](const char *what, hipError_t e) -> sq_batch * {
         sq_set_error("sq_feeder_upload: %s: %s", what, hipGetErrorString(e));
+        if (early) (void)hipStreamSynchronize(fb->early_stream);
         (void)hipStreamSynchronize(ctx->stream);   /* nothing may still be writing the blocks that go back */
         if (b->ready) (void)hipEventDestroy(b->ready);
         sq_dev_put(ctx, b->d_buf);
@@ -658,9 +740,16 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
         return nullptr;
     };
     hipError_t e = hipSuccess;
-    if (b->buf_len && (e = hipMemcpyAsync(b->d_buf, fb->pin(), b->buf_len, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("text upload", e);
+    if (early) {
+        if (b->n > metas_there && (e = hipMemcpyAsync(b->d_metas + metas_there, fb->metas() + metas_there, (b->n - metas_there) * sizeof(sq_meta),
+                                                      hipMemcpyHostToDevice, fb->early_stream)) != hipSuccess) return fail("meta upload", e);
+        if ((e = hipEventRecord(f->copy_done, fb->early_stream)) != hipSuccess) return fail("event", e);
+        if ((e = hipStreamWaitEvent(ctx->stream, f->copy_done, 0)) != hipSuccess) return fail("event", e);
+    } else {
+        if (b->buf_len && (e = hipMemcpyAsync(b->d_buf, fb->pin(), b->buf_len, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("text upload", e);
+        if (b->n && (e = hipMemcpyAsync(b->d_metas, fb->metas(), b->n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("meta upload", e);
+    }
     if ((e = hipMemsetAsync(b->d_buf + b->buf_len, 0, 64, ctx->stream)) != hipSuccess) return fail("padding", e);
-    if (b->n && (e = hipMemcpyAsync(b->d_metas, fb->metas(), b->n * sizeof(sq_meta), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("meta upload", e);
     fb->in_flight = true;   /* from here on the pinned block may be read by a copy: free_block waits (for the event, or the stream) */
     if (!fb->copied && (e = hipEventCreateWithFlags(&fb->copied, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
     if ((e = hipEventRecord(fb->copied, ctx->stream)) != hipSuccess) return fail("event", e);

@@ -2197,6 +2197,10 @@ struct sq_qcmetrics {
     struct Seen { uint64_t id; uint64_t max_length; };
     std::vector<Seen> seen;
     uint64_t max_length_flushed = 0;
+    /* sq_qcmetrics_poll: the flag as it was behind the passes queued when the poll was armed */
+    uint64_t *polled = nullptr;     /* page-locked */
+    hipEvent_t poll_event = nullptr;
+    bool poll_armed = false;
 };
 
 struct sq_adaptercounter {
@@ -2279,6 +2283,8 @@ SQ_EXPORT void sq_qcmetrics_free(sq_qcmetrics *m)
 {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->polled) (void)hipHostFree(m->polled);
+    if (m->poll_event) (void)hipEventDestroy(m->poll_event);
     for (void *p : {(void *)m->d_base, (void *)m->d_phred, (void *)m->d_ea_base, (void *)m->d_ea_phred,
                     (void *)m->d_gc, (void *)m->d_ps, (void *)m->d_thr, (void *)m->d_thr_sum, (void *)m->d_first_bad})
         if (p) (void)hipFree(p);
@@ -3366,6 +3372,27 @@ SQ_EXPORT int sq_qcmetrics_flush(sq_qcmetrics *m)
     m->max_length_flushed = m->max_length;
     m->seen.clear();
     return SQ_OK;
+}
+
+/* Without waiting: have the passes that were queued when the poll was armed ended, and with no invalid phred character
+ * flagged?  The first call arms the poll (0); later calls answer 0 (not yet), 1 (yes: the arrays handed in before the
+ * arming call are counted for good, the caller may let go of them; the poll is disarmed) or -1 (a character is flagged:
+ * sq_qcmetrics_flush and what follows it see to that; disarmed).  Nothing else changes: a caller that never polls keeps
+ * its arrays until it flushes, as before. */
+SQ_EXPORT int sq_qcmetrics_poll(sq_qcmetrics *m)
+{
+    sq_ctx *ctx = m->ctx;
+    if (!m->poll_armed) {
+        if (!m->polled && hipHostMalloc((void **)&m->polled, 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); m->polled = nullptr; return 0; }
+        if (!m->poll_event && hipEventCreateWithFlags(&m->poll_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); m->poll_event = nullptr; return 0; }
+        if (hipMemcpyAsync(m->polled, m->d_first_bad, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipEventRecord(m->poll_event, ctx->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        m->poll_armed = true;
+        return 0;
+    }
+    if (hipEventQuery(m->poll_event) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    m->poll_armed = false;
+    return *m->polled == UINT64_MAX ? 1 : -1;
 }
 
 /* index of the first record among [start, end) of b with a quality byte outside 33 .. 126, -1: none */
