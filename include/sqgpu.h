@@ -156,6 +156,9 @@ void sq_route_reset(sq_ctx *ctx);
 /* Diagnostics: seconds the process's feeders have spent moving to a new block, in the record split and in fresh
  * allocations of the page-locked pool, and the number of those allocations (out[0..3]); reset != 0: start again. */
 void sq_feeder_debug_times(double *out, int reset);
+/* ... of feeders that read their source by themselves: seconds the caller's thread waited for text and for the walker,
+ * seconds the walker and (summed) the workers were at work (out[0..3]). */
+void sq_feeder_debug_waits(double *out, int reset);
 /* Diagnostics: the context's pool of device blocks (texts and metas of record arrays): hipMalloc calls, hipFree calls,
  * blocks idle in the pool, blocks of freed arrays still waiting for the kernels queued when they were freed (out[0..3]). */
 void sq_pool_counts(sq_ctx *ctx, uint64_t *out);

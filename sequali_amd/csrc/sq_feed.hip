@@ -48,6 +48,8 @@ std::vector<PinBuf> g_pool;
 /* where the feeder's time goes (scripts/exp_e2e_default_timeline.py): seconds in roll_block, in the record split,
    in fresh allocations of the pool; fresh allocations */
 double g_feed_times[4] = {0, 0, 0, 0};
+/* seconds the caller's thread waited for text and for the walker; seconds the walker and the workers were at work (sq_feeder_debug_waits) */
+std::atomic<uint64_t> g_feed_ns[4];
 inline double feed_now()
 {
     timespec ts;
@@ -115,6 +117,18 @@ struct FeedBlock {
     /* the block's place in HBM, taken when the block is opened (a feeder with a source and a device): every piece goes up
        as soon as its worker has it, the metas every 64 K records, on the feeder's copy stream -- when the block is sealed
        all but its tail is there already (early_bad: a copy failed, sq_feeder_upload sends everything again) */
+    /* the walker (feed_walker): the records of the block's text, split once, ahead of the caller's loop -- metas()[0 ..
+       walk_n) are written, every newline below walk_scanned has been looked at; walk_stopped: it gave up in front of
+       record walk_n, which starts at walk_next (a malformed record, the meta area full): sq_feeder_next splits that window
+       itself.  The stats of the walked records are kept per 4096 of them (the block is sealed behind any record) */
+    std::atomic<size_t> walk_n{0}, walk_scanned{0};
+    std::atomic<bool> walk_stopped{false};
+    std::atomic<uint32_t> high_min{UINT32_MAX};   /* the lowest first_high of the finished pieces */
+    size_t walk_next = 0;
+    struct Chunk { uint64_t s[SQ_STATS_N]; };
+    std::vector<Chunk> chunks;
+    bool walked = false;     /* arrays were handed out from the walker's metas: `stats` does not hold them yet */
+    bool walk_off = false;   /* the caller's thread splits this block's remaining windows itself */
     sq_ctx *ctx = nullptr;
     hipStream_t early_stream = nullptr;
     uint8_t *d_text = nullptr;
@@ -158,6 +172,8 @@ struct sq_feeder {
     std::vector<std::thread> workers;
     int busy = 0;             /* workers copying right now */
     bool stop = false, paused = false;
+    bool walk_on = false;     /* a walker thread splits the records ahead of sq_feeder_next */
+    std::thread walker;
     hipStream_t copy_stream = nullptr;   /* the early uploads (FeedBlock::d_text); null: blocks go up when they are sealed */
     hipEvent_t copy_done = nullptr;
 };
@@ -195,6 +211,7 @@ void feed_worker(sq_feeder *f)
         f->src_off += n;
         f->busy++;
         lk.unlock();
+        const double t_work = feed_now();
         uint8_t *dst = b->pin() + pc->from;
         bool ok = true;
         if (f->src_mem) {
@@ -228,11 +245,13 @@ void feed_worker(sq_feeder *f)
             (void)hipGetLastError();
             sent = false;
         }
+        g_feed_ns[3] += (uint64_t)(1e9 * (feed_now() - t_work));
         lk.lock();
         f->busy--;
         if (!sent) b->early_bad = true;
         if (!ok) f->src_failed = true;
         pc->done = true;
+        if (pc->first_high < b->high_min.load(std::memory_order_relaxed)) b->high_min.store(pc->first_high, std::memory_order_relaxed);
         /* the text is there up to the end of the longest run of finished pieces */
         size_t used = b->used;
         for (FeedBlock::Piece *q : b->pieces) {
@@ -255,6 +274,94 @@ void feed_resume(sq_feeder *f)
 {
     f->paused = false;
     f->cv_work.notify_all();
+    f->cv_data.notify_all();   /* the walker waits there */
+}
+
+constexpr size_t WALK_CHUNK = 4096;   /* records whose stats are kept together */
+
+/* the walker of a feeder with a source: the records of the open block as far as its text is there, in the block's meta
+   area, by the record loop sq_feeder_next itself uses (sq_split_range_indexed over the workers' notes) */
+void feed_walker(sq_feeder *f)
+{
+    std::unique_lock<std::mutex> lk(f->mu);
+    std::vector<SqNlPiece> idx;
+    for (;;) {
+        FeedBlock *b = nullptr;
+        for (;;) {
+            if (f->stop) return;
+            b = f->paused ? nullptr : open_block(f);
+            if (b && !b->walk_off && !b->walk_stopped.load(std::memory_order_relaxed) && b->walk_scanned.load(std::memory_order_relaxed) < b->used) break;
+            f->cv_data.wait(lk);
+        }
+        const size_t upto = b->used;
+        idx.clear();
+        for (const FeedBlock::Piece *q : b->pieces)
+            if (q->done && q->to > b->walk_next && q->from < upto) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->after.data(), q->nl.size(), q->first_high});
+        f->busy++;
+        lk.unlock();
+        const double t_walk = feed_now();
+        size_t n = b->walk_n.load(std::memory_order_relaxed), at = b->walk_next;
+        bool stop = false;
+        for (;;) {
+            const size_t chunk = n / WALK_CHUNK;
+            if (b->chunks.size() <= chunk) b->chunks.resize(chunk + 1, FeedBlock::Chunk{});
+            const size_t cap = std::min(b->meta_cap - n, WALK_CHUNK - n % WALK_CHUNK);
+            if (cap == 0) { stop = true; break; }   /* the meta area is full: the caller's thread makes a bigger one */
+            size_t consumed = 0;
+            const int64_t r = sq_split_range_indexed(b->pin(), at, upto, b->metas() + n, cap, &consumed, b->chunks[chunk].s, (size_t)-1, nullptr,
+                                                     idx.data(), idx.size());
+            if (r < 0) { stop = true; break; }      /* a malformed record: the caller's thread finds it again, with its window */
+            n += (size_t)r;
+            at += consumed;
+            if ((size_t)r < cap) break;             /* what follows is not complete yet */
+        }
+        b->walk_next = at;
+        b->walk_n.store(n, std::memory_order_release);
+        if (stop) b->walk_stopped.store(true, std::memory_order_release);
+        b->walk_scanned.store(upto, std::memory_order_release);
+        g_feed_ns[2] += (uint64_t)(1e9 * (feed_now() - t_walk));
+        lk.lock();
+        f->busy--;
+        f->cv_data.notify_all();
+    }
+}
+
+/* the stats of the block's first n records out of the walker's chunks (the walker is not running) */
+void walk_stats(FeedBlock *b, size_t n)
+{
+    uint64_t *S = b->stats;
+    auto fold = [&](const uint64_t *c) {
+        S[0] += c[0];
+        for (int i = 1; i <= 4; i++) S[i] = std::max(S[i], c[i]);
+        for (int i = 5; i < SQ_STATS_N; i++) S[i] += c[i];
+    };
+    size_t k = 0;
+    for (; (k + 1) * WALK_CHUNK <= n && k < b->chunks.size(); k++) fold(b->chunks[k].s);
+    for (size_t i = k * WALK_CHUNK; i < n; i++) {
+        const sq_meta &m = b->metas()[i];
+        const uint64_t L = m.sequence_length, span = (uint64_t)m.qualities_offset + L;
+        S[0] += L;
+        if (L > S[1]) S[1] = L;
+        if (m.name_length > S[2]) S[2] = m.name_length;
+        if (span > S[3]) S[3] = span;
+        if (~L > S[4]) S[4] = ~L;
+        S[5 + (L < SQ_LEN_BINS - 1 ? L : SQ_LEN_BINS - 1)]++;
+    }
+    b->walked = false;
+}
+
+/* from here on the caller's thread splits the open block's windows itself (the walker stays away from the block) */
+void walk_leave(sq_feeder *f, FeedBlock *b)
+{
+    if (b->walk_off) return;
+    {
+        std::unique_lock<std::mutex> lk(f->mu);
+        const bool was = f->paused;
+        feed_pause(f, lk);
+        b->walk_off = true;
+        if (!was) feed_resume(f);
+    }
+    if (b->walked) walk_stats(b, b->n_records);
 }
 
 FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
@@ -320,6 +427,7 @@ int roll_block(sq_feeder *f, size_t room)
     if (o) {
         o->sealed = true;
         o->sealed_bytes = f->pos;
+        if (o->walked) walk_stats(o, o->n_records);
     }
     FeedBlock *n = new_block(f, carry + room);
     if (!n) { sq_set_error("out of memory for a staging block"); return SQ_ERR_MEMORY; }
@@ -353,9 +461,12 @@ int roll_block(sq_feeder *f, size_t room)
                 const int64_t r = sq_first_non_ascii_fast(n->pin(), pc->first_high);
                 if (r >= 0) pc->first_high = (uint32_t)r;
             }
+            n->high_min.store(pc->first_high, std::memory_order_relaxed);
             n->pieces.push_back(pc);
         }
-    }
+        if (!f->walk_on) n->walk_off = true;
+    } else
+        n->walk_off = true;
     f->logical_end -= o ? f->pos : 0;
     f->pos = 0;
     if (o && o->n_records == 0) {   /* nothing in it: not a block anyone will ask for */
@@ -398,7 +509,9 @@ SQ_EXPORT void sq_feeder_free(sq_feeder *f)
     if (!f->workers.empty()) {
         { std::lock_guard<std::mutex> g(f->mu); f->stop = true; }
         f->cv_work.notify_all();
+        f->cv_data.notify_all();
         for (std::thread &t : f->workers) t.join();
+        if (f->walker.joinable()) f->walker.join();
     }
     for (FeedBlock *b : f->blocks) free_block(b);
     if (f->copy_stream) { (void)hipStreamSynchronize(f->copy_stream); (void)hipStreamDestroy(f->copy_stream); }
@@ -432,6 +545,12 @@ static int feeder_start(sq_feeder *f)
     if (f->src_end - f->src_off < ((uint64_t)4 << 20)) n = 1;   /* a few pieces: one worker (a parser over a few records should not start four threads) */
     if (const char *v = getenv("SQ_FEED_WORKERS")) n = (unsigned)std::max(1, std::min(16, atoi(v)));   /* (experiments) */
     for (unsigned i = 0; i < n; i++) f->workers.emplace_back(feed_worker, f);
+    /* and one more thread splits the records as the text arrives (SQ_FEED_WALKER=0: sq_feeder_next does, window by window) */
+    const char *w = getenv("SQ_FEED_WALKER");
+    if (!(w && (w[0] == '0' || w[0] == 0)) && hc > 2) {
+        f->walk_on = true;
+        f->walker = std::thread(feed_walker, f);
+    }
     return SQ_OK;
 }
 SQ_EXPORT int sq_feeder_set_source_memory(sq_feeder *f, const uint8_t *text, size_t len)
@@ -481,6 +600,10 @@ SQ_EXPORT int sq_feeder_filled(sq_feeder *f, size_t n)
 SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_records, sq_feed_array *out)
 {
     FeedBlock *b = open_block(f);
+    if (f->walk_on && (min_records > 1 || max_records < ((size_t)1 << 62))) {   /* (__next__ asks for 1 .. 2^63 - 1 or SIZE_MAX records: all a window holds) */   /* FastqParser.read(n): the caller's thread splits from here on */
+        { std::lock_guard<std::mutex> g(f->mu); f->walk_on = false; }
+        if (b) walk_leave(f, b);
+    }
     if (!b) {
         if (roll_block(f, f->read_in) != SQ_OK) return SQ_ERR_MEMORY;
         b = open_block(f);
@@ -504,7 +627,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         const size_t want = f->first ? (f->read_in > f->arr_len ? f->read_in - f->arr_len : 0) : f->read_in;
         if (want > 0) {
             size_t used_now = b->used;
-            if (f->has_source) {   /* the workers bring the bytes: wait until this read's are there, the source is exhausted or the block is full */
+            if (f->has_source && !b->walk_off && b->walk_scanned.load(std::memory_order_acquire) >= f->pos + f->arr_len + want) {
+                used_now = b->walk_scanned.load(std::memory_order_acquire);   /* the walker has been through this read's bytes: they are there */
+            } else if (f->has_source) {   /* the workers bring the bytes: wait until this read's are there, the source is exhausted or the block is full */
                 std::unique_lock<std::mutex> lk(f->mu);
                 const size_t upto = f->pos + f->arr_len + want;
                 for (;;) {
@@ -518,7 +643,9 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                     if (drained) f->file_eof = true;
                     if (used_now >= upto || drained || (b->reserved >= b->cap && f->busy == 0 && b->used == b->reserved)) break;
                     f->cv_work.notify_all();
+                    const double t_wait = feed_now();
                     f->cv_data.wait(lk);
+                    g_feed_ns[0] += (uint64_t)(1e9 * (feed_now() - t_wait));
                 }
             }
             const size_t have = used_now - (f->pos + f->arr_len);
@@ -567,9 +694,45 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
            round's metas are overwritten with the same values) */
         b->n_records = f->arr_first_record;
         size_t consumed = 0;
-        int64_t n;
+        int64_t n = 0;
         uint64_t stats[SQ_STATS_N];
-        for (;;) {
+        bool from_walker = false;
+        if (!b->walk_off) {   /* the walker's records that end inside the window */
+            const size_t wend = f->pos + f->arr_len;
+            auto there = [&]() { return b->walk_stopped.load(std::memory_order_acquire) || b->walk_scanned.load(std::memory_order_acquire) >= wend; };
+            if (!there()) {
+                std::unique_lock<std::mutex> lk(f->mu);
+                const double t_wait = feed_now();
+                while (!there()) f->cv_data.wait(lk);
+                g_feed_ns[1] += (uint64_t)(1e9 * (feed_now() - t_wait));
+            }
+            const bool stopped = b->walk_stopped.load(std::memory_order_acquire);
+            const size_t wn = b->walk_n.load(std::memory_order_acquire), lo = b->n_records;
+            const sq_meta *M = b->metas();
+            auto ends_inside = [&](size_t k) { return M[k].record_start + M[k].tags_offset < wend; };   /* its fourth newline */
+            size_t a = lo, z = wn, step = 512;   /* the records in front of a end inside, record z does not (or is not there) */
+            while (a < z) {
+                const size_t probe = std::min(z - 1, a + step - 1);
+                if (ends_inside(probe)) { a = probe + 1; step *= 2; }
+                else { z = probe; break; }
+            }
+            while (a < z) {
+                const size_t mid = a + (z - a) / 2;
+                if (ends_inside(mid)) a = mid + 1; else z = mid;
+            }
+            /* what the record loop over this window would do that the walker's records do not tell: raise for a byte >= 0x80
+               among the new bytes; look at the record the walker gave up on.  Then it runs (and the block is its from here on) */
+            bool leave = fresh_from != (size_t)-1 && b->high_min.load(std::memory_order_relaxed) < wend;
+            if (stopped && a == wn && b->walk_next + 2 < wend) leave = true;
+            if (leave)
+                walk_leave(f, b);
+            else {
+                n = (int64_t)(a - lo);
+                consumed = n ? (size_t)(M[a - 1].record_start + M[a - 1].tags_offset + 1) - f->pos : 0;
+                from_walker = true;
+            }
+        }
+        while (!from_walker) {
             const size_t cap = std::min(b->meta_cap - b->n_records, max_records);
             memcpy(stats, b->stats, sizeof stats);
             int64_t bad = -1;
@@ -605,7 +768,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
                 f->in_array = false;
                 return SQ_ERR_EOF;
             }
-            memcpy(b->stats, stats, sizeof stats);
+            if (from_walker) b->walked = true; else memcpy(b->stats, stats, sizeof stats);
             out->block_id = b->id;
             out->byte_start = f->pos;
             out->byte_len = f->arr_len;
@@ -763,6 +926,11 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
 SQ_EXPORT void sq_feeder_debug_times(double *out, int reset)
 {
     for (int i = 0; i < 4; i++) { out[i] = g_feed_times[i]; if (reset) g_feed_times[i] = 0; }
+}
+
+SQ_EXPORT void sq_feeder_debug_waits(double *out, int reset)
+{
+    for (int i = 0; i < 4; i++) { out[i] = 1e-9 * (double)g_feed_ns[i].load(); if (reset) g_feed_ns[i] = 0; }
 }
 
 SQ_EXPORT void sq_feeder_release(sq_feeder *f, uint64_t block_id)

@@ -126,3 +126,60 @@ def test_a_parser_dropped_in_the_middle_of_its_file():
         p = FastqParser(io.BytesIO(text), 128 * 1024)
         assert len(next(p)) > 0
         del p
+
+
+# -- the walker (feed_walker, csrc/sq_feed.hip): one more thread splits the records as the text arrives and sq_feeder_next
+# hands out the ones that end inside its window; the window's own record loop runs where the walker cannot answer
+
+def test_tiny_records_fill_the_meta_area_in_front_of_the_text():
+    """records of 10 bytes: a block's meta area (one meta per 96 bytes of text) is full long before its text is -- the walker
+    stops there, the caller's thread makes a bigger one and goes on"""
+    text = b"@a\nA\n+\nI\n" * 400_000
+    for buffersize in (128 * 1024, 1 << 20):
+        got = _arrays(io.BytesIO(text), buffersize)
+        assert got == _arrays(Fed(text), buffersize)
+        assert sum(n for n, _, _ in got) == 400_000
+
+
+@pytest.mark.parametrize("what", ["no_at", "no_plus", "lengths", "non_ascii"])
+def test_a_damaged_record_at_every_place_of_a_window(what):
+    """the damaged record slides through the windows of a small buffer (its start, its `+`, its end on either side of a
+    window's end), in the first window and far behind it"""
+    rng = np.random.default_rng(61)
+    breaks = {"no_at": lambda r: b"X" + r[1:], "no_plus": lambda r: r.replace(b"\n+\n", b"\n-\n", 1),
+              "lengths": lambda r: r[:-2] + b"\n", "non_ascii": lambda r: r[:-3] + b"\xc3" + r[-2:]}
+    for bad in list(range(0, 12)) + list(range(3000, 3040, 3)):
+        text = _text(rng, 3100, 60, bad=(bad, breaks[what]))
+        for buffersize in (700, 4096):
+            assert _arrays(io.BytesIO(text), buffersize) == _arrays(Fed(text), buffersize), (bad, buffersize)
+
+
+def test_read_n_in_the_middle_of_an_iteration():
+    """FastqParser.read(n) asks for record counts the walker's windows do not know: the caller's thread takes over, in the
+    middle of a block, and the arrays stay those of the fed parser"""
+    rng = np.random.default_rng(71)
+    text = _text(rng, 40_000, 200)
+
+    def mixed(fileobj):
+        p = FastqParser(fileobj, 64 * 1024)
+        out = []
+        for _ in range(20):
+            a = next(p)
+            out.append((len(a), bytes(a.obj), a._metas.tobytes()))
+        for k in (3, 1000, 1):
+            a = p.read(k)
+            out.append((len(a), bytes(a.obj), a._metas.tobytes()))
+        out.extend((len(a), bytes(a.obj), a._metas.tobytes()) for a in p)
+        return out
+
+    assert mixed(io.BytesIO(text)) == mixed(Fed(text))
+
+
+@pytest.mark.parametrize("walker", ["0", "1"])
+def test_with_and_without_the_walker(monkeypatch, walker):
+    monkeypatch.setenv("SQ_FEED_WALKER", walker)
+    rng = np.random.default_rng(81)
+    text = _text(rng, 50_000, 300)
+    assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
+    text = _text(rng, 20_000, 300, bad=(15_000, lambda r: r.replace(b"\n+\n", b"\n-\n", 1)))
+    assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
