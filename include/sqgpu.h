@@ -138,6 +138,9 @@ uint64_t sq_feeder_block_bytes(sq_feeder *f, uint64_t block_id);
 int sq_feeder_block_is_open(sq_feeder *f, uint64_t block_id);
 /* a sealed block as a record array in HBM (one async copy from pinned memory); NULL on failure */
 sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id);
+/* a feeder that reads its source by itself: the blocks will be asked for in HBM -- from the open one on they go up while they
+ * fill (without the call the first sq_feeder_upload says so; a parser that is only iterated uploads nothing) */
+int sq_feeder_expect_uploads(sq_feeder *f);
 /* the host copy of a sealed block is no longer needed */
 void sq_feeder_release(sq_feeder *f, uint64_t block_id);
 

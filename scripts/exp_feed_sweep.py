@@ -47,7 +47,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"{kind} {times[0]:.1f} / {times[2]:.1f} (per pass: waits for text {200 * w[0]:.1f} for the walker {200 * w[1]:.1f}, walker busy {200 * w[2]:.1f}, workers {200 * w[3]:.1f})")
     print(f"workers {os.environ.get('SQ_FEED_WORKERS', 'default')} walker {os.environ.get('SQ_FEED_WALKER', 'default')}: ms per 2 M reads (best / median of 5): " + ", ".join(out), flush=True)
 else:
-    for workers in ("4", "8"):
+    for workers in (sys.argv[1:] or ["4"]):
         for walker in ("1", "0"):
             env = dict(os.environ, SQ_FEED_WORKERS=workers, SQ_FEED_WALKER=walker)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)

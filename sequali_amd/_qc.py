@@ -429,7 +429,12 @@ class _Block:
             v._metas = self.array._metas[r0:r1] if self.array._metas is not None else None
             v._parent = parent          # the memory belongs to the block's batch
             v._blk, v._blk_r0 = getattr(self.array, "_blk", None), r0    # (a weak reference: see seal)
-        v._children = self._children_of(s0, s1)
+        # (one list per stretch: the block is sealed, and every module of a driver loop asks for the same stretch)
+        cache = self.__dict__.setdefault("_children_lists", {})
+        children = cache.get((s0, s1))
+        if children is None:
+            children = cache[(s0, s1)] = self._children_of(s0, s1)
+        v._children = children
         return v
 
 
@@ -460,6 +465,7 @@ class _Feeder:
             raise MemoryError(_lib.last_error())
         self.source = None     # what the feeder's workers read from (kept alive until they have stopped: __del__)
         self.sealed: List[int] = []
+        self.expects = False   # sq_feeder_expect_uploads has been called
         _LIVE_FEEDERS.add(self)
 
     def __del__(self):
@@ -470,6 +476,11 @@ class _Feeder:
             pass
         self.h = None
         self.source = None
+
+    def expect_uploads(self) -> None:
+        self.expects = True
+        if self.h:
+            lib().sq_feeder_expect_uploads(self.h)
 
     def retire(self, blk: "_FeedBlock") -> None:
         """a block has been closed: the oldest pinned copies go back to the pool.  A block that somebody
@@ -715,6 +726,8 @@ class _Deferring:
                 if last[0] is blk and last[2] == slot and len(last) == 3:
                     last[2] = slot + 1   # the block's writers are known, nothing has been sealed since the last call
                     return True
+            if not blk.feeder.expects:   # a module takes the parser's arrays: its blocks go to HBM while they fill
+                blk.feeder.expect_uploads()
         elif not self._small(arr):
             self._drain()
             return False
@@ -813,6 +826,24 @@ class _Deferring:
             q = w()
             if q is not None and q is not self:
                 q._drain(through=blk)
+
+
+class _DeferringArrays(_Deferring):
+    """... of a module that takes single record arrays"""
+
+    def add_record_array(self, record_array: "FastqRecordArrayView") -> None:
+        """add_record_array of every module (QCMetrics_add_record_array :2183 and its siblings)"""
+        if type(record_array) is _FedArray:     # the driver loop's case, without a call: the next array of the parser's open block
+            t = self._todo
+            if t:
+                last = t[-1]
+                blk, slot = record_array._staged
+                if last[0] is blk and last[2] == slot and len(last) == 3:
+                    last[2] = slot + 1
+                    return
+        arr = _require_array(record_array)
+        if not self._enqueue(arr):
+            self._run(arr)
 
 
 class _HostBuffer:
@@ -1222,7 +1253,7 @@ def _u64_array(fn, handle, n_hint: Optional[int] = None) -> array.array:
     return a
 
 
-class QCMetrics(_Deferring):
+class QCMetrics(_DeferringArrays):
     """_qcmodule.c:1786-2385"""
 
     def __init__(self, end_anchor_length: int = DEFAULT_END_ANCHOR_LENGTH):
@@ -1242,11 +1273,6 @@ class QCMetrics(_Deferring):
                 lib().sq_qcmetrics_free(self._handle)
         except Exception:
             pass
-
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
 
     def _staged_in(self, blk, arr) -> None:
         arr._writeback = weakref.ref(self)
@@ -1392,7 +1418,7 @@ class QCMetrics(_Deferring):
         return self._table(lib().sq_qcmetrics_phred_scores)
 
 
-class AdapterCounter(_Deferring):
+class AdapterCounter(_DeferringArrays):
     """_qcmodule.c:2391-2969"""
 
     def __init__(self, adapters: Iterable[str]):
@@ -1428,11 +1454,6 @@ class AdapterCounter(_Deferring):
         except Exception:
             pass
 
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
-
     def _run(self, arr: FastqRecordArrayView) -> None:
         check(lib().sq_adaptercounter_add_batch(self._handle, arr._device().handle))
 
@@ -1464,7 +1485,7 @@ class AdapterCounter(_Deferring):
         return out
 
 
-class PerTileQuality(_Deferring):
+class PerTileQuality(_DeferringArrays):
     """_qcmodule.c:2975-3397"""
 
     def __init__(self):
@@ -1525,7 +1546,7 @@ class PerTileQuality(_Deferring):
         return [(int(ids[i]), err[i].tolist(), [int(x) for x in cnt[i]]) for i in range(nt)]
 
 
-class FusedPass(_Deferring):
+class FusedPass(_DeferringArrays):
     """One pass over each record array for any of QCMetrics / AdapterCounter /
     PerTileQuality (sq_fused_add_batch): the same results as calling the three
     add_record_array methods in turn, with the records read from HBM once."""
@@ -1540,11 +1561,6 @@ class FusedPass(_Deferring):
         for mod in (qc_metrics, adapter_counter, per_tile_quality):
             if mod is not None:
                 mod._upstream.append(self)   # the module's getters run this pass first
-
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
 
     def _staged_in(self, blk, arr) -> None:
         if self.qc_metrics is not None:
@@ -1628,7 +1644,7 @@ def _kmer_to_sequence(kmer: int, k: int) -> str:
     return "".join("ACGT"[(kmer >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
-class OverrepresentedSequences(_Deferring):
+class OverrepresentedSequences(_DeferringArrays):
     """_qcmodule.c:3435-4236"""
 
     def __init__(self, max_unique_fragments: int = DEFAULT_MAX_UNIQUE_FRAGMENTS,
@@ -1659,11 +1675,6 @@ class OverrepresentedSequences(_Deferring):
                 lib().sq_overrep_free(self._handle)
         except Exception:
             pass
-
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
 
     def _run(self, arr: FastqRecordArrayView) -> None:
         before = self._first_record + lib().sq_overrep_number_of_sequences(self._handle)
@@ -1737,7 +1748,7 @@ class OverrepresentedSequences(_Deferring):
         return res
 
 
-class DedupEstimator(_Deferring):
+class DedupEstimator(_DeferringArrays):
     """_qcmodule.c:4270-4802"""
 
     def __init__(self, max_stored_fingerprints: int = DEFAULT_DEDUP_MAX_STORED_FINGERPRINTS, *,
@@ -1767,11 +1778,6 @@ class DedupEstimator(_Deferring):
         """Shard of a multi-rank job: only hash now, insert when the shard in front is done
         (sequali_amd.dist.merge_dedup)."""
         check(lib().sq_dedup_set_deferred(self._h, 1 if on else 0))
-
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
 
     def _run(self, arr: FastqRecordArrayView) -> None:
         check(lib().sq_dedup_add_batch(self._handle, arr._device().handle))
@@ -1911,7 +1917,7 @@ class NanoporeReadInfo:
         self.parent_id_hash = int(rec["parent_id_hash"])
 
 
-class NanoStats(_Deferring):
+class NanoStats(_DeferringArrays):
     """_qcmodule.c:4874-5430: per read start time, channel, duration, length,
     summed error rate and parent id hash, from the BAM tags when the record has any, else
     from the nanopore FASTQ header.  Reads FastqMeta.accumulated_error_rate where the
@@ -1930,11 +1936,6 @@ class NanoStats(_Deferring):
                 lib().sq_nanostats_free(self._handle)
         except Exception:
             pass
-
-    def add_record_array(self, record_array: FastqRecordArrayView) -> None:
-        arr = _require_array(record_array)
-        if not self._enqueue(arr):
-            self._run(arr)
 
     def _run(self, arr: FastqRecordArrayView) -> None:
         # the array's QCMetrics pass, if it has one enqueued, must have left accumulated_error_rate

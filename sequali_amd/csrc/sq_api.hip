@@ -96,6 +96,7 @@ SQ_EXPORT void sq_shutdown(sq_ctx *ctx)
     }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
+    if (ctx->feed_stream) { (void)hipStreamSynchronize(ctx->feed_stream); (void)hipStreamDestroy(ctx->feed_stream); }
     if (ctx->copied) (void)hipEventDestroy(ctx->copied);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_stats) (void)hipHostFree(ctx->pinned_stats);

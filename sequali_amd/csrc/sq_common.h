@@ -112,6 +112,7 @@ struct sq_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   /* uploads of FASTQ text (sq_batch_from_fastq): they run beside the counting of the batch before */
     hipEvent_t copied = nullptr;
+    hipStream_t feed_stream = nullptr;   /* the feeders' early uploads of their staging blocks (sq_feed.hip; made when the first one asks) */
     hipStream_t prep_stream = nullptr;   /* PerTileQuality's pass over the headers (tile ids, table slots): it runs beside the counting of the batch before */
     int num_cus = 256;
     /* small pinned scratch for scalar read-backs */

@@ -132,6 +132,7 @@ struct FeedBlock {
     sq_ctx *ctx = nullptr;
     hipStream_t early_stream = nullptr;
     uint8_t *d_text = nullptr;
+    size_t sent_to = 0;      /* the walker sends: the text in front of this offset is on its way (it belongs to the walker while the block is open) */
     sq_meta *d_metas = nullptr;
     size_t metas_sent = 0;
     std::atomic<bool> early_bad{false};
@@ -176,6 +177,8 @@ struct sq_feeder {
     std::thread walker;
     hipStream_t copy_stream = nullptr;   /* the early uploads (FeedBlock::d_text); null: blocks go up when they are sealed */
     hipEvent_t copy_done = nullptr;
+    bool want_early = false;    /* somebody will ask for the blocks in HBM (sq_feeder_expect_uploads, or the first sq_feeder_upload): a parser that is only iterated uploads nothing */
+    bool walker_sends = false;  /* the walker issues the early copies, stretch by stretch as the text arrives (else the workers, piece by piece) */
 };
 
 namespace {
@@ -210,6 +213,7 @@ void feed_worker(sq_feeder *f)
         const uint64_t at = f->src_off;
         f->src_off += n;
         f->busy++;
+        uint8_t *const d_text = f->walker_sends ? nullptr : b->d_text;
         lk.unlock();
         const double t_work = feed_now();
         uint8_t *dst = b->pin() + pc->from;
@@ -241,7 +245,7 @@ void feed_worker(sq_feeder *f)
             for (size_t i = 0; i < pc->nl.size(); i++) pc->after[i] = (size_t)pc->nl[i] + 1 < pc->to ? text[pc->nl[i] + 1] : 0;
         }
         bool sent = true;
-        if (ok && b->d_text && hipMemcpyAsync(b->d_text + pc->from, dst, n, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
+        if (ok && d_text && hipMemcpyAsync(d_text + pc->from, dst, n, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
             (void)hipGetLastError();
             sent = false;
         }
@@ -283,22 +287,43 @@ constexpr size_t WALK_CHUNK = 4096;   /* records whose stats are kept together *
    area, by the record loop sq_feeder_next itself uses (sq_split_range_indexed over the workers' notes) */
 void feed_walker(sq_feeder *f)
 {
+    if (f->copy_stream) (void)hipSetDevice(f->ctx->device);
     std::unique_lock<std::mutex> lk(f->mu);
     std::vector<SqNlPiece> idx;
     for (;;) {
         FeedBlock *b = nullptr;
+        bool walk = false, send = false;
         for (;;) {
             if (f->stop) return;
             b = f->paused ? nullptr : open_block(f);
-            if (b && !b->walk_off && !b->walk_stopped.load(std::memory_order_relaxed) && b->walk_scanned.load(std::memory_order_relaxed) < b->used) break;
+            if (b) {
+                walk = !b->walk_off && !b->walk_stopped.load(std::memory_order_relaxed) && b->walk_scanned.load(std::memory_order_relaxed) < b->used;
+                send = f->walker_sends && b->d_text && !b->early_bad && b->sent_to < b->used;
+                if (walk || send) break;
+            }
             f->cv_data.wait(lk);
         }
         const size_t upto = b->used;
         idx.clear();
-        for (const FeedBlock::Piece *q : b->pieces)
-            if (q->done && q->to > b->walk_next && q->from < upto) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->after.data(), q->nl.size(), q->first_high});
+        if (walk)
+            for (const FeedBlock::Piece *q : b->pieces)
+                if (q->done && q->to > b->walk_next && q->from < upto) idx.push_back(SqNlPiece{q->from, q->to, q->nl.data(), q->after.data(), q->nl.size(), q->first_high});
+        uint8_t *const d_text = b->d_text;
         f->busy++;
         lk.unlock();
+        if (send) {   /* first: the copy runs while the records are split */
+            if (hipMemcpyAsync(d_text + b->sent_to, b->pin() + b->sent_to, upto - b->sent_to, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                b->early_bad = true;
+            }
+            b->sent_to = upto;
+        }
+        if (!walk) {
+            lk.lock();
+            f->busy--;
+            f->cv_data.notify_all();
+            continue;
+        }
         const double t_walk = feed_now();
         size_t n = b->walk_n.load(std::memory_order_relaxed), at = b->walk_next;
         bool stop = false;
@@ -364,6 +389,14 @@ void walk_leave(sq_feeder *f, FeedBlock *b)
     if (b->walked) walk_stats(b, b->n_records);
 }
 
+/* the block's place in HBM (the caller's thread; the workers and the walker see it under the feeder's lock) */
+void early_place(sq_feeder *f, FeedBlock *b)
+{
+    if (b->d_text || b->early_bad) return;
+    b->d_text = (uint8_t *)sq_dev_get(f->ctx, b->cap + 64);
+    b->d_metas = b->d_text ? (sq_meta *)sq_dev_get(f->ctx, b->meta_cap * sizeof(sq_meta)) : nullptr;   /* neither there: the block goes up when it is sealed */
+}
+
 FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
 {
     /* the first block is small: a parser over a few records should not lock 64 MiB of pages */
@@ -381,8 +414,7 @@ FeedBlock *new_block(sq_feeder *f, size_t min_bytes)
     if (f->copy_stream) {
         b->ctx = f->ctx;
         b->early_stream = f->copy_stream;
-        b->d_text = (uint8_t *)sq_dev_get(f->ctx, cap + 64);
-        b->d_metas = b->d_text ? (sq_meta *)sq_dev_get(f->ctx, b->meta_cap * sizeof(sq_meta)) : nullptr;   /* neither there: the block goes up when it is sealed */
+        if (f->want_early) early_place(f, b);
     }
     f->blocks.push_back(b);
     return b;
@@ -433,7 +465,7 @@ int roll_block(sq_feeder *f, size_t room)
     if (!n) { sq_set_error("out of memory for a staging block"); return SQ_ERR_MEMORY; }
     if (carry) memcpy(n->pin(), o->pin() + f->pos, carry);
     n->used = carry;
-    if (carry && n->d_text && hipMemcpyAsync(n->d_text, n->pin(), carry, hipMemcpyHostToDevice, n->early_stream) != hipSuccess) {
+    if (carry && n->d_text && !f->walker_sends && hipMemcpyAsync(n->d_text, n->pin(), carry, hipMemcpyHostToDevice, n->early_stream) != hipSuccess) {
         (void)hipGetLastError();
         n->early_bad = true;
     }
@@ -514,7 +546,6 @@ SQ_EXPORT void sq_feeder_free(sq_feeder *f)
         if (f->walker.joinable()) f->walker.join();
     }
     for (FeedBlock *b : f->blocks) free_block(b);
-    if (f->copy_stream) { (void)hipStreamSynchronize(f->copy_stream); (void)hipStreamDestroy(f->copy_stream); }
     if (f->copy_done) (void)hipEventDestroy(f->copy_done);
     delete f;
 }
@@ -533,12 +564,15 @@ static int feeder_start(sq_feeder *f)
        caller-fed feeder) */
     const char *early = getenv("SQ_FEED_EARLY");
     if (f->ctx && !(early && (early[0] == '0' || early[0] == 0))) {
-        if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&f->copy_done, hipEventDisableTiming) != hipSuccess) {
+        /* one stream for the feeders of a context (making one takes a millisecond or two: per parser that showed) */
+        if (!f->ctx->feed_stream && hipStreamCreateWithFlags(&f->ctx->feed_stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
-            if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
-            f->copy_stream = nullptr;
+            f->ctx->feed_stream = nullptr;
         }
+        if (f->ctx->feed_stream && hipEventCreateWithFlags(&f->copy_done, hipEventDisableTiming) == hipSuccess)
+            f->copy_stream = f->ctx->feed_stream;
+        else
+            (void)hipGetLastError();
     }
     const unsigned hc = std::thread::hardware_concurrency();
     unsigned n = std::max(1u, std::min(4u, hc > 1 ? hc - 1 : 1u));
@@ -549,6 +583,7 @@ static int feeder_start(sq_feeder *f)
     const char *w = getenv("SQ_FEED_WALKER");
     if (!(w && (w[0] == '0' || w[0] == 0)) && hc > 2) {
         f->walk_on = true;
+        f->walker_sends = f->copy_stream != nullptr;
         f->walker = std::thread(feed_walker, f);
     }
     return SQ_OK;
@@ -844,6 +879,26 @@ SQ_EXPORT int sq_feeder_block_is_open(sq_feeder *f, uint64_t block_id)
     return b && !b->sealed;
 }
 
+/* The caller will ask for the parser's blocks in HBM (sq_feeder_upload): from the open block on they go up while they fill.
+ * Without this call the first upload says so; a parser that is only iterated uploads nothing. */
+SQ_EXPORT int sq_feeder_expect_uploads(sq_feeder *f)
+{
+    if (f->want_early || !f->copy_stream) return SQ_OK;
+    std::unique_lock<std::mutex> lk(f->mu);
+    f->want_early = true;
+    FeedBlock *b = open_block(f);
+    if (!b) return SQ_OK;
+    feed_pause(f, lk);
+    early_place(f, b);
+    if (b->d_text && !f->walker_sends && b->used &&
+        hipMemcpyAsync(b->d_text, b->pin(), b->used, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {   /* what the workers brought before */
+        (void)hipGetLastError();
+        b->early_bad = true;
+    }
+    feed_resume(f);
+    return SQ_OK;
+}
+
 /* A sealed block as a record array in HBM: one asynchronous copy of its text and one of its
  * metas from pinned memory on the context's stream (add_record_array's staging copy, SURVEY 8b
  * "ownership": the caller's array is borrowed for the call only; here the block IS the copy). */
@@ -854,6 +909,7 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     if (!fb->sealed) { sq_set_error("sq_feeder_upload: block %llu is still open", (unsigned long long)block_id); return nullptr; }
     if (!f->ctx) { sq_set_error("sq_feeder_upload: the parser was made without a device context"); return nullptr; }
     sq_ctx *ctx = f->ctx;
+    if (!f->want_early) (void)sq_feeder_expect_uploads(f);
     sq_batch *b = new sq_batch();
     b->ctx = ctx;
     b->buf_len = fb->sealed_bytes;
@@ -904,6 +960,9 @@ SQ_EXPORT sq_batch *sq_feeder_upload(sq_feeder *f, uint64_t block_id)
     };
     hipError_t e = hipSuccess;
     if (early) {
+        const size_t sent = f->walker_sends ? std::min(fb->sent_to, b->buf_len) : b->buf_len;   /* (the walker is at the next block) */
+        if (sent < b->buf_len && (e = hipMemcpyAsync(b->d_buf + sent, fb->pin() + sent, b->buf_len - sent, hipMemcpyHostToDevice, fb->early_stream)) != hipSuccess)
+            return fail("text upload", e);
         if (b->n > metas_there && (e = hipMemcpyAsync(b->d_metas + metas_there, fb->metas() + metas_there, (b->n - metas_there) * sizeof(sq_meta),
                                                       hipMemcpyHostToDevice, fb->early_stream)) != hipSuccess) return fail("meta upload", e);
         if ((e = hipEventRecord(f->copy_done, fb->early_stream)) != hipSuccess) return fail("event", e);
