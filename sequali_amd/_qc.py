@@ -746,6 +746,10 @@ class _Deferring:
             self._drain()
             return False
         (b1, s1), (b2, s2) = _stage(a1), _stage(a2)
+        for b in (b1, b2):
+            f = getattr(b, "feeder", None)
+            if f is not None and not f.expects:   # the parsers' blocks go to HBM while they fill
+                f.expect_uploads()
         t = self._todo
         if t and len(t[-1]) == 6 and t[-1][0] is b1 and t[-1][2] == s1 and t[-1][3] is b2 and t[-1][5] == s2:
             t[-1][2], t[-1][5] = s1 + 1, s2 + 1

@@ -247,3 +247,109 @@ def test_batches_of_one_block_run_in_call_order():
             np.testing.assert_allclose(np.array(e), er, rtol=1e-6)
     assert got[3].number_of_reads == ref[3].number_of_reads == n
     np.testing.assert_array_equal(np.array(fq.phred_scores(), np.uint64), ref[0].phred_scores())
+
+
+def _pool_counts():
+    import ctypes as C
+    from sequali_amd import _lib
+    out = (C.c_uint64 * 4)()
+    _lib.lib().sq_pool_counts(_lib.context(), out)
+    return list(out)
+
+
+def test_a_second_pass_over_a_file_allocates_no_device_memory_and_qcmetrics_holds_few_blocks(monkeypatch):
+    """Round 6: every staging block of a file used to be a fresh hipMalloc -- the context's pool was full of sizes nobody asked
+    for, and QCMetrics kept every block's copy in HBM until its flush (an invalid phred character is only found there).  Now
+    the pool evicts what has lain longest, freed arrays hand their blocks back behind an event, and QCMetrics finds out
+    without waiting which passes have ended clean (sq_qcmetrics_poll).  Small blocks so that a small file has many."""
+    from sequali_amd import AdapterCounter, FastqParser, FusedPass, QCMetrics, _qc, synth
+    monkeypatch.setattr(_qc, "_STAGE_LIMIT", 1 << 20)
+    n = 60_000
+    text = synth.illumina_fastq(0, n)
+    buf, metas = split_fastq(text)
+    want = oracle.QCMetrics()
+    want.add(buf, metas)
+    for rep in range(3):
+        before = _pool_counts()
+        blocks = _qc.staging_stats["blocks"]
+        q = QCMetrics()
+        f = FusedPass(q, AdapterCounter(list(synth.ILLUMINA_PROBES)), None)
+        held = 0
+        for a in FastqParser(io.BytesIO(text)):
+            f.add_record_array(a)
+            held = max(held, len(q._pending))
+        np.testing.assert_array_equal(u64(q.base_count_table()), want.base_count_table())
+        np.testing.assert_array_equal(u64(q.phred_count_table()), want.phred_count_table())
+        assert _qc.staging_stats["blocks"] - blocks >= 15
+        assert held <= 6, f"QCMetrics held {held} staging blocks' arrays"
+        del q, f, a
+        after = _pool_counts()
+        if rep:
+            assert after[0] == before[0], f"pass {rep}: {after[0] - before[0]} hipMalloc calls"
+            assert after[1] - before[1] <= 4, f"pass {rep}: {after[1] - before[1]} hipFree calls"    # (stale sizes leave the pool)
+
+
+def test_an_invalid_phred_character_behind_blocks_that_were_let_go(monkeypatch):
+    """the arrays in front of the offending block have been let go of by then (sq_qcmetrics_poll); the flush still raises, and
+    the tables are the reference's behind the call that raised (:2102-2105)"""
+    from sequali_amd import FastqParser, QCMetrics, _qc, synth
+    monkeypatch.setattr(_qc, "_STAGE_LIMIT", 1 << 20)
+    n = 40_000
+    text = bytearray(synth.illumina_fastq(0, n))
+    buf, metas = split_fastq(bytes(text))
+    bad = 33_333
+    at = int(metas["record_start"][bad]) + int(metas["qualities_offset"][bad]) + 7
+    text[at] = 0x1F            # not a phred character
+    buf, metas = split_fastq(bytes(text))
+    q = QCMetrics()
+    arrays = []
+    with pytest.raises(ValueError, match="Not a valid phred character"):
+        for a in FastqParser(io.BytesIO(bytes(text))):
+            arrays.append(len(a))
+            q.add_record_array(a)
+        q.flush()
+    # the reference raises inside the offender's call: that array counted up to the read in front of it, the offender's bases
+    # and the phreds in front of the character (:2102-2105).  Here the error is found at the flush, so the caller's loop has
+    # handed in the arrays behind it too: a caller of the reference who caught the exception and went on
+    want = oracle.QCMetrics()
+    first, raised = 0, 0
+    for k in arrays:
+        try:
+            want.add(buf, metas[first:first + k])
+        except ValueError:
+            raised += 1
+        first += k
+    assert raised == 1
+    assert q.number_of_reads == want.number_of_reads
+    np.testing.assert_array_equal(u64(q.base_count_table()), want.base_count_table())
+    np.testing.assert_array_equal(u64(q.phred_count_table()), want.phred_count_table())
+
+
+@pytest.mark.parametrize("early,walker", [("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")])
+def test_blocks_sent_while_they_fill_and_when_they_are_sealed(monkeypatch, early, walker):
+    """the four ways a staging block reaches HBM (by the walker as the text arrives, by the workers piece by piece, with one
+    copy when it is sealed; records split by the walker or window by window): the same tables"""
+    from sequali_amd import AdapterCounter, FastqParser, FusedPass, PerTileQuality, QCMetrics, _qc, synth
+    monkeypatch.setenv("SQ_FEED_EARLY", early)
+    monkeypatch.setenv("SQ_FEED_WALKER", walker)
+    monkeypatch.setattr(_qc, "_STAGE_LIMIT", 3 << 20)
+    n = 50_000
+    text = synth.illumina_fastq(0, n)
+    buf, metas = split_fastq(text)
+    rq, rp = oracle.QCMetrics(), oracle.PerTileQuality()
+    rq.add(buf, metas)
+    rp.add(buf, metas)
+    q, p = QCMetrics(), PerTileQuality()
+    f = FusedPass(q, AdapterCounter(list(synth.ILLUMINA_PROBES)), p)
+    for i, a in enumerate(FastqParser(io.BytesIO(text))):
+        f.add_record_array(a)
+        if i == 40:
+            assert q.number_of_reads > 0     # a getter in the middle of a block: sealed with its tail still on its way
+    np.testing.assert_array_equal(u64(q.base_count_table()), rq.base_count_table())
+    np.testing.assert_array_equal(u64(q.phred_count_table()), rq.phred_count_table())
+    np.testing.assert_array_equal(u64(q.gc_content()), rq.gc_content())
+    assert p.number_of_reads == rp.number_of_reads == n
+    for (t, e, c), (tr, er, cr) in zip(p.get_tile_counts(), rp.get_tile_counts()):
+        assert t == tr
+        np.testing.assert_array_equal(u64(c), cr)
+        np.testing.assert_allclose(np.array(e), er, rtol=1e-6, atol=0)
