@@ -347,10 +347,10 @@ def _array_of_sequences(seqs: List[str]) -> FastqRecordArrayView:
 # for the call only, :575-607) into a staging block per source, and a module remembers which
 # stretch of which block it still has to count.  A block is uploaded once, by whoever needs it
 # first, when it holds _STAGE_LIMIT bytes, or when a getter, a flush or anything else that looks
-# at a module's state (its `_h`) asks for it: O(1) launches per 64 MiB and module whatever the
+# at a module's state (its `_h`) asks for it: O(1) launches per 128 MiB and module whatever the
 # size of the arrays.  Deferred work surfaces errors and warnings when it runs, not in the call
 # that brought the array (already so for QCMetrics' invalid phred character).
-_STAGE_LIMIT = int(os.environ.get("SQ_STAGE_BYTES", str(64 << 20)))   # 0: no staging
+_STAGE_LIMIT = int(os.environ.get("SQ_STAGE_BYTES", str(128 << 20)))   # 0: no staging (64 MiB until round 6: what a block costs is per block -- the passes' read-backs, the move to the next block -- 28 -> 22 ms per 2 M reads with six modules, profiles/r6/exp_stage_bytes.txt)
 _STAGE_ARRAY_MAX = 8 << 20      # arrays from this size on are uploaded on their own
 staging_stats = {"blocks": 0, "runs": 0}   # blocks uploaded, module launches on (parts of) blocks
 _USE_FEEDER = os.environ.get("SQ_FEEDER", "1") != "0"   # FastqParser over pinned staging blocks (csrc/sq_feed.hip)

@@ -7,7 +7,7 @@
  * enlarges the buffer by `read_in_size` while it holds fewer than `min_records`.  An array is
  * therefore a *window* of the file: it starts where the last complete record of the previous
  * array ended and is `read_in_size` bytes long (more after enlarging, less at the end of the
- * file).  Here the file's text is read once, into a pinned block of up to 64 MiB; arrays are
+ * file).  Here the file's text is read once, into a pinned block of up to 128 MiB; arrays are
  * windows of that block (no copy of the leftover: it already lies where the next array starts),
  * their metas are written once, relative to the block, which is what the device wants; a block
  * goes to HBM with one asynchronous copy from pinned memory and no copy on the host.
@@ -84,7 +84,7 @@ void pool_put(PinBuf b)
     if (!b.p) return;
     size_t held = 0;
     for (const PinBuf &x : g_pool) held += x.bytes;
-    if (held + b.bytes > (1u << 30)) {   /* two parsers' worth of 64 MiB blocks: the blocks of one that has just ended often come back after the next one has started */
+    if (held + b.bytes > ((size_t)2 << 30)) {   /* two parsers' worth of 128 MiB blocks (and their metas): the blocks of one that has just ended often come back after the next one has started */
         if (b.pinned) (void)hipHostFree(b.p); else free(b.p);
         return;
     }
@@ -531,7 +531,7 @@ SQ_EXPORT sq_feeder *sq_feeder_new(sq_ctx *ctx, size_t read_in_size, size_t bloc
     sq_feeder *f = new sq_feeder();
     f->ctx = ctx;
     f->read_in = read_in_size;
-    f->block_bytes = block_bytes ? block_bytes : ((size_t)64 << 20);
+    f->block_bytes = block_bytes ? block_bytes : ((size_t)128 << 20);
     return f;
 }
 
