@@ -143,11 +143,14 @@ def host_cpu():
 
 
 def csrc_sha():
-    """SHA-256 over the kernel sources: profiles/traffic.json records the one it was measured on"""
+    """SHA-256 over the kernel sources: profiles/traffic.json records the one it was measured on (every file of csrc/ but the
+    two that hold no device code: the parser's host side, sq_feed.hip, and its byte scans, sq_hostsimd.cpp)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sequali_amd", "csrc")
     for name in sorted(os.listdir(d)):
+        if name in ("sq_feed.hip", "sq_hostsimd.cpp"):
+            continue
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -38,6 +38,8 @@ int64_t sq_split_range_indexed(const uint8_t *base, size_t start, size_t end_off
                                uint64_t stats[SQ_STATS_N], size_t ascii_from, int64_t *non_ascii, const SqNlPiece *pieces, size_t n_pieces);
 size_t sq_scan_newlines(const uint8_t *p, size_t n, uint32_t base, uint32_t *out, size_t cap, size_t *scanned, uint32_t *high);   /* sq_hostsimd.cpp */
 int64_t sq_first_non_ascii_fast(const uint8_t *p, size_t n);
+size_t sq_copy_scan_newlines(uint8_t *dst, const uint8_t *src, size_t n, uint32_t base, uint32_t *out, uint8_t *after, size_t cap, size_t *copied,
+                             uint32_t *high);   /* sq_hostsimd.cpp */
 
 namespace {
 
@@ -178,6 +180,7 @@ struct sq_feeder {
     hipStream_t copy_stream = nullptr;   /* the early uploads (FeedBlock::d_text); null: blocks go up when they are sealed */
     hipEvent_t copy_done = nullptr;
     bool want_early = false;    /* somebody will ask for the blocks in HBM (sq_feeder_expect_uploads, or the first sq_feeder_upload): a parser that is only iterated uploads nothing */
+    bool plain_copy = false;    /* (SQ_FEED_COPY=plain: memcpy, then the scan over the block -- the way before the fused pass) */
     bool walker_sends = false;  /* the walker issues the early copies, stretch by stretch as the text arrives (else the workers, piece by piece) */
 };
 
@@ -218,31 +221,45 @@ void feed_worker(sq_feeder *f)
         const double t_work = feed_now();
         uint8_t *dst = b->pin() + pc->from;
         bool ok = true;
-        if (f->src_mem) {
-            memcpy(dst, f->src_mem + at, n);
+        if (f->src_mem && !f->plain_copy) {   /* copy and scan in one pass over the source (streaming stores: nobody reads the block through the cache) */
+            pc->nl.reserve(n / 64 + 16);
+            pc->after.reserve(n / 64 + 16);
+            size_t done = 0;
+            while (done < n) {
+                uint32_t tmp[2048], high = UINT32_MAX;
+                uint8_t tmp_after[2048];
+                size_t copied = 0;
+                const size_t k = sq_copy_scan_newlines(dst + done, f->src_mem + at + done, n - done, (uint32_t)(pc->from + done), tmp, tmp_after, 2048, &copied, &high);
+                pc->nl.insert(pc->nl.end(), tmp, tmp + k);
+                pc->after.insert(pc->after.end(), tmp_after, tmp_after + k);
+                if (high != UINT32_MAX && pc->first_high == UINT32_MAX) pc->first_high = high;
+                done += copied;
+                if (!copied) break;
+            }
         } else {
-            size_t got = 0;
+            size_t got = f->src_mem ? n : 0;
+            if (f->src_mem) memcpy(dst, f->src_mem + at, n);
             while (got < n) {
                 const ssize_t r = pread(f->src_fd, dst + got, n - got, (off_t)(at + got));
                 if (r <= 0) { ok = false; break; }   /* the file is shorter than it was, or an I/O error */
                 got += (size_t)r;
             }
-        }
-        if (ok) {
-            pc->nl.reserve(n / 64 + 16);
-            size_t done = 0;
-            while (done < n) {
-                uint32_t tmp[2048], high = UINT32_MAX;
-                size_t scanned = 0;
-                const size_t k = sq_scan_newlines(dst + done, n - done, (uint32_t)(pc->from + done), tmp, 2048, &scanned, &high);
-                pc->nl.insert(pc->nl.end(), tmp, tmp + k);
-                if (high != UINT32_MAX && pc->first_high == UINT32_MAX) pc->first_high = high;
-                done += scanned;
-                if (!scanned) break;
+            if (ok) {
+                pc->nl.reserve(n / 64 + 16);
+                size_t done = 0;
+                while (done < n) {
+                    uint32_t tmp[2048], high = UINT32_MAX;
+                    size_t scanned = 0;
+                    const size_t k = sq_scan_newlines(dst + done, n - done, (uint32_t)(pc->from + done), tmp, 2048, &scanned, &high);
+                    pc->nl.insert(pc->nl.end(), tmp, tmp + k);
+                    if (high != UINT32_MAX && pc->first_high == UINT32_MAX) pc->first_high = high;
+                    done += scanned;
+                    if (!scanned) break;
+                }
+                pc->after.resize(pc->nl.size());
+                const uint8_t *text = b->pin();
+                for (size_t i = 0; i < pc->nl.size(); i++) pc->after[i] = (size_t)pc->nl[i] + 1 < pc->to ? text[pc->nl[i] + 1] : 0;
             }
-            pc->after.resize(pc->nl.size());
-            const uint8_t *text = b->pin();
-            for (size_t i = 0; i < pc->nl.size(); i++) pc->after[i] = (size_t)pc->nl[i] + 1 < pc->to ? text[pc->nl[i] + 1] : 0;
         }
         bool sent = true;
         if (ok && d_text && hipMemcpyAsync(d_text + pc->from, dst, n, hipMemcpyHostToDevice, b->early_stream) != hipSuccess) {
@@ -574,6 +591,7 @@ static int feeder_start(sq_feeder *f)
         else
             (void)hipGetLastError();
     }
+    if (const char *v = getenv("SQ_FEED_COPY")) f->plain_copy = !strcmp(v, "plain");
     const unsigned hc = std::thread::hardware_concurrency();
     unsigned n = std::max(1u, std::min(4u, hc > 1 ? hc - 1 : 1u));
     if (f->src_end - f->src_off < ((uint64_t)4 << 20)) n = 1;   /* a few pieces: one worker (a parser over a few records should not start four threads) */

@@ -57,6 +57,40 @@ __attribute__((target("avx2"))) int64_t first_non_ascii_avx2(const uint8_t *p, s
     return -1;
 }
 
+/* scan_nl_avx2 over src while its bytes go to dst with streaming stores (nobody reads dst through the cache: the copy engines
+   and the device do), and the byte behind every newline noted from src (0: it lies behind the n bytes) */
+__attribute__((target("avx2"))) size_t copy_scan_nl_avx2(uint8_t *dst, const uint8_t *src, size_t n, uint32_t base, uint32_t *out, uint8_t *after,
+                                                         size_t cap, size_t *copied, uint32_t *high)
+{
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t k = 0, i = 0;
+    auto byte = [&](size_t j) {
+        const uint8_t c = src[j];
+        dst[j] = c;
+        if (c == '\n') { out[k] = base + (uint32_t)j; after[k++] = j + 1 < n ? src[j + 1] : 0; }
+        if ((c & 0x80) && *high == UINT32_MAX) *high = base + (uint32_t)j;
+    };
+    for (; i < n && k < cap && ((uintptr_t)(dst + i) & 31); i++) byte(i);
+    for (; i + 64 <= n && k + 64 <= cap; i += 64) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32));
+        _mm256_stream_si256((__m256i *)(dst + i), a);
+        _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        uint64_t m = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, nl)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, nl)) << 32);
+        const uint64_t h = (uint64_t)(uint32_t)_mm256_movemask_epi8(a) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(b) << 32);
+        if (__builtin_expect(h != 0, 0) && *high == UINT32_MAX) *high = base + (uint32_t)i + (uint32_t)__builtin_ctzll(h);
+        while (m) {
+            const size_t j = i + (size_t)__builtin_ctzll(m);
+            out[k] = base + (uint32_t)j;
+            after[k++] = j + 1 < n ? src[j + 1] : 0;
+            m &= m - 1;
+        }
+    }
+    for (; i < n && k < cap && (i + 64 > n); i++) byte(i);
+    _mm_sfence();
+    *copied = i;
+    return k;
+}
+
 const bool g_avx2 = __builtin_cpu_supports("avx2");
 
 }  // namespace
@@ -67,6 +101,23 @@ const bool g_avx2 = __builtin_cpu_supports("avx2");
 size_t sq_scan_newlines(const uint8_t *p, size_t n, uint32_t base, uint32_t *out, size_t cap, size_t *scanned, uint32_t *high)
 {
     return g_avx2 ? scan_nl_avx2(p, n, base, out, cap, scanned, high) : scan_nl_plain(p, n, base, out, cap, scanned, high);
+}
+
+/* sq_scan_newlines of src[0, n) while those bytes are copied to dst; after[k]: the byte behind newline k, 0 where that lies
+ * behind the n bytes.  *copied: the bytes done (all n unless out is full) */
+size_t sq_copy_scan_newlines(uint8_t *dst, const uint8_t *src, size_t n, uint32_t base, uint32_t *out, uint8_t *after, size_t cap, size_t *copied,
+                             uint32_t *high)
+{
+    if (g_avx2) return copy_scan_nl_avx2(dst, src, n, base, out, after, cap, copied, high);
+    size_t k = 0, i = 0;
+    for (; i < n && k < cap; i++) {
+        const uint8_t c = src[i];
+        dst[i] = c;
+        if (c == '\n') { out[k] = base + (uint32_t)i; after[k++] = i + 1 < n ? src[i + 1] : 0; }
+        if ((c & 0x80) && *high == UINT32_MAX) *high = base + (uint32_t)i;
+    }
+    *copied = i;
+    return k;
 }
 
 int64_t sq_first_non_ascii_fast(const uint8_t *p, size_t n)
