@@ -679,7 +679,7 @@ SQ_EXPORT int sq_feeder_next(sq_feeder *f, size_t min_records, size_t max_record
         /* one readinto of the reference: the free part of a new buffer of read_in bytes, later read_in more */
         const size_t want = f->first ? (f->read_in > f->arr_len ? f->read_in - f->arr_len : 0) : f->read_in;
         if (want > 0) {
-            size_t used_now = b->used;
+            size_t used_now = f->has_source ? 0 : b->used;   /* (with a source: `used` is the workers', read under the lock below) */
             if (f->has_source && !b->walk_off && b->walk_scanned.load(std::memory_order_acquire) >= f->pos + f->arr_len + want) {
                 used_now = b->walk_scanned.load(std::memory_order_acquire);   /* the walker has been through this read's bytes: they are there */
             } else if (f->has_source) {   /* the workers bring the bytes: wait until this read's are there, the source is exhausted or the block is full */
