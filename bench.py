@@ -146,7 +146,9 @@ def csrc_sha():
     """SHA-256 over the kernel sources: profiles/traffic.json records the one it was measured on (every file of csrc/ but the
     two that hold no device code: the parser's host side, sq_feed.hip, and its byte scans, sq_hostsimd.cpp)"""
     import hashlib
+    from sequali_amd import build as _build
     h = hashlib.sha256()
+    h.update(" ".join(_build.FLAGS).encode())     # the same sources under other compiler flags are other kernels
     d = os.path.join(ROOT, "sequali_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name in ("sq_feed.hip", "sq_hostsimd.cpp"):

@@ -3,7 +3,7 @@
 # other objects into scripts/build/libsqgpu_$1.so.  usage: scripts/build_exp.sh NAME [flags ...]
 name=$1; shift
 only="-DSQ_SPAN_ONLY_NW=${NW:-5}"; [ "$NW" = all ] && only=""
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -Wno-unused-function $only $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden -Wno-unused-function -Xclang -no-enable-noundef-analysis $only $*"
 mkdir -p scripts/build
 hipcc $F -c sequali_amd/csrc/sq_span.hip -o scripts/build/sq_span_$name.o || exit 1
 B=sequali_amd/build

@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsqgpu.so")
 SOURCES = ["sq_span.hip", "sq_span_w6.hip", "sq_pair.hip", "sq_qc.hip", "sq_api.hip", "sq_ends.hip", "sq_nano.hip", "sq_feed.hip", "sq_dist.hip", "sq_hostsimd.cpp"]   # the slowest first
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-Xclang", "-no-enable-noundef-analysis"]
 
 
 # Builds of k_span (sq_span_kernel.h: <NW, AD, SEG, W4T, SPLIT, LONG, PT, PAIR>) that the DEFAULT dispatch launches (sq_span_launch,

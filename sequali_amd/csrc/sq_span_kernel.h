@@ -492,7 +492,14 @@ __global__ void __launch_bounds__(64 * span_max_waves(NW, SPLIT, SEG, LONG, PT))
        lane -- U > 44 at two windows -- and deletes the tests U - 1 > 35 / 39 / 43 that guard the chain's last steps far below:
        k_span<1|2,QC,uniform,both> then summed the error rates of the text behind a short read's qualities (NaN: 'Not a
        valid phred character' for every read of 1-15 and 33-47 bases; profiles/r5/exp_late_kernel_ab.txt, item 4).  The
-       padding code always worked on opaque copies; now the reason is known. */
+       padding code always worked on opaque copies; now the reason is known.
+       Round 6, the root cause (scripts/hipcc_speculation_noundef/): a compiler bug, not undefined behaviour here.  clang marks
+       the result of min() `noundef`; InstCombine makes the U - p0 inside the `p0 < U` arm a `sub nuw`; AMD LLVM 22's
+       SpeculativeExecutionPass hoists `call noundef @llvm.umin(4, sub nuw U, p0)` above the branch WITHOUT dropping the
+       `noundef` -- for U < p0 the hoisted call now returns poison where it promised not to, which is undefined behaviour the
+       source never had -- and ConstraintElimination, entitled to by that IR, concludes U >= p0 >= 48 and folds the guards.
+       The library is built with -Xclang -no-enable-noundef-analysis since (build.py: no such promises, nothing to keep while
+       hoisting; same-box A/B of every configuration: no difference); the opaque copy stays. */
     uint32_t keep_u0 = 0xFFFFFFFFu, keep_u1 = 0xFFFFFFFFu;
     if constexpr (!SEG && !PT && !LONG) {
         uint32_t Uo = U;
