@@ -180,6 +180,7 @@ struct sq_feeder {
     hipStream_t copy_stream = nullptr;   /* the early uploads (FeedBlock::d_text); null: blocks go up when they are sealed */
     hipEvent_t copy_done = nullptr;
     bool want_early = false;    /* somebody will ask for the blocks in HBM (sq_feeder_expect_uploads, or the first sq_feeder_upload): a parser that is only iterated uploads nothing */
+    bool walk_plain = false;    /* (SQ_FEED_WALKER=plain: every record by the record loop, none by the fast lane) */
     bool plain_copy = false;    /* (SQ_FEED_COPY=plain: memcpy, then the scan over the block -- the way before the fused pass) */
     bool walker_sends = false;  /* the walker issues the early copies, stretch by stretch as the text arrives (else the workers, piece by piece) */
 };
@@ -300,6 +301,52 @@ void feed_resume(sq_feeder *f)
 
 constexpr size_t WALK_CHUNK = 4096;   /* records whose stats are kept together */
 
+/* The walker's fast lane: the well-formed records from *at on whose four newlines lie in ONE piece and in front of `upto`,
+   straight from that piece's notes (four offsets and two of the bytes behind them per record; the text is looked at once
+   per call).  Returns how many (<= cap) and moves *at behind them.  It stops in front of anything else -- a record that
+   crosses into the next piece, a record whose `@`, `+` or lengths are not right, a byte the notes do not hold -- and the
+   record loop itself (sq_split_range_indexed) takes that one: every error is still its error. */
+size_t walk_fast(const uint8_t *text, const SqNlPiece *pieces, size_t n_pieces, size_t *at, size_t upto, sq_meta *metas, size_t cap, uint64_t *S)
+{
+    size_t rec = *at, n = 0, k = 0;
+    while (k < n_pieces && pieces[k].to <= rec) k++;
+    if (k == n_pieces || rec < pieces[k].from || rec >= upto) return 0;
+    const SqNlPiece &pc = pieces[k];
+    size_t j = (size_t)(std::lower_bound(pc.nl, pc.nl + pc.n_nl, (uint32_t)rec) - pc.nl);
+    uint8_t first = text[rec];
+    while (n < cap && j + 3 < pc.n_nl) {
+        const uint32_t e0 = pc.nl[j], e1 = pc.nl[j + 1], e2 = pc.nl[j + 2], e3 = pc.nl[j + 3];
+        if (e3 >= upto || first != '@' || pc.after[j + 1] != '+') break;
+        const uint32_t name = (uint32_t)rec + 1, seq = e0 + 1, qual = e2 + 1, L = e1 - seq;
+        if (L != e3 - qual) break;
+        sq_meta *m = &metas[n++];
+        m->record_start = name;
+        m->name_length = e0 - name;
+        m->sequence_offset = seq - name;
+        m->sequence_length = L;
+        m->qualities_offset = qual - name;
+        m->tags_offset = e3 - name;
+        m->tags_length = 0;
+        m->accumulated_error_rate = 0.0;
+        const uint64_t span = (uint64_t)m->qualities_offset + L;
+        S[0] += L;
+        if (L > S[1]) S[1] = L;
+        if (m->name_length > S[2]) S[2] = m->name_length;
+        if (span > S[3]) S[3] = span;
+        if (~(uint64_t)L > S[4]) S[4] = ~(uint64_t)L;
+        S[5 + (L < (uint32_t)SQ_LEN_BINS - 1 ? L : (uint32_t)SQ_LEN_BINS - 1)]++;
+        rec = (size_t)e3 + 1;
+        first = pc.after[j + 3];
+        j += 4;
+        if (first == 0) {   /* behind the piece, or a zero byte: the text knows (as far as it is there) */
+            if (rec >= upto) break;
+            first = text[rec];
+        }
+    }
+    *at = rec;
+    return n;
+}
+
 /* the walker of a feeder with a source: the records of the open block as far as its text is there, in the block's meta
    area, by the record loop sq_feeder_next itself uses (sq_split_range_indexed over the workers' notes) */
 void feed_walker(sq_feeder *f)
@@ -349,13 +396,17 @@ void feed_walker(sq_feeder *f)
             if (b->chunks.size() <= chunk) b->chunks.resize(chunk + 1, FeedBlock::Chunk{});
             const size_t cap = std::min(b->meta_cap - n, WALK_CHUNK - n % WALK_CHUNK);
             if (cap == 0) { stop = true; break; }   /* the meta area is full: the caller's thread makes a bigger one */
+            const size_t got = f->walk_plain ? 0 : walk_fast(b->pin(), idx.data(), idx.size(), &at, upto, b->metas() + n, cap, b->chunks[chunk].s);
+            n += got;
+            if (got == cap) continue;
+            /* the record the fast lane stopped in front of (it crosses pieces, or something is wrong with it), by the record loop */
             size_t consumed = 0;
-            const int64_t r = sq_split_range_indexed(b->pin(), at, upto, b->metas() + n, cap, &consumed, b->chunks[chunk].s, (size_t)-1, nullptr,
-                                                     idx.data(), idx.size());
+            const int64_t r = sq_split_range_indexed(b->pin(), at, upto, b->metas() + n, f->walk_plain ? cap : 1, &consumed, b->chunks[chunk].s, (size_t)-1,
+                                                     nullptr, idx.data(), idx.size());
             if (r < 0) { stop = true; break; }      /* a malformed record: the caller's thread finds it again, with its window */
             n += (size_t)r;
             at += consumed;
-            if ((size_t)r < cap) break;             /* what follows is not complete yet */
+            if (r == 0 || (f->walk_plain && (size_t)r < cap)) break;   /* what follows is not complete yet */
         }
         b->walk_next = at;
         b->walk_n.store(n, std::memory_order_release);
@@ -599,6 +650,7 @@ static int feeder_start(sq_feeder *f)
     for (unsigned i = 0; i < n; i++) f->workers.emplace_back(feed_worker, f);
     /* and one more thread splits the records as the text arrives (SQ_FEED_WALKER=0: sq_feeder_next does, window by window) */
     const char *w = getenv("SQ_FEED_WALKER");
+    f->walk_plain = w && !strcmp(w, "plain");
     if (!(w && (w[0] == '0' || w[0] == 0)) && hc > 2) {
         f->walk_on = true;
         f->walker_sends = f->copy_stream != nullptr;

@@ -175,7 +175,7 @@ def test_read_n_in_the_middle_of_an_iteration():
     assert mixed(io.BytesIO(text)) == mixed(Fed(text))
 
 
-@pytest.mark.parametrize("walker", ["0", "1"])
+@pytest.mark.parametrize("walker", ["0", "1", "plain"])
 def test_with_and_without_the_walker(monkeypatch, walker):
     monkeypatch.setenv("SQ_FEED_WALKER", walker)
     rng = np.random.default_rng(81)
