@@ -183,3 +183,13 @@ def test_with_and_without_the_walker(monkeypatch, walker):
     assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
     text = _text(rng, 20_000, 300, bad=(15_000, lambda r: r.replace(b"\n+\n", b"\n-\n", 1)))
     assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
+
+
+def test_the_workers_plain_copy(monkeypatch):
+    """SQ_FEED_COPY=plain: memcpy, then the scan over the block (the way before the fused pass) -- the same arrays"""
+    monkeypatch.setenv("SQ_FEED_COPY", "plain")
+    rng = np.random.default_rng(91)
+    text = _text(rng, 50_000, 300)
+    assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
+    text = _text(rng, 20_000, 300, bad=(15_000, lambda r: r[:8] + b"\xc3" + r[9:]))
+    assert _arrays(io.BytesIO(text), 128 * 1024) == _arrays(Fed(text), 128 * 1024)
