@@ -629,14 +629,16 @@ class _FedArray(FastqRecordArrayView):
     """a record array of a FastqParser: a window of a pinned staging block.  `obj` and the metas
     are made when somebody looks at them; the modules only note which block and slot it is."""
 
+    # (what every new array starts with lives on the class: the parser makes 5000 of these per 2 M reads)
+    _batch = None
+    _writeback = None
+    _obj = None
+    _m = None
+    _m_version = -1
+
     def __init__(self, blk: _FeedBlock, slot: int, b0: int, blen: int, r0: int, n: int):
         self._blk, self._slot, self._b0, self._blen, self._r0, self._n = blk, slot, b0, blen, r0, n
-        self._batch = None
-        self._writeback = None
         self._staged = (blk, slot)
-        self._obj = None
-        self._m = None
-        self._m_version = -1
 
     def __len__(self) -> int:
         return self._n
@@ -976,7 +978,7 @@ class FastqParser:
     def __next__(self) -> FastqRecordArrayView:
         fast = self._fast_next
         if fast is not None:        # the driver loop's case: the feeder reads the file itself, one foreign call per array
-            rc = fast[0](fast[1], 1, _MAX_RECORDS, fast[2])
+            rc = fast[0](fast[1], fast[4], fast[5], fast[2])
             if rc == 0:
                 info = fast[3]
                 n = info.n_records
@@ -1017,7 +1019,7 @@ class FastqParser:
             self._source = f.source = _feeder_source(f, self._file)
             if self._source is not None:
                 info = _FeedArrayInfo()
-                self._fast_next = (lib().sq_feeder_next, f.h, C.byref(info), info)
+                self._fast_next = (lib().sq_feeder_next, f.h, C.byref(info), info, C.c_size_t(1), C.c_size_t(_MAX_RECORDS))
         info = _FeedArrayInfo()
         room = C.c_size_t(0)
         while True:
